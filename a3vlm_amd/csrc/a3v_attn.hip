@@ -1,0 +1,457 @@
+// Attention for gfx950: softmax(q k^T / sqrt(hd) [+ right-aligned causal]) v.
+//
+// Layout contract (elements, explicit strides): q/out [b][s][h][hd]; k [b][hkv][s][hd];
+// vt = V TRANSPOSED [b][hkv][hd][s].  V^T lets both MFMA products run "transposed":
+//     S^T = K . Q^T   (A = K rows from LDS, B = Q rows from registers)
+//     O^T = V^T . P^T (A = V^T rows from LDS, B = P straight from the S^T accumulators)
+// With v_mfma_f32_32x32x16_bf16 the C/D map is col = lane&31, row = (r&3)+8(r>>2)+4(lane>>5),
+// so a lane owns ONE query column of S^T and of O^T: the online softmax (max, exp, sum,
+// rescale) is lane-local plus one lane<->lane+32 exchange, and P never leaves registers --
+// the 16 accumulator values of a lane are, in register order, exactly the k-elements the
+// P^T B-operand wants when V^T rows are read at kv = base + 4*(lane>>5) + {0..3, 8..11}.
+//
+//  * attn_prefill_bf16_kernel<HD,CAUSAL>: 4 waves x 32 query rows, KV tiles of 64 through
+//    LDS (K rows XOR-swizzled for ds_read_b128, V^T rows for ds_read_b64), global->register
+//    prefetch of the next tile issued before the MFMAs of the current one.
+//  * attn_decode_bf16_kernel<HD>: Sq == 1, split-KV (flash-decoding), HBM-bound streaming of
+//    K rows / V^T rows with 16-byte loads, + combine kernel.
+//  * attn_f32_kernel: fp32 parity path (any Sq), one wave per (b, h, q).
+#include "a3v_common.h"
+
+namespace {
+
+struct AttnArgs {
+  const void* q; const void* k; const void* vt; void* out;
+  int64_t q_sb, q_ss, q_sh;     // q strides: batch, seq, head
+  int64_t k_sb, k_sh, k_ss;     // k strides: batch, kv-head, seq   (hd contiguous)
+  int64_t v_sb, v_sh, v_sd;     // vt strides: batch, kv-head, d    (seq contiguous)
+  int64_t o_sb, o_ss, o_sh;
+  int B, Sq, Sk, H, Hkv;
+  float scale_log2;             // log2(e) / sqrt(hd)
+  float scale;
+};
+
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_prefill_bf16_kernel(AttnArgs p) {
+  constexpr int KVB = 64;
+  constexpr int KROW = HD * 2;            // bytes per K row in LDS
+  constexpr int KCH = HD / 8;             // 16-B chunks per K row
+  constexpr int K_LOADS = KVB * KCH / 256;   // 16-B chunks per thread (4 for HD=128, 2 for 64)
+  constexpr int V_LOADS = HD * 8 / 256;      // V^T tile: HD rows x 8 chunks of 16 B
+  __shared__ __attribute__((aligned(16))) char lds[KVB * KROW + HD * 128];
+  char* Ks = lds;
+  char* Vs = lds + KVB * KROW;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qt = gridDim.x - 1 - blockIdx.x;   // heavy (late) causal tiles first
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int hk = h / (p.H / p.Hkv);
+  const int q0 = qt * 128 + wave * 32;
+  const int off = p.Sk - p.Sq;                 // right alignment (llama_ens5.py:181-185)
+
+  const bf16_t* Q = (const bf16_t*)p.q + b * p.q_sb + h * p.q_sh;
+  const bf16_t* K = (const bf16_t*)p.k + b * p.k_sb + hk * p.k_sh;
+  const bf16_t* VT = (const bf16_t*)p.vt + b * p.v_sb + hk * p.v_sh;
+
+  const int ql = lane & 31, hh = lane >> 5;
+  int qrow = q0 + ql;
+  const int qrow_c = qrow < p.Sq ? qrow : p.Sq - 1;
+  // Q fragments (B operand): Q[q][16*ks + 8*hh + e]
+  bf16x8 qf[HD / 16];
+#pragma unroll
+  for (int ks = 0; ks < HD / 16; ++ks)
+    qf[ks] = *reinterpret_cast<const bf16x8*>(Q + (int64_t)qrow_c * p.q_ss + ks * 16 + hh * 8);
+
+  f32x16 o[HD / 32];
+#pragma unroll
+  for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  // kv range for this block: all q rows of the block
+  int kv_end = p.Sk;
+  if (CAUSAL) {
+    const int last_q = min(qt * 128 + 127, p.Sq - 1);
+    kv_end = min(p.Sk, last_q + off + 1);
+  }
+  const int n_tiles = (kv_end + KVB - 1) / KVB;
+
+  u32x4 kreg[K_LOADS], vreg[V_LOADS];
+  auto load_tile = [&](int kv0) {
+#pragma unroll
+    for (int i = 0; i < K_LOADS; ++i) {
+      const int id = tid + i * 256;
+      const int row = id / KCH, ch = id % KCH;
+      int kr = kv0 + row;
+      kr = kr < p.Sk ? kr : p.Sk - 1;
+      kreg[i] = *reinterpret_cast<const u32x4*>(K + (int64_t)kr * p.k_ss + ch * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < V_LOADS; ++i) {
+      const int id = tid + i * 256;
+      const int d = id >> 3, ch = id & 7;
+      const int kv = kv0 + ch * 8;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (kv + 8 <= p.Sk) {
+        v = *reinterpret_cast<const u32x4*>(VT + (int64_t)d * p.v_sd + kv);
+      } else if (kv < p.Sk) {   // ragged tail: zero the columns >= Sk (0 * garbage must stay 0)
+        const unsigned short* src = reinterpret_cast<const unsigned short*>(VT + (int64_t)d * p.v_sd + kv);
+        unsigned short e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = (kv + j < p.Sk) ? src[j] : (unsigned short)0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (unsigned)e[2 * j] | ((unsigned)e[2 * j + 1] << 16);
+      }
+      vreg[i] = v;
+    }
+  };
+  auto write_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < K_LOADS; ++i) {
+      const int id = tid + i * 256;
+      const int row = id / KCH, ch = id % KCH;
+      const int sw = (HD == 128) ? (row & 15) : ((row >> 1) & 7);
+      *reinterpret_cast<u32x4*>(Ks + row * KROW + ((ch ^ sw) << 4)) = kreg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < V_LOADS; ++i) {
+      const int id = tid + i * 256;
+      const int d = id >> 3, ch = id & 7;
+      const int g = (d >> 1) & 15;
+      u32x2 lo = {vreg[i][0], vreg[i][1]}, hi = {vreg[i][2], vreg[i][3]};
+      *reinterpret_cast<u32x2*>(Vs + d * 128 + (((2 * ch) ^ g) << 3)) = lo;
+      *reinterpret_cast<u32x2*>(Vs + d * 128 + (((2 * ch + 1) ^ g) << 3)) = hi;
+    }
+  };
+
+  if (n_tiles > 0) load_tile(0);
+  for (int t = 0; t < n_tiles; ++t) {
+    const int kv0 = t * KVB;
+    __syncthreads();
+    write_tile();
+    __syncthreads();
+    if (t + 1 < n_tiles) load_tile(kv0 + KVB);
+
+    // ---- S^T = K . Q^T : two 32-row kv blocks ----
+    f32x16 s[2];
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[tb][r] = 0.f;
+      const int row = tb * 32 + ql;
+      const int sw = (HD == 128) ? (row & 15) : ((row >> 1) & 7);
+      const char* kp = Ks + row * KROW;
+#pragma unroll
+      for (int ks = 0; ks < HD / 16; ++ks) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kp + (((2 * ks + hh) ^ sw) << 4));
+        s[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[tb], 0, 0, 0);
+      }
+    }
+    // ---- mask + online softmax (lane owns query column ql; kv = 32tb + (r&3)+8(r>>2)+4hh) ----
+    const int qlim = CAUSAL ? (qrow + off) : 0x7fffffff;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kv = kv0 + tb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const bool ok = (kv < p.Sk) && (kv <= qlim);
+        s[tb][r] = ok ? s[tb][r] : -INFINITY;
+        mx = fmaxf(mx, s[tb][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    // rows past Sq (clamped duplicates) and fully-masked tiles keep m finite once any tile was seen
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = exp2f((m_run - m_use) * p.scale_log2);
+    m_run = m_new;
+    float lsum = 0.f;
+    bf16x8 pf[2][2];
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = exp2f((s[tb][r] - m_use) * p.scale_log2);
+        lsum += pv;
+        pf[tb][r >> 3][r & 7] = f2bf(pv);
+      }
+    l_run = l_run * alpha + lsum;
+#pragma unroll
+    for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+    // ---- O^T += V^T . P^T ----
+#pragma unroll
+    for (int d = 0; d < HD / 32; ++d) {
+      const int drow = d * 32 + ql;
+      const int g = (drow >> 1) & 15;
+      const char* vp = Vs + drow * 128;
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const int ca = 8 * tb + 4 * c + hh;
+          const u32x2 a0 = *reinterpret_cast<const u32x2*>(vp + ((ca ^ g) << 3));
+          const u32x2 a1 = *reinterpret_cast<const u32x2*>(vp + (((ca + 2) ^ g) << 3));
+          const u32x4 av = {a0[0], a0[1], a1[0], a1[1]};
+          bf16x8 vf;
+          __builtin_memcpy(&vf, &av, 16);
+          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[tb][c], o[d], 0, 0, 0);
+        }
+    }
+  }
+
+  // ---- normalise and store O[q][d], d = 32*db + 8*g + 4*hh + {0..3} ----
+  float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+  if (qrow < p.Sq) {
+    bf16_t* O = (bf16_t*)p.out + b * p.o_sb + (int64_t)qrow * p.o_ss + h * p.o_sh;
+#pragma unroll
+    for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        bf16x4 ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ov[e] = f2bf(o[d][g4 * 4 + e] * inv);
+        *reinterpret_cast<bf16x4*>(O + d * 32 + g4 * 8 + hh * 4) = ov;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// Decode (Sq == 1): grid (nsplit, H, B); block 256.  part[b][h][split] = {o[HD], m, l}
+// ------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(256) void attn_decode_bf16_kernel(AttnArgs p, float* part, int nsplit, int chunk) {
+  constexpr int LPR = HD / 8;            // lanes per K row (16-B each)
+  constexpr int RPW = 64 / LPR;          // K rows per wave-load
+  extern __shared__ __attribute__((aligned(16))) char dsm[];
+  float* sc = reinterpret_cast<float*>(dsm);       // chunk scores / probabilities
+  __shared__ float red[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sp = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int hk = h / (p.H / p.Hkv);
+  const int kv_lo = sp * chunk;
+  const int kv_hi = min(p.Sk, kv_lo + chunk);
+  const int n = kv_hi - kv_lo;
+  float* po = part + ((int64_t)(b * p.H + h) * nsplit + sp) * (HD + 2);
+  if (n <= 0) {
+    if (tid < HD) po[tid] = 0.f;
+    if (tid == 0) { po[HD] = -INFINITY; po[HD + 1] = 0.f; }
+    return;
+  }
+  const bf16_t* Q = (const bf16_t*)p.q + b * p.q_sb + h * p.q_sh;
+  const bf16_t* K = (const bf16_t*)p.k + b * p.k_sb + hk * p.k_sh;
+  const bf16_t* VT = (const bf16_t*)p.vt + b * p.v_sb + hk * p.v_sh;
+
+  // phase 1: scores.  lane -> (row-in-group, 8 d's)
+  float qv[8];
+  load8(Q + (lane % LPR) * 8, qv);
+  for (int r0 = wave * RPW; r0 < n; r0 += 4 * RPW) {
+    const int r = r0 + lane / LPR;
+    float acc = 0.f;
+    if (r < n) {
+      float kvv[8];
+      load8(K + (int64_t)(kv_lo + r) * p.k_ss + (lane % LPR) * 8, kvv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc = fmaf(qv[e], kvv[e], acc);
+    }
+#pragma unroll
+    for (int o2 = LPR / 2; o2 > 0; o2 >>= 1) acc += __shfl_xor(acc, o2, 64);
+    if (r < n && (lane % LPR) == 0) sc[r] = acc * p.scale;
+  }
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int i = tid; i < n; i += 256) mx = fmaxf(mx, sc[i]);
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float ls = 0.f;
+  for (int i = tid; i < n; i += 256) {
+    const float e = __expf(sc[i] - mx);
+    // P is rounded to bf16 before P.V in the prefill kernel and in bf16 SDPA; keep fp32 sum
+    sc[i] = e;
+    ls += e;
+  }
+  ls = wave_sum(ls);
+  __syncthreads();
+  if (lane == 0) red[4 + wave] = ls;
+  __syncthreads();
+  ls = red[4] + red[5] + red[6] + red[7];
+  // zero-pad the probabilities to a multiple of 8 for the vector loop
+  const int n8 = (n + 7) & ~7;
+  for (int i = n + tid; i < n8; i += 256) sc[i] = 0.f;
+  __syncthreads();
+
+  // phase 2: o[d] = sum_kv p[kv] * VT[d][kv].  wave -> d rows, lanes -> 8-kv chunks
+  for (int d = wave; d < HD; d += 4) {
+    const bf16_t* vrow = VT + (int64_t)d * p.v_sd + kv_lo;
+    float acc = 0.f;
+    for (int c = lane * 8; c < n8; c += 64 * 8) {
+      float vv[8];
+      if (kv_lo + c + 8 <= p.Sk) {
+        load8(vrow + c, vv);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vv[e] = (kv_lo + c + e < p.Sk) ? bf2f(vrow[c + e]) : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc = fmaf(sc[c + e], vv[e], acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) po[d] = acc;
+  }
+  if (tid == 0) { po[HD] = mx; po[HD + 1] = ls; }
+}
+
+template <int HD>
+__global__ void attn_decode_combine_kernel(const float* part, void* out, int64_t o_sb, int64_t o_sh,
+                                           int H, int nsplit, int dtype) {
+  const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
+  const float* pp = part + (int64_t)(b * H + h) * nsplit * (HD + 2);
+  float m = -INFINITY;
+  for (int s = 0; s < nsplit; ++s) m = fmaxf(m, pp[s * (HD + 2) + HD]);
+  float acc = 0.f, l = 0.f;
+  for (int s = 0; s < nsplit; ++s) {
+    const float ms = pp[s * (HD + 2) + HD];
+    const float w = (ms == -INFINITY) ? 0.f : __expf(ms - m);
+    acc += w * pp[s * (HD + 2) + d];
+    l += w * pp[s * (HD + 2) + HD + 1];
+  }
+  const float v = acc / l;
+  if (dtype == A3V_BF16) ((bf16_t*)out)[b * o_sb + h * o_sh + d] = f2bf(v);
+  else ((float*)out)[b * o_sb + h * o_sh + d] = v;
+}
+
+// ------------------------------------------------------------------------------------
+// fp32 parity attention: one wave per (q row, head, batch); any hd <= 256, any Sq.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void attn_f32_kernel(AttnArgs p, int hd, int causal) {
+  __shared__ float pbuf[64];
+  __shared__ float qs[256];
+  const int lane = threadIdx.x;
+  const int qi = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int hk = h / (p.H / p.Hkv);
+  const float* Q = (const float*)p.q + b * p.q_sb + (int64_t)qi * p.q_ss + h * p.q_sh;
+  const float* K = (const float*)p.k + b * p.k_sb + hk * p.k_sh;
+  const float* VT = (const float*)p.vt + b * p.v_sb + hk * p.v_sh;
+  for (int d = lane; d < hd; d += 64) qs[d] = Q[d];
+  __syncthreads();
+  const int kv_end = causal ? min(p.Sk, qi + (p.Sk - p.Sq) + 1) : p.Sk;
+  float m = -INFINITY, l = 0.f;
+  float o[4] = {0.f, 0.f, 0.f, 0.f};   // d = lane + 64*i
+  for (int kv0 = 0; kv0 < kv_end; kv0 += 64) {
+    const int kv = kv0 + lane;
+    float s = -INFINITY;
+    if (kv < kv_end) {
+      const float* kr = K + (int64_t)kv * p.k_ss;
+      float a = 0.f;
+      for (int d = 0; d < hd; ++d) a = fmaf(qs[d], kr[d], a);
+      s = a * p.scale;
+    }
+    const float mt = wave_max(s);
+    const float mn = fmaxf(m, mt);
+    const float alpha = __expf(m - mn);   // m = -inf on the first tile -> 0
+    const float pv = (kv < kv_end) ? __expf(s - mn) : 0.f;
+    l = l * alpha + wave_sum(pv);
+    m = mn;
+    __syncthreads();
+    pbuf[lane] = pv;
+    __syncthreads();
+    const int cnt = min(64, kv_end - kv0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int d = lane + 64 * i;
+      if (d < hd) {
+        const float* vr = VT + (int64_t)d * p.v_sd + kv0;
+        float a = o[i] * alpha;
+        for (int j = 0; j < cnt; ++j) a = fmaf(pbuf[j], vr[j], a);
+        o[i] = a;
+      }
+    }
+  }
+  float* O = (float*)p.out + b * p.o_sb + (int64_t)qi * p.o_ss + h * p.o_sh;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int d = lane + 64 * i;
+    if (d < hd) O[d] = o[i] / l;
+  }
+}
+
+inline void decode_plan(int B, int H, int Sk, int* nsplit, int* chunk) {
+  int want = (1024 + B * H - 1) / (B * H);
+  int maxs = (Sk + 127) / 128;
+  int ns = want < maxs ? want : maxs;
+  if (ns < 1) ns = 1;
+  int ch = (Sk + ns - 1) / ns;
+  ch = (ch + 63) & ~63;
+  ns = (Sk + ch - 1) / ch;
+  *nsplit = ns;
+  *chunk = ch;
+}
+
+}  // namespace
+
+extern "C" int64_t a3v_attention_scratch_floats(int B, int H, int hd, int Sk) {
+  int ns, ch;
+  decode_plan(B, H, Sk, &ns, &ch);
+  return (int64_t)B * H * ns * (hd + 2);
+}
+
+extern "C" int a3v_attention(const void* q, const void* k, const void* vt, void* out, int B, int Sq, int Sk,
+                             int H, int Hkv, int hd, const int64_t* strides, int causal, float* scratch,
+                             int dtype, void* stream) {
+  if (!q || !k || !vt || !out || !strides || B <= 0 || Sq <= 0 || Sk <= 0 || H <= 0 || Hkv <= 0) return A3V_ERR_ARG;
+  if (H % Hkv) return A3V_ERR_SHAPE;
+  if (causal && Sk < Sq) return A3V_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  AttnArgs p;
+  p.q = q; p.k = k; p.vt = vt; p.out = out;
+  p.q_sb = strides[0]; p.q_ss = strides[1]; p.q_sh = strides[2];
+  p.k_sb = strides[3]; p.k_sh = strides[4]; p.k_ss = strides[5];
+  p.v_sb = strides[6]; p.v_sh = strides[7]; p.v_sd = strides[8];
+  p.o_sb = strides[9]; p.o_ss = strides[10]; p.o_sh = strides[11];
+  p.B = B; p.Sq = Sq; p.Sk = Sk; p.H = H; p.Hkv = Hkv;
+  p.scale = 1.0f / sqrtf((float)hd);
+  p.scale_log2 = p.scale * 1.4426950408889634f;
+  if (dtype == A3V_F32) {
+    if (hd > 256) return A3V_ERR_SHAPE;
+    hipLaunchKernelGGL(attn_f32_kernel, dim3(Sq, H, B), dim3(64), 0, st, p, hd, causal);
+    A3V_LAUNCH_CHECK();
+    return A3V_OK;
+  }
+  if (dtype != A3V_BF16) return A3V_ERR_DTYPE;
+  if (hd != 128 && hd != 64) return A3V_ERR_SHAPE;
+  for (int i = 0; i < 12; ++i)
+    if (i != 2 && i != 4 && i != 11 && (strides[i] % 8)) return A3V_ERR_SHAPE;  // 16-B vector access
+  if ((strides[2] % 8) || (strides[4] % 8) || (strides[11] % 4)) return A3V_ERR_SHAPE;
+  if (Sq == 1) {
+    if (!scratch) return A3V_ERR_ARG;
+    int ns, ch;
+    decode_plan(B, H, Sk, &ns, &ch);
+    const size_t shm = (size_t)(ch + 8) * sizeof(float);
+    if (hd == 128) {
+      hipLaunchKernelGGL(attn_decode_bf16_kernel<128>, dim3(ns, H, B), dim3(256), shm, st, p, scratch, ns, ch);
+      A3V_LAUNCH_CHECK();
+      hipLaunchKernelGGL(attn_decode_combine_kernel<128>, dim3(H, B), dim3(128), 0, st, scratch, out, p.o_sb, p.o_sh, H, ns, dtype);
+    } else {
+      hipLaunchKernelGGL(attn_decode_bf16_kernel<64>, dim3(ns, H, B), dim3(256), shm, st, p, scratch, ns, ch);
+      A3V_LAUNCH_CHECK();
+      hipLaunchKernelGGL(attn_decode_combine_kernel<64>, dim3(H, B), dim3(64), 0, st, scratch, out, p.o_sb, p.o_sh, H, ns, dtype);
+    }
+    A3V_LAUNCH_CHECK();
+    return A3V_OK;
+  }
+  dim3 grid((Sq + 127) / 128, H, B);
+  if (hd == 128) {
+    if (causal) hipLaunchKernelGGL((attn_prefill_bf16_kernel<128, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((attn_prefill_bf16_kernel<128, false>), grid, dim3(256), 0, st, p);
+  } else {
+    if (causal) hipLaunchKernelGGL((attn_prefill_bf16_kernel<64, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((attn_prefill_bf16_kernel<64, false>), grid, dim3(256), 0, st, p);
+  }
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}

@@ -1,0 +1,543 @@
+// HBM-bound row kernels of the path (gfx950): norms, RoPE + KV-cache write, embedding /
+// sequence assembly, patch im2col, view split, argmax, cross-entropy.
+// All are one-pass streaming kernels with 16-byte per-lane accesses; each row is read once
+// and written once (algorithmic bytes = in + out), reductions via wave shuffles.
+#include "a3v_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------- RMSNorm
+// model/components.py:39,52-53: (x.float() * rsqrt(mean(x^2)+eps)).type_as(x) * weight
+template <typename TX, typename TW, typename TY>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const TX* __restrict__ x, int64_t ldx, const TW* __restrict__ w,
+                                                      TY* __restrict__ y, int64_t ldy, int dim, float eps) {
+  __shared__ float red[4];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const TX* xr = x + (int64_t)row * ldx;
+  TY* yr = y + (int64_t)row * ldy;
+  constexpr int MAXV = 4;  // dim <= 256*8*4 = 8192
+  float v[MAXV][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = (tid + i * 256) * 8;
+    if (c < dim) {
+      load8(xr + c, v[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ss = fmaf(v[i][e], v[i][e], ss);
+    }
+  }
+  ss = block_sum<256>(ss, red);
+  const float inv = rsqrtf(ss / (float)dim + eps);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = (tid + i * 256) * 8;
+    if (c < dim) {
+      float wv[8], o[8];
+      load8(w + c, wv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = Cvt<TX>::rnd(v[i][e] * inv) * wv[e];
+      store8(yr + c, o);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- LayerNorm (torch.nn.LayerNorm)
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ w,
+                                                        const T* __restrict__ b, T* __restrict__ y, int64_t ldy,
+                                                        const int32_t* __restrict__ row_map, int dim, float eps) {
+  __shared__ float red[4];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const T* xr = x + (int64_t)row * ldx;
+  T* yr = y + (int64_t)(row_map ? row_map[row] : row) * ldy;
+  constexpr int MAXV = 4;
+  float v[MAXV][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = (tid + i * 256) * 8;
+    if (c < dim) {
+      load8(xr + c, v[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[i][e];
+    }
+  }
+  const float mean = block_sum<256>(s, red) / (float)dim;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = (tid + i * 256) * 8;
+    if (c < dim) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q = fmaf(d, d, q); }
+    }
+  }
+  const float rstd = rsqrtf(block_sum<256>(q, red) / (float)dim + eps);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = (tid + i * 256) * 8;
+    if (c < dim) {
+      float wv[8], bv[8], o[8];
+      load8(w + c, wv);
+      load8(b + c, bv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd * wv[e] + bv[e];
+      store8(yr + c, o);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- RoPE + KV-cache write
+// grid (ceil(S/64), H + 2*Hkv, B); block 256 handles 64 tokens x one head (hd <= 128).
+// q heads: rotate -> q_out; k heads: rotate -> k_cache[b,hk,pos,:]; v heads: transpose
+// through LDS -> vt_cache[b,hk,:,pos] (contiguous along pos).
+template <typename T>
+__global__ __launch_bounds__(256) void rope_kv_kernel(const T* __restrict__ qkv, int64_t ldqkv, T* __restrict__ q_out,
+                                                      int64_t ldq, T* __restrict__ k_cache, T* __restrict__ vt_cache,
+                                                      const float* __restrict__ cos_sin, int S, int H, int Hkv, int hd,
+                                                      int Smax, int start_pos, int rope_pos0) {
+  __shared__ T tile[64][128 + 8];
+  const int s0 = blockIdx.x * 64, slot = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x;
+  const int cpr = hd / 8;                 // 8-element chunks per row
+  const int n_chunks = 64 * cpr;
+  const T* src = qkv + (int64_t)b * S * ldqkv + (int64_t)slot * hd;
+  if (slot < H + Hkv) {
+    const bool is_q = slot < H;
+    for (int id = tid; id < n_chunks; id += 256) {
+      const int r = id / cpr, c = (id % cpr) * 8;
+      const int s = s0 + r;
+      if (s >= S) continue;
+      float v[8], o[8];
+      load8(src + (int64_t)s * ldqkv + c, v);
+      const float* cs = cos_sin + ((int64_t)(rope_pos0 + s) * (hd / 2) + c / 2) * 2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float co = cs[2 * e], si = cs[2 * e + 1];
+        const float a = v[2 * e], bb = v[2 * e + 1];
+        o[2 * e] = a * co - bb * si;
+        o[2 * e + 1] = a * si + bb * co;
+      }
+      if (is_q) {
+        store8(q_out + ((int64_t)b * S + s) * ldq + (int64_t)slot * hd + c, o);
+      } else {
+        const int hk = slot - H;
+        store8(k_cache + (((int64_t)b * Hkv + hk) * Smax + start_pos + s) * hd + c, o);
+      }
+    }
+    return;
+  }
+  // V: [64 tok][hd] -> vt[hd][64 tok]
+  const int hk = slot - H - Hkv;
+  for (int id = tid; id < n_chunks; id += 256) {
+    const int r = id / cpr, c = (id % cpr) * 8;
+    const int s = s0 + r;
+    float v[8];
+    if (s < S) load8(src + (int64_t)s * ldqkv + c, v);
+    else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) Cvt<T>::st(&tile[r][c + e], v[e]);
+  }
+  __syncthreads();
+  T* dst = vt_cache + ((int64_t)b * Hkv + hk) * (int64_t)hd * Smax + start_pos + s0;
+  const int nvalid = min(64, S - s0);
+  // thread -> (d, 8 consecutive tokens); 16-B stores when the destination is aligned
+  const bool aligned = ((start_pos + s0) % 8 == 0) && (Smax % 8 == 0);
+  for (int id = tid; id < hd * 8; id += 256) {
+    const int d = id >> 3, t0 = (id & 7) * 8;
+    if (t0 >= nvalid) continue;
+    T* dp = dst + (int64_t)d * Smax + t0;
+    if (aligned && t0 + 8 <= nvalid) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = Cvt<T>::ld(&tile[t0 + e][d]);
+      store8(dp, o);
+    } else {
+      for (int e = 0; e < 8 && t0 + e < nvalid; ++e) dp[e] = tile[t0 + e][d];
+    }
+  }
+}
+
+// v [N, L, H*hd] (row stride ldv) -> vt [N, H, hd, Lpad]   (ViT: transposed V for attention)
+template <typename T>
+__global__ __launch_bounds__(256) void vt_pack_kernel(const T* __restrict__ v, int64_t ldv, T* __restrict__ vt,
+                                                      int L, int H, int hd, int Lpad) {
+  __shared__ T tile[64][128 + 8];
+  const int s0 = blockIdx.x * 64, h = blockIdx.y, n = blockIdx.z;
+  const int tid = threadIdx.x, cpr = hd / 8;
+  const T* src = v + (int64_t)n * L * ldv + (int64_t)h * hd;
+  for (int id = tid; id < 64 * cpr; id += 256) {
+    const int r = id / cpr, c = (id % cpr) * 8;
+    float x[8];
+    if (s0 + r < L) load8(src + (int64_t)(s0 + r) * ldv + c, x);
+    else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) Cvt<T>::st(&tile[r][c + e], x[e]);
+  }
+  __syncthreads();
+  T* dst = vt + ((int64_t)n * H + h) * (int64_t)hd * Lpad + s0;
+  for (int id = tid; id < hd * 8; id += 256) {
+    const int d = id >> 3, t0 = (id & 7) * 8;
+    if (s0 + t0 >= Lpad) continue;
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = Cvt<T>::ld(&tile[t0 + e][d]);   // rows >= L are zero
+    store8(dst + (int64_t)d * Lpad + t0, o);
+  }
+}
+
+// ---------------------------------------------------------------- embedding / assembly
+template <typename TT, typename TH>
+__global__ __launch_bounds__(256) void embed_assemble_kernel(const int64_t* __restrict__ tokens, int64_t ld_tok,
+                                                             const TT* __restrict__ table, TH* __restrict__ h, int T,
+                                                             int W, int dim, int vocab) {
+  const int S = T + W;
+  const int row = blockIdx.x;           // b*S + s
+  const int b = row / S, s = row % S;
+  if (s >= 1 && s <= W) return;         // image words: written by the projector epilogue
+  const int t = s == 0 ? 0 : s - W;
+  int64_t tok = tokens[(int64_t)b * ld_tok + t];
+  tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
+  const TT* src = table + tok * dim;
+  TH* dst = h + (int64_t)row * dim;
+  for (int c = threadIdx.x * 8; c < dim; c += 256 * 8) {
+    float v[8];
+    load8(src + c, v);
+    store8(dst + c, v);
+  }
+}
+
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void fill_rows_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int64_t ldd,
+                                                        const int32_t* __restrict__ row_idx, int dim) {
+  TD* d = dst + (int64_t)row_idx[blockIdx.x] * ldd;
+  for (int c = threadIdx.x * 8; c < dim; c += 256 * 8) {
+    float v[8];
+    load8(src + c, v);
+    store8(d + c, v);
+  }
+}
+
+// ---------------------------------------------------------------- patch embed helpers
+template <typename TI, typename T>
+__global__ __launch_bounds__(256) void im2col_kernel(const TI* __restrict__ img, T* __restrict__ cols, int Hi, int Wi,
+                                                     int P, int Kpad) {
+  const int g = Wi / P, gh = Hi / P;
+  const int row = blockIdx.x;                 // n*gh*g + gy*g + gx
+  const int n = row / (gh * g), gy = (row / g) % gh, gx = row % g;
+  const int K = 3 * P * P;
+  T* out = cols + (int64_t)row * Kpad;
+  for (int k = threadIdx.x; k < Kpad; k += 256) {
+    float v = 0.f;
+    if (k < K) {
+      const int c = k / (P * P), py = (k / P) % P, px = k % P;
+      v = Cvt<TI>::ld(img + (((int64_t)n * 3 + c) * Hi + gy * P + py) * Wi + gx * P + px);
+    }
+    Cvt<T>::st(out + k, v);
+  }
+}
+
+// x[n,0,:] = cls + pos[0];  x[n,1+t,:] = patch[n*T+t,:] + pos[1+t]   (bf16: cls.to(dtype)
+// + zeros, then (x + pos) rounded once per element -- llama_ens5.py:358-362)
+template <typename T>
+__global__ __launch_bounds__(256) void vit_embed_kernel(const T* __restrict__ patch, const T* __restrict__ cls,
+                                                        const T* __restrict__ pos, T* __restrict__ x, int Ttok, int width) {
+  const int row = blockIdx.x;                 // n*(T+1) + t
+  const int n = row / (Ttok + 1), t = row % (Ttok + 1);
+  const T* src = t == 0 ? cls : patch + ((int64_t)n * Ttok + (t - 1)) * width;
+  const T* pr = pos + (int64_t)t * width;
+  T* dst = x + (int64_t)row * width;
+  for (int c = threadIdx.x * 8; c < width; c += 256 * 8) {
+    float a[8], p[8], o[8];
+    load8(src + c, a);
+    load8(pr + c, p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = a[e] + p[e];
+    store8(dst + c, o);
+  }
+}
+
+// LLM/llama_ens5.py:383-385: out[0:B] = bicubic(fp16) 2x downsample, out[(1+i)B:(2+i)B] = quadrant i.
+// align_corners=False, A=-0.75, scale 2 -> source x = 2*dst + 0.5: taps {-1,0,1,2} with
+// weights {-3/32, 19/32, 19/32, -3/32}, indices clamped at the border.
+template <typename TI, typename T>
+__global__ __launch_bounds__(256) void split_views_kernel(const TI* __restrict__ img, T* __restrict__ out, int B, int c) {
+  const int64_t total = (int64_t)5 * B * 3 * c * c;
+  const int S2 = 2 * c;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int x = i % c, y = (i / c) % c, ch = (i / ((int64_t)c * c)) % 3;
+    const int nb = i / ((int64_t)3 * c * c);
+    const int v = nb / B, b = nb % B;
+    const TI* src = img + ((int64_t)b * 3 + ch) * S2 * S2;
+    float r;
+    if (v == 0) {
+      const float wt[4] = {-0.09375f, 0.59375f, 0.59375f, -0.09375f};
+      float acc = 0.f;
+#pragma unroll
+      for (int dy = 0; dy < 4; ++dy) {
+        const int yy = min(max(2 * y - 1 + dy, 0), S2 - 1);
+        float rowacc = 0.f;
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx) {
+          const int xx = min(max(2 * x - 1 + dx, 0), S2 - 1);
+          const float px = (float)(_Float16)Cvt<TI>::ld(src + (int64_t)yy * S2 + xx);   // image.half()
+          rowacc += wt[dx] * px;
+        }
+        acc += wt[dy] * rowacc;
+      }
+      r = (float)(_Float16)acc;
+    } else {
+      const int oy = (v - 1) / 2 * c, ox = (v - 1) % 2 * c;
+      r = Cvt<TI>::ld(src + (int64_t)(oy + y) * S2 + ox + x);
+    }
+    Cvt<T>::st(out + i, r);
+  }
+}
+
+// ---------------------------------------------------------------- argmax / CE
+__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ logits, int64_t ld, int64_t* __restrict__ out, int V) {
+  __shared__ float bv[4];
+  __shared__ int bi[4];
+  const float* r = logits + (int64_t)blockIdx.x * ld;
+  float best = -INFINITY;
+  int idx = 0x7fffffff;
+  for (int i = threadIdx.x; i < V; i += 256) {
+    const float v = r[i];
+    if (v > best || (v == best && i < idx)) { best = v; idx = i; }
+  }
+  // NaN handling follows torch only for finite rows (the path never produces NaN logits)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(idx, o, 64);
+    if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+  }
+  if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = idx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+    out[blockIdx.x] = idx == 0x7fffffff ? 0 : idx;
+  }
+}
+
+__global__ __launch_bounds__(256) void count_valid_kernel(const int64_t* __restrict__ labels, int rows, int32_t* __restrict__ out) {
+  __shared__ float red[4];
+  float c = 0.f;
+  for (int i = threadIdx.x; i < rows; i += 256) c += labels[i] != 0 ? 1.f : 0.f;
+  c = block_sum<256>(c, red);
+  if (threadIdx.x == 0) *out = (int32_t)(c + 0.5f);
+}
+
+// row_loss[r] = logsumexp(logits[r]) - logits[r][label] (0 if label == 0: ignore_index)
+// dlogits[r][v] = (softmax - onehot) * grad_scale / n_valid
+template <typename T>
+__global__ __launch_bounds__(256) void cross_entropy_kernel(const T* __restrict__ logits, int64_t ld,
+                                                            const int64_t* __restrict__ labels, float* __restrict__ row_loss,
+                                                            T* __restrict__ dlogits, int64_t ldd,
+                                                            const int32_t* __restrict__ n_valid, float grad_scale, int V) {
+  __shared__ float red[4];
+  __shared__ float bmax[4];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const T* lr = logits + (int64_t)row * ld;
+  const int64_t lab = labels[row];
+  if (lab == 0) {
+    if (tid == 0) row_loss[row] = 0.f;
+    if (dlogits)
+      for (int i = tid; i < V; i += 256) Cvt<T>::st(dlogits + (int64_t)row * ldd + i, 0.f);
+    return;
+  }
+  float mx = -INFINITY;
+  for (int i = tid; i < V; i += 256) mx = fmaxf(mx, Cvt<T>::ld(lr + i));
+  mx = wave_max(mx);
+  if ((tid & 63) == 0) bmax[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(bmax[0], bmax[1]), fmaxf(bmax[2], bmax[3]));
+  float s = 0.f;
+  for (int i = tid; i < V; i += 256) s += __expf(Cvt<T>::ld(lr + i) - mx);
+  s = block_sum<256>(s, red);
+  const float lse = mx + __logf(s);
+  if (tid == 0) row_loss[row] = lse - Cvt<T>::ld(lr + lab);
+  if (dlogits) {
+    const float g = grad_scale / (float)(*n_valid);
+    for (int i = tid; i < V; i += 256) {
+      float pr = __expf(Cvt<T>::ld(lr + i) - lse);
+      if (i == lab) pr -= 1.f;
+      Cvt<T>::st(dlogits + (int64_t)row * ldd + i, pr * g);
+    }
+  }
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int a3v_rmsnorm(const void* x, int64_t ldx, const void* w, void* y, int64_t ldy, int rows, int dim,
+                           float eps, int x_dtype, int w_dtype, int y_dtype, void* stream) {
+  if (!x || !w || !y || rows <= 0) return A3V_ERR_ARG;
+  if (dim % 8 || dim > 8192 || ldx % 8 || ldy % 8) return A3V_ERR_SHAPE;
+  const int key = x_dtype * 4 + w_dtype * 2 + y_dtype;
+  dim3 g(rows), b(256);
+  switch (key) {
+    case 0: hipLaunchKernelGGL((rmsnorm_kernel<bf16_t, bf16_t, bf16_t>), g, b, 0, ST, (const bf16_t*)x, ldx, (const bf16_t*)w, (bf16_t*)y, ldy, dim, eps); break;
+    case 7: hipLaunchKernelGGL((rmsnorm_kernel<float, float, float>), g, b, 0, ST, (const float*)x, ldx, (const float*)w, (float*)y, ldy, dim, eps); break;
+    case 6: hipLaunchKernelGGL((rmsnorm_kernel<float, float, bf16_t>), g, b, 0, ST, (const float*)x, ldx, (const float*)w, (bf16_t*)y, ldy, dim, eps); break;
+    case 4: hipLaunchKernelGGL((rmsnorm_kernel<float, bf16_t, bf16_t>), g, b, 0, ST, (const float*)x, ldx, (const bf16_t*)w, (bf16_t*)y, ldy, dim, eps); break;
+    case 2: hipLaunchKernelGGL((rmsnorm_kernel<bf16_t, float, bf16_t>), g, b, 0, ST, (const bf16_t*)x, ldx, (const float*)w, (bf16_t*)y, ldy, dim, eps); break;
+    default: return A3V_ERR_DTYPE;
+  }
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}
+
+extern "C" int a3v_layernorm(const void* x, int64_t ldx, const void* w, const void* b, void* y, int64_t ldy,
+                             const int32_t* row_map, int rows, int dim, float eps, int dtype, void* stream) {
+  if (!x || !w || !b || !y || rows <= 0) return A3V_ERR_ARG;
+  if (dim % 8 || dim > 8192 || ldx % 8 || ldy % 8) return A3V_ERR_SHAPE;
+  if (dtype == A3V_BF16)
+    hipLaunchKernelGGL(layernorm_kernel<bf16_t>, dim3(rows), dim3(256), 0, ST, (const bf16_t*)x, ldx, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)y, ldy, row_map, dim, eps);
+  else if (dtype == A3V_F32)
+    hipLaunchKernelGGL(layernorm_kernel<float>, dim3(rows), dim3(256), 0, ST, (const float*)x, ldx, (const float*)w, (const float*)b, (float*)y, ldy, row_map, dim, eps);
+  else return A3V_ERR_DTYPE;
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}
+
+extern "C" int a3v_rope_kvcache(const void* qkv, int64_t ldqkv, void* q_out, int64_t ldq, void* k_cache, void* vt_cache,
+                                const float* cos_sin, int B, int S, int H, int Hkv, int hd, int Smax,
+                                int start_pos, int rope_pos0, int dtype, void* stream) {
+  if (!qkv || !q_out || !k_cache || !vt_cache || !cos_sin || B <= 0 || S <= 0) return A3V_ERR_ARG;
+  if (hd % 8 || hd > 128 || ldqkv % 8 || ldq % 8 || start_pos + S > Smax) return A3V_ERR_SHAPE;
+  dim3 g((S + 63) / 64, H + 2 * Hkv, B);
+  if (dtype == A3V_BF16)
+    hipLaunchKernelGGL(rope_kv_kernel<bf16_t>, g, dim3(256), 0, ST, (const bf16_t*)qkv, ldqkv, (bf16_t*)q_out, ldq, (bf16_t*)k_cache, (bf16_t*)vt_cache, cos_sin, S, H, Hkv, hd, Smax, start_pos, rope_pos0);
+  else if (dtype == A3V_F32)
+    hipLaunchKernelGGL(rope_kv_kernel<float>, g, dim3(256), 0, ST, (const float*)qkv, ldqkv, (float*)q_out, ldq, (float*)k_cache, (float*)vt_cache, cos_sin, S, H, Hkv, hd, Smax, start_pos, rope_pos0);
+  else return A3V_ERR_DTYPE;
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}
+
+extern "C" int a3v_vt_pack(const void* v, int64_t ldv, void* vt, int N, int L, int H, int hd, int Lpad, int dtype, void* stream) {
+  if (!v || !vt || N <= 0 || L <= 0) return A3V_ERR_ARG;
+  if (hd % 8 || hd > 128 || ldv % 8 || Lpad % 8 || Lpad < L) return A3V_ERR_SHAPE;
+  dim3 g((Lpad + 63) / 64, H, N);
+  if (dtype == A3V_BF16)
+    hipLaunchKernelGGL(vt_pack_kernel<bf16_t>, g, dim3(256), 0, ST, (const bf16_t*)v, ldv, (bf16_t*)vt, L, H, hd, Lpad);
+  else if (dtype == A3V_F32)
+    hipLaunchKernelGGL(vt_pack_kernel<float>, g, dim3(256), 0, ST, (const float*)v, ldv, (float*)vt, L, H, hd, Lpad);
+  else return A3V_ERR_DTYPE;
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}
+
+extern "C" int a3v_embed_assemble(const int64_t* tokens, int64_t ld_tok, const void* table, void* h, int B, int T, int W,
+                                  int dim, int vocab, int table_dtype, int h_dtype, void* stream) {
+  if (!tokens || !table || !h || B <= 0 || T <= 0 || W < 0) return A3V_ERR_ARG;
+  if (dim % 8) return A3V_ERR_SHAPE;
+  dim3 g(B * (T + W)), b(256);
+  const int key = table_dtype * 2 + h_dtype;
+  switch (key) {
+    case 0: hipLaunchKernelGGL((embed_assemble_kernel<bf16_t, bf16_t>), g, b, 0, ST, tokens, ld_tok, (const bf16_t*)table, (bf16_t*)h, T, W, dim, vocab); break;
+    case 3: hipLaunchKernelGGL((embed_assemble_kernel<float, float>), g, b, 0, ST, tokens, ld_tok, (const float*)table, (float*)h, T, W, dim, vocab); break;
+    case 2: hipLaunchKernelGGL((embed_assemble_kernel<float, bf16_t>), g, b, 0, ST, tokens, ld_tok, (const float*)table, (bf16_t*)h, T, W, dim, vocab); break;
+    case 1: hipLaunchKernelGGL((embed_assemble_kernel<bf16_t, float>), g, b, 0, ST, tokens, ld_tok, (const bf16_t*)table, (float*)h, T, W, dim, vocab); break;
+    default: return A3V_ERR_DTYPE;
+  }
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}
+
+extern "C" int a3v_fill_rows(const void* src, void* dst, int64_t ldd, const int32_t* row_idx, int n_rows, int dim,
+                             int src_dtype, int dst_dtype, void* stream) {
+  if (!src || !dst || !row_idx || n_rows <= 0) return A3V_ERR_ARG;
+  if (dim % 8 || ldd % 8) return A3V_ERR_SHAPE;
+  dim3 g(n_rows), b(256);
+  const int key = src_dtype * 2 + dst_dtype;
+  switch (key) {
+    case 0: hipLaunchKernelGGL((fill_rows_kernel<bf16_t, bf16_t>), g, b, 0, ST, (const bf16_t*)src, (bf16_t*)dst, ldd, row_idx, dim); break;
+    case 3: hipLaunchKernelGGL((fill_rows_kernel<float, float>), g, b, 0, ST, (const float*)src, (float*)dst, ldd, row_idx, dim); break;
+    case 2: hipLaunchKernelGGL((fill_rows_kernel<float, bf16_t>), g, b, 0, ST, (const float*)src, (bf16_t*)dst, ldd, row_idx, dim); break;
+    case 1: hipLaunchKernelGGL((fill_rows_kernel<bf16_t, float>), g, b, 0, ST, (const bf16_t*)src, (float*)dst, ldd, row_idx, dim); break;
+    default: return A3V_ERR_DTYPE;
+  }
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}
+
+extern "C" int a3v_patch_im2col(const void* img, void* cols, int N, int Hi, int Wi, int P, int Kpad, int in_dtype,
+                                int out_dtype, void* stream) {
+  if (!img || !cols || N <= 0 || P <= 0) return A3V_ERR_ARG;
+  if (Hi % P || Wi % P || Kpad < 3 * P * P) return A3V_ERR_SHAPE;
+  dim3 g(N * (Hi / P) * (Wi / P)), b(256);
+  switch (in_dtype * 2 + out_dtype) {
+    case 0: hipLaunchKernelGGL((im2col_kernel<bf16_t, bf16_t>), g, b, 0, ST, (const bf16_t*)img, (bf16_t*)cols, Hi, Wi, P, Kpad); break;
+    case 2: hipLaunchKernelGGL((im2col_kernel<float, bf16_t>), g, b, 0, ST, (const float*)img, (bf16_t*)cols, Hi, Wi, P, Kpad); break;
+    case 3: hipLaunchKernelGGL((im2col_kernel<float, float>), g, b, 0, ST, (const float*)img, (float*)cols, Hi, Wi, P, Kpad); break;
+    default: return A3V_ERR_DTYPE;
+  }
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}
+
+extern "C" int a3v_vit_embed(const void* patch, const void* cls, const void* pos, void* x, int N, int T, int width, int dtype, void* stream) {
+  if (!patch || !cls || !pos || !x || N <= 0 || T <= 0) return A3V_ERR_ARG;
+  if (width % 8) return A3V_ERR_SHAPE;
+  dim3 g(N * (T + 1));
+  if (dtype == A3V_BF16) hipLaunchKernelGGL(vit_embed_kernel<bf16_t>, g, dim3(256), 0, ST, (const bf16_t*)patch, (const bf16_t*)cls, (const bf16_t*)pos, (bf16_t*)x, T, width);
+  else if (dtype == A3V_F32) hipLaunchKernelGGL(vit_embed_kernel<float>, g, dim3(256), 0, ST, (const float*)patch, (const float*)cls, (const float*)pos, (float*)x, T, width);
+  else return A3V_ERR_DTYPE;
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}
+
+extern "C" int a3v_split_views(const void* img, void* out, int B, int crop, int in_dtype, int out_dtype, void* stream) {
+  if (!img || !out || B <= 0 || crop <= 0) return A3V_ERR_ARG;
+  const int64_t total = (int64_t)5 * B * 3 * crop * crop;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  dim3 g(blocks), b(256);
+  switch (in_dtype * 2 + out_dtype) {
+    case 0: hipLaunchKernelGGL((split_views_kernel<bf16_t, bf16_t>), g, b, 0, ST, (const bf16_t*)img, (bf16_t*)out, B, crop); break;
+    case 2: hipLaunchKernelGGL((split_views_kernel<float, bf16_t>), g, b, 0, ST, (const float*)img, (bf16_t*)out, B, crop); break;
+    case 3: hipLaunchKernelGGL((split_views_kernel<float, float>), g, b, 0, ST, (const float*)img, (float*)out, B, crop); break;
+    default: return A3V_ERR_DTYPE;
+  }
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}
+
+extern "C" int a3v_argmax(const float* logits, int64_t ld, int64_t* out, int B, int V, void* stream) {
+  if (!logits || !out || B <= 0 || V <= 0) return A3V_ERR_ARG;
+  hipLaunchKernelGGL(argmax_kernel, dim3(B), dim3(256), 0, ST, logits, ld, out, V);
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}
+
+extern "C" int a3v_count_valid(const int64_t* labels, int rows, int32_t* n_valid_dev, void* stream) {
+  if (!labels || !n_valid_dev || rows <= 0) return A3V_ERR_ARG;
+  hipLaunchKernelGGL(count_valid_kernel, dim3(1), dim3(256), 0, ST, labels, rows, n_valid_dev);
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}
+
+extern "C" int a3v_cross_entropy(const void* logits, int64_t ld, const int64_t* labels, float* row_loss, void* dlogits,
+                                 int64_t ldd, const int32_t* n_valid_dev, float grad_scale, int rows, int V, int dtype,
+                                 void* stream) {
+  if (!logits || !labels || !row_loss || rows <= 0 || V <= 0) return A3V_ERR_ARG;
+  if (dlogits && !n_valid_dev) return A3V_ERR_ARG;
+  if (dtype == A3V_BF16)
+    hipLaunchKernelGGL(cross_entropy_kernel<bf16_t>, dim3(rows), dim3(256), 0, ST, (const bf16_t*)logits, ld, labels, row_loss, (bf16_t*)dlogits, ldd, n_valid_dev, grad_scale, V);
+  else if (dtype == A3V_F32)
+    hipLaunchKernelGGL(cross_entropy_kernel<float>, dim3(rows), dim3(256), 0, ST, (const float*)logits, ld, labels, row_loss, (float*)dlogits, ldd, n_valid_dev, grad_scale, V);
+  else return A3V_ERR_DTYPE;
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}

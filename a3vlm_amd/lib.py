@@ -1,0 +1,73 @@
+"""ctypes loader for liba3vlm_hip.so (the C-ABI declared in include/a3vlm_hip.h).
+
+There is NO fallback: if the shared library is missing or a symbol is absent the first
+use raises, so a GPU run can never silently route around the HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liba3vlm_hip.so")
+
+BF16, F32 = 0, 1
+EPI_NONE, EPI_BIAS, EPI_GELU, EPI_QUICKGELU, EPI_RESIDUAL, EPI_SWIGLU, EPI_OUT_F32, EPI_RES_F32 = 0, 1, 2, 4, 8, 16, 32, 64
+
+P, I, L, F = c_void_p, c_int, c_int64, c_float
+
+# name -> (restype, argtypes); mirrors include/a3vlm_hip.h one to one
+SIGNATURES = {
+    "a3v_version": (I, []),
+    "a3v_gemm_nt": (I, [P, L, P, L, P, L, I, I, I, P, P, L, I, I, P]),
+    "a3v_gemm_skinny_split": (I, [I, I, I]),
+    "a3v_gemm_skinny": (I, [P, L, P, L, P, L, I, I, I, P, L, I, P, P]),
+    "a3v_rmsnorm": (I, [P, L, P, P, L, I, I, F, I, I, I, P]),
+    "a3v_layernorm": (I, [P, L, P, P, P, L, P, I, I, F, I, P]),
+    "a3v_rope_kvcache": (I, [P, L, P, L, P, P, P, I, I, I, I, I, I, I, I, I, P]),
+    "a3v_vt_pack": (I, [P, L, P, I, I, I, I, I, I, P]),
+    "a3v_attention_scratch_floats": (L, [I, I, I, I]),
+    "a3v_attention": (I, [P, P, P, P, I, I, I, I, I, I, ctypes.POINTER(c_int64), I, P, I, P]),
+    "a3v_embed_assemble": (I, [P, L, P, P, I, I, I, I, I, I, I, P]),
+    "a3v_fill_rows": (I, [P, P, L, P, I, I, I, I, P]),
+    "a3v_patch_im2col": (I, [P, P, I, I, I, I, I, I, I, P]),
+    "a3v_split_views": (I, [P, P, I, I, I, I, P]),
+    "a3v_vit_embed": (I, [P, P, P, P, I, I, I, I, P]),
+    "a3v_argmax": (I, [P, L, P, I, I, P]),
+    "a3v_count_valid": (I, [P, I, P, P]),
+    "a3v_cross_entropy": (I, [P, L, P, P, P, L, P, F, I, I, I, P]),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the library once; raise loudly when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C a3vlm_amd/csrc`). "
+            "a3vlm_amd has no non-HIP fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the export is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class A3VError(RuntimeError):
+    pass
+
+
+_ERR = {-1: "A3V_ERR_SHAPE (unsupported size/alignment)", -2: "A3V_ERR_DTYPE", -3: "A3V_ERR_ARG"}
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise A3VError(f"{what} failed: {_ERR.get(rc, f'hipError_t {rc}')}")

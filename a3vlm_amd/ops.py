@@ -1,0 +1,181 @@
+"""Thin tensor wrappers over the C-ABI (include/a3vlm_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every op below is one
+call into liba3vlm_hip.so with raw device pointers on torch's CURRENT stream.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import lib as _l
+from .lib import BF16, F32, EPI_BIAS, EPI_GELU, EPI_QUICKGELU, EPI_RESIDUAL, EPI_SWIGLU, EPI_OUT_F32, EPI_RES_F32  # noqa: F401
+
+_DT = {torch.bfloat16: BF16, torch.float32: F32}
+
+
+def dt(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"a3vlm_amd supports bf16/fp32 tensors, got {t.dtype}")
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("a3vlm_amd ops need device tensors (no CPU fallback exists)")
+
+
+def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, residual=None,
+            epilogue: int = 0) -> torch.Tensor:
+    """out[M, N or N/2] = epilogue(a[M,K] @ w[N,K]^T); a/w/out 2-D with unit inner stride."""
+    _dev(a, w, out, bias, residual)
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and a.stride(1) == 1 and w.stride(1) == 1 and out.stride(1) == 1
+    ep = epilogue
+    if bias is not None:
+        ep |= EPI_BIAS
+    if residual is not None and not (ep & EPI_RES_F32):
+        ep |= EPI_RESIDUAL
+    rc = _l.load().a3v_gemm_nt(_p(a), a.stride(0), _p(w), w.stride(0), _p(out), out.stride(0), M, N, K,
+                               _p(bias), _p(residual), residual.stride(0) if residual is not None else 0,
+                               ep, dt(a), _stream())
+    _l.check(rc, f"a3v_gemm_nt(M={M},N={N},K={K},epi={ep})")
+    return out
+
+
+def gemm_skinny_split(M: int, N: int, K: int) -> int:
+    return _l.load().a3v_gemm_skinny_split(M, N, K)
+
+
+def gemm_skinny(a, w, out, partial, *, residual=None, epilogue: int = 0):
+    _dev(a, w, out, partial, residual)
+    M, K = a.shape
+    N = w.shape[0]
+    ep = epilogue | (EPI_RESIDUAL if residual is not None else 0)
+    rc = _l.load().a3v_gemm_skinny(_p(a), a.stride(0), _p(w), w.stride(0), _p(out), out.stride(0), M, N, K,
+                                   _p(residual), residual.stride(0) if residual is not None else 0, ep,
+                                   _p(partial), _stream())
+    _l.check(rc, f"a3v_gemm_skinny(M={M},N={N},K={K},epi={ep})")
+    return out
+
+
+def rmsnorm(x, w, out, eps: float):
+    _dev(x, w, out)
+    rows, dim = x.shape
+    rc = _l.load().a3v_rmsnorm(_p(x), x.stride(0), _p(w), _p(out), out.stride(0), rows, dim, eps,
+                               dt(x), dt(w), dt(out), _stream())
+    _l.check(rc, "a3v_rmsnorm")
+    return out
+
+
+def layernorm(x, w, b, out, eps: float = 1e-5, row_map=None, rows: Optional[int] = None):
+    _dev(x, w, b, out, row_map)
+    n, dim = x.shape
+    rc = _l.load().a3v_layernorm(_p(x), x.stride(0), _p(w), _p(b), _p(out), out.stride(0), _p(row_map),
+                                 n if rows is None else rows, dim, eps, dt(x), _stream())
+    _l.check(rc, "a3v_layernorm")
+    return out
+
+
+def rope_kvcache(qkv, q_out, k_cache, vt_cache, cos_sin, B, S, H, Hkv, hd, start_pos, rope_pos0):
+    _dev(qkv, q_out, k_cache, vt_cache, cos_sin)
+    Smax = k_cache.shape[2]
+    rc = _l.load().a3v_rope_kvcache(_p(qkv), qkv.stride(0), _p(q_out), q_out.stride(0), _p(k_cache), _p(vt_cache),
+                                    _p(cos_sin), B, S, H, Hkv, hd, Smax, start_pos, rope_pos0, dt(qkv), _stream())
+    _l.check(rc, "a3v_rope_kvcache")
+
+
+def vt_pack(v, ldv, vt, N, L, H, hd, Lpad):
+    _dev(v, vt)
+    rc = _l.load().a3v_vt_pack(_p(v), ldv, _p(vt), N, L, H, hd, Lpad, dt(v), _stream())
+    _l.check(rc, "a3v_vt_pack")
+
+
+def attention_scratch_floats(B, H, hd, Sk) -> int:
+    return _l.load().a3v_attention_scratch_floats(B, H, hd, Sk)
+
+
+_Strides = ctypes.c_int64 * 12
+
+
+def attention(q, k, vt, out, B, Sq, Sk, H, Hkv, hd, strides, causal: bool, scratch=None):
+    _dev(q, k, vt, out, scratch)
+    rc = _l.load().a3v_attention(_p(q), _p(k), _p(vt), _p(out), B, Sq, Sk, H, Hkv, hd, _Strides(*strides),
+                                 1 if causal else 0, _p(scratch), dt(q), _stream())
+    _l.check(rc, f"a3v_attention(B={B},Sq={Sq},Sk={Sk},H={H},hd={hd})")
+    return out
+
+
+def embed_assemble(tokens, table, h, B, T, W, dim):
+    _dev(tokens, table, h)
+    assert tokens.dtype == torch.int64 and tokens.stride(1) == 1
+    rc = _l.load().a3v_embed_assemble(_p(tokens), tokens.stride(0), _p(table), _p(h), B, T, W, dim, table.shape[0],
+                                      dt(table), dt(h), _stream())
+    _l.check(rc, "a3v_embed_assemble")
+
+
+def fill_rows(src, dst, row_idx):
+    _dev(src, dst, row_idx)
+    assert row_idx.dtype == torch.int32
+    rc = _l.load().a3v_fill_rows(_p(src), _p(dst), dst.stride(0), _p(row_idx), row_idx.numel(), dst.shape[1],
+                                 dt(src), dt(dst), _stream())
+    _l.check(rc, "a3v_fill_rows")
+
+
+def patch_im2col(img, cols, P):
+    _dev(img, cols)
+    N, C, Hi, Wi = img.shape
+    assert C == 3 and img.is_contiguous()
+    rc = _l.load().a3v_patch_im2col(_p(img), _p(cols), N, Hi, Wi, P, cols.shape[1], dt(img), dt(cols), _stream())
+    _l.check(rc, "a3v_patch_im2col")
+
+
+def split_views(img, out):
+    _dev(img, out)
+    B, C, S2, _ = img.shape
+    assert C == 3 and img.is_contiguous() and out.is_contiguous()
+    rc = _l.load().a3v_split_views(_p(img), _p(out), B, S2 // 2, dt(img), dt(out), _stream())
+    _l.check(rc, "a3v_split_views")
+
+
+def vit_embed(patch, cls, pos, x, N, T, width):
+    _dev(patch, cls, pos, x)
+    rc = _l.load().a3v_vit_embed(_p(patch), _p(cls), _p(pos), _p(x), N, T, width, dt(patch), _stream())
+    _l.check(rc, "a3v_vit_embed")
+
+
+def argmax(logits, out):
+    _dev(logits, out)
+    assert logits.dtype == torch.float32 and out.dtype == torch.int64
+    B, V = logits.shape
+    rc = _l.load().a3v_argmax(_p(logits), logits.stride(0), _p(out), B, V, _stream())
+    _l.check(rc, "a3v_argmax")
+    return out
+
+
+def count_valid(labels, n_valid):
+    _dev(labels, n_valid)
+    rc = _l.load().a3v_count_valid(_p(labels), labels.numel(), _p(n_valid), _stream())
+    _l.check(rc, "a3v_count_valid")
+
+
+def cross_entropy(logits, labels, row_loss, dlogits=None, n_valid=None, grad_scale: float = 1.0):
+    _dev(logits, labels, row_loss, dlogits, n_valid)
+    rows, V = logits.shape
+    rc = _l.load().a3v_cross_entropy(_p(logits), logits.stride(0), _p(labels), _p(row_loss), _p(dlogits),
+                                     dlogits.stride(0) if dlogits is not None else 0, _p(n_valid), grad_scale,
+                                     rows, V, dt(logits), _stream())
+    _l.check(rc, "a3v_cross_entropy")

@@ -1,0 +1,157 @@
+/*
+ * a3vlm_hip.h -- C ABI of liba3vlm_hip.so: the MI355X (gfx950 / CDNA4) kernels of the
+ * A3VLM multimodal hot path (ViT patch-embed + encoder -> projector -> Llama decoder
+ * -> LM head / CE / greedy decode).
+ *
+ * The reference (changhaonan/A3VLM) is pure Python on PyTorch and has no FFI of its
+ * own: its "native" layer is whatever ATen/cuBLAS/flash-attn kernel each torch call
+ * reaches.  Each entry point below therefore cites the
+ * reference call site (path:line under model/accessory/) whose arithmetic it
+ * replaces.  The reference-side binding is a ctypes stub.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is a DEVICE pointer unless noted.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream); kernels are
+ *    enqueued asynchronously on it and never synchronise.
+ *  - never allocates; scratch is passed in by the caller.
+ *  - no global mutable state; re-entrant from any host thread.
+ *  - return value: 0 on success, a hipError_t (>0) from the launch, or a negative
+ *    A3V_ERR_* for argument errors.  The Python host raises RuntimeError on != 0.
+ *  - dtype codes: A3V_BF16 activations/weights are bfloat16 with fp32 accumulation
+ *    (the throughput path); A3V_F32 is the fp32 parity path (same op order).
+ *  - row-major everywhere; `ld*` are leading dimensions in ELEMENTS.
+ */
+#ifndef A3VLM_HIP_H
+#define A3VLM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { A3V_BF16 = 0, A3V_F32 = 1 };
+
+enum {
+  A3V_OK = 0,
+  A3V_ERR_SHAPE = -1,   /* unsupported size / alignment */
+  A3V_ERR_DTYPE = -2,
+  A3V_ERR_ARG = -3
+};
+
+/* GEMM epilogue flags (bit-or) */
+enum {
+  A3V_EPI_NONE = 0,
+  A3V_EPI_BIAS = 1,        /* + bias[n]                                             */
+  A3V_EPI_GELU = 2,        /* erf GELU   (open_clip mlp)          */
+  A3V_EPI_QUICKGELU = 4,   /* x*sigmoid(1.702x) (open_clip 'openai' pretrained cfg)  */
+  A3V_EPI_RESIDUAL = 8,    /* out = residual + y  (LLM/llama_ens5.py:238,241)        */
+  A3V_EPI_SWIGLU = 16,     /* W rows interleaved [w1 blk16 | w3 blk16]: out[:, N/2] =
+                              silu(x w1^T) * (x w3^T)   (LLM/llama_ens5.py:213-217)   */
+  A3V_EPI_OUT_F32 = 32,    /* store fp32 (logits .float(), LLM/llama_ens5.py:531)     */
+  A3V_EPI_RES_F32 = 64     /* residual stream (and output) kept in fp32 (training
+                              under autocast: engine_finetune.py:44-50)               */
+};
+
+int a3v_version(void);
+
+/* C[M,N] = epilogue(A[M,K] @ W[N,K]^T).  Replaces every F.linear on the path:
+ * wq/wk/wv/wo (LLM/llama_ens5.py:63-90,112,169), w1/w2/w3 (:202-217), output (:267-269,
+ * 486,530), visual_proj[0] (:330-333), the open_clip in_proj/out_proj/c_fc/c_proj, and
+ * conv1 as an im2col GEMM (:354).  bf16: K % 64 == 0, lda/ldw % 8 == 0, N % 4 == 0.
+ * With A3V_EPI_SWIGLU, N counts the interleaved rows (2*ffn) and C has N/2 columns. */
+int a3v_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
+                int M, int N, int K, const void* bias, const void* residual, int64_t ldr,
+                int epilogue, int dtype, void* stream);
+
+/* Skinny-M (decode) form of the same contract, M <= 16: streams W once from HBM.
+ * `partial` is an fp32 scratch of split*M*N floats (split returned by
+ * a3v_gemm_skinny_split).  Epilogues: NONE, RESIDUAL, SWIGLU, OUT_F32. */
+int a3v_gemm_skinny_split(int M, int N, int K);
+int a3v_gemm_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
+                    int M, int N, int K, const void* residual, int64_t ldr, int epilogue,
+                    void* partial, void* stream);
+
+/* y = rmsnorm(x) * w  with the reference's rounding order (model/components.py:39,52-53):
+ * fp32 normalise -> cast to x's dtype -> multiply by weight.  x_dtype may be A3V_F32 with
+ * y bf16 (training under autocast: fp32 residual stream feeding bf16 GEMMs). */
+int a3v_rmsnorm(const void* x, int64_t ldx, const void* w, void* y, int64_t ldy, int rows, int dim,
+                float eps, int x_dtype, int w_dtype, int y_dtype, void* stream);
+
+/* y[row_map ? row_map[r] : r] = layernorm(x[r]) * w + b   (torch.nn.LayerNorm, eps 1e-5):
+ * open_clip ln_pre/ln_1/ln_2/ln_post and the projector LayerNorm (LLM/llama_ens5.py:325-333,
+ * 363,370).  row_map (int32, device) lets the projector write straight into the
+ * [BOS | image tokens | text] sequence buffer (:471-479). */
+int a3v_layernorm(const void* x, int64_t ldx, const void* w, const void* b, void* y, int64_t ldy,
+                  const int32_t* row_map, int rows, int dim, float eps, int dtype, void* stream);
+
+/* RoPE on q,k (interleaved pairs, fp32 math, LLM/llama_ens5.py:118 + restated llama.py) and
+ * KV-cache write (:124-129) from a fused qkv activation [B*S, (H+2*Hkv)*hd]:
+ *   q_out [B*S, ldq]            rotated q (may alias qkv: in-place, ldq = ldqkv)
+ *   k_cache[B,Hkv,Smax,hd]      rotated k at positions start_pos..start_pos+S-1
+ *   vt_cache[B,Hkv,hd,Smax]     v TRANSPOSED (this library's cache layout: the attention
+ *                               kernels consume V^T tiles with no in-loop transpose)
+ * cos_sin: fp32 table [n_pos, hd/2, 2]; row = rope_pos0 + s. */
+int a3v_rope_kvcache(const void* qkv, int64_t ldqkv, void* q_out, int64_t ldq, void* k_cache,
+                     void* vt_cache, const float* cos_sin, int B, int S, int H, int Hkv, int hd,
+                     int Smax, int start_pos, int rope_pos0, int dtype, void* stream);
+
+/* v [N, L, H*hd] (row stride ldv, e.g. the v third of nn.MultiheadAttention's packed
+ * in_proj output) -> vt [N, H, hd, Lpad] zero padded: the V^T operand of a3v_attention. */
+int a3v_vt_pack(const void* v, int64_t ldv, void* vt, int N, int L, int H, int hd, int Lpad,
+                int dtype, void* stream);
+
+/* softmax(q k^T / sqrt(hd) [+ right-aligned causal mask]) v, flash style, fp32 softmax.
+ * Replaces F.scaled_dot_product_attention / flash_attn_func (LLM/llama_ens5.py:142-167,
+ * mask :181-185) and nn.MultiheadAttention's core (open_clip resblocks).
+ * strides (ELEMENTS, host array of 12): q {batch, seq, head}, k {batch, kv-head, seq},
+ * vt {batch, kv-head, d}, out {batch, seq, head}; hd is contiguous in q/k/out and seq is
+ * contiguous in vt.  bf16: hd in {64,128}, strides multiples of 8.  Sq == 1 selects the
+ * split-KV decode kernel (`scratch`: fp32, a3v_attention_scratch_floats() entries; may be
+ * NULL when Sq > 1).  causal requires Sk >= Sq (queries are the LAST Sq positions). */
+int64_t a3v_attention_scratch_floats(int B, int H, int hd, int Sk);
+int a3v_attention(const void* q, const void* k, const void* vt, void* out, int B, int Sq, int Sk,
+                  int H, int Hkv, int hd, const int64_t* strides, int causal, float* scratch,
+                  int dtype, void* stream);
+
+/* h[b, s, :] for the sequence [BOS | image words | text]: rows s==0 and s>W come from the
+ * embedding table (tok_embeddings, LLM/llama_ens5.py:464,495), rows 1..W are left untouched
+ * (written by a3v_layernorm(row_map) / a3v_fill_rows).  tokens int64 [B,T]. */
+int a3v_embed_assemble(const int64_t* tokens, int64_t ld_tok, const void* table, void* h, int B,
+                       int T, int W, int dim, int vocab, int table_dtype, int h_dtype, void* stream);
+
+/* dst[row_idx[i], :] = src[0, :]  (start_img / end_img tags, LLM/llama_ens5.py:472-474) */
+int a3v_fill_rows(const void* src, void* dst, int64_t ldd, const int32_t* row_idx, int n_rows,
+                  int dim, int src_dtype, int dst_dtype, void* stream);
+
+/* im2col for the k=s=P, bias-free patch-embed conv (LLM/llama_ens5.py:354): img [N,3,Hi,Wi]
+ * -> cols [N*g*g, Kpad] with k = c*P*P + py*P + px (conv1.weight.view(width,-1) order),
+ * zero padded to Kpad. */
+int a3v_patch_im2col(const void* img, void* cols, int N, int Hi, int Wi, int P, int Kpad,
+                     int in_dtype, int out_dtype, void* stream);
+
+/* LLM/llama_ens5.py:383-385: img [B,3,2c,2c] -> out [5B,3,c,c] = [fp16 bicubic 2x downsample
+ * of the whole image ; top-left ; top-right ; bottom-left ; bottom-right]. */
+int a3v_split_views(const void* img, void* out, int B, int crop, int in_dtype, int out_dtype,
+                    void* stream);
+
+/* x[n, 0, :] = cls + pos[0]; x[n, 1+t, :] = patch[n*T+t, :] + pos[1+t]  (:358-362) */
+int a3v_vit_embed(const void* patch, const void* cls, const void* pos, void* x, int N, int T,
+                  int width, int dtype, void* stream);
+
+/* torch.argmax(logits, -1) with first-index tie break (model/meta.py:460).  fp32 [B,V]. */
+int a3v_argmax(const float* logits, int64_t ld, int64_t* out, int B, int V, void* stream);
+
+/* CrossEntropyLoss(ignore_index=0) pieces (model/meta.py:67,256-262): per-row loss (fp32)
+ * and, if dlogits != NULL, d(mean loss)/dlogits scaled by grad_scale / n_valid where
+ * n_valid is read from n_valid_dev (device int32, produced by a3v_count_valid).
+ * logits bf16 or f32 [rows, V]; labels int64 (already shifted). */
+int a3v_count_valid(const int64_t* labels, int rows, int32_t* n_valid_dev, void* stream);
+int a3v_cross_entropy(const void* logits, int64_t ld, const int64_t* labels, float* row_loss,
+                      void* dlogits, int64_t ldd, const int32_t* n_valid_dev, float grad_scale,
+                      int rows, int V, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* A3VLM_HIP_H */

@@ -1,0 +1,414 @@
+"""-m gpu: every HIP kernel, called through the C-ABI, against the CPU oracle ops on the same
+seeded inputs.  fp32 path: fp32 round-off tolerances.  bf16 path: the oracle is evaluated on the
+same bf16-rounded inputs with fp32 accumulation and the comparison allows 1-2 bf16 ulps
+(rel 2^-8 .. 2^-7) -- the tolerance is written next to each check."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from a3vlm_amd import ops  # noqa: E402
+from oracle import ref_cpu  # noqa: E402
+
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+def rt(x):  # bf16 round trip in fp32
+    return x.to(BF).float()
+
+
+def assert_close(got, want, rtol, atol, what=""):
+    got = got.detach().float().cpu()
+    want = want.detach().float().cpu()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    err = (got - want).abs()
+    bound = atol + rtol * want.abs()
+    bad = err > bound
+    if bad.any():
+        i = torch.nonzero(bad)[0].tolist()
+        raise AssertionError(f"{what}: {int(bad.sum())}/{bad.numel()} out of tol; first at {i}: got {got[tuple(i)]:.6g} "
+                             f"want {want[tuple(i)]:.6g}; max err {err.max():.4g}")
+
+
+def gen(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (100, 132, 192), (8728 // 8, 256, 4096),
+                                   (1, 128, 64), (300, 4096, 1024), (129, 32000 // 10 // 4 * 4, 256)])
+def test_gemm_bf16_plain(M, N, K):
+    a, w = rt(gen(M, K, seed=1)), rt(gen(N, K, seed=2, scale=0.05))
+    out = torch.empty(M, N, dtype=BF, device=DEV)
+    ops.gemm_nt(a.to(BF).to(DEV), w.to(BF).to(DEV), out)
+    want = a @ w.t()
+    assert_close(out, want, rtol=2 ** -7, atol=1e-3 * math.sqrt(K) * 0.05, what=f"gemm {M}x{N}x{K}")
+
+
+def test_gemm_bf16_transpose_detecting():
+    """A = [I | 0] against an ASYMMETRIC W: catches swapped row/col in the MFMA C-write."""
+    M, N, K = 128, 256, 128
+    a = torch.zeros(M, K)
+    a[:, :M] = torch.eye(M)
+    w = torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251 - 125
+    out = torch.empty(M, N, dtype=BF, device=DEV)
+    ops.gemm_nt(a.to(BF).to(DEV), w.to(BF).to(DEV), out)
+    want = w[:, :M].t()
+    assert torch.equal(out.float().cpu(), rt(want))
+
+
+def test_gemm_bf16_strided_operands():
+    M, N, K = 200, 192, 128
+    abig, wbig = rt(gen(M, K + 64, seed=3)), rt(gen(N, K + 128, seed=4, scale=0.1))
+    obig = torch.zeros(M, N + 64, dtype=BF, device=DEV)
+    ad, wd = abig.to(BF).to(DEV), wbig.to(BF).to(DEV)
+    ops.gemm_nt(ad[:, 64:], wd[:, 128:], obig[:, 32:32 + N])
+    want = abig[:, 64:] @ wbig[:, 128:].t()
+    assert_close(obig[:, 32:32 + N], want, rtol=2 ** -7, atol=5e-3, what="strided gemm")
+    assert float(obig[:, :32].abs().sum()) == 0 and float(obig[:, 32 + N:].abs().sum()) == 0
+
+
+def test_gemm_bf16_epilogues():
+    M, N, K = 150, 256, 128
+    a, w = rt(gen(M, K, seed=5)), rt(gen(N, K, seed=6, scale=0.08))
+    bias, res = rt(gen(N, seed=7)), rt(gen(M, N, seed=8))
+    ad, wd = a.to(BF).to(DEV), w.to(BF).to(DEV)
+    lin = a @ w.t()
+    # bias + erf GELU: F.linear -> bf16, gelu -> bf16
+    out = torch.empty(M, N, dtype=BF, device=DEV)
+    ops.gemm_nt(ad, wd, out, bias=bias.to(BF).to(DEV), epilogue=ops.EPI_GELU)
+    want = rt(F.gelu(rt(lin + bias)))
+    assert_close(out, want, rtol=2 ** -6, atol=4e-3, what="bias+gelu")
+    ops.gemm_nt(ad, wd, out, bias=bias.to(BF).to(DEV), epilogue=ops.EPI_QUICKGELU)
+    y = rt(lin + bias)
+    assert_close(out, rt(y * torch.sigmoid(1.702 * y)), rtol=2 ** -6, atol=4e-3, what="bias+quickgelu")
+    # bias + residual, in place on the residual buffer (x = x + linear(...))
+    hbuf = res.to(BF).to(DEV).clone()
+    ops.gemm_nt(ad, wd, hbuf, bias=bias.to(BF).to(DEV), residual=hbuf)
+    assert_close(hbuf, rt(res + rt(lin + bias)), rtol=2 ** -6, atol=8e-3, what="bias+residual in place")
+    # fp32 output of bf16-rounded logits
+    o32 = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm_nt(ad, wd, o32, epilogue=ops.EPI_OUT_F32)
+    assert_close(o32, rt(lin), rtol=2 ** -7, atol=4e-3, what="out f32")
+    assert torch.equal(o32.cpu(), rt(o32.cpu())), "fp32 logits must be bf16-representable (output(h).float())"
+    # fp32 residual stream
+    r32 = gen(M, N, seed=9).to(DEV)
+    o32b = torch.empty_like(r32)
+    ops.gemm_nt(ad, wd, o32b, residual=r32, epilogue=ops.EPI_RES_F32)
+    assert_close(o32b, r32.cpu() + rt(lin), rtol=2 ** -7, atol=4e-3, what="res f32")
+
+
+def pack_w13(w1, w3):
+    nb = w1.shape[0] // 16
+    return torch.stack([w1.view(nb, 16, -1), w3.view(nb, 16, -1)], dim=1).reshape(2 * w1.shape[0], -1).contiguous()
+
+
+@pytest.mark.parametrize("M", [4, 150])
+def test_gemm_bf16_swiglu(M):
+    F_, K = 192, 128
+    a, w1, w3 = rt(gen(M, K, seed=10)), rt(gen(F_, K, seed=11, scale=0.1)), rt(gen(F_, K, seed=12, scale=0.1))
+    w13 = pack_w13(w1, w3).to(BF).to(DEV)
+    out = torch.empty(M, F_, dtype=BF, device=DEV)
+    ops.gemm_nt(a.to(BF).to(DEV), w13, out, epilogue=ops.EPI_SWIGLU)
+    want = rt(rt(F.silu(rt(a @ w1.t()))) * rt(a @ w3.t()))
+    assert_close(out, want, rtol=2 ** -6, atol=4e-3, what="swiglu")
+    if M <= 16:
+        part = torch.empty(8 * 16 * 2 * F_, dtype=torch.float32, device=DEV)
+        out2 = torch.empty(M, F_, dtype=BF, device=DEV)
+        ops.gemm_skinny(a.to(BF).to(DEV), w13, out2, part, epilogue=ops.EPI_SWIGLU)
+        assert_close(out2, want, rtol=2 ** -6, atol=4e-3, what="skinny swiglu")
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 256, 128), (8, 4096, 4096), (16, 1000, 1376), (5, 32000, 512)])
+def test_gemm_skinny(M, N, K):
+    a, w = rt(gen(M, K, seed=13)), rt(gen(N, K, seed=14, scale=0.05))
+    res = rt(gen(M, N, seed=15))
+    ad, wd = a.to(BF).to(DEV), w.to(BF).to(DEV)
+    part = torch.empty(8 * 16 * N, dtype=torch.float32, device=DEV)
+    lin = a @ w.t()
+    out = torch.empty(M, N, dtype=BF, device=DEV)
+    ops.gemm_skinny(ad, wd, out, part)
+    assert_close(out, lin, rtol=2 ** -7, atol=2e-3 * math.sqrt(K) * 0.05 + 1e-3, what="skinny")
+    hb = res.to(BF).to(DEV).clone()
+    ops.gemm_skinny(ad, wd, hb, part, residual=hb)
+    assert_close(hb, rt(res + rt(lin)), rtol=2 ** -6, atol=1e-2, what="skinny residual")
+    o32 = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm_skinny(ad, wd, o32, part, epilogue=ops.EPI_OUT_F32)
+    assert_close(o32, rt(lin), rtol=2 ** -7, atol=2e-3 * math.sqrt(K) * 0.05 + 1e-3, what="skinny f32 out")
+
+
+@pytest.mark.parametrize("M,N,K", [(70, 96, 64), (64, 64, 16), (130, 200, 640)])
+def test_gemm_f32(M, N, K):
+    a, w, bias, res = gen(M, K, seed=16), gen(N, K, seed=17, scale=0.1), gen(N, seed=18), gen(M, N, seed=19)
+    out = torch.empty(M, N, device=DEV)
+    ops.gemm_nt(a.to(DEV), w.to(DEV), out, bias=bias.to(DEV), residual=res.to(DEV), epilogue=ops.EPI_GELU)
+    want = res + F.gelu(a @ w.t() + bias)
+    assert_close(out, want, rtol=1e-5, atol=2e-5, what="gemm f32")
+    if N % 32 == 0:
+        w1, w3 = w[: N // 2], w[N // 2:]
+        o2 = torch.empty(M, N // 2, device=DEV)
+        ops.gemm_nt(a.to(DEV), pack_w13(w1, w3).to(DEV), o2, epilogue=ops.EPI_SWIGLU)
+        assert_close(o2, F.silu(a @ w1.t()) * (a @ w3.t()), rtol=1e-5, atol=2e-5, what="swiglu f32")
+
+
+def test_gemm_rejects_bad_shapes():
+    a = torch.zeros(4, 40, dtype=BF, device=DEV)
+    w = torch.zeros(8, 40, dtype=BF, device=DEV)
+    with pytest.raises(RuntimeError):
+        ops.gemm_nt(a, w, torch.empty(4, 8, dtype=BF, device=DEV))
+
+
+# ------------------------------------------------------------------ norms
+@pytest.mark.parametrize("dim", [64, 1024, 4096, 5120])
+def test_rmsnorm(dim):
+    x, w = gen(37, dim, seed=20, scale=2.0), 1 + 0.1 * gen(dim, seed=21)
+    out = torch.empty(37, dim, device=DEV)
+    ops.rmsnorm(x.to(DEV), w.to(DEV), out, 1e-5)
+    assert_close(out, ref_cpu.rmsnorm(x, w, 1e-5), rtol=1e-5, atol=1e-6, what="rmsnorm f32")
+    xb, wb = x.to(BF), w.to(BF)
+    ob = torch.empty(37, dim, dtype=BF, device=DEV)
+    ops.rmsnorm(xb.to(DEV), wb.to(DEV), ob, 1e-5)
+    want = ref_cpu.rmsnorm(xb, wb, 1e-5)   # bf16 semantic of the reference (two roundings)
+    mism = (ob.cpu() != want).float().mean().item()
+    assert mism < 2e-3, f"bf16 rmsnorm: {mism:.2%} elements differ (fp32 reduction order only)"
+    assert_close(ob, want, rtol=2 ** -7, atol=1e-6, what="rmsnorm bf16")
+    # fp32 residual stream -> bf16 activations (autocast training)
+    o2 = torch.empty(37, dim, dtype=BF, device=DEV)
+    ops.rmsnorm(x.to(DEV), w.to(DEV), o2, 1e-5)
+    assert_close(o2, ref_cpu.rmsnorm(x, w, 1e-5).to(BF), rtol=2 ** -7, atol=1e-6, what="rmsnorm f32->bf16")
+
+
+def test_rmsnorm_strided_rows():
+    B, S, dim = 3, 5, 128
+    h = gen(B * S, dim, seed=22)
+    hd_ = h.to(DEV)
+    last = hd_.view(B, S, dim)[:, -1, :]
+    out = torch.empty(B, dim, device=DEV)
+    ops.rmsnorm(last, torch.ones(dim, device=DEV), out, 1e-5)
+    assert_close(out, ref_cpu.rmsnorm(h.view(B, S, dim)[:, -1], torch.ones(dim), 1e-5), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("dim,dtype", [(64, torch.float32), (1024, BF), (4096, BF), (5120, torch.float32)])
+def test_layernorm_and_row_map(dim, dtype):
+    rows = 29
+    x, w, b = gen(rows, dim, seed=23, scale=3.0), 1 + 0.1 * gen(dim, seed=24), 0.1 * gen(dim, seed=25)
+    xd, wd, bd = x.to(dtype).to(DEV), w.to(dtype).to(DEV), b.to(dtype).to(DEV)
+    want = F.layer_norm(x.to(dtype).float(), (dim,), w.to(dtype).float(), b.to(dtype).float(), 1e-5)
+    out = torch.empty(rows, dim, dtype=dtype, device=DEV)
+    ops.layernorm(xd, wd, bd, out)
+    tol = dict(rtol=1e-5, atol=2e-5) if dtype == torch.float32 else dict(rtol=2 ** -7, atol=2e-3)
+    assert_close(out, want, what="layernorm", **tol)
+    perm = torch.randperm(rows * 2, generator=torch.Generator().manual_seed(1))[:rows].to(torch.int32)
+    big = torch.zeros(rows * 2, dim, dtype=dtype, device=DEV)
+    ops.layernorm(xd, wd, bd, big, row_map=perm.to(DEV))
+    assert_close(big[perm.long().to(DEV)], want, what="layernorm row_map", **tol)
+    untouched = torch.ones(rows * 2, dtype=torch.bool)
+    untouched[perm.long()] = False
+    assert float(big[untouched.to(DEV)].abs().sum()) == 0
+    xd2 = xd.clone()
+    ops.layernorm(xd2, wd, bd, xd2)   # in place
+    assert_close(xd2, want, what="layernorm in place", **tol)
+
+
+# ------------------------------------------------------------------ RoPE + KV cache
+@pytest.mark.parametrize("dtype", [torch.float32, BF])
+@pytest.mark.parametrize("B,S,H,Hkv,hd,start", [(2, 5, 4, 2, 16, 0), (2, 1, 4, 2, 16, 7), (1, 130, 2, 2, 128, 3), (2, 70, 4, 4, 64, 64)])
+def test_rope_kvcache(dtype, B, S, H, Hkv, hd, start):
+    from a3vlm_amd.model.LLM.llama_ens5 import precompute_cos_sin
+    Smax = 256
+    width = (H + 2 * Hkv) * hd
+    qkv = gen(B * S, width, seed=26).to(dtype)
+    cs = precompute_cos_sin(hd, 512, 10000.0, None)
+    fc = ref_cpu.precompute_freqs_cis(hd, 512)
+    assert torch.equal(cs[..., 0], fc.real) and torch.equal(cs[..., 1], fc.imag)
+    q = qkv[:, :H * hd].view(B, S, H, hd)
+    k = qkv[:, H * hd:(H + Hkv) * hd].view(B, S, Hkv, hd)
+    v = qkv[:, (H + Hkv) * hd:].view(B, S, Hkv, hd)
+    oq, ok = ref_cpu.apply_rotary_emb(q, k, fc[start:start + S])
+    qkv_d = qkv.to(DEV).clone()
+    kc = torch.full((B, Hkv, Smax, hd), 7.0, dtype=dtype, device=DEV)
+    vc = torch.full((B, Hkv, hd, Smax), 7.0, dtype=dtype, device=DEV)
+    ops.rope_kvcache(qkv_d, qkv_d, kc, vc, cs.to(DEV), B, S, H, Hkv, hd, start, start)
+    tol = dict(rtol=1e-6, atol=1e-6) if dtype == torch.float32 else dict(rtol=2 ** -8, atol=1e-6)
+    assert_close(qkv_d[:, :H * hd].view(B, S, H, hd), oq, what="rope q (in place)", **tol)
+    assert_close(kc[:, :, start:start + S].permute(0, 2, 1, 3), ok, what="k cache", **tol)
+    assert torch.equal(vc[:, :, :, start:start + S].permute(0, 3, 1, 2).cpu(), v), "v^T cache must be an exact copy"
+    assert float((kc[:, :, :start] - 7).abs().sum()) == 0 and float((kc[:, :, start + S:] - 7).abs().sum()) == 0
+    assert float((vc[..., :start] - 7).abs().sum()) == 0 and float((vc[..., start + S:] - 7).abs().sum()) == 0
+
+
+# ------------------------------------------------------------------ attention
+def oracle_attn(q, k, v, causal):
+    """q [B,Sq,H,hd], k/v [B,Sk,Hkv,hd] -> [B,Sq,H,hd] via ref_cpu.sdpa + right-aligned mask."""
+    n_rep = q.shape[2] // k.shape[2]
+    kk = ref_cpu.repeat_kv(k, n_rep).transpose(1, 2)
+    vv = ref_cpu.repeat_kv(v, n_rep).transpose(1, 2)
+    m = ref_cpu.make_causal_mask(q.shape[1], k.shape[1]) if causal else None
+    return ref_cpu.sdpa(q.transpose(1, 2), kk, vv, m).transpose(1, 2)
+
+
+def run_attn(q, k, v, causal, dtype, Smax=None):
+    B, Sq, H, hd = q.shape
+    Sk, Hkv = k.shape[1], k.shape[2]
+    Smax = Smax or (Sk + 63) // 64 * 64
+    qd = q.to(dtype).to(DEV).contiguous()
+    kc = torch.zeros(B, Hkv, Smax, hd, dtype=dtype, device=DEV)
+    vc = torch.full((B, Hkv, hd, Smax), float("nan"), dtype=dtype, device=DEV)   # poison beyond Sk
+    kc[:, :, :Sk] = k.to(dtype).permute(0, 2, 1, 3).to(DEV)
+    vc[:, :, :, :Sk] = v.to(dtype).permute(0, 2, 3, 1).to(DEV)
+    out = torch.empty(B, Sq, H, hd, dtype=dtype, device=DEV)
+    strides = (Sq * H * hd, H * hd, hd, Hkv * Smax * hd, Smax * hd, hd, Hkv * hd * Smax, hd * Smax, Smax, Sq * H * hd, H * hd, hd)
+    scratch = None
+    if Sq == 1 and dtype == BF:
+        scratch = torch.empty(ops.attention_scratch_floats(B, H, hd, Sk), dtype=torch.float32, device=DEV)
+    ops.attention(qd, kc, vc, out, B, Sq, Sk, H, Hkv, hd, strides, causal, scratch)
+    return out
+
+
+@pytest.mark.parametrize("B,Sq,Sk,H,Hkv,hd,causal", [
+    (2, 6, 6, 4, 2, 16, True), (2, 1, 6, 4, 2, 16, False), (2, 2, 5, 4, 2, 16, True),
+    (1, 70, 70, 2, 1, 128, True), (2, 33, 97, 2, 2, 64, False)])
+def test_attention_f32(B, Sq, Sk, H, Hkv, hd, causal):
+    q, k, v = gen(B, Sq, H, hd, seed=30), gen(B, Sk, Hkv, hd, seed=31), gen(B, Sk, Hkv, hd, seed=32)
+    out = run_attn(q, k, v, causal, torch.float32)
+    assert_close(out, oracle_attn(q, k, v, causal), rtol=1e-4, atol=2e-5, what="attn f32")
+
+
+@pytest.mark.parametrize("B,Sq,Sk,H,Hkv,hd,causal", [
+    (1, 128, 128, 2, 2, 128, True), (2, 300, 300, 4, 2, 128, True), (1, 100, 427, 2, 1, 128, True),
+    (2, 577, 577, 4, 4, 64, False), (1, 257, 257, 2, 2, 64, False), (1, 64, 64, 1, 1, 64, True),
+    (1, 1091, 1091, 2, 2, 128, True), (3, 50, 50, 2, 2, 128, False)])
+def test_attention_prefill_bf16(B, Sq, Sk, H, Hkv, hd, causal):
+    q, k, v = rt(gen(B, Sq, H, hd, seed=33)), rt(gen(B, Sk, Hkv, hd, seed=34)), rt(gen(B, Sk, Hkv, hd, seed=35))
+    out = run_attn(q, k, v, causal, BF)
+    want = oracle_attn(q, k, v, causal)
+    # P is rounded to bf16 before P.V (as flash-attn / bf16 SDPA do): abs error ~ 2^-9 * |v|max
+    assert_close(out, want, rtol=2 ** -6, atol=1.5e-2, what="attn prefill bf16")
+    assert torch.isfinite(out.float()).all()
+
+
+def test_attention_prefill_bf16_spike_rescale():
+    """Forces the online-softmax rescale: one key row dominates late in the sequence."""
+    B, S, H, hd = 1, 256, 1, 128
+    q, k, v = rt(gen(B, S, H, hd, seed=36)), rt(gen(B, S, H, hd, seed=37)), rt(gen(B, S, H, hd, seed=38))
+    k[0, 200, 0] = q[0, 220, 0] * 4.0     # query 220+ see a huge score at key 200 (tile 3)
+    out = run_attn(q, k, v, True, BF)
+    assert_close(out, oracle_attn(q, k, v, True), rtol=2 ** -6, atol=1.5e-2, what="attn spike")
+
+
+@pytest.mark.parametrize("B,Sk,H,Hkv,hd", [(2, 6, 4, 2, 64), (8, 1091, 4, 4, 128), (1, 4000, 2, 1, 128), (3, 129, 2, 2, 128)])
+def test_attention_decode_bf16(B, Sk, H, Hkv, hd):
+    q, k, v = rt(gen(B, 1, H, hd, seed=39)), rt(gen(B, Sk, Hkv, hd, seed=40)), rt(gen(B, Sk, Hkv, hd, seed=41))
+    out = run_attn(q, k, v, False, BF, Smax=4096)
+    assert_close(out, oracle_attn(q, k, v, False), rtol=2 ** -7, atol=4e-3, what="attn decode bf16")
+
+
+def test_vt_pack():
+    N, L, H, hd = 3, 77, 4, 64
+    W = H * hd
+    qkv = gen(N * L, 3 * W, seed=42).to(BF)
+    Lpad = 128
+    vt = torch.full((N, H, hd, Lpad), 5.0, dtype=BF, device=DEV)
+    qd = qkv.to(DEV)
+    ops.vt_pack(qd[:, 2 * W:], 3 * W, vt, N, L, H, hd, Lpad)
+    v = qkv[:, 2 * W:].view(N, L, H, hd)
+    assert torch.equal(vt[..., :L].cpu(), v.permute(0, 2, 3, 1))
+    assert float(vt[..., L:].float().abs().sum()) == 0, "padding must be zero"
+
+
+# ------------------------------------------------------------------ assembly / vision helpers
+def test_embed_assemble_and_fill_rows():
+    B, T, W, dim, V = 2, 5, 7, 64, 50
+    table = gen(V, dim, seed=43)
+    tok = torch.randint(0, V, (B, T), generator=torch.Generator().manual_seed(2))
+    h = torch.full((B * (T + W), dim), -1.0, device=DEV)
+    ops.embed_assemble(tok.to(DEV), table.to(DEV), h, B, T, W, dim)
+    hv = h.view(B, T + W, dim).cpu()
+    emb = F.embedding(tok, table)
+    assert torch.equal(hv[:, 0], emb[:, 0]) and torch.equal(hv[:, W + 1:], emb[:, 1:])
+    assert float((hv[:, 1:W + 1] + 1).abs().sum()) == 0
+    tag = gen(dim, seed=44)
+    rows = torch.tensor([1, 4, 13], dtype=torch.int32, device=DEV)
+    ops.fill_rows(tag.to(DEV), h, rows)
+    assert torch.equal(h[rows.long()].cpu(), tag.expand(3, dim))
+    hb = torch.zeros(B * T, dim, dtype=BF, device=DEV)
+    ops.embed_assemble(tok.to(DEV), table.to(DEV), hb, B, T, 0, dim)   # fp32 table -> bf16 stream
+    assert torch.equal(hb.view(B, T, dim).cpu(), emb.to(BF))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, BF])
+def test_patch_embed_conv_as_gemm(dtype):
+    N, P, g, width = 3, 14, 4, 64
+    img = gen(N, 3, g * P, g * P, seed=45)
+    wconv = gen(width, 3, P, P, seed=46, scale=0.05).to(dtype)
+    K, Kpad = 3 * P * P, 640
+    cols = torch.empty(N * g * g, Kpad, dtype=dtype, device=DEV)
+    ops.patch_im2col(img.to(DEV), cols, P)      # fp32 image in, model dtype out
+    w2 = torch.zeros(width, Kpad, dtype=dtype)
+    w2[:, :K] = wconv.reshape(width, -1)
+    out = torch.empty(N * g * g, width, dtype=dtype, device=DEV)
+    ops.gemm_nt(cols, w2.to(DEV), out)
+    want = F.conv2d(img.to(dtype).float(), wconv.float(), None, stride=P).flatten(2).permute(0, 2, 1).reshape(N * g * g, width)
+    tol = dict(rtol=1e-5, atol=2e-5) if dtype == torch.float32 else dict(rtol=2 ** -7, atol=1e-2)
+    assert_close(out, want, what="patch embed", **tol)
+
+
+def test_vit_embed():
+    N, T, W = 2, 16, 64
+    patch, cls, pos = gen(N * T, W, seed=47), gen(W, seed=48), gen(T + 1, W, seed=49)
+    x = torch.empty(N * (T + 1), W, device=DEV)
+    ops.vit_embed(patch.to(DEV), cls.to(DEV), pos.to(DEV), x, N, T, W)
+    want = torch.cat([cls.expand(N, 1, W), patch.view(N, T, W)], dim=1) + pos
+    assert_close(x.view(N, T + 1, W), want, rtol=0, atol=0, what="vit embed")
+
+
+@pytest.mark.parametrize("out_dtype", [torch.float32, BF])
+def test_split_views(out_dtype):
+    B, c = 2, 28
+    img = gen(B, 3, 2 * c, 2 * c, seed=50)
+    out = torch.empty(5 * B, 3, c, c, dtype=out_dtype, device=DEV)
+    ops.split_views(img.to(DEV), out)
+    want = ref_cpu.split_views(img, c).to(out_dtype)
+    assert torch.equal(out[B:].cpu(), want[B:]), "quadrant crops are copies"
+    # bicubic in fp16: one fp16 ulp of slack for the accumulation order
+    assert_close(out[:B], want[:B], rtol=2 ** -9 if out_dtype == torch.float32 else 2 ** -7, atol=2e-3, what="bicubic view")
+
+
+# ------------------------------------------------------------------ argmax / CE
+def test_argmax_first_index_ties():
+    B, V = 5, 32000
+    lg = gen(B, V, seed=51)
+    lg[0, 100] = lg[0, 20000] = 50.0
+    lg[1, 31999] = 60.0
+    lg[2, 0] = 60.0
+    lg[3] = 1.0
+    out = torch.empty(B, dtype=torch.long, device=DEV)
+    ops.argmax(lg.to(DEV), out)
+    assert out.cpu().tolist() == torch.argmax(lg, dim=-1).tolist()
+    assert out[0].item() == 100 and out[3].item() == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, BF])
+def test_cross_entropy(dtype):
+    rows, V = 23, 32000
+    lg = (gen(rows, V, seed=52) * 3).to(dtype)
+    lab = torch.randint(1, V, (rows,), generator=torch.Generator().manual_seed(3))
+    lab[::5] = 0
+    row_loss = torch.empty(rows, device=DEV)
+    dl = torch.empty(rows, V, dtype=dtype, device=DEV)
+    nv = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.count_valid(lab.to(DEV), nv)
+    assert int(nv.item()) == int((lab != 0).sum())
+    ops.cross_entropy(lg.to(DEV), lab.to(DEV), row_loss, dl, nv, 1.0)
+    lgf = lg.float().requires_grad_(True)
+    want = F.cross_entropy(lgf, lab, ignore_index=0, reduction="none")
+    assert_close(row_loss, want.detach(), rtol=1e-5, atol=1e-5, what="ce rows")
+    F.cross_entropy(lgf, lab, ignore_index=0).backward()
+    tol = dict(rtol=1e-4, atol=1e-8) if dtype == torch.float32 else dict(rtol=2 ** -7, atol=1e-7)
+    assert_close(dl, lgf.grad, what="ce grad", **tol)

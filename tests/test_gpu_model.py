@@ -1,0 +1,264 @@
+"""-m gpu: the HIP plugin / MetaModel end to end against (a) the golden vectors captured from the
+reference (tests/golden, fp32 path, token ids bit-exact) and (b) the CPU oracle on seeded inputs
+(bf16 path with stated tolerances), plus size-independent properties at larger geometry."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from a3vlm_amd.model.LLM import llama_ens5 as plugin  # noqa: E402
+from a3vlm_amd.model.meta import MetaModel  # noqa: E402
+from oracle import ref_cpu  # noqa: E402
+from oracle.gen_golden import TINY, VIT, convnext_tokens, extra_feature_inputs, synth_image  # noqa: E402
+
+DEV = "cuda"
+BF = torch.bfloat16
+# north_star tolerance: 1e-3 relative on outputs of the fp32 path (logits scaled by their max)
+REL = 1e-3
+
+
+def rel_err(got, want):
+    got = got.detach().float().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    want = np.asarray(want, dtype=np.float32)
+    return float(np.abs(got - want).max() / (np.abs(want).max() + 1e-12))
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    with open(os.path.join(golden_dir, "meta_tiny.json")) as f:
+        j = json.load(f)
+    return dict(dec=np.load(os.path.join(golden_dir, "decoder_tiny.npz")),
+                meta=np.load(os.path.join(golden_dir, "meta_tiny.npz")),
+                vis=np.load(os.path.join(golden_dir, "vision_tiny.npz")), j=j, dir=golden_dir)
+
+
+def tiny_model(V, dtype=torch.float32, max_seq_len=64, with_visual=False, **vis):
+    args = plugin.ModelArgs(vocab_size=V, **{**TINY, "max_seq_len": max_seq_len}, **vis)
+    m = plugin.Transformer(args, with_visual=with_visual)
+    oargs = ref_cpu.OracleArgs(vocab_size=V, **{**TINY, "max_seq_len": max_seq_len})
+    sd = ref_cpu.make_decoder_weights(oargs, seed=0, std=0.08)
+    return m, oargs, sd
+
+
+def test_g4_forward_logits_fp32(gold):
+    V = gold["j"]["vocab_size"]
+    m, _, sd = tiny_model(V)
+    m.load_state_dict(sd)
+    m.to(DEV)
+    ex = torch.from_numpy(gold["dec"]["g4_examples"]).to(DEV)
+    out = m(ex)
+    assert out.shape == (2, 12, V) and out.dtype == torch.float32
+    assert rel_err(out, gold["dec"]["g4_logits"]) < REL
+    assert (out.argmax(-1).cpu().numpy() == gold["dec"]["g4_logits"].argmax(-1)).all()
+
+
+def test_g4_forward_inference_fp32(gold):
+    V = gold["j"]["vocab_size"]
+    m, _, sd = tiny_model(V)
+    m.load_state_dict(sd)
+    m.to(DEV)
+    ex = torch.from_numpy(gold["dec"]["g4_examples"]).to(DEV)
+    want = gold["dec"]["g4_inf_logits"]
+    lg = [m.forward_inference(ex[:, :7], 0).clone()]
+    for t in range(7, 11):
+        lg.append(m.forward_inference(ex[:, t:t + 1], t).clone())
+    for i, l in enumerate(lg):
+        assert l.dtype == torch.float32
+        assert rel_err(l, want[i]) < REL, f"step {i}"
+        assert (l.argmax(-1).cpu().numpy() == want[i].argmax(-1)).all()
+    # KV-cache contents (reference layout [B,S,Hkv,hd]) vs ours (K [B,Hkv,S,hd], V^T [B,Hkv,hd,S])
+    k0 = m._k_cache[0][:, :, :11].permute(0, 2, 1, 3)
+    v1 = m._vt_cache[1][:, :, :, :11].permute(0, 3, 1, 2)
+    assert rel_err(k0, gold["dec"]["g4_kcache_l0"]) < REL
+    assert rel_err(v1, gold["dec"]["g4_vcache_l1"]) < REL
+
+
+def test_state_dict_names_match_reference(gold):
+    V = gold["j"]["vocab_size"]
+    m, _, _ = tiny_model(V)
+    assert sorted(m.state_dict().keys()) == list(gold["dec"]["dec_state_keys"])
+    assert sorted(m.get_trainable_params().keys()) == list(gold["dec"]["dec_trainable"])
+    args = plugin.ModelArgs(vocab_size=V, **TINY, vit_width=VIT["width"], vit_layers=VIT["layers"], vit_heads=VIT["heads"],
+                            extra_feat_dim=3072 + 1536, qformer_tokens=32)
+    mv = plugin.Transformer(args, with_visual=True)
+    vis_keys = sorted(k for k in mv.state_dict().keys() if k.startswith(("clip.", "visual_proj", "qformer_proj", "start_", "end_")))
+    assert vis_keys == list(gold["vis"]["vis_state_keys"])
+    assert not any(n.startswith("clip.") for n in mv.get_trainable_params())
+    assert mv.image_words == 1455 and mv.image_size == 448
+
+
+def meta_model(gold, dtype=torch.float32):
+    mm = MetaModel("llama_ens5", os.path.join(gold["dir"], "tiny_params.json"),
+                   os.path.join(gold["dir"], "tokenizer.model"), with_visual=False, max_seq_len=64)
+    oargs = ref_cpu.OracleArgs(vocab_size=gold["j"]["vocab_size"], **TINY)
+    sd = ref_cpu.make_decoder_weights(oargs, seed=0, std=0.08)
+    mm.llma.load_state_dict(sd)
+    return mm.to(dtype).to(DEV)
+
+
+def test_g5_meta_forward_loss_fp32(gold):
+    mm = meta_model(gold)
+    g = gold["meta"]
+    ex = torch.from_numpy(g["g5_examples"]).to(DEV)
+    la, _ = mm(ex, torch.from_numpy(g["g5_labels_a"]).to(DEV))
+    assert abs(float(la) - float(g["g5_loss_a"])) < REL * float(g["g5_loss_a"])
+    lb, _ = mm(torch.from_numpy(g["g5_examples_b"]).to(DEV), torch.from_numpy(g["g5_labels_b"]).to(DEV))
+    assert abs(float(lb) - float(g["g5_loss_b"])) < REL * float(g["g5_loss_b"])
+    lc, _ = mm(ex, torch.zeros_like(ex))
+    assert float(lc) == 0.0
+
+
+@pytest.mark.parametrize("key,max_gen,stops", [("gen12", 12, ()), ("gen48", 48, ()), ("genstop", 12, ("li", "ab"))])
+def test_g6_generate_greedy_bit_exact_fp32(gold, key, max_gen, stops):
+    mm = meta_model(gold)
+    texts, ids = mm.generate(gold["j"]["prompts"], None, max_gen_len=max_gen, temperature=0.0,
+                             additional_stop_symbols=stops, return_ids=True)
+    assert ids == gold["j"][key + "_ids"]
+    assert texts == gold["j"][key + "_text"]
+
+
+def vision_model(gold, dtype=torch.float32):
+    V = gold["j"]["vocab_size"]
+    args = plugin.ModelArgs(vocab_size=V, **{**TINY, "max_seq_len": 1600}, vit_width=VIT["width"], vit_layers=VIT["layers"],
+                            vit_heads=VIT["heads"], vit_patch=VIT["patch"], vit_crop=224, n_views=5,
+                            extra_feat_dim=3072 + 1536, qformer_tokens=32)
+    m = plugin.Transformer(args, with_visual=True)
+    sd = ref_cpu.make_decoder_weights(ref_cpu.OracleArgs(vocab_size=V, **TINY), seed=0, std=0.08)
+    vsd = ref_cpu.make_vision_weights(64, width=VIT["width"], layers=VIT["layers"], patch=VIT["patch"], grid=VIT["grid"],
+                                      in_feat=VIT["width"] + 3072 + 1536, with_qformer=True, seed=1, std=0.05)
+    res = m.load_state_dict({**sd, **vsd}, strict=True)
+    return m.to(dtype).to(DEV), sd, vsd
+
+
+def test_g7_g8_vision_fp32(gold):
+    v = gold["vis"]
+    m, sd, vsd = vision_model(gold)
+    B = 2
+    img = synth_image(B).to(DEV)
+    views = torch.empty(5 * B, 3, 224, 224, device=DEV)
+    from a3vlm_amd import ops
+    ops.split_views(img, views)
+    feats = m.clip_encode_image(views[:3].contiguous()).view(3, 257, -1)
+    assert rel_err(feats, v["g7_clip_feats"]) < REL
+    qf, cnx, dino = extra_feature_inputs(5 * B)
+    extra = [convnext_tokens(cnx).to(DEV), dino.to(DEV)]
+    ex = torch.from_numpy(v["g8_examples"]).to(DEV)
+    out = m(ex, img, qformer_feats=qf.to(DEV), extra_feats=extra)
+    assert rel_err(out, v["g8_logits"]) < REL
+    # the assembled image words inside the sequence buffer vs the reference's per-view tokens
+    S = ex.shape[1] + m.image_words
+    l0 = m.forward_inference(ex[:, :6], 0, img, qformer_feats=qf.to(DEV), extra_feats=extra).clone()
+    assert m.cache_image_words == int(v["g8_cache_image_words"]) == 1455
+    l1 = m.forward_inference(ex[:, 6:7], 6).clone()
+    l2 = m.forward_inference(ex[:, 7:8], 7).clone()
+    for i, l in enumerate((l0, l1, l2)):
+        assert rel_err(l, v["g8_inf_logits"][i]) < REL, f"inference step {i}"
+        assert (l.argmax(-1).cpu().numpy() == v["g8_inf_logits"][i].argmax(-1)).all()
+
+
+def test_image_words_layout_fp32(gold):
+    """encode_image_into writes [start | qformer | clip | end] x 5 views at rows 1..1455 (llama_ens5.py:471-479)."""
+    v = gold["vis"]
+    m, sd, vsd = vision_model(gold)
+    B, T = 2, 4
+    img = synth_image(B).to(DEV)
+    qf, cnx, dino = extra_feature_inputs(5 * B)
+    W = m.image_words
+    S = T + W
+    h = torch.zeros(B * S, 64, device=DEV)
+    m._pack(check=True)
+    m.encode_image_into(h, img, B, S, qf.to(DEV), [convnext_tokens(cnx).to(DEV), dino.to(DEV)])
+    hv = h.view(B, S, 64)[:, 1:1 + W].cpu()
+    views = torch.from_numpy(v["g8_views"])                       # [5, B, 289, 64]
+    want = ref_cpu.assemble_image_tokens(list(views), vsd["start_img"], vsd["end_img"])
+    assert rel_err(hv, want.numpy()) < REL
+    assert float(h.view(B, S, 64)[:, 0].abs().sum()) == 0 and float(h.view(B, S, 64)[:, 1 + W:].abs().sum()) == 0
+
+
+# ------------------------------------------------------------------ bf16 path vs the oracle
+def test_decoder_bf16_vs_oracle(gold):
+    """bf16 kernels (fp32 accumulate, reference rounding points) vs the oracle run in bf16 on CPU.
+    Accumulation order differs, so agreement is at the bf16-ulp level: 3e-2 of max|logit|
+    (the reference's own bf16-vs-fp32 deviation on this model, fixture g4_logits_bf16, is ~2e-2)."""
+    V = gold["j"]["vocab_size"]
+    m, oargs, sd = tiny_model(V)
+    m.load_state_dict(sd)
+    m.to(BF).to(DEV)
+    ex = torch.from_numpy(gold["dec"]["g4_examples"])
+    d = ref_cpu.OracleDecoder(oargs, {k: v.to(BF) for k, v in sd.items()})
+    want = d.forward(ex).float()
+    out = m(ex.to(DEV))
+    assert out.dtype == BF
+    assert rel_err(out, want.numpy()) < 3e-2
+    assert rel_err(out, gold["dec"]["g4_logits_bf16"]) < 3e-2      # the reference's own bf16 run
+    lg = m.forward_inference(ex[:, :7].to(DEV), 0)
+    assert rel_err(lg, d.forward_inference(ex[:, :7], 0).numpy()) < 3e-2
+    lg = m.forward_inference(ex[:, 7:8].to(DEV), 7)
+    assert rel_err(lg, d.forward_inference(ex[:, 7:8], 7).numpy()) < 3e-2
+
+
+def test_loss_bf16_within_1e2(gold):
+    mm = meta_model(gold, BF)
+    g = gold["meta"]
+    la, _ = mm(torch.from_numpy(g["g5_examples"]).to(DEV), torch.from_numpy(g["g5_labels_a"]).to(DEV))
+    assert abs(float(la) - float(g["g5_loss_a"])) < 1e-2 * float(g["g5_loss_a"])
+
+
+# ------------------------------------------------------------------ properties at larger geometry
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (BF, 4e-2)])
+def test_prefill_decode_consistency_medium(dtype, tol):
+    """forward (teacher forced) == prefill + decode steps, hd=128, GQA, 3 layers, ragged sizes."""
+    args = plugin.ModelArgs(dim=512, n_layers=3, n_heads=4, n_kv_heads=2, vocab_size=1000, multiple_of=64, max_seq_len=256)
+    torch.manual_seed(0)
+    m = plugin.Transformer(args).to(dtype).to(DEV)
+    B, T = 3, 150
+    ex = torch.randint(3, 1000, (B, T), device=DEV)
+    full = m(ex).float()
+    lg = m.forward_inference(ex[:, :147], 0).float().clone()
+    scale = full.abs().max()
+    assert ((lg - full[:, 146]).abs().max() / scale) < tol
+    for t in range(147, 150):
+        lg = m.forward_inference(ex[:, t:t + 1], t).float()
+        assert ((lg - full[:, t]).abs().max() / scale) < tol, t
+
+
+def test_batch_row_independence_bf16():
+    """A row's logits do not depend on what else is in the batch (sharding contract of DP replicas)."""
+    args = plugin.ModelArgs(dim=256, n_layers=2, n_heads=2, vocab_size=512, multiple_of=64, max_seq_len=128)
+    torch.manual_seed(1)
+    m = plugin.Transformer(args).to(BF).to(DEV)
+    ex = torch.randint(3, 512, (4, 40), device=DEV)
+    a = m(ex).clone()
+    b = m(ex[1:3]).clone()
+    assert torch.equal(a[1:3], b)
+
+
+def test_vit_single_crop_geometry_bf16():
+    """Geometry S (BASELINE-literal): one 336x336 crop, ViT patch 14 -> 577 + 2 image words; vs oracle."""
+    args = plugin.ModelArgs(dim=128, n_layers=1, n_heads=2, vocab_size=256, multiple_of=64, max_seq_len=1024,
+                            vit_width=128, vit_layers=2, vit_heads=2, vit_crop=336, n_views=1)
+    m = plugin.Transformer(args, with_visual=True)
+    assert m.image_words == 579 and m.image_size == 336
+    oargs = ref_cpu.OracleArgs(dim=128, n_layers=1, n_heads=2, vocab_size=256, multiple_of=64, max_seq_len=1024)
+    sd = ref_cpu.make_decoder_weights(oargs, seed=3, std=0.05)
+    vsd = ref_cpu.make_vision_weights(128, width=128, layers=2, patch=14, grid=24, seed=4, std=0.05)
+    m.load_state_dict({**sd, **vsd})
+    B = 2
+    img = synth_image(B, size=336, seed=9)
+    ex = torch.randint(3, 256, (B, 10), generator=torch.Generator().manual_seed(5))
+    ex[:, 0] = 1
+    # fp32 path vs oracle
+    m.to(DEV)
+    views = ref_cpu.encode_image(img, vsd, vit_layers=2, vit_heads=2, n_views=1)
+    itok = ref_cpu.assemble_image_tokens(views, vsd["start_img"], vsd["end_img"])
+    want = ref_cpu.OracleDecoder(oargs, sd).forward(ex, itok)
+    out = m(ex.to(DEV), img.to(DEV))
+    assert rel_err(out, want.numpy()) < REL
+    # bf16 path, same inputs
+    m.to(BF)
+    outb = m(ex.to(DEV), img.to(DEV))
+    assert rel_err(outb, want.numpy()) < 5e-2

