@@ -326,18 +326,20 @@ __global__ void attn_decode_combine_kernel(const float* part, void* out, int64_t
 }
 
 // ------------------------------------------------------------------------------------
-// fp32 parity attention: one wave per (q row, head, batch); any hd <= 256, any Sq.
+// Generic attention (fp32 parity path; also bf16 with head dims the MFMA kernels do not
+// cover): one wave per (q row, head, batch); any hd <= 256, any Sq.  fp32 math throughout.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void attn_f32_kernel(AttnArgs p, int hd, int causal) {
+template <typename T>
+__global__ __launch_bounds__(64) void attn_generic_kernel(AttnArgs p, int hd, int causal) {
   __shared__ float pbuf[64];
   __shared__ float qs[256];
   const int lane = threadIdx.x;
   const int qi = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int hk = h / (p.H / p.Hkv);
-  const float* Q = (const float*)p.q + b * p.q_sb + (int64_t)qi * p.q_ss + h * p.q_sh;
-  const float* K = (const float*)p.k + b * p.k_sb + hk * p.k_sh;
-  const float* VT = (const float*)p.vt + b * p.v_sb + hk * p.v_sh;
-  for (int d = lane; d < hd; d += 64) qs[d] = Q[d];
+  const T* Q = (const T*)p.q + b * p.q_sb + (int64_t)qi * p.q_ss + h * p.q_sh;
+  const T* K = (const T*)p.k + b * p.k_sb + hk * p.k_sh;
+  const T* VT = (const T*)p.vt + b * p.v_sb + hk * p.v_sh;
+  for (int d = lane; d < hd; d += 64) qs[d] = Cvt<T>::ld(Q + d);
   __syncthreads();
   const int kv_end = causal ? min(p.Sk, qi + (p.Sk - p.Sq) + 1) : p.Sk;
   float m = -INFINITY, l = 0.f;
@@ -346,9 +348,9 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(AttnArgs p, int hd, int ca
     const int kv = kv0 + lane;
     float s = -INFINITY;
     if (kv < kv_end) {
-      const float* kr = K + (int64_t)kv * p.k_ss;
+      const T* kr = K + (int64_t)kv * p.k_ss;
       float a = 0.f;
-      for (int d = 0; d < hd; ++d) a = fmaf(qs[d], kr[d], a);
+      for (int d = 0; d < hd; ++d) a = fmaf(qs[d], Cvt<T>::ld(kr + d), a);
       s = a * p.scale;
     }
     const float mt = wave_max(s);
@@ -365,18 +367,18 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(AttnArgs p, int hd, int ca
     for (int i = 0; i < 4; ++i) {
       const int d = lane + 64 * i;
       if (d < hd) {
-        const float* vr = VT + (int64_t)d * p.v_sd + kv0;
+        const T* vr = VT + (int64_t)d * p.v_sd + kv0;
         float a = o[i] * alpha;
-        for (int j = 0; j < cnt; ++j) a = fmaf(pbuf[j], vr[j], a);
+        for (int j = 0; j < cnt; ++j) a = fmaf(pbuf[j], Cvt<T>::ld(vr + j), a);
         o[i] = a;
       }
     }
   }
-  float* O = (float*)p.out + b * p.o_sb + (int64_t)qi * p.o_ss + h * p.o_sh;
+  T* O = (T*)p.out + b * p.o_sb + (int64_t)qi * p.o_ss + h * p.o_sh;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int d = lane + 64 * i;
-    if (d < hd) O[d] = o[i] / l;
+    if (d < hd) Cvt<T>::st(O + d, o[i] / l);
   }
 }
 
@@ -418,12 +420,17 @@ extern "C" int a3v_attention(const void* q, const void* k, const void* vt, void*
   p.scale_log2 = p.scale * 1.4426950408889634f;
   if (dtype == A3V_F32) {
     if (hd > 256) return A3V_ERR_SHAPE;
-    hipLaunchKernelGGL(attn_f32_kernel, dim3(Sq, H, B), dim3(64), 0, st, p, hd, causal);
+    hipLaunchKernelGGL(attn_generic_kernel<float>, dim3(Sq, H, B), dim3(64), 0, st, p, hd, causal);
     A3V_LAUNCH_CHECK();
     return A3V_OK;
   }
   if (dtype != A3V_BF16) return A3V_ERR_DTYPE;
-  if (hd != 128 && hd != 64) return A3V_ERR_SHAPE;
+  if (hd != 128 && hd != 64) {   // bf16 with an uncommon head dim: generic (slow, correct) kernel
+    if (hd > 256) return A3V_ERR_SHAPE;
+    hipLaunchKernelGGL(attn_generic_kernel<bf16_t>, dim3(Sq, H, B), dim3(64), 0, st, p, hd, causal);
+    A3V_LAUNCH_CHECK();
+    return A3V_OK;
+  }
   for (int i = 0; i < 12; ++i)
     if (i != 2 && i != 4 && i != 11 && (strides[i] % 8)) return A3V_ERR_SHAPE;  // 16-B vector access
   if ((strides[2] % 8) || (strides[4] % 8) || (strides[11] % 4)) return A3V_ERR_SHAPE;

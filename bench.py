@@ -158,9 +158,24 @@ def cpu_baseline(args, T, W, seconds):
     layer); if the time budget runs out the decoder is cut after k layers and the rate is reported for the
     layers actually run, scaled by the algorithmic FLOP ratio (stated in `sample`)."""
     from oracle import ref_cpu
-    cores = os.cpu_count() or 1
+    ncpu = os.cpu_count() or 1
+    # pick the fastest (threads, dtype) for torch's CPU kernels on this host with one FFN-sized matmul
+    xs = torch.randn(T + W, args.dim)
+    ws = torch.randn(4096, args.dim) * 0.02
+    best = None
+    for th in sorted({min(ncpu, t) for t in (16, 32, 64, 128, ncpu)}):
+        torch.set_num_threads(th)
+        for dtc in (torch.float32, torch.bfloat16):
+            xa, wa = xs.to(dtc), ws.to(dtc)
+            torch.nn.functional.linear(xa, wa)
+            t0 = time.perf_counter()
+            for _ in range(2):
+                torch.nn.functional.linear(xa, wa)
+            el = (time.perf_counter() - t0) / 2
+            if best is None or el < best[0]:
+                best = (el, th, dtc)
+    _, cores, dt = best
     torch.set_num_threads(cores)
-    dt = torch.bfloat16
     oargs = ref_cpu.OracleArgs(dim=args.dim, n_layers=1, n_heads=args.n_heads, n_kv_heads=args.n_kv_heads,
                                vocab_size=args.vocab_size, multiple_of=args.multiple_of, max_seq_len=2048)
     sd1 = ref_cpu.make_decoder_weights(oargs, seed=0, std=0.02, dtype=dt)
@@ -192,7 +207,7 @@ def cpu_baseline(args, T, W, seconds):
     t_dec = el - t_vit
     full = t_vit + t_dec * (args.n_layers / done)
     return dict(value=round(1.0 / full, 5), unit="samples/s", cores=cores, kind="port",
-                sample=(f"oracle/ref_cpu.py bf16, 1 sample (336x336 image, {T}-token prompt, S={S}): ViT-L/14 24 blocks "
+                sample=(f"oracle/ref_cpu.py {str(dt).split('.')[-1]} on {cores} of {ncpu} host threads (fastest of a threads x dtype probe), 1 sample (336x336 image, {T}-token prompt, S={S}): ViT-L/14 24 blocks "
                         f"{t_vit:.1f}s + {done}/{args.n_layers} decoder layers {t_dec:.1f}s (weights aliased across layers)"
                         + ("" if done == args.n_layers else f"; decoder time scaled x{args.n_layers / done:.2f} by layer count")),
                 seconds=round(el, 1))
