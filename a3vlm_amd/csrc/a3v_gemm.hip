@@ -20,8 +20,7 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int STAGE_BYTES = (BM + BN) * BK * 2;  // 32 KiB
+constexpr int BK = 64;
 constexpr int GROUP_M = 8;
 
 struct GemmArgs {
@@ -33,19 +32,22 @@ struct GemmArgs {
   int64_t lda, ldw, ldc, ldr;
   int M, N, K, epi;
   int tiles_m, tiles_n;
+  int dbg;   // ablation switches for tuning runs (0 in production): 1 = no DMA in the k-loop, 2 = no ds_read in the k-loop
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float quick_gelu(float x) { return x / (1.f + __expf(-1.702f * x)); }
 __device__ __forceinline__ float silu(float x) { return x / (1.f + __expf(-x)); }
 
-// Stage one 128-row x 64-k bf16 tile (16 KiB) with LDS-DMA.  16 chunks of 8 rows; a wave
-// issues 4 chunk loads, 1 KiB each: lane -> (row = chunk*8 + lane/8, physical slot = lane%8).
+// Stage one ROWS-row x 64-k bf16 tile with LDS-DMA.  Chunks of 8 rows (1 KiB = one wave
+// instruction); lane -> (row = chunk*8 + lane/8, physical 16-B slot = lane%8).
+template <int ROWS, int NWAVES>
 __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, int64_t ld, int row0,
                                            int last_row, int k0, char* lds_tile, int wave, int lane) {
+  constexpr int PER_WAVE = ROWS / 8 / NWAVES;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = wave * 4 + i;
+  for (int i = 0; i < PER_WAVE; ++i) {
+    const int c = wave * PER_WAVE + i;
     const int r = c * 8 + (lane >> 3);
     const int s = (lane & 7) ^ ((r >> 1) & 7);
     int gr = row0 + r;
@@ -56,82 +58,23 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, int64_t
   }
 }
 
-__global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs p) {
-  __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE_BYTES];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-
-  // ---- XCD-aware tile map (bijective for any grid size) ----
-  const int nwg = gridDim.x;
-  int bid = blockIdx.x;
-  {
-    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  const int per_group = GROUP_M * p.tiles_n;
-  const int group = bid / per_group;
-  const int first_m = group * GROUP_M;
-  const int gsz = min(p.tiles_m - first_m, GROUP_M);
-  const int in_g = bid - group * per_group;
-  const int tm = first_m + in_g % gsz;
-  const int tn = in_g / gsz;
-  const int m0 = tm * BM, n0 = tn * BN;
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nk = p.K / BK;
-  stage_tile(p.A, p.lda, m0, p.M - 1, 0, lds, wave, lane);
-  stage_tile(p.W, p.ldw, n0, p.N - 1, 0, lds + BM * BK * 2, wave, lane);
-  __syncthreads();
-
-  const int frow = lane & 15;            // row inside a 16-row MFMA tile
-  const int fsw = (lane >> 1) & 7;       // ((row>>1)&7) -- tile bases are multiples of 16
-  const int fks = lane >> 4;             // k-slot 0..3 inside a K=32 slice
-  for (int t = 0; t < nk; ++t) {
-    char* cur = lds + (t & 1) * STAGE_BYTES;
-    if (t + 1 < nk) {
-      char* nxt = lds + ((t + 1) & 1) * STAGE_BYTES;
-      stage_tile(p.A, p.lda, m0, p.M - 1, (t + 1) * BK, nxt, wave, lane);
-      stage_tile(p.W, p.ldw, n0, p.N - 1, (t + 1) * BK, nxt + BM * BK * 2, wave, lane);
-    }
-    const char* At = cur + (wm * 64 + frow) * 128;
-    const char* Wt = cur + BM * BK * 2 + (wn * 64 + frow) * 128;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int off = ((kk * 4 + fks) ^ fsw) << 4;
-      bf16x8 af[4], wf[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(At + i * 16 * 128 + off);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(Wt + j * 16 * 128 + off);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
-    }
-    __syncthreads();
-  }
-
+// Epilogue shared by the tile kernels.  The lane holds, for each (i, j) MFMA tile,
+// C[m = mbase + 16 i + (lane&15)][n = nbase + 16 j + 4 (lane>>4) + 0..3].
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GemmArgs& p, int mbase, int nbase, int lane) {
   // ---- epilogue: lane holds C[m][n..n+3], m = .. + (lane&15), n = .. + (lane>>4)*4 ----
   const int epi = p.epi;
   const int mrow = lane & 15;
   const int ncol = (lane >> 4) * 4;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + mrow;
+  for (int i = 0; i < TM; ++i) {
+    const int m = mbase + i * 16 + mrow;
     if (m >= p.M) continue;
     if (epi & A3V_EPI_SWIGLU) {
       // W rows interleaved in blocks of 16: even 16-block = w1 (gate), odd = w3 (up)
 #pragma unroll
-      for (int j = 0; j < 4; j += 2) {
-        const int n = n0 + wn * 64 + j * 16;        // interleaved row of the gate block
+      for (int j = 0; j < TN; j += 2) {
+        const int n = nbase + j * 16;        // interleaved row of the gate block
         if (n >= p.N) continue;
         const int oc = (n >> 1) + ncol;             // output column
         bf16x4 o;
@@ -146,8 +89,8 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs p) {
       continue;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + ncol;
+    for (int j = 0; j < TN; ++j) {
+      const int n = nbase + j * 16 + ncol;
       if (n >= p.N) continue;
       float v[4];
 #pragma unroll
@@ -192,6 +135,483 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs p) {
       }
     }
   }
+}
+
+// TBM x TBN block tile, WAVES_M x WAVES_N waves, each wave (TBM/WAVES_M) x (TBN/WAVES_N).
+template <int TBM, int TBN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_bf16_kernel(GemmArgs p) {
+  constexpr int NW = WAVES_M * WAVES_N;
+  constexpr int WTM = TBM / WAVES_M, WTN = TBN / WAVES_N;   // wave tile
+  constexpr int TM = WTM / 16, TN = WTN / 16;               // MFMA tiles per wave
+  constexpr int STAGE = (TBM + TBN) * BK * 2;
+  static_assert(TN % 2 == 0, "SwiGLU pairing needs an even number of 16-column tiles per wave");
+  __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  // ---- XCD-aware tile map (bijective for any grid size) ----
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int per_group = GROUP_M * p.tiles_n;
+  const int group = bid / per_group;
+  const int first_m = group * GROUP_M;
+  const int gsz = min(p.tiles_m - first_m, GROUP_M);
+  const int in_g = bid - group * per_group;
+  const int tm = first_m + in_g % gsz;
+  const int tn = in_g / gsz;
+  const int m0 = tm * TBM, n0 = tn * TBN;
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / BK;
+  stage_tile<TBM, NW>(p.A, p.lda, m0, p.M - 1, 0, lds, wave, lane);
+  stage_tile<TBN, NW>(p.W, p.ldw, n0, p.N - 1, 0, lds + TBM * BK * 2, wave, lane);
+  __syncthreads();
+
+  const int frow = lane & 15;            // row inside a 16-row MFMA tile
+  const int fsw = (lane >> 1) & 7;       // ((row>>1)&7) -- tile bases are multiples of 16
+  const int fks = lane >> 4;             // k-slot 0..3 inside a K=32 slice
+  for (int t = 0; t < nk; ++t) {
+    char* cur = lds + (t & 1) * STAGE;
+    if (t + 1 < nk) {
+      char* nxt = lds + ((t + 1) & 1) * STAGE;
+      stage_tile<TBM, NW>(p.A, p.lda, m0, p.M - 1, (t + 1) * BK, nxt, wave, lane);
+      stage_tile<TBN, NW>(p.W, p.ldw, n0, p.N - 1, (t + 1) * BK, nxt + TBM * BK * 2, wave, lane);
+    }
+    const char* At = cur + (wm * WTM + frow) * 128;
+    const char* Wt = cur + TBM * BK * 2 + (wn * WTN + frow) * 128;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int off = ((kk * 4 + fks) ^ fsw) << 4;
+      bf16x8 af[TM], wf[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(Wt + j * 16 * 128 + off);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(At + i * 16 * 128 + off);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  gemm_epilogue<TM, TN>(acc, p, m0 + wm * WTM, n0 + wn * WTN, lane);
+}
+
+// Epilogue for v_mfma_f32_32x32x16 accumulators (D = W_frag x A_frag): for tile (i, j) the lane holds
+// C[m = mbase + 32 i + (lane&31)][n = nbase + 32 j + 8 g + 4 (lane>>5) + 0..3], g = reg/4.
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue32(f32x16 (&acc)[TM][TN], const GemmArgs& p, int mbase, int nbase, int lane) {
+  const int epi = p.epi;
+  const int mrow = lane & 31;
+  const int hh4 = (lane >> 5) * 4;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = mbase + i * 32 + mrow;
+    if (m >= p.M) continue;
+    if (epi & A3V_EPI_SWIGLU) {
+      // 16-row interleave: tile rows 0..15 = gate, 16..31 = up  ->  reg groups g (gate) / g+2 (up)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = nbase + j * 32;
+        if (n >= p.N) continue;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const int oc = (n >> 1) + 8 * g + hh4;
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float gt = rbf(acc[i][j][4 * g + r]);
+            const float up = rbf(acc[i][j][4 * (g + 2) + r]);
+            o[r] = f2bf(rbf(silu(gt)) * up);
+          }
+          *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + oc) = o;
+        }
+      }
+      continue;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = nbase + j * 32 + 8 * g + hh4;
+        if (n >= p.N) continue;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][4 * g + r];
+        if (epi & A3V_EPI_BIAS) {
+          const bf16x4 b = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(p.bias) + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += bf2f(b[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = rbf(v[r]);
+        if (epi & A3V_EPI_GELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = rbf(gelu_erf(v[r]));
+        } else if (epi & A3V_EPI_QUICKGELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = rbf(quick_gelu(v[r]));
+        }
+        if (epi & A3V_EPI_RES_F32) {
+          const f32x4 rr = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.res) + (int64_t)m * p.ldr + n);
+          f32x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = rr[r] + v[r];
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n) = o;
+          continue;
+        }
+        if (epi & A3V_EPI_RESIDUAL) {
+          const bf16x4 rr = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(p.res) + (int64_t)m * p.ldr + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = bf2f(rr[r]) + v[r];
+        }
+        if (epi & A3V_EPI_OUT_F32) {
+          f32x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = v[r];
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n) = o;
+        } else {
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = f2bf(v[r]);
+          *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + n) = o;
+        }
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// 256x256x64 "ping-pong" kernel: 8 waves = 2 groups of 4 (wr = wave/4 owns 128 rows of A; the
+// waves w and w+4 share a SIMD).  Each group alternates a LOAD interval (24 ds_read_b128 for a
+// whole K-tile of its 128x64 wave tile, + its share of the LDS-DMA for a later K-tile) and an
+// MFMA interval (64 v_mfma_f32_16x16x32_bf16 from registers); the groups run ONE barrier apart,
+// so on every SIMD one wave feeds the matrix pipe while its partner reads LDS / issues DMA.
+//
+//   interval:   1      2      3      4      5      6
+//   group 0:   L(0)   M(0)   L(1)   M(1)   L(2)   M(2) ...      L(t): reads buf[t&1]
+//   group 1:    -     L(0)   M(0)   L(1)   M(1)   L(2) ...
+//   DMA issue:               t=2           t=3           ...    tile t+2 -> buf[t&1]: by group 0 in
+//   DMA wait :                      t=2           t=3    ...    L(t+1), by group 1 in M(t) (same interval:
+//                                                                 the first one after BOTH groups read tile t)
+// Ordering rules used (guide: "read a staged buffer one phase AFTER the wait that retires it"):
+// every wave waits vmcnt(0) for its own DMA pieces in the interval after it issued them, then the
+// interval barrier publishes them; readers start one barrier later.  A wave retires its own
+// ds_reads (lgkmcnt(0)) BEFORE the barrier that ends its LOAD interval, so a buffer is only
+// re-staged after every read of it has returned.
+#ifdef PP_PIN
+#define PP_SB() __builtin_amdgcn_sched_barrier(0)
+#else
+#define PP_SB() do {} while (0)
+#endif
+#define A3V_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define A3V_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define A3V_BARRIER()                      \
+  do {                                     \
+    asm volatile("" ::: "memory");         \
+    __builtin_amdgcn_s_barrier();          \
+    asm volatile("" ::: "memory");         \
+  } while (0)
+
+template <int DBG>
+__global__ __launch_bounds__(512) void gemm_nt_bf16_pp_kernel(GemmArgs p) {
+  constexpr int TBM = 256, TBN = 256, NW = 8, WTM = 128, WTN = 64, TM = 8, TN = 4;
+  constexpr int STAGE = (TBM + TBN) * BK * 2;   // 64 KiB
+  __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int per_group = GROUP_M * p.tiles_n;
+  const int group = bid / per_group;
+  const int first_m = group * GROUP_M;
+  const int gsz = min(p.tiles_m - first_m, GROUP_M);
+  const int in_g = bid - group * per_group;
+  const int tm = first_m + in_g % gsz;
+  const int tn = in_g / gsz;
+  const int m0 = tm * TBM, n0 = tn * TBN;
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / BK;
+  // LDS-DMA through buffer descriptors: rows past M / N are out of range and read as zero (no
+  // clamping VALU), addresses are {SGPR descriptor, 32-bit VGPR offset, SGPR k-offset}.
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)(((int64_t)(p.M - 1) * p.lda + p.K) * 2), 0x00020000);
+  const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)(((int64_t)(p.N - 1) * p.ldw + p.K) * 2), 0x00020000);
+  // per-lane byte offset inside an 8-row chunk: row = lane/8, 16-B slot = (lane%8) ^ ((chunk*4 + lane/16) & 7)
+  const unsigned lr = lane >> 3;
+  unsigned voA[2], voW[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par) {
+    const unsigned sl = (lane & 7) ^ ((par * 4 + (lane >> 4)) & 7);
+    voA[par] = (unsigned)((lr * p.lda + sl * 8) * 2);
+    voW[par] = (unsigned)((lr * p.ldw + sl * 8) * 2);
+  }
+  // one 1-KiB DMA piece: c in [0,8): 0..3 -> A chunks, 4..7 -> W chunks of this wave
+  auto stage_piece = [&](int t, int c) {
+    const int ch = wave * 4 + (c & 3);
+    char* dst = lds + (t & 1) * STAGE + (c >= 4 ? TBM * BK * 2 : 0) + ch * 1024;
+    if (c < 4) {
+      // (row-chunk + k) offset is wave-uniform and changes with t: an SGPR sum added per piece, so
+      // nothing per-piece stays live in VGPRs across the loop
+      const unsigned so = (unsigned)(((int64_t)(m0 + ch * 8) * p.lda + t * BK) * 2);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)dst, 16, voA[c & 1] + so, 0, 0, 0);
+    } else {
+      const unsigned so = (unsigned)(((int64_t)(n0 + ch * 8) * p.ldw + t * BK) * 2);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)dst, 16, voW[c & 1] + so, 0, 0, 0);
+    }
+  };
+  auto stage = [&](int t) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) stage_piece(t, c);
+  };
+  stage(0);
+  if (nk > 1) stage(1);
+  A3V_WAIT_VM0();
+  A3V_BARRIER();
+
+  const int frow = lane & 15, fsw = (lane >> 1) & 7, fks = lane >> 4;
+  const int off0 = ((0 * 4 + fks) ^ fsw) << 4, off1 = ((1 * 4 + fks) ^ fsw) << 4;
+  const int a_base = (wr * WTM + frow) * 128;
+  const int w_base = TBM * BK * 2 + (wc * WTN + frow) * 128;
+  bf16x8 af0[TM], af1[TM], wf0[TN], wf1[TN];
+
+#define PP_READ_FRAGS(cur)                                                                           \
+  do {                                                                                               \
+    const char* At_ = (cur) + a_base;                                                                \
+    const char* Wt_ = (cur) + w_base;                                                                \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                 \
+      wf0[j] = *reinterpret_cast<const bf16x8*>(Wt_ + j * 2048 + off0);                              \
+      wf1[j] = *reinterpret_cast<const bf16x8*>(Wt_ + j * 2048 + off1);                              \
+    }                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                 \
+      af0[i] = *reinterpret_cast<const bf16x8*>(At_ + i * 2048 + off0);                              \
+      af1[i] = *reinterpret_cast<const bf16x8*>(At_ + i * 2048 + off1);                              \
+    }                                                                                                \
+  } while (0)
+
+#define PP_MFMA_ALL()                                                                                \
+  do {                                                                                               \
+    __builtin_amdgcn_s_setprio(1);                                                                   \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                   \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                 \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[j], af0[i], acc[i][j], 0, 0, 0);     \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                   \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                 \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[j], af1[i], acc[i][j], 0, 0, 0);     \
+    __builtin_amdgcn_s_setprio(0);                                                                   \
+  } while (0)
+
+  constexpr bool do_dma = !(DBG & 1), do_rd = !(DBG & 2);
+  if (wr == 0) {
+    for (int t = 0; t < nk; ++t) {
+      if (do_rd || t == 0) PP_READ_FRAGS(lds + (t & 1) * STAGE);
+      if (do_dma && t >= 1 && t + 1 < nk) stage(t + 1);
+      A3V_WAIT_LGKM0();
+      A3V_BARRIER();
+      PP_MFMA_ALL();
+      A3V_WAIT_VM0();
+      A3V_BARRIER();
+    }
+    A3V_BARRIER();
+  } else {
+    A3V_BARRIER();
+    for (int t = 0; t < nk; ++t) {
+      if (do_rd || t == 0) PP_READ_FRAGS(lds + (t & 1) * STAGE);
+      A3V_WAIT_LGKM0();
+      A3V_WAIT_VM0();
+      A3V_BARRIER();
+#ifndef PP_INTERLEAVE
+      if (do_dma && t + 2 < nk) stage(t + 2);
+      PP_MFMA_ALL();
+#else
+      {
+        // DMA pieces spread through the MFMA stream: one piece per 8 MFMAs
+        const bool has = do_dma && (t + 2 < nk);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          if (has) stage_piece(t + 2, c);
+          PP_SB();
+          if (c < 4) {
+#pragma unroll
+            for (int i = 2 * c; i < 2 * c + 2; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[j], af0[i], acc[i][j], 0, 0, 0);
+          } else {
+#pragma unroll
+            for (int i = 2 * (c - 4); i < 2 * (c - 4) + 2; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[j], af1[i], acc[i][j], 0, 0, 0);
+          }
+          PP_SB();
+        }
+        __builtin_amdgcn_s_setprio(0);
+      }
+#endif
+      A3V_BARRIER();
+    }
+  }
+#undef PP_READ_FRAGS
+#undef PP_MFMA_ALL
+  gemm_epilogue<TM, TN>(acc, p, m0 + wr * WTM, n0 + wc * WTN, lane);
+}
+
+// Same schedule with v_mfma_f32_32x32x16_bf16 (8-pass, higher sustained rate than 16x16x32):
+// wave tile 128x64 = 4x2 tiles of 32x32, 4 k-steps of 16 per K-tile, 32 MFMAs per interval.
+template <int DBG>
+__global__ __launch_bounds__(512) void gemm_nt_bf16_pp32_kernel(GemmArgs p) {
+  constexpr int TBM = 256, TBN = 256, NW = 8, WTM = 128, WTN = 64, TM = 4, TN = 2;
+  constexpr int STAGE = (TBM + TBN) * BK * 2;   // 64 KiB
+  __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int per_group = GROUP_M * p.tiles_n;
+  const int group = bid / per_group;
+  const int first_m = group * GROUP_M;
+  const int gsz = min(p.tiles_m - first_m, GROUP_M);
+  const int in_g = bid - group * per_group;
+  const int tm = first_m + in_g % gsz;
+  const int tn = in_g / gsz;
+  const int m0 = tm * TBM, n0 = tn * TBN;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = p.K / BK;
+  // LDS-DMA through buffer descriptors: rows past M / N are out of range and read as zero (no
+  // clamping VALU), addresses are {SGPR descriptor, 32-bit VGPR offset, SGPR k-offset}.
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)(((int64_t)(p.M - 1) * p.lda + p.K) * 2), 0x00020000);
+  const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)(((int64_t)(p.N - 1) * p.ldw + p.K) * 2), 0x00020000);
+  // per-lane byte offset inside an 8-row chunk: row = lane/8, 16-B slot = (lane%8) ^ ((chunk*4 + lane/16) & 7)
+  const unsigned lr = lane >> 3;
+  unsigned voA[2], voW[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par) {
+    const unsigned sl = (lane & 7) ^ ((par * 4 + (lane >> 4)) & 7);
+    voA[par] = (unsigned)((lr * p.lda + sl * 8) * 2);
+    voW[par] = (unsigned)((lr * p.ldw + sl * 8) * 2);
+  }
+  // one 1-KiB DMA piece: c in [0,8): 0..3 -> A chunks, 4..7 -> W chunks of this wave
+  auto stage_piece = [&](int t, int c) {
+    const int ch = wave * 4 + (c & 3);
+    char* dst = lds + (t & 1) * STAGE + (c >= 4 ? TBM * BK * 2 : 0) + ch * 1024;
+    if (c < 4) {
+      // (row-chunk + k) offset is wave-uniform and changes with t: an SGPR sum added per piece, so
+      // nothing per-piece stays live in VGPRs across the loop
+      const unsigned so = (unsigned)(((int64_t)(m0 + ch * 8) * p.lda + t * BK) * 2);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)dst, 16, voA[c & 1] + so, 0, 0, 0);
+    } else {
+      const unsigned so = (unsigned)(((int64_t)(n0 + ch * 8) * p.ldw + t * BK) * 2);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)dst, 16, voW[c & 1] + so, 0, 0, 0);
+    }
+  };
+  auto stage = [&](int t) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) stage_piece(t, c);
+  };
+  stage(0);
+  if (nk > 1) stage(1);
+  A3V_WAIT_VM0();
+  A3V_BARRIER();
+
+  // fragments: lane -> row (lane&31) of a 32-row tile, 16-B slot kk*2 + (lane>>5) of the 64-k row
+  const int frow = lane & 31, fsw = (lane >> 1) & 7, fhh = lane >> 5;
+  int offk[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) offk[kk] = ((kk * 2 + fhh) ^ fsw) << 4;
+  const int a_base = (wr * WTM + frow) * 128;
+  const int w_base = TBM * BK * 2 + (wc * WTN + frow) * 128;
+  bf16x8 af[4][TM], wf[4][TN];
+
+#define PP_READ_FRAGS(cur)                                                                           \
+  do {                                                                                               \
+    const char* At_ = (cur) + a_base;                                                                \
+    const char* Wt_ = (cur) + w_base;                                                                \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                               \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                 \
+        wf[kk][j] = *reinterpret_cast<const bf16x8*>(Wt_ + j * 4096 + offk[kk]);                     \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                 \
+        af[kk][i] = *reinterpret_cast<const bf16x8*>(At_ + i * 4096 + offk[kk]);                     \
+    }                                                                                                \
+  } while (0)
+
+#define PP_MFMA_ALL()                                                                                \
+  do {                                                                                               \
+    __builtin_amdgcn_s_setprio(1);                                                                   \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                 \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                 \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                               \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][j], af[kk][i], acc[i][j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                   \
+  } while (0)
+
+  constexpr bool do_dma = !(DBG & 1), do_rd = !(DBG & 2);
+  if (wr == 0) {
+    for (int t = 0; t < nk; ++t) {
+      if (do_rd || t == 0) PP_READ_FRAGS(lds + (t & 1) * STAGE);
+      if (do_dma && t >= 1 && t + 1 < nk) stage(t + 1);
+      A3V_WAIT_LGKM0();
+      A3V_BARRIER();
+      PP_MFMA_ALL();
+      A3V_WAIT_VM0();
+      A3V_BARRIER();
+    }
+    A3V_BARRIER();
+  } else {
+    A3V_BARRIER();
+    for (int t = 0; t < nk; ++t) {
+      if (do_rd || t == 0) PP_READ_FRAGS(lds + (t & 1) * STAGE);
+      A3V_WAIT_LGKM0();
+      A3V_WAIT_VM0();
+      A3V_BARRIER();
+      if (do_dma && t + 2 < nk) stage(t + 2);
+      PP_MFMA_ALL();
+      A3V_BARRIER();
+    }
+  }
+#undef PP_READ_FRAGS
+#undef PP_MFMA_ALL
+  gemm_epilogue32<TM, TN>(acc, p, m0 + wr * WTM, n0 + wc * WTN, lane);
 }
 
 // ------------------------------------------------------------------------------------
@@ -411,9 +831,71 @@ extern "C" int a3v_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ld
   GemmArgs p;
   p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.C = C; p.bias = bias; p.res = residual;
   p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr;
-  p.M = M; p.N = N; p.K = K; p.epi = epilogue;
-  p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
-  hipLaunchKernelGGL(gemm_nt_bf16_kernel, dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
+  p.M = M; p.N = N; p.K = K; p.epi = epilogue & 0xffff;
+  p.dbg = (epilogue >> 24) & 0xf;
+  // Tile choice.  256x256 ping-pong (8 waves, 1 block/CU) for the rows that fill whole 256-row
+  // tiles when its grid keeps the 256 CUs busy (>= 75 % of its last round); the remaining (< 256)
+  // rows, and every problem the big tile would quantise badly, go to the 128x128 kernel (4 waves,
+  // 2 blocks/CU).  A3V_EPI_TILE_* force one configuration for the whole problem (tuning / tests).
+  auto launch = [&](int cfg, GemmArgs q) {
+    if (cfg == 128) {
+      q.tiles_m = (q.M + 127) / 128; q.tiles_n = (q.N + 127) / 128;
+      hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 128, 2, 2>), dim3(q.tiles_m * q.tiles_n), dim3(256), 0, st, q);
+      return;
+    }
+    q.tiles_m = (q.M + 255) / 256; q.tiles_n = (q.N + 255) / 256;
+    const dim3 g(q.tiles_m * q.tiles_n), b(512);
+    if (cfg == 256) hipLaunchKernelGGL((gemm_nt_bf16_kernel<256, 256, 2, 4>), g, b, 0, st, q);
+    else if (cfg == 258) hipLaunchKernelGGL(gemm_nt_bf16_pp32_kernel<0>, g, b, 0, st, q);
+    else {
+      switch (q.dbg) {
+        case 0: hipLaunchKernelGGL(gemm_nt_bf16_pp_kernel<0>, g, b, 0, st, q); break;
+#ifdef A3V_ABLATION
+        case 1: hipLaunchKernelGGL(gemm_nt_bf16_pp_kernel<1>, g, b, 0, st, q); break;
+        case 2: hipLaunchKernelGGL(gemm_nt_bf16_pp_kernel<2>, g, b, 0, st, q); break;
+        case 3: hipLaunchKernelGGL(gemm_nt_bf16_pp_kernel<3>, g, b, 0, st, q); break;
+#endif
+        default: break;
+      }
+    }
+  };
+  const int64_t bytesA = ((int64_t)(M - 1) * lda + K) * 2, bytesW = ((int64_t)(N - 1) * ldw + K) * 2;
+  const bool desc_ok = bytesA < (1LL << 31) && bytesW < (1LL << 31);   // buffer descriptors: 32-bit offsets
+  if (epilogue & (A3V_EPI_TILE_256PP32 | A3V_EPI_TILE_256PP | A3V_EPI_TILE_256 | A3V_EPI_TILE_128)) {
+    int cfg = 128;
+    if (epilogue & A3V_EPI_TILE_256PP32) cfg = 258;
+    else if (epilogue & A3V_EPI_TILE_256PP) cfg = 257;
+    else if (epilogue & A3V_EPI_TILE_256) cfg = 256;
+    if (cfg > 256 && !desc_ok) return A3V_ERR_SHAPE;
+    launch(cfg, p);
+  } else {
+    auto last_fill = [](long tiles, long* rounds) {
+      *rounds = (tiles + 255) / 256;
+      return tiles ? (double)(tiles - (*rounds - 1) * 256) / 256.0 : 0.0;
+    };
+    const long tn256 = (N + 255) / 256;
+    long r_all, r_big;
+    const double f_all = last_fill((long)((M + 255) / 256) * tn256, &r_all);
+    const int m_big = (M / 256) * 256;
+    const double f_big = last_fill((long)(m_big / 256) * tn256, &r_big);
+    const bool eligible = desc_ok && M >= 512 && N >= 512;
+    if (eligible && (r_all >= 6 || f_all >= 0.5)) {
+      launch(257, p);                       // ping-pong alone: its own tail is small or well filled
+    } else if (eligible && M > m_big && f_big >= 0.75) {
+      GemmArgs q = p;                       // whole rounds on the big tile, the last < 256 rows on 128x128
+      q.M = m_big;
+      launch(257, q);
+      GemmArgs r = p;
+      r.M = M - m_big;
+      r.A = p.A + (int64_t)m_big * lda;
+      const int esz = (p.epi & (A3V_EPI_OUT_F32 | A3V_EPI_RES_F32)) ? 4 : 2;
+      r.C = (char*)p.C + (int64_t)m_big * ldc * esz;
+      if (p.res) r.res = (const char*)p.res + (int64_t)m_big * ldr * ((p.epi & A3V_EPI_RES_F32) ? 4 : 2);
+      launch(128, r);
+    } else {
+      launch(128, p);
+    }
+  }
   A3V_LAUNCH_CHECK();
   return A3V_OK;
 }

@@ -49,8 +49,12 @@ enum {
   A3V_EPI_SWIGLU = 16,     /* W rows interleaved [w1 blk16 | w3 blk16]: out[:, N/2] =
                               silu(x w1^T) * (x w3^T)   (LLM/llama_ens5.py:213-217)   */
   A3V_EPI_OUT_F32 = 32,    /* store fp32 (logits .float(), LLM/llama_ens5.py:531)     */
-  A3V_EPI_RES_F32 = 64     /* residual stream (and output) kept in fp32 (training
+  A3V_EPI_RES_F32 = 64,    /* residual stream (and output) kept in fp32 (training
                               under autocast: engine_finetune.py:44-50)               */
+  A3V_EPI_TILE_128 = 1 << 16,  /* force the 128x128 tile kernel (tuning / tests)       */
+  A3V_EPI_TILE_256 = 1 << 17,  /* force the 256x256 tile kernel (tuning / tests)       */
+  A3V_EPI_TILE_256PP = 1 << 18,/* force the 256x256 ping-pong kernel (tuning / tests)  */
+  A3V_EPI_TILE_256PP32 = 1 << 19 /* ... its 32x32x16-MFMA form                         */
 };
 
 int a3v_version(void);

@@ -51,6 +51,30 @@ def test_gemm_bf16_plain(M, N, K):
     assert_close(out, want, rtol=2 ** -7, atol=1e-3 * math.sqrt(K) * 0.05, what=f"gemm {M}x{N}x{K}")
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 520, 128), (1000, 1300, 256), (257, 4096, 64), (2048, 2048, 1024), (515, 777 // 4 * 4, 192)])
+def test_gemm_bf16_tile_configs_agree(M, N, K):
+    """128x128 and 256x256 tile kernels accumulate every output in the same k order: bit-identical."""
+    from a3vlm_amd import lib
+    a, w = gen(M, K, seed=60).to(BF).to(DEV), (gen(N, K, seed=61, scale=0.05)).to(BF).to(DEV)
+    bias = gen(N, seed=62).to(BF).to(DEV)
+    o1 = torch.empty(M, N, dtype=BF, device=DEV)
+    o2 = torch.empty(M, N, dtype=BF, device=DEV)
+    ops.gemm_nt(a, w, o1, bias=bias, epilogue=ops.EPI_GELU | lib.EPI_TILE_128)
+    ops.gemm_nt(a, w, o2, bias=bias, epilogue=ops.EPI_GELU | lib.EPI_TILE_256)
+    assert torch.equal(o1, o2)
+    want = rt(F.gelu(rt(a.float().cpu() @ w.float().cpu().t() + bias.float().cpu())))
+    o3 = torch.empty(M, N, dtype=BF, device=DEV)
+    for _ in range(3):   # ping-pong kernel: repeat to give a race a chance to show
+        o3.zero_()
+        ops.gemm_nt(a, w, o3, bias=bias, epilogue=ops.EPI_GELU | lib.EPI_TILE_256PP)
+        assert torch.equal(o1, o3)
+        o3.zero_()   # 32x32x16 MFMA form: different in-instruction summation order -> tolerance, not bits
+        ops.gemm_nt(a, w, o3, bias=bias, epilogue=ops.EPI_GELU | lib.EPI_TILE_256PP32)
+        assert_close(o3, want, rtol=2 ** -6, atol=4e-3, what="gemm pp32")
+    want = rt(F.gelu(rt(a.float().cpu() @ w.float().cpu().t() + bias.float().cpu())))
+    assert_close(o2, want, rtol=2 ** -6, atol=4e-3, what="gemm 256 tile")
+
+
 def test_gemm_bf16_transpose_detecting():
     """A = [I | 0] against an ASYMMETRIC W: catches swapped row/col in the MFMA C-write."""
     M, N, K = 128, 256, 128
