@@ -325,7 +325,7 @@ __device__ __forceinline__ void gemm_epilogue32(f32x16 (&acc)[TM][TN], const Gem
     asm volatile("" ::: "memory");         \
   } while (0)
 
-template <int DBG>
+template <int DBG, int SCHED>
 __global__ __launch_bounds__(512) void gemm_nt_bf16_pp_kernel(GemmArgs p) {
   constexpr int TBM = 256, TBN = 256, NW = 8, WTM = 128, WTN = 64, TM = 8, TN = 4;
   constexpr int STAGE = (TBM + TBN) * BK * 2;   // 64 KiB
@@ -426,24 +426,72 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_pp_kernel(GemmArgs p) {
   } while (0)
 
   constexpr bool do_dma = !(DBG & 1), do_rd = !(DBG & 2);
-  if (wr == 0) {
+  // DBG == 4: cycle stamps (s_memtime) of block 0, waves 0 and 4, into the buffer passed as `bias`
+  unsigned long long* stamps = (DBG == 4 && blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0)
+                                   ? (unsigned long long*)p.bias + (wave ? 1 : 0) * 64 * 8 : nullptr;
+#define PP_STAMP(t, k) do { if (DBG == 4 && stamps && (t) < 64) stamps[(t) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+  if constexpr (SCHED == 1) {
+    // Schedule 1: both groups issue the DMA of tile t+1 in their own LOAD interval (the MFMA intervals
+    // carry no VMEM issue) and wait for it at the end of that interval.  That only works if the DMA
+    // hits in L2, so every wave also TOUCHES one 128-B line of tile t+3 per K-tile (one dword per lane:
+    // waves 0-3 cover the 256 A rows, waves 4-7 the 256 W rows) -- a software L2 prefetch that takes
+    // the fabric (MALL/HBM) latency out of the DMA's completion time.  The touch is the youngest VMEM
+    // op at the interval's wait, hence vmcnt(1).
+    const unsigned pf_vo = (unsigned)((int64_t)((wave & 3) * 64 + lane) * (wr ? p.ldw : p.lda) * 2
+                                      + (int64_t)(wr ? n0 : m0) * (wr ? p.ldw : p.lda) * 2);
+    const auto pf_rs = wr ? rsW : rsA;
+    int pf = 0;
+    if (wr == 1) A3V_BARRIER();
     for (int t = 0; t < nk; ++t) {
+      PP_STAMP(t, 0);
+      asm volatile("" ::"v"(pf));            // retire the previous touch (compiler-inserted vmcnt)
+      PP_READ_FRAGS(lds + (t & 1) * STAGE);
+      if (do_dma && t >= 1 && t + 1 < nk) stage(t + 1);
+      {
+        const int tp = min(t + 3, nk - 1);
+        pf = __builtin_amdgcn_raw_buffer_load_b32(pf_rs, pf_vo, tp * BK * 2, 0);
+      }
+      A3V_WAIT_LGKM0();
+      PP_STAMP(t, 1);
+      asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      PP_STAMP(t, 2);
+      A3V_BARRIER();
+      PP_STAMP(t, 3);
+      PP_MFMA_ALL();
+      PP_STAMP(t, 4);
+      A3V_BARRIER();
+      PP_STAMP(t, 5);
+    }
+    asm volatile("" ::"v"(pf));
+    if (wr == 0) A3V_BARRIER();
+  } else if (wr == 0) {
+    for (int t = 0; t < nk; ++t) {
+      PP_STAMP(t, 0);
       if (do_rd || t == 0) PP_READ_FRAGS(lds + (t & 1) * STAGE);
       if (do_dma && t >= 1 && t + 1 < nk) stage(t + 1);
       A3V_WAIT_LGKM0();
+      PP_STAMP(t, 1);
       A3V_BARRIER();
+      PP_STAMP(t, 2);
       PP_MFMA_ALL();
+      PP_STAMP(t, 3);
       A3V_WAIT_VM0();
+      PP_STAMP(t, 4);
       A3V_BARRIER();
+      PP_STAMP(t, 5);
     }
     A3V_BARRIER();
   } else {
     A3V_BARRIER();
     for (int t = 0; t < nk; ++t) {
+      PP_STAMP(t, 0);
       if (do_rd || t == 0) PP_READ_FRAGS(lds + (t & 1) * STAGE);
       A3V_WAIT_LGKM0();
+      PP_STAMP(t, 1);
       A3V_WAIT_VM0();
+      PP_STAMP(t, 2);
       A3V_BARRIER();
+      PP_STAMP(t, 3);
 #ifndef PP_INTERLEAVE
       if (do_dma && t + 2 < nk) stage(t + 2);
       PP_MFMA_ALL();
@@ -474,9 +522,12 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_pp_kernel(GemmArgs p) {
         __builtin_amdgcn_s_setprio(0);
       }
 #endif
+      PP_STAMP(t, 4);
       A3V_BARRIER();
+      PP_STAMP(t, 5);
     }
   }
+#undef PP_STAMP
 #undef PP_READ_FRAGS
 #undef PP_MFMA_ALL
   gemm_epilogue<TM, TN>(acc, p, m0 + wr * WTM, n0 + wc * WTN, lane);
@@ -849,11 +900,14 @@ extern "C" int a3v_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ld
     else if (cfg == 258) hipLaunchKernelGGL(gemm_nt_bf16_pp32_kernel<0>, g, b, 0, st, q);
     else {
       switch (q.dbg) {
-        case 0: hipLaunchKernelGGL(gemm_nt_bf16_pp_kernel<0>, g, b, 0, st, q); break;
+        case 0: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<0, 0>), g, b, 0, st, q); break;
 #ifdef A3V_ABLATION
-        case 1: hipLaunchKernelGGL(gemm_nt_bf16_pp_kernel<1>, g, b, 0, st, q); break;
-        case 2: hipLaunchKernelGGL(gemm_nt_bf16_pp_kernel<2>, g, b, 0, st, q); break;
-        case 3: hipLaunchKernelGGL(gemm_nt_bf16_pp_kernel<3>, g, b, 0, st, q); break;
+        case 1: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<1, 0>), g, b, 0, st, q); break;
+        case 2: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<2, 0>), g, b, 0, st, q); break;
+        case 3: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<3, 0>), g, b, 0, st, q); break;
+        case 4: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<4, 0>), g, b, 0, st, q); break;
+        case 8: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<0, 1>), g, b, 0, st, q); break;
+        case 12: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<4, 1>), g, b, 0, st, q); break;
 #endif
         default: break;
       }

@@ -12,7 +12,7 @@ shapes = [(8728, 12288, 4096, 0), (8728, 4096, 4096, ops.EPI_RESIDUAL), (8728, 2
           (4616, 1024, 4096, 0), (8192, 8192, 8192, 0), (4096, 4096, 4096, 0)]
 cfgs = {"t128": lib.EPI_TILE_128, "pp": lib.EPI_TILE_256PP, "auto": 0}
 if os.environ.get("PP_ONLY"):
-    cfgs = {"pp": lib.EPI_TILE_256PP, "pp32": lib.EPI_TILE_256PP32}
+    cfgs = {"pp": lib.EPI_TILE_256PP, "pp_s1": lib.EPI_TILE_256PP | (8 << 24)}
     shapes = [(8192, 8192, 8192, 0), (8728, 22016, 4096, ops.EPI_SWIGLU), (8728, 12288, 4096, 0), (8728, 4096, 4096, ops.EPI_RESIDUAL), (8728, 4096, 11008, ops.EPI_RESIDUAL)]
 if os.environ.get("ABLATE"):
     cfgs = {"pp": lib.EPI_TILE_256PP, "pp_nodma": lib.EPI_TILE_256PP | (1 << 24), "pp_nord": lib.EPI_TILE_256PP | (2 << 24),
@@ -48,8 +48,8 @@ for (M, N, K, epi) in shapes:
     if not (epi & ops.EPI_RESIDUAL):
         if "t128" in outs and "pp" in outs and "auto" in outs:
             row["bit_equal"] = bool(torch.equal(outs["t128"], outs["auto"])) and bool(torch.equal(outs["t128"], outs["pp"]))
-    if "pp32" in outs and "pp" in outs:
-        d = (outs["pp32"].float() - outs["pp"].float()).abs().max().item()
-        row["pp32_vs_pp_maxabs"] = round(d, 5)
+    if "pp_s1" in outs and "pp" in outs:
+        d = (outs["pp_s1"].float() - outs["pp"].float()).abs().max().item()
+        row["s1_vs_pp_maxabs"] = round(d, 5)
         row["pp_absmax"] = round(outs["pp"].float().abs().max().item(), 3)
     print(json.dumps(row), flush=True)
