@@ -29,6 +29,7 @@ struct AttnArgs {
   int B, Sq, Sk, H, Hkv;
   float scale_log2;             // log2(e) / sqrt(hd)
   float scale;
+  float* lse;                   // optional [B,H,Sq] log-sum-exp of the scaled scores (training backward)
 };
 
 template <int HD, bool CAUSAL>
@@ -205,6 +206,8 @@ __global__ __launch_bounds__(256) void attn_prefill_bf16_kernel(AttnArgs p) {
   // ---- normalise and store O[q][d], d = 32*db + 8*g + 4*hh + {0..3} ----
   float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+  if (p.lse && qrow < p.Sq && hh == 0)
+    p.lse[((int64_t)b * p.H + h) * p.Sq + qrow] = m_run * p.scale + __logf(l_tot);
   if (qrow < p.Sq) {
     bf16_t* O = (bf16_t*)p.out + b * p.o_sb + (int64_t)qrow * p.o_ss + h * p.o_sh;
 #pragma unroll
@@ -380,6 +383,7 @@ __global__ __launch_bounds__(64) void attn_generic_kernel(AttnArgs p, int hd, in
     const int d = lane + 64 * i;
     if (d < hd) Cvt<T>::st(O + d, o[i] / l);
   }
+  if (p.lse && lane == 0) p.lse[((int64_t)b * p.H + h) * p.Sq + qi] = m + __logf(l);
 }
 
 inline void decode_plan(int B, int H, int Sk, int* nsplit, int* chunk) {
@@ -402,9 +406,9 @@ extern "C" int64_t a3v_attention_scratch_floats(int B, int H, int hd, int Sk) {
   return (int64_t)B * H * ns * (hd + 2);
 }
 
-extern "C" int a3v_attention(const void* q, const void* k, const void* vt, void* out, int B, int Sq, int Sk,
-                             int H, int Hkv, int hd, const int64_t* strides, int causal, float* scratch,
-                             int dtype, void* stream) {
+static int attention_impl(const void* q, const void* k, const void* vt, void* out, int B, int Sq, int Sk,
+                          int H, int Hkv, int hd, const int64_t* strides, int causal, float* scratch,
+                          float* lse, int dtype, void* stream) {
   if (!q || !k || !vt || !out || !strides || B <= 0 || Sq <= 0 || Sk <= 0 || H <= 0 || Hkv <= 0) return A3V_ERR_ARG;
   if (H % Hkv) return A3V_ERR_SHAPE;
   if (causal && Sk < Sq) return A3V_ERR_SHAPE;
@@ -418,6 +422,8 @@ extern "C" int a3v_attention(const void* q, const void* k, const void* vt, void*
   p.B = B; p.Sq = Sq; p.Sk = Sk; p.H = H; p.Hkv = Hkv;
   p.scale = 1.0f / sqrtf((float)hd);
   p.scale_log2 = p.scale * 1.4426950408889634f;
+  p.lse = lse;
+  if (lse && Sq == 1 && dtype == A3V_BF16 && (hd == 64 || hd == 128)) return A3V_ERR_ARG;  // decode kernel has no LSE output
   if (dtype == A3V_F32) {
     if (hd > 256) return A3V_ERR_SHAPE;
     hipLaunchKernelGGL(attn_generic_kernel<float>, dim3(Sq, H, B), dim3(64), 0, st, p, hd, causal);
@@ -461,4 +467,17 @@ extern "C" int a3v_attention(const void* q, const void* k, const void* vt, void*
   }
   A3V_LAUNCH_CHECK();
   return A3V_OK;
+}
+
+extern "C" int a3v_attention(const void* q, const void* k, const void* vt, void* out, int B, int Sq, int Sk,
+                             int H, int Hkv, int hd, const int64_t* strides, int causal, float* scratch,
+                             int dtype, void* stream) {
+  return attention_impl(q, k, vt, out, B, Sq, Sk, H, Hkv, hd, strides, causal, scratch, nullptr, dtype, stream);
+}
+
+extern "C" int a3v_attention_lse(const void* q, const void* k, const void* vt, void* out, float* lse, int B, int Sq,
+                                 int Sk, int H, int Hkv, int hd, const int64_t* strides, int causal, int dtype,
+                                 void* stream) {
+  if (!lse) return A3V_ERR_ARG;
+  return attention_impl(q, k, vt, out, B, Sq, Sk, H, Hkv, hd, strides, causal, nullptr, lse, dtype, stream);
 }

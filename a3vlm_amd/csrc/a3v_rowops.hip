@@ -43,14 +43,14 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const TX* __restrict__ x, 
 }
 
 // ---------------------------------------------------------------- LayerNorm (torch.nn.LayerNorm)
-template <typename T>
-__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ w,
-                                                        const T* __restrict__ b, T* __restrict__ y, int64_t ldy,
+template <typename T, typename TP, typename TY>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, int64_t ldx, const TP* __restrict__ w,
+                                                        const TP* __restrict__ b, TY* __restrict__ y, int64_t ldy,
                                                         const int32_t* __restrict__ row_map, int dim, float eps) {
   __shared__ float red[4];
   const int row = blockIdx.x, tid = threadIdx.x;
   const T* xr = x + (int64_t)row * ldx;
-  T* yr = y + (int64_t)(row_map ? row_map[row] : row) * ldy;
+  TY* yr = y + (int64_t)(row_map ? row_map[row] : row) * ldy;
   constexpr int MAXV = 4;
   float v[MAXV][8];
   float s = 0.f;
@@ -398,14 +398,17 @@ extern "C" int a3v_rmsnorm(const void* x, int64_t ldx, const void* w, void* y, i
 }
 
 extern "C" int a3v_layernorm(const void* x, int64_t ldx, const void* w, const void* b, void* y, int64_t ldy,
-                             const int32_t* row_map, int rows, int dim, float eps, int dtype, void* stream) {
+                             const int32_t* row_map, int rows, int dim, float eps, int x_dtype, int p_dtype, int y_dtype,
+                             void* stream) {
   if (!x || !w || !b || !y || rows <= 0) return A3V_ERR_ARG;
   if (dim % 8 || dim > 8192 || ldx % 8 || ldy % 8) return A3V_ERR_SHAPE;
-  if (dtype == A3V_BF16)
-    hipLaunchKernelGGL(layernorm_kernel<bf16_t>, dim3(rows), dim3(256), 0, ST, (const bf16_t*)x, ldx, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)y, ldy, row_map, dim, eps);
-  else if (dtype == A3V_F32)
-    hipLaunchKernelGGL(layernorm_kernel<float>, dim3(rows), dim3(256), 0, ST, (const float*)x, ldx, (const float*)w, (const float*)b, (float*)y, ldy, row_map, dim, eps);
-  else return A3V_ERR_DTYPE;
+  dim3 g(rows), t(256);
+  switch (x_dtype * 4 + p_dtype * 2 + y_dtype) {
+    case 0: hipLaunchKernelGGL((layernorm_kernel<bf16_t, bf16_t, bf16_t>), g, t, 0, ST, (const bf16_t*)x, ldx, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)y, ldy, row_map, dim, eps); break;
+    case 7: hipLaunchKernelGGL((layernorm_kernel<float, float, float>), g, t, 0, ST, (const float*)x, ldx, (const float*)w, (const float*)b, (float*)y, ldy, row_map, dim, eps); break;
+    case 3: hipLaunchKernelGGL((layernorm_kernel<bf16_t, float, float>), g, t, 0, ST, (const bf16_t*)x, ldx, (const float*)w, (const float*)b, (float*)y, ldy, row_map, dim, eps); break;
+    default: return A3V_ERR_DTYPE;
+  }
   A3V_LAUNCH_CHECK();
   return A3V_OK;
 }

@@ -1,0 +1,483 @@
+// Backward-path kernels (training): transposes for the dgrad/wgrad GEMMs, RMSNorm / LayerNorm /
+// SwiGLU / RoPE backward, attention backward, embedding scatter, reductions.
+// GEMM-shaped backward work reuses a3v_gemm_nt on transposed images:
+//   dX[M,K] = dY[M,N] W[N,K]        = gemm_nt(dY, W^T[K,N])
+//   dW[N,K] += dY^T[N,M] X[M,K]     = gemm_nt(dY^T[N,Mp], X^T[K,Mp])  (RES_F32 accumulate into the fp32 grad)
+// Activations and their grads are in the activation dtype TA (bf16, or f32 on the parity path); the
+// residual stream, master weights and weight grads are fp32 (reference: autocast(bf16) + fp32 masters,
+// main_finetune.py:212-217, engine_finetune.py:44-68).
+#include "a3v_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ transpose  src[R,C] -> dst[C,Rpad]
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ src, int64_t lds_, int64_t bs_s,
+                                                        T* __restrict__ dst, int64_t ldd, int64_t bs_d, int R, int C, int Rpad) {
+  __shared__ T tile[64][64 + 2];
+  const T* s = src + blockIdx.z * bs_s;
+  T* d = dst + blockIdx.z * bs_d;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < R && c < C) ? s[(int64_t)r * lds_ + c] : (T)0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < C && r < Rpad) d[(int64_t)c * ldd + r] = tile[tx][i];
+  }
+}
+
+// ------------------------------------------------------------------ RMSNorm backward
+// y = w * x * r, r = rsqrt(mean(x^2)+eps).  dx = r*dy*w - x * r^3 * sum(dy*w*x)/dim  (added into dh);
+// dw[j] += sum_rows dy*x*r  (thread-private partial over the block's rows, one atomic per column per block)
+template <typename TA, int RPB>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ w,
+                                                          const TA* __restrict__ dy, int64_t lddy, float* __restrict__ dh,
+                                                          int64_t lddh, float* __restrict__ dw, int rows, int dim, float eps) {
+  __shared__ float red[8];
+  const int tid = threadIdx.x;
+  constexpr int MAXC = 32;                // dim <= 8192
+  float dwp[MAXC];
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) dwp[i] = 0.f;
+  const int row0 = blockIdx.x * RPB;
+  for (int rr = 0; rr < RPB; ++rr) {
+    const int row = row0 + rr;
+    if (row >= rows) break;
+    const float* xr = x + (int64_t)row * ldx;
+    const TA* dyr = dy + (int64_t)row * lddy;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = tid + i * 256;
+      if (c < dim) {
+        const float xv = xr[c], g = Cvt<TA>::ld(dyr + c) * w[c];
+        s1 = fmaf(xv, xv, s1);
+        s2 = fmaf(g, xv, s2);
+      }
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    __syncthreads();
+    if ((tid & 63) == 0) { red[tid >> 6] = s1; red[4 + (tid >> 6)] = s2; }
+    __syncthreads();
+    s1 = red[0] + red[1] + red[2] + red[3];
+    s2 = red[4] + red[5] + red[6] + red[7];
+    const float r = rsqrtf(s1 / (float)dim + eps);
+    const float k2 = r * r * r * s2 / (float)dim;
+    float* dhr = dh + (int64_t)row * lddh;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = tid + i * 256;
+      if (c < dim) {
+        const float xv = xr[c], dyv = Cvt<TA>::ld(dyr + c);
+        dhr[c] += r * dyv * w[c] - xv * k2;
+        dwp[i] += dyv * xv * r;
+      }
+    }
+  }
+  if (dw) {
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = tid + i * 256;
+      if (c < dim) atomicAdd(dw + c, dwp[i]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ LayerNorm backward (projector LN)
+// y = (x-mean)*rstd*w + b (fp32 math); dy rows are gathered through row_map from the fp32 stream.
+template <typename TA, int RPB>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TA* __restrict__ x, int64_t ldx, const float* __restrict__ w,
+                                                            const float* __restrict__ dy, int64_t lddy, const int32_t* __restrict__ row_map,
+                                                            TA* __restrict__ dx, int64_t lddx, float* __restrict__ dw, float* __restrict__ db,
+                                                            int rows, int dim, float eps) {
+  __shared__ float red[12];
+  const int tid = threadIdx.x;
+  constexpr int MAXC = 32;
+  float dwp[MAXC], dbp[MAXC];
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) { dwp[i] = 0.f; dbp[i] = 0.f; }
+  const int row0 = blockIdx.x * RPB;
+  for (int rr = 0; rr < RPB; ++rr) {
+    const int row = row0 + rr;
+    if (row >= rows) break;
+    const TA* xr = x + (int64_t)row * ldx;
+    const float* dyr = dy + (int64_t)(row_map ? row_map[row] : row) * lddy;
+    float s = 0.f, ss = 0.f;
+    for (int c = tid; c < dim; c += 256) { const float v = Cvt<TA>::ld(xr + c); s += v; ss = fmaf(v, v, ss); }
+    s = wave_sum(s); ss = wave_sum(ss);
+    __syncthreads();
+    if ((tid & 63) == 0) { red[tid >> 6] = s; red[4 + (tid >> 6)] = ss; }
+    __syncthreads();
+    s = red[0] + red[1] + red[2] + red[3];
+    ss = red[4] + red[5] + red[6] + red[7];
+    const float mean = s / (float)dim;
+    const float rstd = rsqrtf(fmaxf(ss / (float)dim - mean * mean, 0.f) + eps);
+    float a1 = 0.f, a2 = 0.f;    // sum(dxhat), sum(dxhat*xhat)
+    for (int c = tid; c < dim; c += 256) {
+      const float xh = (Cvt<TA>::ld(xr + c) - mean) * rstd, g = dyr[c] * w[c];
+      a1 += g; a2 = fmaf(g, xh, a2);
+    }
+    a1 = wave_sum(a1); a2 = wave_sum(a2);
+    __syncthreads();
+    if ((tid & 63) == 0) { red[tid >> 6] = a1; red[4 + (tid >> 6)] = a2; }
+    __syncthreads();
+    a1 = (red[0] + red[1] + red[2] + red[3]) / (float)dim;
+    a2 = (red[4] + red[5] + red[6] + red[7]) / (float)dim;
+    TA* dxr = dx + (int64_t)row * lddx;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = tid + i * 256;
+      if (c < dim) {
+        const float xh = (Cvt<TA>::ld(xr + c) - mean) * rstd, dyv = dyr[c];
+        Cvt<TA>::st(dxr + c, rstd * (dyv * w[c] - a1 - xh * a2));
+        dwp[i] += dyv * xh;
+        dbp[i] += dyv;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = tid + i * 256;
+    if (c < dim) { atomicAdd(dw + c, dwp[i]); atomicAdd(db + c, dbp[i]); }
+  }
+}
+
+// ------------------------------------------------------------------ SwiGLU on the interleaved layout
+// gu[r, 32 j + t] = gate col 16 j + t (t<16), gu[r, 32 j + 16 + t] = up col 16 j + t
+template <typename TA>
+__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const TA* __restrict__ gu, int64_t ldg, TA* __restrict__ act, int64_t lda, int rows, int F, int inter) {
+  const int64_t n = (int64_t)rows * F;
+  const int ustep = inter ? 16 : F;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int r = i / F, c = i % F;
+    const TA* p = gu + (int64_t)r * ldg + (inter ? (c >> 4) * 32 + (c & 15) : c);
+    const float g = Cvt<TA>::ld(p), u = Cvt<TA>::ld(p + ustep);
+    const float sg = Cvt<TA>::rnd(g / (1.f + __expf(-g)));
+    Cvt<TA>::st(act + (int64_t)r * lda + c, sg * u);
+  }
+}
+template <typename TA>
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const TA* __restrict__ gu, int64_t ldg, const TA* __restrict__ dact, int64_t lda,
+                                                         TA* __restrict__ dgu, int64_t lddg, int rows, int F, int inter) {
+  const int64_t n = (int64_t)rows * F;
+  const int ustep = inter ? 16 : F;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int r = i / F, c = i % F;
+    const int64_t o = inter ? (int64_t)(c >> 4) * 32 + (c & 15) : c;
+    const float g = Cvt<TA>::ld(gu + (int64_t)r * ldg + o), u = Cvt<TA>::ld(gu + (int64_t)r * ldg + o + ustep);
+    const float da = Cvt<TA>::ld(dact + (int64_t)r * lda + c);
+    const float sig = 1.f / (1.f + __expf(-g));
+    const float sg = g * sig;
+    Cvt<TA>::st(dgu + (int64_t)r * lddg + o, da * u * (sig * (1.f + g * (1.f - sig))));
+    Cvt<TA>::st(dgu + (int64_t)r * lddg + o + ustep, da * sg);
+  }
+}
+
+// ------------------------------------------------------------------ RoPE backward + pack into dqkv
+// dq [B,S,H,hd] (contiguous), dk/dv [B,Hkv,S,hd] -> dqkv [B*S, (H+2Hkv)*hd]; q,k rotated by -theta.
+template <typename TA>
+__global__ __launch_bounds__(256) void rope_bwd_pack_kernel(const TA* __restrict__ dq, const TA* __restrict__ dk, const TA* __restrict__ dv,
+                                                            TA* __restrict__ dqkv, int64_t ld, const float* __restrict__ cos_sin,
+                                                            int S, int H, int Hkv, int hd, int rope_pos0) {
+  const int row = blockIdx.x;              // b*S + s
+  const int b = row / S, s = row % S;
+  const int slots = H + 2 * Hkv, half = hd / 2;
+  for (int i = threadIdx.x; i < slots * half; i += 256) {
+    const int slot = i / half, pr = i % half;
+    const TA* src;
+    if (slot < H) src = dq + ((int64_t)row * H + slot) * hd;
+    else if (slot < H + Hkv) src = dk + (((int64_t)b * Hkv + (slot - H)) * S + s) * hd;
+    else src = dv + (((int64_t)b * Hkv + (slot - H - Hkv)) * S + s) * hd;
+    const float a = Cvt<TA>::ld(src + 2 * pr), bb = Cvt<TA>::ld(src + 2 * pr + 1);
+    TA* dst = dqkv + (int64_t)row * ld + (int64_t)slot * hd + 2 * pr;
+    if (slot < H + Hkv) {
+      const float co = cos_sin[((int64_t)(rope_pos0 + s) * half + pr) * 2], si = cos_sin[((int64_t)(rope_pos0 + s) * half + pr) * 2 + 1];
+      Cvt<TA>::st(dst, a * co + bb * si);
+      Cvt<TA>::st(dst + 1, -a * si + bb * co);
+    } else {
+      Cvt<TA>::st(dst, a);
+      Cvt<TA>::st(dst + 1, bb);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ attention backward, generic (any hd <= 256)
+// D[b,h,q] = sum_d dO*O
+template <typename TA>
+__global__ __launch_bounds__(64) void attn_rowdot_kernel(const TA* __restrict__ o, const TA* __restrict__ dout, float* __restrict__ D, int hd) {
+  const int64_t row = blockIdx.x;       // (b*S + s)*H + h  (o, dout contiguous [B,S,H,hd])
+  float a = 0.f;
+  for (int d = threadIdx.x; d < hd; d += 64) a = fmaf(Cvt<TA>::ld(o + row * hd + d), Cvt<TA>::ld(dout + row * hd + d), a);
+  a = wave_sum(a);
+  if (threadIdx.x == 0) D[row] = a;     // index (b, s, h)
+}
+
+struct AttnBwdArgs {
+  const void* q; const void* k; const void* v; const void* dout;   // q,dout [B,S,H,hd]; k [B,Hkv,S,hd]; v rows via (v_sb,v_ss,v_sh)
+  const float* lse;   // [B,H,S]
+  const float* D;     // [B,S,H]
+  void* dq; void* dk; void* dv;      // dq [B,S,H,hd]; dk,dv [B,Hkv,S,hd]
+  int64_t v_sb, v_ss, v_sh;
+  int64_t k_sb, k_sh;           // k strides: batch, kv-head (seq stride = hd)
+  int B, S, H, Hkv, hd, causal;
+  float scale;
+};
+
+// dQ: one wave per (q, h, b): dq[d] = scale * sum_kv p*(dp - D) * k[kv][d]
+template <typename TA>
+__global__ __launch_bounds__(64) void attn_bwd_dq_generic(AttnBwdArgs p) {
+  __shared__ float qs[256], dos[256];
+  const int lane = threadIdx.x, qi = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int hk = h / (p.H / p.Hkv), hd = p.hd;
+  const TA* Q = (const TA*)p.q + (((int64_t)b * p.S + qi) * p.H + h) * hd;
+  const TA* DO = (const TA*)p.dout + (((int64_t)b * p.S + qi) * p.H + h) * hd;
+  const TA* K = (const TA*)p.k + b * p.k_sb + hk * p.k_sh;
+  const TA* V = (const TA*)p.v + b * p.v_sb + hk * p.v_sh;
+  for (int d = lane; d < hd; d += 64) { qs[d] = Cvt<TA>::ld(Q + d); dos[d] = Cvt<TA>::ld(DO + d); }
+  __syncthreads();
+  const float lse = p.lse[((int64_t)b * p.H + h) * p.S + qi], Dq = p.D[((int64_t)b * p.S + qi) * p.H + h];
+  const int kv_end = p.causal ? qi + 1 : p.S;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int kv = 0; kv < kv_end; ++kv) {
+    float s = 0.f, dp = 0.f;
+    for (int d = lane; d < hd; d += 64) {
+      s = fmaf(qs[d], Cvt<TA>::ld(K + (int64_t)kv * hd + d), s);
+      dp = fmaf(dos[d], Cvt<TA>::ld(V + (int64_t)kv * p.v_ss + d), dp);
+    }
+    s = wave_sum(s); dp = wave_sum(dp);
+    const float pr = __expf(s * p.scale - lse);
+    const float ds = pr * (dp - Dq) * p.scale;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int d = lane + 64 * i;
+      if (d < hd) acc[i] = fmaf(ds, Cvt<TA>::ld(K + (int64_t)kv * hd + d), acc[i]);
+    }
+  }
+  TA* DQ = (TA*)p.dq + (((int64_t)b * p.S + qi) * p.H + h) * hd;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int d = lane + 64 * i;
+    if (d < hd) Cvt<TA>::st(DQ + d, acc[i]);
+  }
+}
+
+// dK, dV: one wave per (kv, hk, b): loops over the n_rep query heads and the queries that see kv
+template <typename TA>
+__global__ __launch_bounds__(64) void attn_bwd_dkv_generic(AttnBwdArgs p) {
+  __shared__ float ks[256], vs[256];
+  const int lane = threadIdx.x, kv = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
+  const int hd = p.hd, nrep = p.H / p.Hkv;
+  const TA* K = (const TA*)p.k + b * p.k_sb + hk * p.k_sh + (int64_t)kv * hd;
+  const TA* V = (const TA*)p.v + b * p.v_sb + hk * p.v_sh + (int64_t)kv * p.v_ss;
+  for (int d = lane; d < hd; d += 64) { ks[d] = Cvt<TA>::ld(K + d); vs[d] = Cvt<TA>::ld(V + d); }
+  __syncthreads();
+  float dk[4] = {0.f, 0.f, 0.f, 0.f}, dv[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int rep = 0; rep < nrep; ++rep) {
+    const int h = hk * nrep + rep;
+    for (int qi = p.causal ? kv : 0; qi < p.S; ++qi) {
+      const TA* Q = (const TA*)p.q + (((int64_t)b * p.S + qi) * p.H + h) * hd;
+      const TA* DO = (const TA*)p.dout + (((int64_t)b * p.S + qi) * p.H + h) * hd;
+      float s = 0.f, dp = 0.f;
+      for (int d = lane; d < hd; d += 64) {
+        s = fmaf(Cvt<TA>::ld(Q + d), ks[d], s);
+        dp = fmaf(Cvt<TA>::ld(DO + d), vs[d], dp);
+      }
+      s = wave_sum(s); dp = wave_sum(dp);
+      const float pr = __expf(s * p.scale - p.lse[((int64_t)b * p.H + h) * p.S + qi]);
+      const float ds = pr * (dp - p.D[((int64_t)b * p.S + qi) * p.H + h]) * p.scale;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int d = lane + 64 * i;
+        if (d < hd) {
+          dk[i] = fmaf(ds, Cvt<TA>::ld(Q + d), dk[i]);
+          dv[i] = fmaf(pr, Cvt<TA>::ld(DO + d), dv[i]);
+        }
+      }
+    }
+  }
+  TA* DK = (TA*)p.dk + (((int64_t)b * p.Hkv + hk) * p.S + kv) * hd;
+  TA* DV = (TA*)p.dv + (((int64_t)b * p.Hkv + hk) * p.S + kv) * hd;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int d = lane + 64 * i;
+    if (d < hd) { Cvt<TA>::st(DK + d, dk[i]); Cvt<TA>::st(DV + d, dv[i]); }
+  }
+}
+
+// ------------------------------------------------------------------ embedding / row reductions
+// d_table[tok] += dh[row] for the text rows of [BOS | W image words | text]
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ tokens, int64_t ld_tok, const float* __restrict__ dh,
+                                                        float* __restrict__ dtable, int T, int W, int dim, int vocab) {
+  const int S = T + W, row = blockIdx.x, b = row / S, s = row % S;
+  if (s >= 1 && s <= W) return;
+  int64_t tok = tokens[(int64_t)b * ld_tok + (s == 0 ? 0 : s - W)];
+  tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
+  for (int c = threadIdx.x; c < dim; c += 256) atomicAdd(dtable + tok * dim + c, dh[(int64_t)row * dim + c]);
+}
+
+// out[c] += sum_i src[row_idx ? row_idx[i] : i][c]
+template <typename T>
+__global__ __launch_bounds__(256) void rows_sum_kernel(const T* __restrict__ src, int64_t ld, const int32_t* __restrict__ row_idx,
+                                                       int n_rows, int dim, float* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= dim) return;
+  const int r0 = blockIdx.y * 64, r1 = min(n_rows, r0 + 64);
+  float a = 0.f;
+  for (int i = r0; i < r1; ++i) a += Cvt<T>::ld(src + (int64_t)(row_idx ? row_idx[i] : i) * ld + c);
+  atomicAdd(out + c, a);
+}
+
+// dst[r, c] = (TD) src[r, c]
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void cast2d_kernel(const TS* __restrict__ src, int64_t lds_, TD* __restrict__ dst, int64_t ldd, int rows, int cols) {
+  const int64_t n = (int64_t)rows * (cols / 8);
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int r = i / (cols / 8), c = (i % (cols / 8)) * 8;
+    float v[8];
+    load8(src + (int64_t)r * lds_ + c, v);
+    store8(dst + (int64_t)r * ldd + c, v);
+  }
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int a3v_cast(const void* src, int64_t ld_src, int src_dtype, void* dst, int64_t ld_dst, int dst_dtype, int rows, int cols, void* stream) {
+  if (!src || !dst || rows <= 0 || cols <= 0) return A3V_ERR_ARG;
+  if (cols % 8 || ld_src % 8 || ld_dst % 8) return A3V_ERR_SHAPE;
+  const int64_t n = (int64_t)rows * (cols / 8);
+  const int blocks = (int)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256);
+  dim3 g(blocks), b(256);
+  switch (src_dtype * 2 + dst_dtype) {
+    case 2: hipLaunchKernelGGL((cast2d_kernel<float, bf16_t>), g, b, 0, ST, (const float*)src, ld_src, (bf16_t*)dst, ld_dst, rows, cols); break;
+    case 1: hipLaunchKernelGGL((cast2d_kernel<bf16_t, float>), g, b, 0, ST, (const bf16_t*)src, ld_src, (float*)dst, ld_dst, rows, cols); break;
+    case 3: hipLaunchKernelGGL((cast2d_kernel<float, float>), g, b, 0, ST, (const float*)src, ld_src, (float*)dst, ld_dst, rows, cols); break;
+    case 0: hipLaunchKernelGGL((cast2d_kernel<bf16_t, bf16_t>), g, b, 0, ST, (const bf16_t*)src, ld_src, (bf16_t*)dst, ld_dst, rows, cols); break;
+    default: return A3V_ERR_DTYPE;
+  }
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}
+
+extern "C" int a3v_transpose(const void* src, int64_t ld_src, int64_t bs_src, void* dst, int64_t ld_dst, int64_t bs_dst,
+                             int R, int C, int Rpad, int batch, int dtype, void* stream) {
+  if (!src || !dst || R <= 0 || C <= 0 || Rpad < R || batch <= 0) return A3V_ERR_ARG;
+  dim3 g((C + 63) / 64, (Rpad + 63) / 64, batch);
+  if (dtype == A3V_BF16) hipLaunchKernelGGL(transpose_kernel<bf16_t>, g, dim3(256), 0, ST, (const bf16_t*)src, ld_src, bs_src, (bf16_t*)dst, ld_dst, bs_dst, R, C, Rpad);
+  else if (dtype == A3V_F32) hipLaunchKernelGGL(transpose_kernel<float>, g, dim3(256), 0, ST, (const float*)src, ld_src, bs_src, (float*)dst, ld_dst, bs_dst, R, C, Rpad);
+  else return A3V_ERR_DTYPE;
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}
+
+extern "C" int a3v_rmsnorm_bwd(const float* x, int64_t ldx, const float* w, const void* dy, int64_t lddy, float* dh, int64_t lddh,
+                               float* dw, int rows, int dim, float eps, int act_dtype, void* stream) {
+  if (!x || !w || !dy || !dh || rows <= 0) return A3V_ERR_ARG;
+  if (dim > 8192) return A3V_ERR_SHAPE;
+  constexpr int RPB = 16;
+  dim3 g((rows + RPB - 1) / RPB);
+  if (act_dtype == A3V_BF16) hipLaunchKernelGGL((rmsnorm_bwd_kernel<bf16_t, RPB>), g, dim3(256), 0, ST, x, ldx, w, (const bf16_t*)dy, lddy, dh, lddh, dw, rows, dim, eps);
+  else if (act_dtype == A3V_F32) hipLaunchKernelGGL((rmsnorm_bwd_kernel<float, RPB>), g, dim3(256), 0, ST, x, ldx, w, (const float*)dy, lddy, dh, lddh, dw, rows, dim, eps);
+  else return A3V_ERR_DTYPE;
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}
+
+extern "C" int a3v_layernorm_bwd(const void* x, int64_t ldx, const float* w, const float* dy, int64_t lddy, const int32_t* row_map,
+                                 void* dx, int64_t lddx, float* dw, float* db, int rows, int dim, float eps, int act_dtype, void* stream) {
+  if (!x || !w || !dy || !dx || !dw || !db || rows <= 0) return A3V_ERR_ARG;
+  if (dim > 8192) return A3V_ERR_SHAPE;
+  constexpr int RPB = 16;
+  dim3 g((rows + RPB - 1) / RPB);
+  if (act_dtype == A3V_BF16) hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, RPB>), g, dim3(256), 0, ST, (const bf16_t*)x, ldx, w, dy, lddy, row_map, (bf16_t*)dx, lddx, dw, db, rows, dim, eps);
+  else if (act_dtype == A3V_F32) hipLaunchKernelGGL((layernorm_bwd_kernel<float, RPB>), g, dim3(256), 0, ST, (const float*)x, ldx, w, dy, lddy, row_map, (float*)dx, lddx, dw, db, rows, dim, eps);
+  else return A3V_ERR_DTYPE;
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}
+
+extern "C" int a3v_swiglu_fwd(const void* gu, int64_t ldg, void* act, int64_t lda, int rows, int F, int interleaved, int dtype, void* stream) {
+  const int inter = interleaved;
+  if (!gu || !act || rows <= 0 || F <= 0 || (F % 16)) return A3V_ERR_ARG;
+  int64_t n = (int64_t)rows * F;
+  int blocks = (int)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256);
+  if (dtype == A3V_BF16) hipLaunchKernelGGL(swiglu_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, ST, (const bf16_t*)gu, ldg, (bf16_t*)act, lda, rows, F, inter);
+  else if (dtype == A3V_F32) hipLaunchKernelGGL(swiglu_fwd_kernel<float>, dim3(blocks), dim3(256), 0, ST, (const float*)gu, ldg, (float*)act, lda, rows, F, inter);
+  else return A3V_ERR_DTYPE;
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}
+
+extern "C" int a3v_swiglu_bwd(const void* gu, int64_t ldg, const void* dact, int64_t lda, void* dgu, int64_t lddg, int rows, int F,
+                              int interleaved, int dtype, void* stream) {
+  const int inter = interleaved;
+  if (!gu || !dact || !dgu || rows <= 0 || F <= 0 || (F % 16)) return A3V_ERR_ARG;
+  int64_t n = (int64_t)rows * F;
+  int blocks = (int)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256);
+  if (dtype == A3V_BF16) hipLaunchKernelGGL(swiglu_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, ST, (const bf16_t*)gu, ldg, (const bf16_t*)dact, lda, (bf16_t*)dgu, lddg, rows, F, inter);
+  else if (dtype == A3V_F32) hipLaunchKernelGGL(swiglu_bwd_kernel<float>, dim3(blocks), dim3(256), 0, ST, (const float*)gu, ldg, (const float*)dact, lda, (float*)dgu, lddg, rows, F, inter);
+  else return A3V_ERR_DTYPE;
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}
+
+extern "C" int a3v_rope_bwd_pack(const void* dq, const void* dk, const void* dv, void* dqkv, int64_t ld, const float* cos_sin,
+                                 int B, int S, int H, int Hkv, int hd, int rope_pos0, int dtype, void* stream) {
+  if (!dq || !dk || !dv || !dqkv || !cos_sin || B <= 0 || S <= 0 || (hd & 1)) return A3V_ERR_ARG;
+  if (dtype == A3V_BF16) hipLaunchKernelGGL(rope_bwd_pack_kernel<bf16_t>, dim3(B * S), dim3(256), 0, ST, (const bf16_t*)dq, (const bf16_t*)dk, (const bf16_t*)dv, (bf16_t*)dqkv, ld, cos_sin, S, H, Hkv, hd, rope_pos0);
+  else if (dtype == A3V_F32) hipLaunchKernelGGL(rope_bwd_pack_kernel<float>, dim3(B * S), dim3(256), 0, ST, (const float*)dq, (const float*)dk, (const float*)dv, (float*)dqkv, ld, cos_sin, S, H, Hkv, hd, rope_pos0);
+  else return A3V_ERR_DTYPE;
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}
+
+// Attention backward (self-attention, Sq == Sk == S, queries/keys at the same positions):
+// inputs q,out,dout [B,S,H,hd] contiguous; k [B,Hkv,S,hd]; v rows addressed by (v_sb, v_ss, v_sh) element strides
+// (e.g. straight out of the fused qkv activation); lse [B,H,S]; scratch D [B,S,H] floats.
+// outputs dq [B,S,H,hd]; dk, dv [B,Hkv,S,hd].
+extern "C" int a3v_attention_bwd(const void* q, const void* k, int64_t k_sb, int64_t k_sh, const void* v, int64_t v_sb, int64_t v_ss, int64_t v_sh,
+                                 const void* out, const void* dout, const float* lse, float* D, void* dq, void* dk, void* dv,
+                                 int B, int S, int H, int Hkv, int hd, int causal, int dtype, void* stream) {
+  if (!q || !k || !v || !out || !dout || !lse || !D || !dq || !dk || !dv || B <= 0 || S <= 0) return A3V_ERR_ARG;
+  if (hd > 256 || (H % Hkv)) return A3V_ERR_SHAPE;
+  AttnBwdArgs p;
+  p.q = q; p.k = k; p.v = v; p.dout = dout; p.lse = lse; p.D = D; p.dq = dq; p.dk = dk; p.dv = dv;
+  p.v_sb = v_sb; p.v_ss = v_ss; p.v_sh = v_sh;
+  p.k_sb = k_sb; p.k_sh = k_sh;
+  p.B = B; p.S = S; p.H = H; p.Hkv = Hkv; p.hd = hd; p.causal = causal;
+  p.scale = 1.0f / sqrtf((float)hd);
+  if (dtype == A3V_BF16) {
+    hipLaunchKernelGGL(attn_rowdot_kernel<bf16_t>, dim3(B * S * H), dim3(64), 0, ST, (const bf16_t*)out, (const bf16_t*)dout, D, hd);
+    hipLaunchKernelGGL(attn_bwd_dq_generic<bf16_t>, dim3(S, H, B), dim3(64), 0, ST, p);
+    hipLaunchKernelGGL(attn_bwd_dkv_generic<bf16_t>, dim3(S, Hkv, B), dim3(64), 0, ST, p);
+  } else if (dtype == A3V_F32) {
+    hipLaunchKernelGGL(attn_rowdot_kernel<float>, dim3(B * S * H), dim3(64), 0, ST, (const float*)out, (const float*)dout, D, hd);
+    hipLaunchKernelGGL(attn_bwd_dq_generic<float>, dim3(S, H, B), dim3(64), 0, ST, p);
+    hipLaunchKernelGGL(attn_bwd_dkv_generic<float>, dim3(S, Hkv, B), dim3(64), 0, ST, p);
+  } else return A3V_ERR_DTYPE;
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}
+
+extern "C" int a3v_embed_bwd(const int64_t* tokens, int64_t ld_tok, const float* dh, float* dtable, int B, int T, int W, int dim,
+                             int vocab, void* stream) {
+  if (!tokens || !dh || !dtable || B <= 0 || T <= 0) return A3V_ERR_ARG;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(B * (T + W)), dim3(256), 0, ST, tokens, ld_tok, dh, dtable, T, W, dim, vocab);
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}
+
+extern "C" int a3v_rows_sum(const void* src, int64_t ld, const int32_t* row_idx, int n_rows, int dim, float* out, int dtype, void* stream) {
+  if (!src || !out || n_rows <= 0 || dim <= 0) return A3V_ERR_ARG;
+  dim3 g((dim + 255) / 256, (n_rows + 63) / 64);
+  if (dtype == A3V_BF16) hipLaunchKernelGGL(rows_sum_kernel<bf16_t>, g, dim3(256), 0, ST, (const bf16_t*)src, ld, row_idx, n_rows, dim, out);
+  else if (dtype == A3V_F32) hipLaunchKernelGGL(rows_sum_kernel<float>, g, dim3(256), 0, ST, (const float*)src, ld, row_idx, n_rows, dim, out);
+  else return A3V_ERR_DTYPE;
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}

@@ -26,7 +26,7 @@ SIGNATURES = {
     "a3v_gemm_skinny_split": (I, [I, I, I]),
     "a3v_gemm_skinny": (I, [P, L, P, L, P, L, I, I, I, P, L, I, P, P]),
     "a3v_rmsnorm": (I, [P, L, P, P, L, I, I, F, I, I, I, P]),
-    "a3v_layernorm": (I, [P, L, P, P, P, L, P, I, I, F, I, P]),
+    "a3v_layernorm": (I, [P, L, P, P, P, L, P, I, I, F, I, I, I, P]),
     "a3v_rope_kvcache": (I, [P, L, P, L, P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "a3v_vt_pack": (I, [P, L, P, I, I, I, I, I, I, P]),
     "a3v_attention_scratch_floats": (L, [I, I, I, I]),
@@ -39,6 +39,17 @@ SIGNATURES = {
     "a3v_argmax": (I, [P, L, P, I, I, P]),
     "a3v_count_valid": (I, [P, I, P, P]),
     "a3v_cross_entropy": (I, [P, L, P, P, P, L, P, F, I, I, I, P]),
+    "a3v_attention_lse": (I, [P, P, P, P, P, I, I, I, I, I, I, ctypes.POINTER(c_int64), I, I, P]),
+    "a3v_transpose": (I, [P, L, L, P, L, L, I, I, I, I, I, P]),
+    "a3v_rmsnorm_bwd": (I, [P, L, P, P, L, P, L, P, I, I, F, I, P]),
+    "a3v_layernorm_bwd": (I, [P, L, P, P, L, P, P, L, P, P, I, I, F, I, P]),
+    "a3v_swiglu_fwd": (I, [P, L, P, L, I, I, I, I, P]),
+    "a3v_swiglu_bwd": (I, [P, L, P, L, P, L, I, I, I, I, P]),
+    "a3v_cast": (I, [P, L, I, P, L, I, I, I, P]),
+    "a3v_rope_bwd_pack": (I, [P, P, P, P, L, P, I, I, I, I, I, I, I, P]),
+    "a3v_attention_bwd": (I, [P, P, L, L, P, L, L, L, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
+    "a3v_embed_bwd": (I, [P, L, P, P, I, I, I, I, I, P]),
+    "a3v_rows_sum": (I, [P, L, P, I, I, P, I, P]),
 }
 
 _lib = None

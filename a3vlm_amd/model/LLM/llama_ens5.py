@@ -286,24 +286,42 @@ class Transformer(nn.Module):
                 nb = w1.shape[0] // 16
                 pk[f"w13.{i}"] = torch.stack([w1.view(nb, 16, -1), w3.view(nb, 16, -1)], dim=1).reshape(2 * w1.shape[0], -1).to(dtp).contiguous()
             if self.with_visual:
-                cw = self.clip.visual.conv1.weight
-                K = cw[0].numel()
-                Kpad = (K + 63) // 64 * 64
-                w2d = torch.zeros(cw.shape[0], Kpad, dtype=dtp, device=cw.device)
-                w2d[:, :K] = cw.reshape(cw.shape[0], -1).to(dtp)
-                pk["conv1"] = w2d
-                pw = getattr(self.visual_proj, "0").weight
-                Kp = pw.shape[1]
-                Kp_pad = (Kp + 63) // 64 * 64
-                if Kp_pad != Kp:
-                    w2 = torch.zeros(pw.shape[0], Kp_pad, dtype=dtp, device=pw.device)
-                    w2[:, :Kp] = pw.to(dtp)
-                    pk["visual_proj"] = w2
-                else:
-                    pk["visual_proj"] = pw.to(dtp).contiguous()
+                pk.update(self._pack_vision())
         self._packed = pk
         self._packed_version = ver
         return pk
+
+    def _pack_vision(self) -> Dict[str, torch.Tensor]:
+        """conv1 as a [width, Kpad] GEMM weight (zero padded to the GEMM's K granule) in the ViT's own dtype;
+        visual_proj.0 padded likewise in the model dtype."""
+        pk: Dict[str, torch.Tensor] = {}
+        with torch.no_grad():
+            cw = self.clip.visual.conv1.weight
+            vdt = cw.dtype
+            K = cw[0].numel()
+            Kpad = (K + 63) // 64 * 64
+            w2d = torch.zeros(cw.shape[0], Kpad, dtype=vdt, device=cw.device)
+            w2d[:, :K] = cw.reshape(cw.shape[0], -1)
+            pk["conv1"] = w2d
+            pw = getattr(self.visual_proj, "0").weight
+            dtp = self._dtype
+            Kp = pw.shape[1]
+            Kp_pad = (Kp + 63) // 64 * 64
+            if Kp_pad != Kp:
+                w2 = torch.zeros(pw.shape[0], Kp_pad, dtype=dtp, device=pw.device)
+                w2[:, :Kp] = pw.to(dtp)
+                pk["visual_proj"] = w2
+            else:
+                pk["visual_proj"] = pw.to(dtp).contiguous()
+        return pk
+
+    def _vision_images(self) -> Dict[str, torch.Tensor]:
+        """Vision-only weight images (used by the training engine, which keeps its own decoder images)."""
+        key = (self.clip.visual.conv1.weight._version, self.clip.visual.conv1.weight.dtype, str(self._device))
+        if getattr(self, "_vis_pack_key", None) != key:
+            self._vis_pack = self._pack_vision()
+            self._vis_pack_key = key
+        return self._vis_pack
 
     def _cos_sin_dev(self) -> torch.Tensor:
         if self._cos_sin is None or self._cos_sin.device != self._device:
@@ -378,26 +396,31 @@ class Transformer(nn.Module):
     def clip_encode_image(self, views: torch.Tensor) -> torch.Tensor:
         """llama_ens5.py:351-375 on [N,3,c,c] views -> [N*L, width] (row = n*L + token)."""
         a = self.args
-        pk = self._pack()
+        pk = self._vision_images()
         vis = self.clip.visual
+        vdt = vis.conv1.weight.dtype
+        _mbuf = self._buf
+
+        def _vbuf(name, shape):
+            return _mbuf(name, shape, vdt)
         N = views.shape[0]
         g, T, L = self._vit_geometry()
         W, Hh = a.vit_width, a.vit_heads
         hd = W // Hh
         Kpad = pk["conv1"].shape[1]
-        cols = self._buf("vit_cols", (N * T, Kpad))
+        cols = _vbuf("vit_cols", (N * T, Kpad))
         ops.patch_im2col(views.contiguous(), cols, a.vit_patch)
-        patch = self._buf("vit_patch", (N * T, W))
+        patch = _vbuf("vit_patch", (N * T, W))
         ops.gemm_nt(cols, pk["conv1"], patch)
-        x = self._buf("vit_x", (N * L, W))
+        x = _vbuf("vit_x", (N * L, W))
         ops.vit_embed(patch, vis.class_embedding, vis.positional_embedding, x, N, T, W)
         ops.layernorm(x, vis.ln_pre.weight, vis.ln_pre.bias, x)
-        y = self._buf("vit_y", (N * L, W))
-        qkv = self._buf("vit_qkv", (N * L, 3 * W))
+        y = _vbuf("vit_y", (N * L, W))
+        qkv = _vbuf("vit_qkv", (N * L, 3 * W))
         Lpad = (L + 63) // 64 * 64
-        vt = self._buf("vit_vt", (N, Hh, hd, Lpad))
-        att = self._buf("vit_att", (N * L, W))
-        mlp = self._buf("vit_mlp", (N * L, 4 * W))
+        vt = _vbuf("vit_vt", (N, Hh, hd, Lpad))
+        att = _vbuf("vit_att", (N * L, W))
+        mlp = _vbuf("vit_mlp", (N * L, 4 * W))
         act = ops.EPI_QUICKGELU if a.vit_quick_gelu else ops.EPI_GELU
         ld = 3 * W
         strides = (L * ld, ld, hd, L * ld, hd, ld, Hh * hd * Lpad, hd * Lpad, Lpad, L * W, W, hd)
@@ -410,7 +433,7 @@ class Transformer(nn.Module):
             ops.layernorm(x, blk.ln_2.weight, blk.ln_2.bias, y)
             ops.gemm_nt(y, blk.mlp.c_fc.weight, mlp, bias=blk.mlp.c_fc.bias, epilogue=act)
             ops.gemm_nt(mlp, blk.mlp.c_proj.weight, x, bias=blk.mlp.c_proj.bias, residual=x)
-        feats = self._buf("vit_feats", (N * L, W))
+        feats = _vbuf("vit_feats", (N * L, W))
         ops.layernorm(x, vis.ln_post.weight, vis.ln_post.bias, feats)
         return feats
 

@@ -109,9 +109,28 @@ class MetaModel(nn.Module):
         # final scalar reduction of B*(T-1) fp32 values: plumbing, not the hot path
         return row_loss.sum() / n_valid.to(torch.float32)[0]
 
+    def train_engine(self, compute_dtype: torch.dtype = None):
+        """The HIP forward/backward engine of the plugin (a3vlm_amd/train.py).  compute dtype: bf16
+        ("autocast") unless the model is all-fp32 (parity path)."""
+        from ..train import TrainEngine
+        if getattr(self, "_engine", None) is None:
+            if compute_dtype is None:
+                frozen = [p for p in self.llma.parameters() if not p.requires_grad]
+                compute_dtype = frozen[0].dtype if frozen else torch.bfloat16
+                if getattr(self, "train_compute_dtype", None) is not None:
+                    compute_dtype = self.train_compute_dtype
+            self._engine = TrainEngine(self.llma, compute_dtype)
+            self._anchor = torch.zeros((), dtype=torch.float32, device=self._device, requires_grad=True)
+        return self._engine
+
     def forward(self, examples, labels, images=None, depth_imgs=None):
         with torch.no_grad():
             examples, labels = self._trim(examples, labels)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.llma.parameters()):
+            # training: loss and gradients through the HIP backward (loss.backward() fills param.grad)
+            from ..train import step_loss
+            eng = self.train_engine()
+            return step_loss(eng, self._anchor, examples, labels, images), {}
         output = self.llma(examples, images)
         additional_loss = {}
         if isinstance(output, tuple):

@@ -85,7 +85,7 @@ def layernorm(x, w, b, out, eps: float = 1e-5, row_map=None, rows: Optional[int]
     _dev(x, w, b, out, row_map)
     n, dim = x.shape
     rc = _l.load().a3v_layernorm(_p(x), x.stride(0), _p(w), _p(b), _p(out), out.stride(0), _p(row_map),
-                                 n if rows is None else rows, dim, eps, dt(x), _stream())
+                                 n if rows is None else rows, dim, eps, dt(x), dt(w), dt(out), _stream())
     _l.check(rc, "a3v_layernorm")
     return out
 
@@ -179,3 +179,85 @@ def cross_entropy(logits, labels, row_loss, dlogits=None, n_valid=None, grad_sca
                                      dlogits.stride(0) if dlogits is not None else 0, _p(n_valid), grad_scale,
                                      rows, V, dt(logits), _stream())
     _l.check(rc, "a3v_cross_entropy")
+
+
+# ------------------------------------------------------------------ training (backward) ops
+def attention_lse(q, k, vt, out, lse, B, Sq, Sk, H, Hkv, hd, strides, causal: bool):
+    _dev(q, k, vt, out, lse)
+    rc = _l.load().a3v_attention_lse(_p(q), _p(k), _p(vt), _p(out), _p(lse), B, Sq, Sk, H, Hkv, hd, _Strides(*strides),
+                                     1 if causal else 0, dt(q), _stream())
+    _l.check(rc, "a3v_attention_lse")
+
+
+def transpose(src, dst, R, C, Rpad, batch=1, bs_src=0, bs_dst=0):
+    """dst[b, c, r] = src[b, r, c]; src/dst 2-D (or batched through element strides)."""
+    _dev(src, dst)
+    rc = _l.load().a3v_transpose(_p(src), src.stride(-2), bs_src, _p(dst), dst.stride(-2), bs_dst, R, C, Rpad, batch,
+                                 dt(src), _stream())
+    _l.check(rc, "a3v_transpose")
+    return dst
+
+
+def cast(src, dst):
+    _dev(src, dst)
+    rows, cols = src.shape
+    rc = _l.load().a3v_cast(_p(src), src.stride(0), dt(src), _p(dst), dst.stride(0), dt(dst), rows, cols, _stream())
+    _l.check(rc, "a3v_cast")
+    return dst
+
+
+def rmsnorm_bwd(x, w, dy, dh, dw, eps):
+    _dev(x, w, dy, dh, dw)
+    assert x.dtype == torch.float32 and w.dtype == torch.float32 and dh.dtype == torch.float32
+    rows, dim = x.shape
+    rc = _l.load().a3v_rmsnorm_bwd(_p(x), x.stride(0), _p(w), _p(dy), dy.stride(0), _p(dh), dh.stride(0), _p(dw), rows, dim,
+                                   eps, dt(dy), _stream())
+    _l.check(rc, "a3v_rmsnorm_bwd")
+
+
+def layernorm_bwd(x, w, dy, row_map, dx, dw, db, eps=1e-5):
+    _dev(x, w, dy, row_map, dx, dw, db)
+    rows, dim = x.shape
+    rc = _l.load().a3v_layernorm_bwd(_p(x), x.stride(0), _p(w), _p(dy), dy.stride(0), _p(row_map), _p(dx), dx.stride(0),
+                                     _p(dw), _p(db), rows, dim, eps, dt(x), _stream())
+    _l.check(rc, "a3v_layernorm_bwd")
+
+
+def swiglu_fwd(gu, act, F, interleaved: bool):
+    _dev(gu, act)
+    rc = _l.load().a3v_swiglu_fwd(_p(gu), gu.stride(0), _p(act), act.stride(0), gu.shape[0], F, 1 if interleaved else 0,
+                                  dt(gu), _stream())
+    _l.check(rc, "a3v_swiglu_fwd")
+
+
+def swiglu_bwd(gu, dact, dgu, F, interleaved: bool):
+    _dev(gu, dact, dgu)
+    rc = _l.load().a3v_swiglu_bwd(_p(gu), gu.stride(0), _p(dact), dact.stride(0), _p(dgu), dgu.stride(0), gu.shape[0], F,
+                                  1 if interleaved else 0, dt(gu), _stream())
+    _l.check(rc, "a3v_swiglu_bwd")
+
+
+def rope_bwd_pack(dq, dk, dv, dqkv, cos_sin, B, S, H, Hkv, hd, rope_pos0=0):
+    _dev(dq, dk, dv, dqkv, cos_sin)
+    rc = _l.load().a3v_rope_bwd_pack(_p(dq), _p(dk), _p(dv), _p(dqkv), dqkv.stride(0), _p(cos_sin), B, S, H, Hkv, hd,
+                                     rope_pos0, dt(dq), _stream())
+    _l.check(rc, "a3v_rope_bwd_pack")
+
+
+def attention_bwd(q, k, k_sb, k_sh, v, v_sb, v_ss, v_sh, out, dout, lse, D, dq, dk, dv, B, S, H, Hkv, hd, causal: bool):
+    _dev(q, k, v, out, dout, lse, D, dq, dk, dv)
+    rc = _l.load().a3v_attention_bwd(_p(q), _p(k), k_sb, k_sh, _p(v), v_sb, v_ss, v_sh, _p(out), _p(dout), _p(lse), _p(D),
+                                     _p(dq), _p(dk), _p(dv), B, S, H, Hkv, hd, 1 if causal else 0, dt(q), _stream())
+    _l.check(rc, "a3v_attention_bwd")
+
+
+def embed_bwd(tokens, dh, dtable, B, T, W, dim):
+    _dev(tokens, dh, dtable)
+    rc = _l.load().a3v_embed_bwd(_p(tokens), tokens.stride(0), _p(dh), _p(dtable), B, T, W, dim, dtable.shape[0], _stream())
+    _l.check(rc, "a3v_embed_bwd")
+
+
+def rows_sum(src, row_idx, n_rows, out):
+    _dev(src, row_idx, out)
+    rc = _l.load().a3v_rows_sum(_p(src), src.stride(0), _p(row_idx), n_rows, src.shape[1], _p(out), dt(src), _stream())
+    _l.check(rc, "a3v_rows_sum")

@@ -1,0 +1,396 @@
+"""Training step of the plugin: forward + backward of the multimodal path through HIP kernels.
+
+Reference semantics (model/accessory/engine_finetune.py:44-68, main_finetune.py:212-217,268-276):
+autocast(bf16) over fp32 master weights of the trainables, bf16 frozen visual encoder, fp32
+residual stream, activation checkpointing per TransformerBlock, loss = CE(ignore_index=0).
+Here that is: one custom autograd node per step whose forward runs the kernels and keeps only each
+block's input (fp32) and whose backward recomputes a block, then back-propagates through it with
+GEMMs on transposed operand images (dgrad / wgrad), RMSNorm / SwiGLU / RoPE / attention backward
+kernels, and accumulates fp32 gradients straight into one flat buffer that ``param.grad`` views
+alias (wq|wk|wv and w1|w3 share fused buffers).  ``on_layer_grads_ready`` lets the DP reducer start
+an all-reduce of a layer's gradient range while earlier layers are still back-propagating.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch
+
+from . import ops
+
+
+def _pad64(n: int) -> int:
+    return (n + 63) // 64 * 64
+
+
+class TrainEngine:
+    def __init__(self, model, compute_dtype: torch.dtype = torch.bfloat16):
+        self.m = model
+        self.act = compute_dtype
+        self._img: Dict[str, torch.Tensor] = {}
+        self._img_version = None
+        self._ws: Dict[tuple, torch.Tensor] = {}
+        self._flat: Optional[torch.Tensor] = None
+        self._views: Dict[str, torch.Tensor] = {}
+        self._ranges: List[Tuple[str, int, int]] = []       # (bucket name, start, end) in the flat grad buffer
+        self.on_layer_grads_ready: Optional[Callable[[str, int, int], None]] = None
+        self._saved = None
+
+    # ------------------------------------------------------------------ buffers
+    def _buf(self, name, shape, dtype=None, zero=False):
+        dtype = dtype or self.act
+        key = (name, tuple(shape), dtype)
+        t = self._ws.get(key)
+        if t is None:
+            t = torch.empty(*shape, dtype=dtype, device=self.m._device)
+            self._ws[key] = t
+        if zero:
+            t.zero_()
+        return t
+
+    def _check_dtypes(self):
+        for n, p in self.m.get_trainable_params().items():
+            if p.dtype != torch.float32:
+                raise TypeError(f"trainable parameter {n} must be fp32 (promote_trainable_params_to_fp32, "
+                                f"util/tensor_type.py:60-66); got {p.dtype}")
+
+    # ------------------------------------------------------------------ flat gradient buffer
+    def _layout(self):
+        """Order = backward completion order reversed (layer-major), so one layer's grads are contiguous."""
+        m = self.m
+        items: List[Tuple[str, List[Tuple[str, torch.nn.Parameter]]]] = []
+        items.append(("embed", [("tok_embeddings.weight", m.tok_embeddings.weight)]))
+        for i, l in enumerate(m.layers):
+            p = f"layers.{i}."
+            items.append((f"layer{i}", [
+                (p + "attention.wq.weight", l.attention.wq.weight), (p + "attention.wk.weight", l.attention.wk.weight),
+                (p + "attention.wv.weight", l.attention.wv.weight), (p + "attention.wo.weight", l.attention.wo.weight),
+                (p + "feed_forward.w1.weight", l.feed_forward.w1.weight), (p + "feed_forward.w3.weight", l.feed_forward.w3.weight),
+                (p + "feed_forward.w2.weight", l.feed_forward.w2.weight),
+                (p + "attention_norm.weight", l.attention_norm.weight), (p + "ffn_norm.weight", l.ffn_norm.weight)]))
+        items.append(("head", [("norm.weight", m.norm.weight), ("output.weight", m.output.weight)]))
+        if m.with_visual:
+            vp0, vp1 = getattr(m.visual_proj, "0"), getattr(m.visual_proj, "1")
+            vis = [("visual_proj.0.weight", vp0.weight), ("visual_proj.0.bias", vp0.bias),
+                   ("visual_proj.1.weight", vp1.weight), ("visual_proj.1.bias", vp1.bias),
+                   ("start_img", m.start_img), ("end_img", m.end_img)]
+            if m.args.qformer_tokens:
+                q0, q1 = getattr(m.qformer_proj, "0"), getattr(m.qformer_proj, "1")
+                vis += [("qformer_proj.0.weight", q0.weight), ("qformer_proj.0.bias", q0.bias),
+                        ("qformer_proj.1.weight", q1.weight), ("qformer_proj.1.bias", q1.bias)]
+            items.append(("vision_proj", vis))
+        return items
+
+    def ensure_grads(self):
+        """Allocate the flat fp32 gradient buffer once; (re)attach zeroed views where .grad is None."""
+        m = self.m
+        if self._flat is None:
+            total = 0
+            offs = {}
+            self._ranges = []
+            for bucket, plist in self._layout():
+                start = total
+                for name, p in plist:
+                    offs[name] = (total, p)
+                    total += (p.numel() + 63) // 64 * 64
+                self._ranges.append((bucket, start, total))
+            self._flat = torch.zeros(total, dtype=torch.float32, device=m._device)
+            for name, (o, p) in offs.items():
+                self._views[name] = self._flat[o:o + p.numel()].view(p.shape)
+            self._params = {name: p for name, (o, p) in offs.items()}
+        for name, p in self._params.items():
+            if not p.requires_grad:
+                continue
+            v = self._views[name]
+            if p.grad is None:
+                v.zero_()
+                p.grad = v
+            elif p.grad.data_ptr() != v.data_ptr():
+                raise RuntimeError(f"{name}.grad was replaced by a foreign tensor; use zero_grad(set_to_none=True) or keep the views")
+
+    def grad_ranges(self):
+        return list(self._ranges)
+
+    def flat_grads(self) -> torch.Tensor:
+        return self._flat
+
+    def _gview(self, first: str, last: str) -> torch.Tensor:
+        """Fused [rows, cols] view over consecutive parameters (wq|wk|wv, w1|w3)."""
+        a, b = self._views[first], self._views[last]
+        cols = a.shape[1]
+        n = (b.data_ptr() - a.data_ptr()) // 4 + b.numel()
+        assert n % cols == 0
+        base = self._flat[(a.data_ptr() - self._flat.data_ptr()) // 4:]
+        return base[:n].view(n // cols, cols)
+
+    # ------------------------------------------------------------------ weight images in the compute dtype
+    def _images(self):
+        m = self.m
+        ver = m._weights_version()
+        if self._img_version == ver:
+            return self._img
+        act = self.act
+        im: Dict[str, torch.Tensor] = {}
+
+        def both(key, w):     # W [N,K] and W^T [K, N] (N padded to 64 for the dgrad GEMM's K dim)
+            wa = w.to(act).contiguous()
+            N, K = wa.shape
+            Np = _pad64(N)
+            if Np != N:
+                wp = torch.zeros(Np, K, dtype=act, device=wa.device)
+                wp[:N] = wa
+            else:
+                wp = wa
+            im[key] = wa
+            wt = torch.empty(K, Np, dtype=act, device=wa.device)
+            ops.transpose(wp, wt, Np, K, Np)
+            im[key + ".t"] = wt
+        with torch.no_grad():
+            for i, l in enumerate(m.layers):
+                a, f = l.attention, l.feed_forward
+                both(f"qkv.{i}", torch.cat([a.wq.weight, a.wk.weight, a.wv.weight], dim=0))
+                both(f"wo.{i}", a.wo.weight)
+                both(f"w13.{i}", torch.cat([f.w1.weight, f.w3.weight], dim=0))
+                both(f"w2.{i}", f.w2.weight)
+            both("out", m.output.weight)
+            if m.with_visual:
+                vp0 = getattr(m.visual_proj, "0")
+                both("vp", vp0.weight)
+                im["vp.b"] = vp0.bias.to(act)
+        self._img, self._img_version = im, ver
+        return im
+
+    # ------------------------------------------------------------------ GEMM helpers
+    def _wgrad(self, dy: torch.Tensor, x: torch.Tensor, grad: torch.Tensor, tag: str):
+        """grad[N,K] (fp32) += dy[M,N]^T @ x[M,K]."""
+        M, N = dy.shape
+        K = x.shape[1]
+        Mp = _pad64(M)
+        dyt = self._buf("wg_dyt" + tag, (N, Mp))
+        xt = self._buf("wg_xt" + tag, (K, Mp))
+        ops.transpose(dy, dyt, M, N, Mp)
+        ops.transpose(x, xt, M, K, Mp)
+        ops.gemm_nt(dyt, xt, grad, residual=grad, epilogue=ops.EPI_RES_F32 if self.act == torch.bfloat16 else 0)
+
+    def _dgrad(self, dy: torch.Tensor, wt: torch.Tensor, out: torch.Tensor):
+        """out[M,K] = dy[M,N] @ W[N,K] with wt = W^T [K, Np]; dy may have N < Np columns -> padded copy."""
+        M, N = dy.shape
+        Np = wt.shape[1]
+        if Np != N:
+            dyp = self._buf("dg_pad", (M, Np), zero=True)
+            dyp[:, :N].copy_(dy)
+            dy = dyp
+        ops.gemm_nt(dy, wt, out)
+
+    # ------------------------------------------------------------------ one decoder block (forward / recompute)
+    def _block_forward(self, i: int, h: torch.Tensor, B: int, S: int, keep: bool):
+        """h (fp32 [B*S, dim]) -> updated in place.  keep=True returns the intermediates the backward needs."""
+        m, a, im = self.m, self.m.args, self._images()
+        H, Hkv, hd, dim, F = m.n_heads, m.n_kv_heads, m.head_dim, a.dim, m.ffn
+        rows = B * S
+        l = m.layers[i]
+        spad = _pad64(S)
+        xn = self._buf("xn", (rows, dim))
+        qkv = self._buf("qkv", (rows, (H + 2 * Hkv) * hd))
+        qrot = self._buf("qrot", (rows, H * hd))
+        kc = self._buf("kc", (B, Hkv, spad, hd))
+        vc = self._buf("vc", (B, Hkv, hd, spad))
+        att = self._buf("att", (rows, H * hd))
+        lse = self._buf("lse", (B, H, S), torch.float32)
+        ops.rmsnorm(h, l.attention_norm.weight, xn, a.norm_eps)
+        ops.gemm_nt(xn, im[f"qkv.{i}"], qkv)
+        ops.rope_kvcache(qkv, qrot, kc, vc, m._cos_sin_dev(), B, S, H, Hkv, hd, 0, 0)
+        strides = (S * H * hd, H * hd, hd, Hkv * spad * hd, spad * hd, hd, Hkv * hd * spad, hd * spad, spad, S * H * hd, H * hd, hd)
+        ops.attention_lse(qrot, kc, vc, att, lse, B, S, S, H, Hkv, hd, strides, True)
+        res_flag = ops.EPI_RES_F32 if self.act == torch.bfloat16 else 0
+        if keep:
+            h_mid = self._buf("h_mid", (rows, dim), torch.float32)
+            ops.gemm_nt(att, im[f"wo.{i}"], h_mid, residual=h, epilogue=res_flag)
+        else:
+            h_mid = h
+            ops.gemm_nt(att, im[f"wo.{i}"], h, residual=h, epilogue=res_flag)
+        xn2 = self._buf("xn2", (rows, dim))
+        gu = self._buf("gu", (rows, 2 * F))
+        actb = self._buf("act", (rows, F))
+        ops.rmsnorm(h_mid, l.ffn_norm.weight, xn2, a.norm_eps)
+        ops.gemm_nt(xn2, im[f"w13.{i}"], gu)
+        ops.swiglu_fwd(gu, actb, F, interleaved=False)
+        if keep:
+            return dict(xn=xn, qkv=qkv, qrot=qrot, kc=kc, att=att, lse=lse, h_mid=h_mid, xn2=xn2, gu=gu, act=actb, spad=spad)
+        ops.gemm_nt(actb, im[f"w2.{i}"], h, residual=h, epilogue=res_flag)
+        return None
+
+    def _block_backward(self, i: int, h_in: torch.Tensor, dh: torch.Tensor, B: int, S: int):
+        m, a, im = self.m, self.m.args, self._images()
+        H, Hkv, hd, dim, F = m.n_heads, m.n_kv_heads, m.head_dim, a.dim, m.ffn
+        rows = B * S
+        l = m.layers[i]
+        pre = f"layers.{i}."
+        k = self._block_forward(i, h_in, B, S, keep=True)
+        # ---- FFN: out = h_mid + w2(silu(g) * u)
+        dha = self._buf("dh_act", (rows, dim))
+        ops.cast(dh, dha)
+        self._wgrad(dha, k["act"], self._views[pre + "feed_forward.w2.weight"], "w2")
+        dact = self._buf("dact", (rows, F))
+        self._dgrad(dha, im[f"w2.{i}.t"], dact)
+        dgu = self._buf("dgu", (rows, 2 * F))
+        ops.swiglu_bwd(k["gu"], dact, dgu, F, interleaved=False)
+        self._wgrad(dgu, k["xn2"], self._gview(pre + "feed_forward.w1.weight", pre + "feed_forward.w3.weight"), "w13")
+        dxn = self._buf("dxn", (rows, dim))
+        self._dgrad(dgu, im[f"w13.{i}.t"], dxn)
+        ops.rmsnorm_bwd(k["h_mid"], l.ffn_norm.weight, dxn, dh, self._views[pre + "ffn_norm.weight"], a.norm_eps)
+        # ---- attention: h_mid = h_in + wo(attn(rope(qkv(norm(h_in)))))
+        ops.cast(dh, dha)
+        self._wgrad(dha, k["att"], self._views[pre + "attention.wo.weight"], "wo")
+        datt = self._buf("datt", (rows, H * hd))
+        self._dgrad(dha, im[f"wo.{i}.t"], datt)
+        dq = self._buf("dq", (rows, H * hd))
+        dk = self._buf("dk", (B, Hkv, S, hd))
+        dv = self._buf("dv", (B, Hkv, S, hd))
+        D = self._buf("attn_D", (B, S, H), torch.float32)
+        qkv = k["qkv"]
+        ld = qkv.stride(0)
+        vrows = qkv[:, (H + Hkv) * hd:]
+        spad = k["spad"]
+        ops.attention_bwd(k["qrot"], k["kc"], Hkv * spad * hd, spad * hd, vrows, S * ld, ld, hd, k["att"], datt, k["lse"], D,
+                          dq, dk, dv, B, S, H, Hkv, hd, True)
+        dqkv = self._buf("dqkv", (rows, (H + 2 * Hkv) * hd))
+        ops.rope_bwd_pack(dq, dk, dv, dqkv, m._cos_sin_dev(), B, S, H, Hkv, hd, 0)
+        self._wgrad(dqkv, k["xn"], self._gview(pre + "attention.wq.weight", pre + "attention.wv.weight"), "qkv")
+        self._dgrad(dqkv, im[f"qkv.{i}.t"], dxn)
+        ops.rmsnorm_bwd(h_in, l.attention_norm.weight, dxn, dh, self._views[pre + "attention_norm.weight"], a.norm_eps)
+
+    # ------------------------------------------------------------------ forward (loss) and backward
+    @torch.no_grad()
+    def forward_loss(self, examples: torch.Tensor, labels: torch.Tensor, image: Optional[torch.Tensor] = None,
+                     qformer_feats=None, extra_feats=None) -> torch.Tensor:
+        self._check_dtypes()
+        m, a = self.m, self.m.args
+        im = self._images()
+        B, T = examples.shape
+        W = m.image_words if image is not None else 0
+        S = T + W
+        rows = B * S
+        dim, V = a.dim, a.vocab_size
+        h = self._buf("h", (rows, dim), torch.float32)
+        ops.embed_assemble(examples.contiguous(), m.tok_embeddings.weight, h, B, T, W, dim)
+        vis = None
+        if image is not None:
+            vis = self._encode_image_train(h, image, B, S, qformer_feats, extra_feats)
+        hs = self._buf("h_saved", (m.n_layers, rows, dim), torch.float32)
+        for i in range(m.n_layers):
+            hs[i].copy_(h)                       # checkpoint = the block input (main_finetune.py:268-276)
+            self._block_forward(i, h, B, S, keep=False)
+        xt = self._buf("xn_text", (B * T, dim))
+        hv = h.view(B, S, dim)
+        for b in range(B):
+            ops.rmsnorm(hv[b, W:], m.norm.weight, xt[b * T:(b + 1) * T], a.norm_eps)
+        logits = self._buf("logits", (B * T, V))
+        ops.gemm_nt(xt, im["out"], logits)
+        lab = self._buf("lab", (B, T), torch.int64, zero=True)
+        lab[:, :T - 1].copy_(labels[:, 1:])      # shift (meta.py:256-257); last position predicts nothing
+        lab = lab.view(-1)
+        n_valid = self._buf("n_valid", (1,), torch.int32)
+        ops.count_valid(lab, n_valid)
+        row_loss = self._buf("row_loss", (B * T,), torch.float32)
+        ops.cross_entropy(logits, lab, row_loss)
+        nv = n_valid.to(torch.float32)[0]
+        loss = torch.where(nv > 0, row_loss.sum() / torch.clamp(nv, min=1.0), torch.zeros_like(nv))   # meta.py:259-262
+        self._saved = dict(B=B, T=T, W=W, S=S, h=h, hs=hs, xt=xt, logits=logits, lab=lab, n_valid=n_valid, tokens=examples.contiguous(), vis=vis)
+        return loss
+
+    @torch.no_grad()
+    def backward(self, grad_scale: float = 1.0) -> None:
+        s = self._saved
+        assert s is not None, "backward() without forward_loss()"
+        m, a = self.m, self.m.args
+        im = self._images()
+        self.ensure_grads()
+        B, T, W, S = s["B"], s["T"], s["W"], s["S"]
+        rows, dim, V = B * S, a.dim, a.vocab_size
+        # ---- CE + LM head + final norm
+        dlog = self._buf("dlogits", (B * T, V))
+        ops.cross_entropy(s["logits"], s["lab"], self._buf("row_loss", (B * T,), torch.float32), dlog, s["n_valid"], grad_scale)
+        self._wgrad(dlog, s["xt"], self._views["output.weight"], "out")
+        dxt = self._buf("dxn_text", (B * T, dim))
+        self._dgrad(dlog, im["out.t"], dxt)
+        dh = self._buf("dh", (rows, dim), torch.float32, zero=True)
+        hv, dhv = s["h"].view(B, S, dim), dh.view(B, S, dim)
+        for b in range(B):
+            ops.rmsnorm_bwd(hv[b, W:], m.norm.weight, dxt[b * T:(b + 1) * T], dhv[b, W:], self._views["norm.weight"], a.norm_eps)
+        self._notify("head")
+        # ---- decoder blocks, last to first (recompute from the saved block input)
+        for i in range(m.n_layers - 1, -1, -1):
+            self._block_backward(i, s["hs"][i], dh, B, S)
+            self._notify(f"layer{i}")
+        # ---- embeddings and projector
+        ops.embed_bwd(s["tokens"], dh, self._views["tok_embeddings.weight"], B, T, W, dim)
+        self._notify("embed")
+        if s["vis"] is not None:
+            self._encode_image_backward(dh, s["vis"], B, S)
+            self._notify("vision_proj")
+        self._saved = None
+
+    def _notify(self, bucket: str):
+        if self.on_layer_grads_ready is None:
+            return
+        for name, st, en in self._ranges:
+            if name == bucket:
+                self.on_layer_grads_ready(name, st, en)
+
+    # ------------------------------------------------------------------ vision (frozen ViT, trainable projector)
+    def _encode_image_train(self, h, image, B, S, qformer_feats, extra_feats):
+        m, a = self.m, self.m.args
+        im = self._images()
+        if a.extra_feat_dim or a.qformer_tokens:
+            raise NotImplementedError("training with the hook-fed encoder streams is not wired yet (next: SURVEY 8(f) N4)")
+        _, _, L = m._vit_geometry()
+        if a.n_views == 5:
+            views = m._buf("views", (5 * B, 3, a.vit_crop, a.vit_crop), m.clip.visual.conv1.weight.dtype)
+            ops.split_views(image.contiguous(), views)
+        else:
+            views = image
+        N = a.n_views * B
+        feats = m.clip_encode_image(views)                      # frozen, compute dtype of the clip params
+        if feats.dtype != self.act:
+            f2 = self._buf("feats_act", tuple(feats.shape))
+            ops.cast(feats, f2)
+            feats = f2
+        proj = self._buf("proj", (N * L, a.dim))
+        ops.gemm_nt(feats, im["vp"], proj, bias=im["vp.b"])
+        vp1 = getattr(m.visual_proj, "1")
+        clip_map, _, start_rows, end_rows = m._image_row_maps(B, S)
+        ops.layernorm(proj, vp1.weight, vp1.bias, h, row_map=clip_map)
+        ops.fill_rows(m.start_img.view(-1), h, start_rows)
+        ops.fill_rows(m.end_img.view(-1), h, end_rows)
+        return dict(feats=feats, proj=proj, clip_map=clip_map, start_rows=start_rows, end_rows=end_rows, N=N, L=L)
+
+    def _encode_image_backward(self, dh, vis, B, S):
+        m, a = self.m, self.m.args
+        vp1 = getattr(m.visual_proj, "1")
+        rowsv = vis["N"] * vis["L"]
+        dproj = self._buf("dproj", (rowsv, a.dim))
+        ops.layernorm_bwd(vis["proj"], vp1.weight, dh, vis["clip_map"], dproj, self._views["visual_proj.1.weight"],
+                          self._views["visual_proj.1.bias"])
+        self._wgrad(dproj, vis["feats"], self._views["visual_proj.0.weight"], "vp")
+        ops.rows_sum(dproj, None, rowsv, self._views["visual_proj.0.bias"])
+        ops.rows_sum(dh, vis["start_rows"], vis["start_rows"].numel(), self._views["start_img"].view(-1))
+        ops.rows_sum(dh, vis["end_rows"], vis["end_rows"].numel(), self._views["end_img"].view(-1))
+
+
+class _StepLoss(torch.autograd.Function):
+    """loss = engine.forward_loss(...); backward runs the HIP backward and fills param.grad itself."""
+
+    @staticmethod
+    def forward(ctx, anchor, engine, examples, labels, image):
+        ctx.engine = engine
+        return engine.forward_loss(examples, labels, image)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ctx.engine.backward(float(grad_out))
+        return torch.zeros((), device=grad_out.device), None, None, None, None
+
+
+def step_loss(engine: TrainEngine, anchor: torch.Tensor, examples, labels, image=None) -> torch.Tensor:
+    return _StepLoss.apply(anchor, engine, examples, labels, image)

@@ -87,7 +87,8 @@ int a3v_rmsnorm(const void* x, int64_t ldx, const void* w, void* y, int64_t ldy,
  * 363,370).  row_map (int32, device) lets the projector write straight into the
  * [BOS | image tokens | text] sequence buffer (:471-479). */
 int a3v_layernorm(const void* x, int64_t ldx, const void* w, const void* b, void* y, int64_t ldy,
-                  const int32_t* row_map, int rows, int dim, float eps, int dtype, void* stream);
+                  const int32_t* row_map, int rows, int dim, float eps, int x_dtype, int p_dtype,
+                  int y_dtype, void* stream);
 
 /* RoPE on q,k (interleaved pairs, fp32 math, LLM/llama_ens5.py:118 + restated llama.py) and
  * KV-cache write (:124-129) from a fused qkv activation [B*S, (H+2*Hkv)*hd]:
@@ -154,6 +155,71 @@ int a3v_count_valid(const int64_t* labels, int rows, int32_t* n_valid_dev, void*
 int a3v_cross_entropy(const void* logits, int64_t ld, const int64_t* labels, float* row_loss,
                       void* dlogits, int64_t ldd, const int32_t* n_valid_dev, float grad_scale,
                       int rows, int V, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Training (backward) entry points.  Reference: autograd through the same modules under
+ * autocast(bf16) with fp32 master weights (engine_finetune.py:44-68, main_finetune.py:212-217).
+ * Convention: activations and their grads use `act_dtype` (bf16 / f32 parity); the residual
+ * stream h, master weights and weight grads are fp32.  GEMM-shaped backward work goes through
+ * a3v_gemm_nt on transposed images built with a3v_transpose.
+ * ------------------------------------------------------------------------------------- */
+
+/* a3v_attention + per-row log-sum-exp lse [B,H,Sq] (fp32) kept for the backward pass. */
+int a3v_attention_lse(const void* q, const void* k, const void* vt, void* out, float* lse, int B,
+                      int Sq, int Sk, int H, int Hkv, int hd, const int64_t* strides, int causal,
+                      int dtype, void* stream);
+
+/* dst[b][c][r] = src[b][r][c] for r < R (zero for R <= r < Rpad); leading dims / batch strides
+ * in elements.  Builds W^T for dgrad and X^T / dY^T for wgrad. */
+int a3v_transpose(const void* src, int64_t ld_src, int64_t bs_src, void* dst, int64_t ld_dst,
+                  int64_t bs_dst, int R, int C, int Rpad, int batch, int dtype, void* stream);
+
+/* backward of a3v_rmsnorm with fp32 x, w: dh += d/dx ; dw += d/dw (may be NULL). dy in act_dtype. */
+int a3v_rmsnorm_bwd(const float* x, int64_t ldx, const float* w, const void* dy, int64_t lddy,
+                    float* dh, int64_t lddh, float* dw, int rows, int dim, float eps, int act_dtype,
+                    void* stream);
+
+/* backward of a3v_layernorm (x in act_dtype, fp32 w; dy fp32 rows gathered through row_map):
+ * dx (act_dtype), dw += , db += . */
+int a3v_layernorm_bwd(const void* x, int64_t ldx, const float* w, const float* dy, int64_t lddy,
+                      const int32_t* row_map, void* dx, int64_t lddx, float* dw, float* db, int rows,
+                      int dim, float eps, int act_dtype, void* stream);
+
+/* SwiGLU on gu [rows, 2F] (the un-fused form of A3V_EPI_SWIGLU, kept for the backward pass):
+ * interleaved = 1: 16-column blocks [gate|up] (inference weight image); 0: [all gates | all ups]
+ * (training image = cat(w1, w3), whose fp32 grad buffer splits into w1.grad / w3.grad views).
+ * act = silu(g)*u ; dgu from dact. */
+int a3v_swiglu_fwd(const void* gu, int64_t ldg, void* act, int64_t lda, int rows, int F,
+                   int interleaved, int dtype, void* stream);
+int a3v_swiglu_bwd(const void* gu, int64_t ldg, const void* dact, int64_t lda, void* dgu,
+                   int64_t lddg, int rows, int F, int interleaved, int dtype, void* stream);
+
+/* inverse RoPE on dq [B,S,H,hd], dk [B,Hkv,S,hd]; dv [B,Hkv,S,hd] copied; packed into
+ * dqkv [B*S, (H+2Hkv)*hd] (the gradient of the fused QKV activation). */
+int a3v_rope_bwd_pack(const void* dq, const void* dk, const void* dv, void* dqkv, int64_t ld,
+                      const float* cos_sin, int B, int S, int H, int Hkv, int hd, int rope_pos0,
+                      int dtype, void* stream);
+
+/* backward of causal / full self-attention (Sq == Sk == S).  q,out,dout,dq [B,S,H,hd]; k,dk,dv
+ * [B,Hkv,S,hd]; k rows [b][hk][s] at k + b*k_sb + hk*k_sh + s*hd; v rows addressed by element
+ * strides (batch, seq, kv-head); lse [B,H,S]; D: fp32 scratch [B,S,H]. */
+int a3v_attention_bwd(const void* q, const void* k, int64_t k_sb, int64_t k_sh, const void* v,
+                      int64_t v_sb, int64_t v_ss, int64_t v_sh, const void* out, const void* dout,
+                      const float* lse, float* D,
+                      void* dq, void* dk, void* dv, int B, int S, int H, int Hkv, int hd, int causal,
+                      int dtype, void* stream);
+
+/* dst = (dst_dtype) src, 2-D with leading dimensions (fp32 grad stream -> bf16 GEMM operand). */
+int a3v_cast(const void* src, int64_t ld_src, int src_dtype, void* dst, int64_t ld_dst, int dst_dtype,
+             int rows, int cols, void* stream);
+
+/* d_table[token] += dh[row] over the text rows of [BOS | W image words | text] (fp32). */
+int a3v_embed_bwd(const int64_t* tokens, int64_t ld_tok, const float* dh, float* dtable, int B, int T,
+                  int W, int dim, int vocab, void* stream);
+
+/* out[c] += sum_i src[row_idx ? row_idx[i] : i][c]  (bias grads, start_img / end_img grads). */
+int a3v_rows_sum(const void* src, int64_t ld, const int32_t* row_idx, int n_rows, int dim, float* out,
+                 int dtype, void* stream);
 
 #ifdef __cplusplus
 }

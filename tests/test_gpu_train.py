@@ -1,0 +1,298 @@
+"""-m gpu: backward kernels and the full training step against torch autograd over the CPU oracle
+(oracle/ref_cpu.py is built from differentiable torch ops, so its autograd IS the reference gradient:
+engine_finetune.py:44-68 semantics).  fp32 parity path: 1e-3 relative; bf16 compute: stated per check."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from a3vlm_amd import ops  # noqa: E402
+from a3vlm_amd.model.LLM import llama_ens5 as plugin  # noqa: E402
+from a3vlm_amd.model.meta import MetaModel  # noqa: E402
+from a3vlm_amd.train import TrainEngine  # noqa: E402
+from a3vlm_amd.util import promote_trainable_params_to_fp32  # noqa: E402
+from oracle import ref_cpu  # noqa: E402
+from oracle.gen_golden import synth_image  # noqa: E402
+
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+def gen(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def relerr(got, want):
+    got, want = got.detach().float().cpu(), want.detach().float().cpu()
+    return float((got - want).abs().max() / (want.abs().max() + 1e-12))
+
+
+# ------------------------------------------------------------------ kernels
+@pytest.mark.parametrize("dtype", [torch.float32, BF])
+def test_transpose_and_cast(dtype):
+    x = gen(3, 70, 130, seed=1).to(dtype)
+    xd = x.to(DEV)
+    out = torch.full((3, 130, 128), 9.0, dtype=dtype, device=DEV)
+    ops.transpose(xd, out, 70, 130, 128, batch=3, bs_src=70 * 130, bs_dst=130 * 128)
+    assert torch.equal(out[:, :, :70].cpu(), x.transpose(1, 2))
+    assert float(out[:, :, 70:].float().abs().sum()) == 0
+    y = gen(37, 64, seed=2)
+    yb = torch.empty(37, 64, dtype=BF, device=DEV)
+    ops.cast(y.to(DEV), yb)
+    assert torch.equal(yb.cpu(), y.to(BF))
+
+
+@pytest.mark.parametrize("act", [torch.float32, BF])
+def test_rmsnorm_bwd(act):
+    rows, dim = 45, 512
+    x = gen(rows, dim, seed=3, scale=2.0).requires_grad_(True)
+    w = (1 + 0.1 * gen(dim, seed=4)).requires_grad_(True)
+    dy = gen(rows, dim, seed=5).to(act)
+    y = ref_cpu.rmsnorm(x, w, 1e-5)
+    y.backward(dy.float())
+    dh0 = gen(rows, dim, seed=6)
+    dh = dh0.to(DEV).clone()
+    dw = torch.zeros(dim, device=DEV)
+    ops.rmsnorm_bwd(x.detach().to(DEV), w.detach().to(DEV), dy.to(DEV), dh, dw, 1e-5)
+    assert relerr(dh.cpu() - dh0, x.grad) < 1e-4
+    assert relerr(dw, w.grad) < 1e-4
+
+
+@pytest.mark.parametrize("act", [torch.float32, BF])
+def test_layernorm_bwd(act):
+    rows, dim = 40, 256
+    x = gen(rows, dim, seed=7, scale=2.0).to(act)
+    w, b = 1 + 0.1 * gen(dim, seed=8), 0.1 * gen(dim, seed=9)
+    xr = x.float().requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    F.layer_norm(xr, (dim,), wr, br, 1e-5).backward(gen(rows, dim, seed=10))
+    perm = torch.randperm(rows * 2, generator=torch.Generator().manual_seed(1))[:rows].to(torch.int32)
+    dy_big = torch.zeros(rows * 2, dim)
+    dy_big[perm.long()] = gen(rows, dim, seed=10)
+    dx = torch.empty(rows, dim, dtype=act, device=DEV)
+    dw, db = torch.zeros(dim, device=DEV), torch.zeros(dim, device=DEV)
+    ops.layernorm_bwd(x.to(DEV), w.to(DEV), dy_big.to(DEV), perm.to(DEV), dx, dw, db)
+    tol = 1e-4 if act == torch.float32 else 1e-2
+    assert relerr(dx, xr.grad) < tol and relerr(dw, wr.grad) < 1e-4 and relerr(db, br.grad) < 1e-4
+    # forward with fp32 params writing fp32 rows (projector under autocast)
+    yb = torch.zeros(rows * 2, dim, device=DEV)
+    ops.layernorm(x.to(DEV), w.to(DEV), b.to(DEV), yb, row_map=perm.to(DEV))
+    assert relerr(yb[perm.long().to(DEV)], F.layer_norm(x.float(), (dim,), w, b, 1e-5)) < 1e-5
+
+
+@pytest.mark.parametrize("inter", [False, True])
+def test_swiglu_fwd_bwd(inter):
+    rows, Fd = 33, 64
+    g, u = gen(rows, Fd, seed=11).requires_grad_(True), gen(rows, Fd, seed=12).requires_grad_(True)
+    da = gen(rows, Fd, seed=13)
+    (F.silu(g) * u).backward(da)
+    if inter:
+        gu = torch.stack([g.detach().view(rows, Fd // 16, 16), u.detach().view(rows, Fd // 16, 16)], dim=2).reshape(rows, 2 * Fd)
+    else:
+        gu = torch.cat([g.detach(), u.detach()], dim=1)
+    gud = gu.to(DEV)
+    act = torch.empty(rows, Fd, device=DEV)
+    ops.swiglu_fwd(gud, act, Fd, inter)
+    assert relerr(act, F.silu(g) * u) < 1e-5
+    dgu = torch.empty(rows, 2 * Fd, device=DEV)
+    ops.swiglu_bwd(gud, da.to(DEV), dgu, Fd, inter)
+    if inter:
+        d = dgu.cpu().view(rows, Fd // 16, 2, 16)
+        dg, du = d[:, :, 0].reshape(rows, Fd), d[:, :, 1].reshape(rows, Fd)
+    else:
+        dg, du = dgu.cpu()[:, :Fd], dgu.cpu()[:, Fd:]
+    assert relerr(dg, g.grad) < 1e-5 and relerr(du, u.grad) < 1e-5
+
+
+def test_rope_bwd_pack():
+    B, S, H, Hkv, hd = 2, 7, 4, 2, 16
+    from a3vlm_amd.model.LLM.llama_ens5 import precompute_cos_sin
+    fc = ref_cpu.precompute_freqs_cis(hd, 64)
+    q, k = gen(B, S, H, hd, seed=14).requires_grad_(True), gen(B, S, Hkv, hd, seed=15).requires_grad_(True)
+    oq, ok = ref_cpu.apply_rotary_emb(q, k, fc[:S])
+    dq, dk, dv = gen(B, S, H, hd, seed=16), gen(B, S, Hkv, hd, seed=17), gen(B, S, Hkv, hd, seed=18)
+    (oq * dq).sum().backward(retain_graph=True)
+    (ok * dk).sum().backward()
+    dqkv = torch.empty(B * S, (H + 2 * Hkv) * hd, device=DEV)
+    ops.rope_bwd_pack(dq.to(DEV), dk.permute(0, 2, 1, 3).contiguous().to(DEV), dv.permute(0, 2, 1, 3).contiguous().to(DEV), dqkv,
+                      precompute_cos_sin(hd, 64, 10000.0, None).to(DEV), B, S, H, Hkv, hd, 0)
+    d = dqkv.cpu()
+    assert relerr(d[:, :H * hd].view(B, S, H, hd), q.grad) < 1e-5
+    assert relerr(d[:, H * hd:(H + Hkv) * hd].view(B, S, Hkv, hd), k.grad) < 1e-5
+    assert torch.equal(d[:, (H + Hkv) * hd:].view(B, S, Hkv, hd), dv)
+
+
+@pytest.mark.parametrize("dtype,B,S,H,Hkv,hd,causal", [(torch.float32, 2, 9, 4, 2, 16, True), (torch.float32, 1, 70, 2, 2, 64, False),
+                                                      (BF, 2, 40, 2, 1, 128, True), (torch.float32, 1, 33, 2, 2, 128, True)])
+def test_attention_lse_and_bwd(dtype, B, S, H, Hkv, hd, causal):
+    q = gen(B, S, H, hd, seed=19).to(dtype).float().requires_grad_(True)
+    k = gen(B, S, Hkv, hd, seed=20).to(dtype).float().requires_grad_(True)
+    v = gen(B, S, Hkv, hd, seed=21).to(dtype).float().requires_grad_(True)
+    do = gen(B, S, H, hd, seed=22).to(dtype).float()
+    n_rep = H // Hkv
+    kk, vv = ref_cpu.repeat_kv(k, n_rep).transpose(1, 2), ref_cpu.repeat_kv(v, n_rep).transpose(1, 2)
+    mask = ref_cpu.make_causal_mask(S, S) if causal else None
+    out = ref_cpu.sdpa(q.transpose(1, 2), kk, vv, mask).transpose(1, 2)
+    out.backward(do)
+    spad = (S + 63) // 64 * 64
+    qd = q.detach().to(dtype).to(DEV).contiguous()
+    kc = torch.zeros(B, Hkv, spad, hd, dtype=dtype, device=DEV)
+    vc = torch.zeros(B, Hkv, hd, spad, dtype=dtype, device=DEV)
+    kc[:, :, :S] = k.detach().to(dtype).permute(0, 2, 1, 3).to(DEV)
+    vc[:, :, :, :S] = v.detach().to(dtype).permute(0, 2, 3, 1).to(DEV)
+    o = torch.empty(B, S, H, hd, dtype=dtype, device=DEV)
+    lse = torch.empty(B, H, S, device=DEV)
+    strides = (S * H * hd, H * hd, hd, Hkv * spad * hd, spad * hd, hd, Hkv * hd * spad, hd * spad, spad, S * H * hd, H * hd, hd)
+    ops.attention_lse(qd, kc, vc, o, lse, B, S, S, H, Hkv, hd, strides, causal)
+    sc = torch.matmul(q.detach().transpose(1, 2), kk.detach().transpose(-1, -2)) / math.sqrt(hd)
+    if causal:
+        sc = sc.masked_fill(~mask, float("-inf"))
+    assert relerr(lse, torch.logsumexp(sc, dim=-1)) < (1e-5 if dtype == torch.float32 else 2e-2)
+    vrows = v.detach().to(dtype).to(DEV).contiguous()      # [B,S,Hkv,hd]
+    dq = torch.empty(B, S, H, hd, dtype=dtype, device=DEV)
+    dk = torch.empty(B, Hkv, S, hd, dtype=dtype, device=DEV)
+    dv = torch.empty(B, Hkv, S, hd, dtype=dtype, device=DEV)
+    D = torch.empty(B, S, H, device=DEV)
+    ops.attention_bwd(qd, kc, Hkv * spad * hd, spad * hd, vrows, S * Hkv * hd, Hkv * hd, hd, o, do.to(dtype).to(DEV), lse, D,
+                      dq, dk, dv, B, S, H, Hkv, hd, causal)
+    tol = 2e-4 if dtype == torch.float32 else 3e-2
+    assert relerr(dq, q.grad) < tol
+    assert relerr(dk.permute(0, 2, 1, 3), k.grad) < tol
+    assert relerr(dv.permute(0, 2, 1, 3), v.grad) < tol
+
+
+def test_embed_bwd_and_rows_sum():
+    B, T, W, dim, V = 2, 5, 3, 64, 30
+    tok = torch.randint(0, V, (B, T), generator=torch.Generator().manual_seed(4))
+    tok[1, 2] = tok[0, 1]        # repeated token -> accumulation
+    dh = gen(B * (T + W), dim, seed=23)
+    dt_ = torch.zeros(V, dim, device=DEV)
+    ops.embed_bwd(tok.to(DEV), dh.to(DEV), dt_, B, T, W, dim)
+    want = torch.zeros(V, dim)
+    dv = dh.view(B, T + W, dim)
+    for b in range(B):
+        for t in range(T):
+            want[tok[b, t]] += dv[b, 0 if t == 0 else W + t]
+    assert relerr(dt_, want) < 1e-6
+    idx = torch.tensor([0, 3, 9], dtype=torch.int32)
+    out = torch.ones(dim, device=DEV)
+    ops.rows_sum(dh.to(DEV), idx.to(DEV), 3, out)
+    assert relerr(out, 1 + dh[idx.long()].sum(0)) < 1e-6
+
+
+# ------------------------------------------------------------------ full training step vs oracle autograd
+TK = dict(dim=64, n_layers=2, n_heads=4, n_kv_heads=2, vocab_size=192, multiple_of=64, max_seq_len=1024)
+
+
+def oracle_loss_and_grads(sd, vsd, ex, lab, img):
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    vtrain = {k: v.clone().requires_grad_(k.startswith(("visual_proj", "start_img", "end_img"))) for k, v in (vsd or {}).items()}
+    oargs = ref_cpu.OracleArgs(**TK)
+    dec = ref_cpu.OracleDecoder(oargs, sd)
+    itok = None
+    if img is not None:
+        views = ref_cpu.encode_image(img, vtrain, vit_layers=2, vit_heads=4, n_views=1)
+        itok = ref_cpu.assemble_image_tokens(views, vtrain["start_img"], vtrain["end_img"])
+    loss = ref_cpu.meta_forward_loss(dec, ex, lab, itok)
+    loss.backward()
+    grads = {k: v.grad for k, v in sd.items()}
+    grads.update({k: v.grad for k, v in vtrain.items() if v.requires_grad})
+    return float(loss), grads
+
+
+def build(with_visual, compute_dtype):
+    args = plugin.ModelArgs(**TK, vit_width=64, vit_layers=2, vit_heads=4, vit_crop=112, n_views=1)
+    m = plugin.Transformer(args, with_visual=with_visual)
+    sd = ref_cpu.make_decoder_weights(ref_cpu.OracleArgs(**TK), seed=0, std=0.08)
+    vsd = ref_cpu.make_vision_weights(64, width=64, layers=2, patch=14, grid=8, seed=1, std=0.05) if with_visual else None
+    m.load_state_dict({**sd, **(vsd or {})})
+    for n, p in m.named_parameters():
+        p.requires_grad = not n.startswith("clip.")
+    m.to(compute_dtype).to(DEV)
+    promote_trainable_params_to_fp32(m)
+    return m, sd, vsd
+
+
+@pytest.mark.parametrize("with_visual", [False, True])
+def test_train_step_fp32_matches_autograd(with_visual):
+    m, sd, vsd = build(with_visual, torch.float32)
+    g = torch.Generator().manual_seed(5)
+    B, T = 2, 12
+    ex = torch.randint(3, 192, (B, T), generator=g)
+    ex[:, 0] = 1
+    lab = ex.clone()
+    lab[:, :4] = 0
+    lab[1, 9:] = 0
+    img = synth_image(B, size=112, seed=3) if with_visual else None
+    want_loss, want = oracle_loss_and_grads(sd, vsd, ex, lab, img)
+    eng = TrainEngine(m, torch.float32)
+    loss = eng.forward_loss(ex.to(DEV), lab.to(DEV), img.to(DEV) if with_visual else None)
+    assert abs(float(loss) - want_loss) < 1e-3 * abs(want_loss)
+    eng.backward(1.0)
+    for name, p in m.get_trainable_params().items():
+        assert p.grad is not None, name
+        e = relerr(p.grad, want[name])
+        assert e < 1e-3, (name, e)
+    # accumulation + grad scale: a second backward with scale 0.5 adds half the gradient
+    eng.forward_loss(ex.to(DEV), lab.to(DEV), img.to(DEV) if with_visual else None)
+    eng.backward(0.5)
+    assert relerr(m.layers[0].feed_forward.w2.weight.grad, 1.5 * want["layers.0.feed_forward.w2.weight"]) < 1e-3
+    assert relerr(m.tok_embeddings.weight.grad, 1.5 * want["tok_embeddings.weight"]) < 1e-3
+
+
+def test_train_step_bf16_close_to_fp32_reference():
+    """autocast-style step (bf16 activations/GEMMs, fp32 masters & grads): bf16-level agreement with the
+    fp32 reference gradient (cosine similarity, since individual small entries carry bf16 noise)."""
+    m, sd, vsd = build(True, BF)
+    g = torch.Generator().manual_seed(6)
+    B, T = 2, 16
+    ex = torch.randint(3, 192, (B, T), generator=g)
+    ex[:, 0] = 1
+    lab = ex.clone()
+    lab[:, :5] = 0
+    img = synth_image(B, size=112, seed=4)
+    want_loss, want = oracle_loss_and_grads(sd, vsd, ex, lab, img)
+    eng = TrainEngine(m, BF)
+    loss = eng.forward_loss(ex.to(DEV), lab.to(DEV), img.to(DEV))
+    assert abs(float(loss) - want_loss) < 2e-2 * abs(want_loss)
+    eng.backward(1.0)
+    for name, p in m.get_trainable_params().items():
+        a, b = p.grad.float().cpu().flatten(), want[name].flatten()
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-20))
+        assert cos > 0.99, (name, cos)
+
+
+def test_metamodel_loss_backward_drop_in(golden_dir=None):
+    """loss, _ = model(examples, labels); loss.backward() -- the trainer's call sequence (engine_finetune.py:50-68)."""
+    import os
+    gd = os.path.join(os.path.dirname(__file__), "golden")
+    mm = MetaModel("llama_ens5", os.path.join(gd, "tiny_params.json"), os.path.join(gd, "tokenizer.model"), with_visual=False, max_seq_len=64)
+    from oracle.gen_golden import TINY
+    sd = ref_cpu.make_decoder_weights(ref_cpu.OracleArgs(vocab_size=192, **TINY), seed=0, std=0.08)
+    mm.llma.load_state_dict(sd)
+    mm.to(DEV)
+    mm.train_compute_dtype = torch.float32
+    g = torch.Generator().manual_seed(7)
+    ex = torch.randint(3, 192, (3, 14), generator=g)
+    ex[:, 0] = 1
+    lab = ex.clone()
+    lab[:, :5] = 0
+    lab[:, 11:] = 0          # trailing pad columns are trimmed by MetaModel.forward
+    loss, extra = mm(ex.to(DEV), lab.to(DEV))
+    assert extra == {}
+    (loss / 2).backward()
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    dec = ref_cpu.OracleDecoder(ref_cpu.OracleArgs(vocab_size=192, **TINY), sdg)
+    want = ref_cpu.meta_forward_loss(dec, ex, lab)
+    (want / 2).backward()
+    assert abs(float(loss) - float(want)) < 1e-3 * float(want)
+    for name, p in mm.llma.named_parameters():
+        assert relerr(p.grad, sdg[name].grad) < 1e-3, name
+    opt = torch.optim.AdamW(mm.parameters(), lr=1e-3, betas=(0.9, 0.95))
+    opt.step()
+    opt.zero_grad()
+    loss2, _ = mm(ex.to(DEV), lab.to(DEV))
+    assert float(loss2) < float(loss)       # one AdamW step on the same batch reduces the loss
