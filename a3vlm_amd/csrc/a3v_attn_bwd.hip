@@ -1,0 +1,330 @@
+// MFMA attention backward for gfx950 (bf16, hd in {64,128}, self-attention Sq == Sk == S).
+//
+// Same "transposed product" trick as the forward kernel (a3v_attn.hip): with v_mfma_f32_32x32x16 the
+// accumulator of  X^T = A . B^T  puts one B-row index on the LANE (col = lane&31) and the A-row index
+// on the 16 registers, and those 16 registers are -- in order -- exactly the k-elements a B operand
+// wants when the matching A operand rows are read at  base + 4*(lane>>5) + {0..3, 8..11}.
+//
+//  dQ kernel (grid over q tiles; mirrors the forward):      lane <-> query
+//      S^T  = K . Q^T ,  dP^T = V . dO^T            (A = K / V rows from LDS, B = Q / dO in registers)
+//      P^T  = exp(S^T*scale - lse[q]) ;  dS^T = P^T o (dP^T - D[q]) * scale     (lane-local)
+//      dQ^T += K^T . dS^T                            (A = K^T rows from LDS, B = dS^T from the accumulators)
+//  dK/dV kernel (grid over kv tiles; loops over queries and the n_rep query heads):   lane <-> key
+//      S    = Q . K^T ,  dP = dO . V^T               (A = Q / dO rows from LDS, B = K / V in registers)
+//      P, dS with lse[q], D[q] per REGISTER row (read from LDS)
+//      dV^T += dO^T . P ,  dK^T += Q^T . dS          (A = dO^T / Q^T rows from LDS, B = P / dS)
+// K^T, Q^T, dO^T come from a3v_transpose into the caller's workspace; no atomics anywhere.
+#include "a3v_common.h"
+
+namespace {
+
+struct BwdArgs {
+  const bf16_t* q; const bf16_t* k; const bf16_t* v; const bf16_t* dout;
+  const bf16_t* kt; const bf16_t* qt; const bf16_t* dot;      // [B,Hkv,hd,Sp], [B,H,hd,Sp], [B,H,hd,Sp]
+  const float* lse; const float* D;                            // [B,H,S], [B,S,H]
+  bf16_t* dq; bf16_t* dk; bf16_t* dv;
+  int64_t k_sb, k_sh, v_sb, v_ss, v_sh;
+  int B, S, Sp, H, Hkv, causal;
+  float scale;
+};
+
+// 64-row x HD tile of row-major bf16 rows -> LDS with the 16-B chunk XOR swizzle of the forward K tile
+template <int HD>
+__device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ base, int64_t row_stride, int row0, int nrows, char* lds, int tid) {
+  constexpr int KCH = HD / 8;
+  constexpr int PER = 64 * KCH / 256;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int id = tid + i * 256;
+    const int row = id / KCH, ch = id % KCH;
+    int r = row0 + row;
+    r = r < nrows ? r : nrows - 1;
+    const u32x4 val = *reinterpret_cast<const u32x4*>(base + (int64_t)r * row_stride + ch * 8);
+    const int sw = (HD == 128) ? (row & 15) : ((row >> 1) & 7);
+    *reinterpret_cast<u32x4*>(lds + row * (HD * 2) + ((ch ^ sw) << 4)) = val;
+  }
+}
+
+// HD rows x 64 columns of a transposed operand [hd][Sp] -> LDS [HD][128 B] with the 8-B chunk swizzle of
+// the forward V^T tile; columns >= ncols are zero-filled (they multiply masked probabilities).
+template <int HD>
+__device__ __forceinline__ void stage_cols(const bf16_t* __restrict__ base, int64_t row_stride, int col0, int ncols, char* lds, int tid) {
+  constexpr int PER = HD * 8 / 256;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int id = tid + i * 256;
+    const int d = id >> 3, ch = id & 7;
+    const int c = col0 + ch * 8;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (c + 8 <= ncols) {
+      v = *reinterpret_cast<const u32x4*>(base + (int64_t)d * row_stride + c);
+    } else if (c < ncols) {
+      const unsigned short* src = reinterpret_cast<const unsigned short*>(base + (int64_t)d * row_stride + c);
+      unsigned short e[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e[j] = (c + j < ncols) ? src[j] : (unsigned short)0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = (unsigned)e[2 * j] | ((unsigned)e[2 * j + 1] << 16);
+    }
+    const int g = (d >> 1) & 15;
+    const u32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
+    *reinterpret_cast<u32x2*>(lds + d * 128 + (((2 * ch) ^ g) << 3)) = lo;
+    *reinterpret_cast<u32x2*>(lds + d * 128 + (((2 * ch + 1) ^ g) << 3)) = hi;
+  }
+}
+
+// A operand fragment of a row tile: row (32 tb + lane&31), 16-B chunk 2 ks + hh
+template <int HD>
+__device__ __forceinline__ bf16x8 frag_rows(const char* lds, int tb, int ks, int ql, int hh) {
+  const int row = tb * 32 + ql;
+  const int sw = (HD == 128) ? (row & 15) : ((row >> 1) & 7);
+  return *reinterpret_cast<const bf16x8*>(lds + row * (HD * 2) + (((2 * ks + hh) ^ sw) << 4));
+}
+
+// A operand fragment of a transposed tile for the accumulator-order contraction: row d = 32 db + lane&31,
+// elements at columns 32 tb + 16 c + 4 hh + {0..3, 8..11}
+__device__ __forceinline__ bf16x8 frag_cols(const char* lds, int db, int tb, int c, int ql, int hh) {
+  const int drow = db * 32 + ql;
+  const int g = (drow >> 1) & 15;
+  const char* vp = lds + drow * 128;
+  const int ca = 8 * tb + 4 * c + hh;
+  const u32x2 a0 = *reinterpret_cast<const u32x2*>(vp + ((ca ^ g) << 3));
+  const u32x2 a1 = *reinterpret_cast<const u32x2*>(vp + (((ca + 2) ^ g) << 3));
+  const u32x4 av = {a0[0], a0[1], a1[0], a1[1]};
+  bf16x8 f;
+  __builtin_memcpy(&f, &av, 16);
+  return f;
+}
+
+// ------------------------------------------------------------------ dQ
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BwdArgs p) {
+  constexpr int TILE = 64 * HD * 2;                 // bytes of one 64-row tile (== HD x 128 B)
+  __shared__ __attribute__((aligned(16))) char lds[3 * TILE];
+  char* Ks = lds; char* Vs = lds + TILE; char* Kts = lds + 2 * TILE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qt = gridDim.x - 1 - blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int hk = h / (p.H / p.Hkv);
+  const int ql = lane & 31, hh = lane >> 5;
+  const int qrow = qt * 128 + wave * 32 + ql;
+  const int qc = qrow < p.S ? qrow : p.S - 1;
+  const bf16_t* Q = p.q + (((int64_t)b * p.S + qc) * p.H + h) * HD;
+  const bf16_t* DO = p.dout + (((int64_t)b * p.S + qc) * p.H + h) * HD;
+  const bf16_t* K = p.k + b * p.k_sb + hk * p.k_sh;
+  const bf16_t* V = p.v + b * p.v_sb + hk * p.v_sh;
+  const bf16_t* KT = p.kt + ((int64_t)b * p.Hkv + hk) * HD * p.Sp;
+  bf16x8 qf[HD / 16], dof[HD / 16];
+#pragma unroll
+  for (int ks = 0; ks < HD / 16; ++ks) {
+    qf[ks] = *reinterpret_cast<const bf16x8*>(Q + ks * 16 + hh * 8);
+    dof[ks] = *reinterpret_cast<const bf16x8*>(DO + ks * 16 + hh * 8);
+  }
+  const float lse = p.lse[((int64_t)b * p.H + h) * p.S + qc];
+  const float Dq = p.D[((int64_t)b * p.S + qc) * p.H + h];
+  f32x16 acc[HD / 32];
+#pragma unroll
+  for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+  int kv_end = p.S;
+  if (p.causal) kv_end = min(p.S, min(qt * 128 + 127, p.S - 1) + 1);
+  const int n_tiles = (kv_end + 63) / 64;
+  for (int t = 0; t < n_tiles; ++t) {
+    const int kv0 = t * 64;
+    __syncthreads();
+    stage_rows<HD>(K, HD, kv0, p.S, Ks, tid);
+    stage_rows<HD>(V, p.v_ss, kv0, p.S, Vs, tid);
+    stage_cols<HD>(KT, p.Sp, kv0, p.S, Kts, tid);
+    __syncthreads();
+    f32x16 s[2], dp[2];
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[tb][r] = 0.f; dp[tb][r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < HD / 16; ++ks) {
+        s[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<HD>(Ks, tb, ks, ql, hh), qf[ks], s[tb], 0, 0, 0);
+        dp[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<HD>(Vs, tb, ks, ql, hh), dof[ks], dp[tb], 0, 0, 0);
+      }
+    }
+    bf16x8 dsf[2][2];
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kv = kv0 + tb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const bool ok = (kv < p.S) && (!p.causal || kv <= qrow);
+        const float pr = ok ? __expf(s[tb][r] * p.scale - lse) : 0.f;
+        dsf[tb][r >> 3][r & 7] = f2bf(pr * (dp[tb][r] - Dq) * p.scale);
+      }
+#pragma unroll
+    for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+          acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(Kts, d, tb, c, ql, hh), dsf[tb][c], acc[d], 0, 0, 0);
+  }
+  if (qrow < p.S) {
+    bf16_t* O = p.dq + (((int64_t)b * p.S + qrow) * p.H + h) * HD;
+#pragma unroll
+    for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        bf16x4 ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ov[e] = f2bf(acc[d][g4 * 4 + e]);
+        *reinterpret_cast<bf16x4*>(O + d * 32 + g4 * 8 + hh * 4) = ov;
+      }
+  }
+}
+
+// ------------------------------------------------------------------ dK, dV
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(BwdArgs p) {
+  constexpr int TILE = 64 * HD * 2;
+  __shared__ __attribute__((aligned(16))) char lds[4 * TILE + 512];
+  char* Qs = lds; char* DOs = lds + TILE; char* Qts = lds + 2 * TILE; char* DOts = lds + 3 * TILE;
+  float* lse_s = reinterpret_cast<float*>(lds + 4 * TILE);       // [64]
+  float* D_s = lse_s + 64;                                       // [64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kt_ = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
+  const int nrep = p.H / p.Hkv;
+  const int kl = lane & 31, hh = lane >> 5;
+  const int kvrow = kt_ * 128 + wave * 32 + kl;
+  const int kc = kvrow < p.S ? kvrow : p.S - 1;
+  const bf16_t* Kr = p.k + b * p.k_sb + hk * p.k_sh + (int64_t)kc * HD;
+  const bf16_t* Vr = p.v + b * p.v_sb + hk * p.v_sh + (int64_t)kc * p.v_ss;
+  bf16x8 kf[HD / 16], vf[HD / 16];
+#pragma unroll
+  for (int ks = 0; ks < HD / 16; ++ks) {
+    kf[ks] = *reinterpret_cast<const bf16x8*>(Kr + ks * 16 + hh * 8);
+    vf[ks] = *reinterpret_cast<const bf16x8*>(Vr + ks * 16 + hh * 8);
+  }
+  f32x16 dkacc[HD / 32], dvacc[HD / 32];
+#pragma unroll
+  for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dkacc[d][r] = 0.f; dvacc[d][r] = 0.f; }
+  const int q_begin = p.causal ? (kt_ * 128) / 64 : 0;      // first q tile that can see this block's keys
+  const int n_qt = (p.S + 63) / 64;
+  for (int rep = 0; rep < nrep; ++rep) {
+    const int h = hk * nrep + rep;
+    const bf16_t* Q = p.q + ((int64_t)b * p.S * p.H + h) * HD;        // row stride H*HD
+    const bf16_t* DO = p.dout + ((int64_t)b * p.S * p.H + h) * HD;
+    const bf16_t* QT = p.qt + ((int64_t)b * p.H + h) * HD * p.Sp;
+    const bf16_t* DOT = p.dot + ((int64_t)b * p.H + h) * HD * p.Sp;
+    for (int t = q_begin; t < n_qt; ++t) {
+      const int q0 = t * 64;
+      __syncthreads();
+      stage_rows<HD>(Q, (int64_t)p.H * HD, q0, p.S, Qs, tid);
+      stage_rows<HD>(DO, (int64_t)p.H * HD, q0, p.S, DOs, tid);
+      stage_cols<HD>(QT, p.Sp, q0, p.S, Qts, tid);
+      stage_cols<HD>(DOT, p.Sp, q0, p.S, DOts, tid);
+      if (tid < 64) {
+        const int qq = min(q0 + tid, p.S - 1);
+        lse_s[tid] = p.lse[((int64_t)b * p.H + h) * p.S + qq];
+        D_s[tid] = p.D[((int64_t)b * p.S + qq) * p.H + h];
+      }
+      __syncthreads();
+      f32x16 s[2], dp[2];
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[tb][r] = 0.f; dp[tb][r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < HD / 16; ++ks) {
+          s[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<HD>(Qs, tb, ks, kl, hh), kf[ks], s[tb], 0, 0, 0);
+          dp[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<HD>(DOs, tb, ks, kl, hh), vf[ks], dp[tb], 0, 0, 0);
+        }
+      }
+      bf16x8 pf[2][2], dsf[2][2];
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ql_ = tb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;      // query row inside the tile
+          const int qg = q0 + ql_;
+          const bool ok = (qg < p.S) && (kvrow < p.S) && (!p.causal || kvrow <= qg);
+          const float pr = ok ? __expf(s[tb][r] * p.scale - lse_s[ql_]) : 0.f;
+          pf[tb][r >> 3][r & 7] = f2bf(pr);
+          dsf[tb][r >> 3][r & 7] = f2bf(pr * (dp[tb][r] - D_s[ql_]) * p.scale);
+        }
+#pragma unroll
+      for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            dvacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(DOts, d, tb, c, kl, hh), pf[tb][c], dvacc[d], 0, 0, 0);
+            dkacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(Qts, d, tb, c, kl, hh), dsf[tb][c], dkacc[d], 0, 0, 0);
+          }
+    }
+  }
+  if (kvrow < p.S) {
+    bf16_t* DK = p.dk + (((int64_t)b * p.Hkv + hk) * p.S + kvrow) * HD;
+    bf16_t* DV = p.dv + (((int64_t)b * p.Hkv + hk) * p.S + kvrow) * HD;
+#pragma unroll
+    for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        bf16x4 a, c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] = f2bf(dkacc[d][g4 * 4 + e]); c[e] = f2bf(dvacc[d][g4 * 4 + e]); }
+        *reinterpret_cast<bf16x4*>(DK + d * 32 + g4 * 8 + hh * 4) = a;
+        *reinterpret_cast<bf16x4*>(DV + d * 32 + g4 * 8 + hh * 4) = c;
+      }
+  }
+}
+
+}  // namespace
+
+// declared in a3v_train.hip
+extern "C" int a3v_transpose(const void* src, int64_t ld_src, int64_t bs_src, void* dst, int64_t ld_dst, int64_t bs_dst,
+                             int R, int C, int Rpad, int batch, int dtype, void* stream);
+
+extern "C" int64_t a3v_attention_bwd_workspace_bytes(int B, int S, int H, int Hkv, int hd) {
+  const int64_t Sp = (S + 63) / 64 * 64;
+  return ((int64_t)B * Hkv + 2 * (int64_t)B * H) * hd * Sp * 2;
+}
+
+// bf16 MFMA path of a3v_attention_bwd (called from a3v_train.hip); D must already hold rowsum(dO o O).
+extern "C" int a3v_attention_bwd_mfma(const void* q, const void* k, int64_t k_sb, int64_t k_sh, const void* v, int64_t v_sb,
+                                      int64_t v_ss, int64_t v_sh, const void* dout, const float* lse, const float* D, void* dq,
+                                      void* dk, void* dv, void* workspace, int B, int S, int H, int Hkv, int hd, int causal,
+                                      void* stream) {
+  if (!workspace || (hd != 64 && hd != 128)) return A3V_ERR_ARG;
+  if ((k_sb % 8) || (k_sh % 8) || (v_sb % 8) || (v_ss % 8) || (v_sh % 8)) return A3V_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const int Sp = (S + 63) / 64 * 64;
+  bf16_t* kt = (bf16_t*)workspace;
+  bf16_t* qt = kt + (int64_t)B * Hkv * hd * Sp;
+  bf16_t* dot = qt + (int64_t)B * H * hd * Sp;
+  int rc;
+  // K^T: per batch b, Hkv matrices [S, hd] (row stride hd, head stride k_sh) -> [hd, Sp]
+  for (int b = 0; b < B; ++b) {
+    rc = a3v_transpose((const bf16_t*)k + b * k_sb, hd, k_sh, kt + (int64_t)b * Hkv * hd * Sp, Sp, (int64_t)hd * Sp, S, hd, Sp, Hkv, A3V_BF16, stream);
+    if (rc) return rc;
+    rc = a3v_transpose((const bf16_t*)q + (int64_t)b * S * H * hd, (int64_t)H * hd, hd, qt + (int64_t)b * H * hd * Sp, Sp, (int64_t)hd * Sp, S, hd, Sp, H, A3V_BF16, stream);
+    if (rc) return rc;
+    rc = a3v_transpose((const bf16_t*)dout + (int64_t)b * S * H * hd, (int64_t)H * hd, hd, dot + (int64_t)b * H * hd * Sp, Sp, (int64_t)hd * Sp, S, hd, Sp, H, A3V_BF16, stream);
+    if (rc) return rc;
+  }
+  BwdArgs p;
+  p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.dout = (const bf16_t*)dout;
+  p.kt = kt; p.qt = qt; p.dot = dot; p.lse = lse; p.D = D;
+  p.dq = (bf16_t*)dq; p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv;
+  p.k_sb = k_sb; p.k_sh = k_sh; p.v_sb = v_sb; p.v_ss = v_ss; p.v_sh = v_sh;
+  p.B = B; p.S = S; p.Sp = Sp; p.H = H; p.Hkv = Hkv; p.causal = causal;
+  p.scale = 1.0f / sqrtf((float)hd);
+  dim3 gq((S + 127) / 128, H, B), gk((S + 127) / 128, Hkv, B);
+  if (hd == 128) {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, gq, dim3(256), 0, st, p);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, gk, dim3(256), 0, st, p);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, gq, dim3(256), 0, st, p);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, gk, dim3(256), 0, st, p);
+  }
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}

@@ -440,9 +440,14 @@ extern "C" int a3v_rope_bwd_pack(const void* dq, const void* dk, const void* dv,
 // inputs q,out,dout [B,S,H,hd] contiguous; k [B,Hkv,S,hd]; v rows addressed by (v_sb, v_ss, v_sh) element strides
 // (e.g. straight out of the fused qkv activation); lse [B,H,S]; scratch D [B,S,H] floats.
 // outputs dq [B,S,H,hd]; dk, dv [B,Hkv,S,hd].
+extern "C" int a3v_attention_bwd_mfma(const void* q, const void* k, int64_t k_sb, int64_t k_sh, const void* v, int64_t v_sb,
+                                      int64_t v_ss, int64_t v_sh, const void* dout, const float* lse, const float* D, void* dq,
+                                      void* dk, void* dv, void* workspace, int B, int S, int H, int Hkv, int hd, int causal,
+                                      void* stream);
+
 extern "C" int a3v_attention_bwd(const void* q, const void* k, int64_t k_sb, int64_t k_sh, const void* v, int64_t v_sb, int64_t v_ss, int64_t v_sh,
                                  const void* out, const void* dout, const float* lse, float* D, void* dq, void* dk, void* dv,
-                                 int B, int S, int H, int Hkv, int hd, int causal, int dtype, void* stream) {
+                                 void* workspace, int B, int S, int H, int Hkv, int hd, int causal, int dtype, void* stream) {
   if (!q || !k || !v || !out || !dout || !lse || !D || !dq || !dk || !dv || B <= 0 || S <= 0) return A3V_ERR_ARG;
   if (hd > 256 || (H % Hkv)) return A3V_ERR_SHAPE;
   AttnBwdArgs p;
@@ -451,6 +456,11 @@ extern "C" int a3v_attention_bwd(const void* q, const void* k, int64_t k_sb, int
   p.k_sb = k_sb; p.k_sh = k_sh;
   p.B = B; p.S = S; p.H = H; p.Hkv = Hkv; p.hd = hd; p.causal = causal;
   p.scale = 1.0f / sqrtf((float)hd);
+  if (dtype == A3V_BF16 && workspace && (hd == 64 || hd == 128)) {     // MFMA kernels (a3v_attn_bwd.hip)
+    hipLaunchKernelGGL(attn_rowdot_kernel<bf16_t>, dim3(B * S * H), dim3(64), 0, ST, (const bf16_t*)out, (const bf16_t*)dout, D, hd);
+    A3V_LAUNCH_CHECK();
+    return a3v_attention_bwd_mfma(q, k, k_sb, k_sh, v, v_sb, v_ss, v_sh, dout, lse, D, dq, dk, dv, workspace, B, S, H, Hkv, hd, causal, stream);
+  }
   if (dtype == A3V_BF16) {
     hipLaunchKernelGGL(attn_rowdot_kernel<bf16_t>, dim3(B * S * H), dim3(64), 0, ST, (const bf16_t*)out, (const bf16_t*)dout, D, hd);
     hipLaunchKernelGGL(attn_bwd_dq_generic<bf16_t>, dim3(S, H, B), dim3(64), 0, ST, p);

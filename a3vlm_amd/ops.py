@@ -244,10 +244,15 @@ def rope_bwd_pack(dq, dk, dv, dqkv, cos_sin, B, S, H, Hkv, hd, rope_pos0=0):
     _l.check(rc, "a3v_rope_bwd_pack")
 
 
-def attention_bwd(q, k, k_sb, k_sh, v, v_sb, v_ss, v_sh, out, dout, lse, D, dq, dk, dv, B, S, H, Hkv, hd, causal: bool):
-    _dev(q, k, v, out, dout, lse, D, dq, dk, dv)
+def attention_bwd_workspace_bytes(B, S, H, Hkv, hd) -> int:
+    return _l.load().a3v_attention_bwd_workspace_bytes(B, S, H, Hkv, hd)
+
+
+def attention_bwd(q, k, k_sb, k_sh, v, v_sb, v_ss, v_sh, out, dout, lse, D, dq, dk, dv, B, S, H, Hkv, hd, causal: bool,
+                  workspace=None):
+    _dev(q, k, v, out, dout, lse, D, dq, dk, dv, workspace)
     rc = _l.load().a3v_attention_bwd(_p(q), _p(k), k_sb, k_sh, _p(v), v_sb, v_ss, v_sh, _p(out), _p(dout), _p(lse), _p(D),
-                                     _p(dq), _p(dk), _p(dv), B, S, H, Hkv, hd, 1 if causal else 0, dt(q), _stream())
+                                     _p(dq), _p(dk), _p(dv), _p(workspace), B, S, H, Hkv, hd, 1 if causal else 0, dt(q), _stream())
     _l.check(rc, "a3v_attention_bwd")
 
 

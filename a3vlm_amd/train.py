@@ -252,8 +252,11 @@ class TrainEngine:
         ld = qkv.stride(0)
         vrows = qkv[:, (H + Hkv) * hd:]
         spad = k["spad"]
+        wsp = None
+        if self.act == torch.bfloat16 and hd in (64, 128):
+            wsp = self._buf("attn_bwd_ws", (ops.attention_bwd_workspace_bytes(B, S, H, Hkv, hd),), torch.uint8)
         ops.attention_bwd(k["qrot"], k["kc"], Hkv * spad * hd, spad * hd, vrows, S * ld, ld, hd, k["att"], datt, k["lse"], D,
-                          dq, dk, dv, B, S, H, Hkv, hd, True)
+                          dq, dk, dv, B, S, H, Hkv, hd, True, workspace=wsp)
         dqkv = self._buf("dqkv", (rows, (H + 2 * Hkv) * hd))
         ops.rope_bwd_pack(dq, dk, dv, dqkv, m._cos_sin_dev(), B, S, H, Hkv, hd, 0)
         self._wgrad(dqkv, k["xn"], self._gview(pre + "attention.wq.weight", pre + "attention.wv.weight"), "qkv")

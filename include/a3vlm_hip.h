@@ -205,9 +205,15 @@ int a3v_rope_bwd_pack(const void* dq, const void* dk, const void* dv, void* dqkv
  * strides (batch, seq, kv-head); lse [B,H,S]; D: fp32 scratch [B,S,H]. */
 int a3v_attention_bwd(const void* q, const void* k, int64_t k_sb, int64_t k_sh, const void* v,
                       int64_t v_sb, int64_t v_ss, int64_t v_sh, const void* out, const void* dout,
-                      const float* lse, float* D,
-                      void* dq, void* dk, void* dv, int B, int S, int H, int Hkv, int hd, int causal,
-                      int dtype, void* stream);
+                      const float* lse, float* D, void* dq, void* dk, void* dv, void* workspace,
+                      int B, int S, int H, int Hkv, int hd, int causal, int dtype, void* stream);
+/* bytes of `workspace` for the bf16 MFMA path (K^T, Q^T, dO^T images); workspace may be NULL, which
+ * selects the generic (slow) kernels. */
+int64_t a3v_attention_bwd_workspace_bytes(int B, int S, int H, int Hkv, int hd);
+int a3v_attention_bwd_mfma(const void* q, const void* k, int64_t k_sb, int64_t k_sh, const void* v,
+                           int64_t v_sb, int64_t v_ss, int64_t v_sh, const void* dout, const float* lse,
+                           const float* D, void* dq, void* dk, void* dv, void* workspace, int B, int S,
+                           int H, int Hkv, int hd, int causal, void* stream);
 
 /* dst = (dst_dtype) src, 2-D with leading dimensions (fp32 grad stream -> bf16 GEMM operand). */
 int a3v_cast(const void* src, int64_t ld_src, int src_dtype, void* dst, int64_t ld_dst, int dst_dtype,

@@ -125,9 +125,12 @@ def test_rope_bwd_pack():
     assert torch.equal(d[:, (H + Hkv) * hd:].view(B, S, Hkv, hd), dv)
 
 
-@pytest.mark.parametrize("dtype,B,S,H,Hkv,hd,causal", [(torch.float32, 2, 9, 4, 2, 16, True), (torch.float32, 1, 70, 2, 2, 64, False),
-                                                      (BF, 2, 40, 2, 1, 128, True), (torch.float32, 1, 33, 2, 2, 128, True)])
-def test_attention_lse_and_bwd(dtype, B, S, H, Hkv, hd, causal):
+@pytest.mark.parametrize("dtype,B,S,H,Hkv,hd,causal,mfma", [
+    (torch.float32, 2, 9, 4, 2, 16, True, False), (torch.float32, 1, 70, 2, 2, 64, False, False),
+    (BF, 2, 40, 2, 1, 128, True, False), (torch.float32, 1, 33, 2, 2, 128, True, False),
+    (BF, 2, 40, 2, 1, 128, True, True), (BF, 1, 300, 4, 2, 128, True, True), (BF, 2, 200, 2, 2, 64, False, True),
+    (BF, 1, 577, 2, 2, 64, False, True), (BF, 2, 129, 2, 2, 128, True, True)])
+def test_attention_lse_and_bwd(dtype, B, S, H, Hkv, hd, causal, mfma):
     q = gen(B, S, H, hd, seed=19).to(dtype).float().requires_grad_(True)
     k = gen(B, S, Hkv, hd, seed=20).to(dtype).float().requires_grad_(True)
     v = gen(B, S, Hkv, hd, seed=21).to(dtype).float().requires_grad_(True)
@@ -156,8 +159,9 @@ def test_attention_lse_and_bwd(dtype, B, S, H, Hkv, hd, causal):
     dk = torch.empty(B, Hkv, S, hd, dtype=dtype, device=DEV)
     dv = torch.empty(B, Hkv, S, hd, dtype=dtype, device=DEV)
     D = torch.empty(B, S, H, device=DEV)
+    ws = torch.empty(ops.attention_bwd_workspace_bytes(B, S, H, Hkv, hd), dtype=torch.uint8, device=DEV) if mfma else None
     ops.attention_bwd(qd, kc, Hkv * spad * hd, spad * hd, vrows, S * Hkv * hd, Hkv * hd, hd, o, do.to(dtype).to(DEV), lse, D,
-                      dq, dk, dv, B, S, H, Hkv, hd, causal)
+                      dq, dk, dv, B, S, H, Hkv, hd, causal, workspace=ws)
     tol = 2e-4 if dtype == torch.float32 else 3e-2
     assert relerr(dq, q.grad) < tol
     assert relerr(dk.permute(0, 2, 1, 3), k.grad) < tol
