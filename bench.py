@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--decode-steps", type=int, default=32)
     ap.add_argument("--model", default="7b", choices=["7b", "13b", "tiny"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the fine-tuning step measurement")
+    ap.add_argument("--train-steps", type=int, default=3)
     ap.add_argument("--cpu-seconds", type=float, default=30.0)
     return ap.parse_args()
 
@@ -149,6 +151,52 @@ def time_gemm_shapes(m, args, B, T, W, dev):
         table.append(dict(M=M, N=N, K=K, count=cnt, us=round(dt * 1e6, 1), tflops=round(fl / dt / 1e12, 1)))
         del a, wt, out
     return tot_f, tot_t, table
+
+
+def train_leg(m, args, B, T, image, tokens, steps, dist, dev):
+    """Full fine-tune step of configs[2]/[3] semantics on this rank's micro-batch: fp32 masters for the trainables
+    (decoder + projector), frozen bf16 ViT, bf16 GEMMs, per-block recompute, AdamW(0.9, 0.95); with N > 1 the
+    gradient buckets are all-reduced over RCCL on a side stream while earlier layers still back-propagate."""
+    from a3vlm_amd.train import TrainEngine
+    from a3vlm_amd.util import promote_trainable_params_to_fp32
+    from a3vlm_amd.dp import GradReducer
+    for n, p in m.named_parameters():
+        p.requires_grad = not n.startswith("clip.")
+    m._ws.clear(); m._packed.clear(); m._packed_version = None; m._destroy_kv_cache()
+    torch.cuda.empty_cache()
+    promote_trainable_params_to_fp32(m)
+    eng = TrainEngine(m, torch.bfloat16)
+    params = [p for p in m.parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(params, lr=2e-5, betas=(0.9, 0.95), weight_decay=0.0, fused=True)
+    red = GradReducer(eng, dist) if dist is not None else None
+    labels = tokens.clone()
+    labels[:, :T // 2] = 0
+
+    def one():
+        loss = eng.forward_loss(tokens, labels, image)
+        eng.backward(1.0)
+        if red is not None:
+            red.finish()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return loss
+
+    one()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = one()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    return el / steps, float(loss), torch.cuda.max_memory_allocated() / 2 ** 30
 
 
 def cpu_baseline(args, T, W, seconds):
@@ -291,6 +339,20 @@ def main():
     ctx = S + 2 + a.decode_steps // 2
     dec_bytes = bytes_decode_step(args, B, ctx)
 
+    train = None
+    if not a.no_train and a.model != "13b":
+        try:
+            sec, tl, mem = train_leg(m, args, B, T, image, tokens, a.train_steps, dist, dev)
+            fl_t = flops_forward(args, B, T, W)
+            # 3x (fwd + dgrad + wgrad) of the trainable part + 1x recompute + frozen ViT forward once
+            vit = fl_t["total"] - (fl_t["gemm"] + fl_t["att"]) + 0.0
+            train = {"samples_s": round(B * world / sec, 2), "ms_per_step": round(sec * 1e3, 1), "loss": round(tl, 4),
+                     "hbm_gib": round(mem, 1), "tflops": round((4 * fl_t["total"]) * world / sec / 1e12, 1),
+                     "config": f"full fine-tune of decoder+projector (6.7 G trainable), bs={B}/GPU, fp32 masters + bf16 GEMMs, "
+                               f"per-block recompute, AdamW fused, dp{world}" + (" with overlapped RCCL all-reduce" if world > 1 else ""),
+                     "flop_convention": "4 x forward FLOPs (3x + recompute; head on all text positions not counted)"}
+        except Exception as e:
+            train = {"samples_s": None, "error": repr(e)[:300]}
     out = None
     if rank == 0:
         fl = flops_forward(args, B, T, W)
@@ -314,6 +376,7 @@ def main():
                                 "frac": round(dec_bytes / (dec_ms * 1e-3) / HBM_PEAK, 4), "bytes_per_step": dec_bytes,
                                 "note": "bf16 weights once per step + KV of all sequences (SURVEY 8(d)); whole step incl. host launch gaps"},
         }
+        out["train"] = train
         if not a.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, T, W, a.cpu_seconds)

@@ -383,5 +383,62 @@ def main():
         print(f"  {fn:28s} {os.path.getsize(os.path.join(GOLD, fn)) / 1024:.1f} KB")
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and len(sys.argv) == 1:
     main()
+
+
+def gen_host():
+    """G10: host-side contracts captured from the reference: FinetuneDistSampler index lists, the LR schedule
+    table and add_weight_decay grouping (tests/golden/host_tiny.json)."""
+    refimport.install(data_stubs=True)
+    import types
+    import accessory.util.lr_sched as lr_sched
+    import pandas  # noqa: F401  (imported by data/alpaca.py)
+    from accessory.data.alpaca import FinetuneDistSampler
+    from accessory.util import misc
+
+    class DS:
+        def __init__(self, sizes):
+            self.g, o = [], 0
+            for s in sizes:
+                self.g.append(list(range(o, o + s)))
+                o += s
+
+        def groups(self):
+            return self.g
+
+        def __len__(self):
+            return sum(len(x) for x in self.g)
+
+    out = {"sampler": []}
+    for (sizes, ws, bs, acc, seed) in [((200, 130), 8, 2, 2, 0), ((64, 48, 100), 2, 4, 1, 3), ((1000,), 8, 8, 1, 1)]:
+        ds = DS(sizes)
+        for rank in sorted({0, ws - 1, ws // 2}):
+            for epoch, start_iter, shuffle in [(0, 0, True), (1, 3, True), (0, 0, False)]:
+                s = FinetuneDistSampler(ds, num_replicas=ws, rank=rank, shuffle=shuffle, seed=seed, batch_size=bs, acc_grad=acc)
+                s.set_epoch(epoch, start_iter)
+                out["sampler"].append(dict(sizes=list(sizes), ws=ws, bs=bs, acc=acc, seed=seed, rank=rank, epoch=epoch,
+                                           start_iter=start_iter, shuffle=shuffle, indices=list(iter(s)), length=len(s)))
+    args = types.SimpleNamespace(lr=2e-5, min_lr=0.0, warmup_epochs=0.03, epochs=3)
+    opt = types.SimpleNamespace(param_groups=[{"lr": 0.0}, {"lr": 0.0, "lr_scale": 0.5}])
+    table = []
+    for e in [0.0, 0.01, 0.03, 0.5, 1.0, 1.7, 2.999]:
+        lr = lr_sched.adjust_learning_rate_epoch(opt, e, args)
+        table.append([e, lr, opt.param_groups[0]["lr"], opt.param_groups[1]["lr"]])
+    out["lr_table"] = table
+    m = nn.Module()
+    m.a = nn.Linear(4, 4)
+    m.attention_norm = nn.LayerNorm(4)
+    m.frozen = nn.Linear(4, 4)
+    for p in m.frozen.parameters():
+        p.requires_grad = False
+    groups = misc.add_weight_decay(m, 0.1)
+    names = {id(p): n for n, p in m.named_parameters()}
+    out["wd_groups"] = [dict(weight_decay=g["weight_decay"], names=sorted(names[id(p)] for p in g["params"])) for g in groups]
+    with open(os.path.join(GOLD, "host_tiny.json"), "w") as f:
+        json.dump(out, f)
+    print("host fixture written:", os.path.getsize(os.path.join(GOLD, "host_tiny.json")), "bytes")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "host":
+    gen_host()

@@ -1,0 +1,143 @@
+"""CPU (-m "not gpu"): the data-parallel machinery with world_size 2 over gloo, and the host-side training
+contracts (sampler / lr schedule / weight-decay groups) against fixtures captured from the reference."""
+import json
+import os
+import types
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from a3vlm_amd.dp import FinetuneDistSampler, GradReducer, clip_grad_norm
+from a3vlm_amd.util import add_weight_decay, adjust_learning_rate_epoch
+
+
+class FakeEngine:
+    """Stands in for TrainEngine: a flat fp32 grad buffer with per-layer ranges (no kernels on CPU)."""
+
+    def __init__(self, sizes):
+        self._flat = torch.zeros(sum(sizes))
+        self._ranges, o = [], 0
+        for i, s in enumerate(sizes):
+            self._ranges.append((f"layer{i}", o, o + s))
+            o += s
+        self.on_layer_grads_ready = None
+
+    def flat_grads(self):
+        return self._flat
+
+    def grad_ranges(self):
+        return list(self._ranges)
+
+
+def _worker(rank, world, port, reduce_dtype, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        eng = FakeEngine([1000, 64, 5000])
+        red = GradReducer(eng, dist, reduce_dtype=reduce_dtype)
+        g = torch.Generator().manual_seed(100 + rank)
+        local = torch.randn(eng.flat_grads().numel(), generator=g)
+        # micro-step 1 of an accumulation pair: no_sync
+        red.enabled = False
+        eng.flat_grads().add_(local)
+        for n, s, e in reversed(eng.grad_ranges()):
+            eng.on_layer_grads_ready(n, s, e)
+        assert torch.equal(eng.flat_grads(), local), "no_sync micro-step must not touch the gradients"
+        # boundary micro-step: buckets are reduced as they become ready (reverse layer order, like backward)
+        red.enabled = True
+        eng.flat_grads().add_(local)
+        for n, s, e in reversed(eng.grad_ranges()):
+            eng.on_layer_grads_ready(n, s, e)
+        red.finish()
+        q.put((rank, eng.flat_grads().clone()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("reduce_dtype", [None, torch.bfloat16])
+def test_grad_reducer_world2_gloo(reduce_dtype):
+    world, port = 2, 29650 + (0 if reduce_dtype is None else 1)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, reduce_dtype, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    locals_ = [torch.randn(6064, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
+    want = sum(2 * l for l in locals_) / world          # FSDP semantics: average of the accumulated gradients
+    tol = 1e-6 if reduce_dtype is None else 2e-2
+    for r in range(world):
+        assert torch.allclose(res[r], want, atol=tol, rtol=tol)
+    assert torch.equal(res[0], res[1]), "replicas must hold identical gradients after the all-reduce"
+
+
+def test_clip_grad_norm_matches_reference_coefficient():
+    ps = [torch.nn.Parameter(torch.ones(10)), torch.nn.Parameter(torch.ones(6))]
+    for p in ps:
+        p.grad = torch.full_like(p, 3.0)
+    norm = clip_grad_norm(ps, max_norm=8.0)
+    assert abs(float(norm) - 12.0) < 1e-5                   # sqrt(16 * 9)
+    coef = 8.0 / (12.0 + 1e-6)
+    assert torch.allclose(ps[0].grad, torch.full((10,), 3.0 * coef))
+    for p in ps:
+        p.grad = torch.full_like(p, 0.1)
+    clip_grad_norm(ps, max_norm=8.0)
+    assert torch.allclose(ps[0].grad, torch.full((10,), 0.1)), "coefficient is clamped to 1"
+
+
+@pytest.fixture(scope="module")
+def host(golden_dir):
+    with open(os.path.join(golden_dir, "host_tiny.json")) as f:
+        return json.load(f)
+
+
+def test_sampler_matches_reference(host):
+    class DS:
+        def __init__(self, sizes):
+            self.g, o = [], 0
+            for s in sizes:
+                self.g.append(list(range(o, o + s)))
+                o += s
+
+        def groups(self):
+            return self.g
+    assert len(host["sampler"]) >= 20
+    for c in host["sampler"]:
+        s = FinetuneDistSampler(DS(c["sizes"]), num_replicas=c["ws"], rank=c["rank"], shuffle=c["shuffle"], seed=c["seed"],
+                                batch_size=c["bs"], acc_grad=c["acc"])
+        s.set_epoch(c["epoch"], c["start_iter"])
+        assert list(iter(s)) == c["indices"] and len(s) == c["length"]
+    with pytest.raises(ValueError):
+        FinetuneDistSampler(DS([8]), num_replicas=2, rank=2, batch_size=1)
+
+
+def test_sampler_shards_are_disjoint_and_cover():
+    class DS:
+        def groups(self):
+            return [list(range(0, 96)), list(range(96, 160))]
+    seen = []
+    for r in range(4):
+        s = FinetuneDistSampler(DS(), num_replicas=4, rank=r, shuffle=True, seed=5, batch_size=2, acc_grad=2)
+        seen += list(iter(s))
+    assert len(seen) == len(set(seen)) == 160
+
+
+def test_lr_schedule_and_weight_decay_groups(host):
+    opt = types.SimpleNamespace(param_groups=[{"lr": 0.0}, {"lr": 0.0, "lr_scale": 0.5}])
+    for e, lr, g0, g1 in host["lr_table"]:
+        got = adjust_learning_rate_epoch(opt, e, lr=2e-5, min_lr=0.0, warmup_epochs=0.03, epochs=3)
+        assert abs(got - lr) < 1e-15 and abs(opt.param_groups[0]["lr"] - g0) < 1e-15 and abs(opt.param_groups[1]["lr"] - g1) < 1e-15
+    m = torch.nn.Module()
+    m.a = torch.nn.Linear(4, 4)
+    m.attention_norm = torch.nn.LayerNorm(4)
+    m.frozen = torch.nn.Linear(4, 4)
+    for p in m.frozen.parameters():
+        p.requires_grad = False
+    names = {id(p): n for n, p in m.named_parameters()}
+    got = [dict(weight_decay=g["weight_decay"], names=sorted(names[id(p)] for p in g["params"])) for g in add_weight_decay(m, 0.1)]
+    assert got == host["wd_groups"]
