@@ -31,7 +31,7 @@ class FakeEngine:
         return list(self._ranges)
 
 
-def _worker(rank, world, port, reduce_dtype, q):
+def _worker(rank, world, port, reduce_dtype, outdir):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -51,23 +51,16 @@ def _worker(rank, world, port, reduce_dtype, q):
         for n, s, e in reversed(eng.grad_ranges()):
             eng.on_layer_grads_ready(n, s, e)
         red.finish()
-        q.put((rank, eng.flat_grads().clone()))
+        torch.save(eng.flat_grads().clone(), os.path.join(outdir, f"rank{rank}.pt"))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("reduce_dtype", [None, torch.bfloat16])
-def test_grad_reducer_world2_gloo(reduce_dtype):
-    world, port = 2, 29650 + (0 if reduce_dtype is None else 1)
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, reduce_dtype, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = dict(q.get(timeout=120) for _ in range(world))
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+def test_grad_reducer_world2_gloo(reduce_dtype, tmp_path):
+    world, port = 2, 29650 + (0 if reduce_dtype is None else 1) + (os.getpid() % 200) * 2
+    mp.spawn(_worker, args=(world, port, reduce_dtype, str(tmp_path)), nprocs=world, join=True)
+    res = {r: torch.load(os.path.join(str(tmp_path), f"rank{r}.pt")) for r in range(world)}
     locals_ = [torch.randn(6064, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
     want = sum(2 * l for l in locals_) / world          # FSDP semantics: average of the accumulated gradients
     tol = 1e-6 if reduce_dtype is None else 2e-2
