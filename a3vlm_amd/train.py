@@ -24,9 +24,14 @@ def _pad64(n: int) -> int:
 
 
 class TrainEngine:
-    def __init__(self, model, compute_dtype: torch.dtype = torch.bfloat16):
+    def __init__(self, model, compute_dtype: torch.dtype = torch.bfloat16, recompute: Optional[bool] = None):
+        """``recompute``: True = keep only each block's input and re-run the block in backward (the reference's
+        activation checkpointing, main_finetune.py:268-276); False = keep every block's intermediates (about
+        1.15 GB per 7B layer at 8 x 1091 tokens -- affordable in 288 GB of HBM and ~1/4 fewer GEMM FLOPs per step).
+        None = decide from free HBM at the first step."""
         self.m = model
         self.act = compute_dtype
+        self.recompute = recompute
         self._img: Dict[str, torch.Tensor] = {}
         self._img_version = None
         self._ws: Dict[tuple, torch.Tensor] = {}
@@ -183,20 +188,24 @@ class TrainEngine:
         ops.gemm_nt(dy, wt, out)
 
     # ------------------------------------------------------------------ one decoder block (forward / recompute)
-    def _block_forward(self, i: int, h: torch.Tensor, B: int, S: int, keep: bool):
-        """h (fp32 [B*S, dim]) -> updated in place.  keep=True returns the intermediates the backward needs."""
+    def _block_forward(self, i: int, h: torch.Tensor, B: int, S: int, keep: bool, tag: str = "", h_out: Optional[torch.Tensor] = None):
+        """One decoder block on the fp32 stream h [B*S, dim].
+        keep=False: h is updated in place (checkpointing forward).
+        keep=True : h is only read; h_mid goes to its own buffer and the intermediates the backward needs are
+        returned; the block output is written to ``h_out`` if given (stored-activation forward, per-layer buffers
+        selected by ``tag``) or not computed at all (recompute inside backward)."""
         m, a, im = self.m, self.m.args, self._images()
         H, Hkv, hd, dim, F = m.n_heads, m.n_kv_heads, m.head_dim, a.dim, m.ffn
         rows = B * S
         l = m.layers[i]
         spad = _pad64(S)
-        xn = self._buf("xn", (rows, dim))
-        qkv = self._buf("qkv", (rows, (H + 2 * Hkv) * hd))
-        qrot = self._buf("qrot", (rows, H * hd))
-        kc = self._buf("kc", (B, Hkv, spad, hd))
+        xn = self._buf("xn" + tag, (rows, dim))
+        qkv = self._buf("qkv" + tag, (rows, (H + 2 * Hkv) * hd))
+        qrot = self._buf("qrot" + tag, (rows, H * hd))
+        kc = self._buf("kc" + tag, (B, Hkv, spad, hd))
         vc = self._buf("vc", (B, Hkv, hd, spad))
-        att = self._buf("att", (rows, H * hd))
-        lse = self._buf("lse", (B, H, S), torch.float32)
+        att = self._buf("att" + tag, (rows, H * hd))
+        lse = self._buf("lse" + tag, (B, H, S), torch.float32)
         ops.rmsnorm(h, l.attention_norm.weight, xn, a.norm_eps)
         ops.gemm_nt(xn, im[f"qkv.{i}"], qkv)
         ops.rope_kvcache(qkv, qrot, kc, vc, m._cos_sin_dev(), B, S, H, Hkv, hd, 0, 0)
@@ -204,21 +213,22 @@ class TrainEngine:
         ops.attention_lse(qrot, kc, vc, att, lse, B, S, S, H, Hkv, hd, strides, True)
         res_flag = ops.EPI_RES_F32 if self.act == torch.bfloat16 else 0
         if keep:
-            h_mid = self._buf("h_mid", (rows, dim), torch.float32)
+            h_mid = self._buf("h_mid" + tag, (rows, dim), torch.float32)
             ops.gemm_nt(att, im[f"wo.{i}"], h_mid, residual=h, epilogue=res_flag)
         else:
             h_mid = h
             ops.gemm_nt(att, im[f"wo.{i}"], h, residual=h, epilogue=res_flag)
-        xn2 = self._buf("xn2", (rows, dim))
-        gu = self._buf("gu", (rows, 2 * F))
-        actb = self._buf("act", (rows, F))
+        xn2 = self._buf("xn2" + tag, (rows, dim))
+        gu = self._buf("gu" + tag, (rows, 2 * F))
+        actb = self._buf("act" + tag, (rows, F))
         ops.rmsnorm(h_mid, l.ffn_norm.weight, xn2, a.norm_eps)
         ops.gemm_nt(xn2, im[f"w13.{i}"], gu)
         ops.swiglu_fwd(gu, actb, F, interleaved=False)
-        if keep:
-            return dict(xn=xn, qkv=qkv, qrot=qrot, kc=kc, att=att, lse=lse, h_mid=h_mid, xn2=xn2, gu=gu, act=actb, spad=spad)
-        ops.gemm_nt(actb, im[f"w2.{i}"], h, residual=h, epilogue=res_flag)
-        return None
+        kept = dict(xn=xn, qkv=qkv, qrot=qrot, kc=kc, att=att, lse=lse, h_mid=h_mid, xn2=xn2, gu=gu, act=actb, spad=spad)
+        if keep and h_out is None:
+            return kept                                   # recompute inside backward: the block output is not needed
+        ops.gemm_nt(actb, im[f"w2.{i}"], h_out if keep else h, residual=h_mid, epilogue=res_flag)
+        return kept
 
     def _block_backward(self, i: int, h_in: torch.Tensor, dh: torch.Tensor, B: int, S: int):
         m, a, im = self.m, self.m.args, self._images()
@@ -226,7 +236,7 @@ class TrainEngine:
         rows = B * S
         l = m.layers[i]
         pre = f"layers.{i}."
-        k = self._block_forward(i, h_in, B, S, keep=True)
+        k = self._saved["kept"][i] if self._saved.get("kept") else self._block_forward(i, h_in, B, S, keep=True)
         # ---- FFN: out = h_mid + w2(silu(g) * u)
         dha = self._buf("dh_act", (rows, dim))
         ops.cast(dh, dha)
@@ -281,9 +291,19 @@ class TrainEngine:
         if image is not None:
             vis = self._encode_image_train(h, image, B, S, qformer_feats, extra_feats)
         hs = self._buf("h_saved", (m.n_layers, rows, dim), torch.float32)
+        if self.recompute is None:
+            F_, Hq = m.ffn, (m.n_heads + 2 * m.n_kv_heads) * m.head_dim
+            esz = 2 if self.act == torch.bfloat16 else 4
+            need = m.n_layers * rows * ((2 * dim + Hq + 2 * m.n_heads * m.head_dim + 3 * F_) * esz + dim * 4) * 1.1
+            free, _ = torch.cuda.mem_get_info(m._device)
+            self.recompute = need > 0.5 * free
+        kept = []
         for i in range(m.n_layers):
-            hs[i].copy_(h)                       # checkpoint = the block input (main_finetune.py:268-276)
-            self._block_forward(i, h, B, S, keep=False)
+            hs[i].copy_(h)                       # the block input (checkpoint, main_finetune.py:268-276)
+            if self.recompute:
+                self._block_forward(i, h, B, S, keep=False)
+            else:
+                kept.append(self._block_forward(i, hs[i], B, S, keep=True, tag=f".L{i}", h_out=h))
         xt = self._buf("xn_text", (B * T, dim))
         hv = h.view(B, S, dim)
         for b in range(B):
@@ -299,7 +319,8 @@ class TrainEngine:
         ops.cross_entropy(logits, lab, row_loss)
         nv = n_valid.to(torch.float32)[0]
         loss = torch.where(nv > 0, row_loss.sum() / torch.clamp(nv, min=1.0), torch.zeros_like(nv))   # meta.py:259-262
-        self._saved = dict(B=B, T=T, W=W, S=S, h=h, hs=hs, xt=xt, logits=logits, lab=lab, n_valid=n_valid, tokens=examples.contiguous(), vis=vis)
+        self._saved = dict(B=B, T=T, W=W, S=S, h=h, hs=hs, xt=xt, logits=logits, lab=lab, n_valid=n_valid, tokens=examples.contiguous(), vis=vis,
+                           kept=kept if not self.recompute else None)
         return loss
 
     @torch.no_grad()

@@ -347,10 +347,12 @@ def main():
             # 3x (fwd + dgrad + wgrad) of the trainable part + 1x recompute + frozen ViT forward once
             vit = fl_t["total"] - (fl_t["gemm"] + fl_t["att"]) + 0.0
             train = {"samples_s": round(B * world / sec, 2), "ms_per_step": round(sec * 1e3, 1), "loss": round(tl, 4),
-                     "hbm_gib": round(mem, 1), "tflops": round((4 * fl_t["total"]) * world / sec / 1e12, 1),
-                     "config": f"full fine-tune of decoder+projector (6.7 G trainable), bs={B}/GPU, fp32 masters + bf16 GEMMs, "
-                               f"per-block recompute, AdamW fused, dp{world}" + (" with overlapped RCCL all-reduce" if world > 1 else ""),
-                     "flop_convention": "4 x forward FLOPs (3x + recompute; head on all text positions not counted)"}
+                     "hbm_gib": round(mem, 1), "tflops": round((3 * fl_t["total"]) * world / sec / 1e12, 1),
+                     "mfma_frac": round(3 * fl_t["total"] / sec / MFMA_PEAK_BF16, 4),
+                     "config": f"full fine-tune of decoder+projector (6.7 G trainable), bs={B}/GPU, {T}-token prompts + 579 image words, fp32 masters + "
+                               f"bf16 GEMMs, block activations kept in HBM (no recompute), fused AdamW, dp{world}"
+                               + (" with RCCL all-reduce of per-layer fp32 grad buckets overlapped with backward" if world > 1 else ""),
+                     "flop_convention": "3 x forward FLOPs of the step (SURVEY 8(d)); LM head on all text positions and the frozen ViT counted once are ignored"}
         except Exception as e:
             train = {"samples_s": None, "error": repr(e)[:300]}
     out = None

@@ -220,8 +220,8 @@ def build(with_visual, compute_dtype):
     return m, sd, vsd
 
 
-@pytest.mark.parametrize("with_visual", [False, True])
-def test_train_step_fp32_matches_autograd(with_visual):
+@pytest.mark.parametrize("with_visual,recompute", [(False, True), (True, True), (True, False)])
+def test_train_step_fp32_matches_autograd(with_visual, recompute):
     m, sd, vsd = build(with_visual, torch.float32)
     g = torch.Generator().manual_seed(5)
     B, T = 2, 12
@@ -232,7 +232,7 @@ def test_train_step_fp32_matches_autograd(with_visual):
     lab[1, 9:] = 0
     img = synth_image(B, size=112, seed=3) if with_visual else None
     want_loss, want = oracle_loss_and_grads(sd, vsd, ex, lab, img)
-    eng = TrainEngine(m, torch.float32)
+    eng = TrainEngine(m, torch.float32, recompute=recompute)
     loss = eng.forward_loss(ex.to(DEV), lab.to(DEV), img.to(DEV) if with_visual else None)
     assert abs(float(loss) - want_loss) < 1e-3 * abs(want_loss)
     eng.backward(1.0)
