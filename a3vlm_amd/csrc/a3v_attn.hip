@@ -248,21 +248,29 @@ __global__ __launch_bounds__(256) void attn_decode_bf16_kernel(AttnArgs p, float
   const bf16_t* K = (const bf16_t*)p.k + b * p.k_sb + hk * p.k_sh;
   const bf16_t* VT = (const bf16_t*)p.vt + b * p.v_sb + hk * p.v_sh;
 
-  // phase 1: scores.  lane -> (row-in-group, 8 d's)
+  // phase 1: scores.  lane -> (row-in-group, 8 d's); U independent row groups in flight per wave
   float qv[8];
   load8(Q + (lane % LPR) * 8, qv);
-  for (int r0 = wave * RPW; r0 < n; r0 += 4 * RPW) {
-    const int r = r0 + lane / LPR;
-    float acc = 0.f;
-    if (r < n) {
-      float kvv[8];
-      load8(K + (int64_t)(kv_lo + r) * p.k_ss + (lane % LPR) * 8, kvv);
+  constexpr int U = 8;
+  const int lr = lane / LPR, lc = (lane % LPR) * 8;
+  for (int r0 = wave * RPW * U; r0 < n; r0 += 4 * RPW * U) {
+    bf16x8 kk[U];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc = fmaf(qv[e], kvv[e], acc);
+    for (int u = 0; u < U; ++u) {
+      int r = r0 + u * RPW + lr;
+      r = r < n ? r : n - 1;
+      kk[u] = *reinterpret_cast<const bf16x8*>(K + (int64_t)(kv_lo + r) * p.k_ss + lc);
     }
 #pragma unroll
-    for (int o2 = LPR / 2; o2 > 0; o2 >>= 1) acc += __shfl_xor(acc, o2, 64);
-    if (r < n && (lane % LPR) == 0) sc[r] = acc * p.scale;
+    for (int u = 0; u < U; ++u) {
+      float acc = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc = fmaf(qv[e], (float)kk[u][e], acc);
+#pragma unroll
+      for (int o2 = LPR / 2; o2 > 0; o2 >>= 1) acc += __shfl_xor(acc, o2, 64);
+      const int r = r0 + u * RPW + lr;
+      if (r < n && (lane % LPR) == 0) sc[r] = acc * p.scale;
+    }
   }
   __syncthreads();
   float mx = -INFINITY;
@@ -288,23 +296,33 @@ __global__ __launch_bounds__(256) void attn_decode_bf16_kernel(AttnArgs p, float
   for (int i = n + tid; i < n8; i += 256) sc[i] = 0.f;
   __syncthreads();
 
-  // phase 2: o[d] = sum_kv p[kv] * VT[d][kv].  wave -> d rows, lanes -> 8-kv chunks
-  for (int d = wave; d < HD; d += 4) {
-    const bf16_t* vrow = VT + (int64_t)d * p.v_sd + kv_lo;
-    float acc = 0.f;
+  // phase 2: o[d] = sum_kv p[kv] * VT[d][kv].  wave -> HD/4 consecutive d rows, 8 rows (8 x 16 B per lane) in
+  // flight per batch, lanes -> 8-kv chunks of the row; one shuffle reduction per row at the end of a batch.
+  // Loads are unconditional 16-B vectors (kv_lo + n8 <= Skmax: the cache row is allocated to a multiple of 64);
+  // columns >= Sk are masked on the VALUES after the load (a select on the load itself would serialise them).
+  constexpr int DB = 8;
+  for (int d0 = wave * (HD / 4); d0 < (wave + 1) * (HD / 4); d0 += DB) {
+    float acc[DB];
+#pragma unroll
+    for (int j = 0; j < DB; ++j) acc[j] = 0.f;
     for (int c = lane * 8; c < n8; c += 64 * 8) {
-      float vv[8];
-      if (kv_lo + c + 8 <= p.Sk) {
-        load8(vrow + c, vv);
-      } else {
+      bf16x8 vv[DB];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) vv[e] = (kv_lo + c + e < p.Sk) ? bf2f(vrow[c + e]) : 0.f;
-      }
+      for (int j = 0; j < DB; ++j) vv[j] = *reinterpret_cast<const bf16x8*>(VT + (int64_t)(d0 + j) * p.v_sd + kv_lo + c);
+      float pv[8];
+      const int nvalid = p.Sk - (kv_lo + c);          // >= 8 except in the last chunk
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc = fmaf(sc[c + e], vv[e], acc);
+      for (int e = 0; e < 8; ++e) pv[e] = e < nvalid ? sc[c + e] : 0.f;
+#pragma unroll
+      for (int j = 0; j < DB; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[j] = fmaf(pv[e], e < nvalid ? (float)vv[j][e] : 0.f, acc[j]);
     }
-    acc = wave_sum(acc);
-    if (lane == 0) po[d] = acc;
+#pragma unroll
+    for (int j = 0; j < DB; ++j) {
+      const float t = wave_sum(acc[j]);
+      if (lane == 0) po[d0 + j] = t;
+    }
   }
   if (tid == 0) { po[HD] = mx; po[HD + 1] = ls; }
 }

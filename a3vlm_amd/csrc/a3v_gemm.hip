@@ -770,6 +770,115 @@ __global__ __launch_bounds__(256) void gemm_skinny_epilogue_kernel(SkinnyEpiArgs
 }
 
 // ------------------------------------------------------------------------------------
+// Skinny GEMM, single launch: one 8-wave block per 16 (or 32 with SwiGLU: gate block + up block)
+// rows of W.  The block's waves split K, each streams its slice of the W rows straight into MFMA
+// operand registers (8 independent 16-B non-temporal loads in flight per lane), the eight partial
+// 16x16 accumulators are summed through LDS and wave 0 applies the epilogue.  W is read from HBM
+// exactly once, nothing is written but C: algorithmic bytes = 2 N K (+ M K x re-reads from L2).
+// ------------------------------------------------------------------------------------
+struct Skinny1Args {
+  const bf16_t* A;
+  const bf16_t* W;
+  void* C;
+  const void* res;
+  int64_t lda, ldw, ldc, ldr;
+  int M, N, K, epi, kslice;
+};
+
+template <int TILES>   // 1: 16 rows per block; 2: 32 rows (interleaved gate/up pair)
+__global__ __launch_bounds__(512) void gemm_skinny1_bf16_kernel(Skinny1Args p) {
+  __shared__ float red[8][TILES][64][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n0 = blockIdx.x * 16 * TILES;
+  const int row = lane & 15, kq = (lane >> 4) * 8;
+  const int ar = row < p.M ? row : p.M - 1;
+  const bf16_t* ap = p.A + (int64_t)ar * p.lda + wave * p.kslice + kq;
+  const bf16_t* wp[TILES];
+#pragma unroll
+  for (int t = 0; t < TILES; ++t) {
+    int wr = n0 + t * 16 + row;
+    wr = wr < p.N ? wr : p.N - 1;
+    wp[t] = p.W + (int64_t)wr * p.ldw + wave * p.kslice + kq;
+  }
+  f32x4 acc[TILES][2];
+#pragma unroll
+  for (int t = 0; t < TILES; ++t) { acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  const int kend = min(p.kslice, p.K - wave * p.kslice);     // the last wave may own a shorter (or empty) slice
+  constexpr int U = TILES == 1 ? 8 : 4;                      // 32-k steps per unrolled iteration
+  int k = 0;
+  for (; k + U * 32 <= kend; k += U * 32) {
+    bf16x8 w[TILES][U], a[U];
+#pragma unroll
+    for (int t = 0; t < TILES; ++t)
+#pragma unroll
+      for (int q = 0; q < U; ++q) w[t][q] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp[t] + k + q * 32));
+#pragma unroll
+    for (int q = 0; q < U; ++q) a[q] = *reinterpret_cast<const bf16x8*>(ap + k + q * 32);
+#pragma unroll
+    for (int t = 0; t < TILES; ++t)
+#pragma unroll
+      for (int q = 0; q < U; ++q) acc[t][q & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[t][q], a[q], acc[t][q & 1], 0, 0, 0);
+  }
+  for (; k < kend; k += 32) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap + k);
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+      const bf16x8 w = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp[t] + k));
+      acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a, acc[t][0], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < TILES; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][t][lane][r] = acc[t][0][r] + acc[t][1][r];
+  __syncthreads();
+  if (wave != 0) return;
+  float v[TILES][4];
+#pragma unroll
+  for (int t = 0; t < TILES; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float a = 0.f;
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8) a += red[w8][t][lane][r];
+      v[t][r] = a;
+    }
+  // D[n = (lane>>4)*4 + r][m = lane&15]
+  const int m = lane & 15;
+  if (m >= p.M) return;
+  if (TILES == 2) {        // SwiGLU: tile 0 = gate rows, tile 1 = up rows of the same 16 output columns
+    const int oc = (n0 >> 1) + (lane >> 4) * 4;
+    if (n0 >= p.N) return;
+    bf16x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = f2bf(rbf(silu(rbf(v[0][r]))) * rbf(v[TILES - 1][r]));
+    *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + oc) = o;
+    return;
+  }
+  const int n = n0 + (lane >> 4) * 4;
+  if (n >= p.N) return;
+  float o4[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) o4[r] = rbf(v[0][r]);
+  if (p.epi & A3V_EPI_RESIDUAL) {
+    const bf16x4 rr = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(p.res) + (int64_t)m * p.ldr + n);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o4[r] += bf2f(rr[r]);
+  }
+  if (p.epi & A3V_EPI_OUT_F32) {
+    f32x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = o4[r];
+    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n) = o;
+  } else {
+    bf16x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = f2bf(o4[r]);
+    *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + n) = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // fp32 parity GEMM: 64(m) x 64(tile rows of W) x 16, 256 threads, 4x4 outputs per thread.
 // A thread owns tile columns {2tx, 2tx+1, 32+2tx, 33+2tx}; with SWIGLU the tile's rows
 // 0..31 are gate rows and 32..63 the matching up rows, so the pairing is thread-local.
@@ -975,6 +1084,18 @@ extern "C" int a3v_gemm_skinny(const void* A, int64_t lda, const void* W, int64_
   if (epilogue & ~(A3V_EPI_RESIDUAL | A3V_EPI_SWIGLU | A3V_EPI_OUT_F32)) return A3V_ERR_ARG;
   if ((epilogue & A3V_EPI_RESIDUAL) && (!residual || (ldr % 4))) return A3V_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
+  {
+    // single-launch path (partial scratch unused): 8 waves split K in 32-element granules
+    Skinny1Args q;
+    q.A = (const bf16_t*)A; q.W = (const bf16_t*)W; q.C = C; q.res = residual;
+    q.lda = lda; q.ldw = ldw; q.ldc = ldc; q.ldr = ldr;
+    q.M = M; q.N = N; q.K = K; q.epi = epilogue;
+    q.kslice = ((K / 32 + 7) / 8) * 32;
+    if (epilogue & A3V_EPI_SWIGLU) hipLaunchKernelGGL(gemm_skinny1_bf16_kernel<2>, dim3((N + 31) / 32), dim3(512), 0, st, q);
+    else hipLaunchKernelGGL(gemm_skinny1_bf16_kernel<1>, dim3((N + 15) / 16), dim3(512), 0, st, q);
+    A3V_LAUNCH_CHECK();
+    return A3V_OK;
+  }
   SkinnyArgs p;
   p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.part = (float*)partial;
   p.lda = lda; p.ldw = ldw; p.M = M; p.N = N; p.K = K;

@@ -162,6 +162,32 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(const T* __restrict__ qkv,
   }
 }
 
+// Decode form (S <= 4 tokens per sequence): one 64-thread block per (slot, token, batch); no LDS tile.
+template <typename T>
+__global__ __launch_bounds__(64) void rope_kv_small_kernel(const T* __restrict__ qkv, int64_t ldqkv, T* __restrict__ q_out,
+                                                           int64_t ldq, T* __restrict__ k_cache, T* __restrict__ vt_cache,
+                                                           const float* __restrict__ cos_sin, int S, int H, int Hkv, int hd,
+                                                           int Smax, int start_pos, int rope_pos0) {
+  const int slot = blockIdx.x, s = blockIdx.y, b = blockIdx.z;
+  const T* src = qkv + ((int64_t)b * S + s) * ldqkv + (int64_t)slot * hd;
+  const int half = hd / 2;
+  for (int pr = threadIdx.x; pr < half; pr += 64) {
+    const float a = Cvt<T>::ld(src + 2 * pr), bb = Cvt<T>::ld(src + 2 * pr + 1);
+    if (slot < H + Hkv) {
+      const float co = cos_sin[((int64_t)(rope_pos0 + s) * half + pr) * 2], si = cos_sin[((int64_t)(rope_pos0 + s) * half + pr) * 2 + 1];
+      const float o0 = a * co - bb * si, o1 = a * si + bb * co;
+      T* dst = slot < H ? q_out + ((int64_t)b * S + s) * ldq + (int64_t)slot * hd + 2 * pr
+                        : k_cache + (((int64_t)b * Hkv + (slot - H)) * Smax + start_pos + s) * hd + 2 * pr;
+      Cvt<T>::st(dst, o0);
+      Cvt<T>::st(dst + 1, o1);
+    } else {
+      T* dst = vt_cache + (((int64_t)b * Hkv + (slot - H - Hkv)) * hd + 2 * pr) * (int64_t)Smax + start_pos + s;
+      Cvt<T>::st(dst, a);
+      Cvt<T>::st(dst + Smax, bb);
+    }
+  }
+}
+
 // v [N, L, H*hd] (row stride ldv) -> vt [N, H, hd, Lpad]   (ViT: transposed V for attention)
 template <typename T>
 __global__ __launch_bounds__(256) void vt_pack_kernel(const T* __restrict__ v, int64_t ldv, T* __restrict__ vt,
@@ -418,6 +444,16 @@ extern "C" int a3v_rope_kvcache(const void* qkv, int64_t ldqkv, void* q_out, int
                                 int start_pos, int rope_pos0, int dtype, void* stream) {
   if (!qkv || !q_out || !k_cache || !vt_cache || !cos_sin || B <= 0 || S <= 0) return A3V_ERR_ARG;
   if (hd % 8 || hd > 128 || ldqkv % 8 || ldq % 8 || start_pos + S > Smax) return A3V_ERR_SHAPE;
+  if (S <= 4) {
+    dim3 gs(H + 2 * Hkv, S, B);
+    if (dtype == A3V_BF16)
+      hipLaunchKernelGGL(rope_kv_small_kernel<bf16_t>, gs, dim3(64), 0, ST, (const bf16_t*)qkv, ldqkv, (bf16_t*)q_out, ldq, (bf16_t*)k_cache, (bf16_t*)vt_cache, cos_sin, S, H, Hkv, hd, Smax, start_pos, rope_pos0);
+    else if (dtype == A3V_F32)
+      hipLaunchKernelGGL(rope_kv_small_kernel<float>, gs, dim3(64), 0, ST, (const float*)qkv, ldqkv, (float*)q_out, ldq, (float*)k_cache, (float*)vt_cache, cos_sin, S, H, Hkv, hd, Smax, start_pos, rope_pos0);
+    else return A3V_ERR_DTYPE;
+    A3V_LAUNCH_CHECK();
+    return A3V_OK;
+  }
   dim3 g((S + 63) / 64, H + 2 * Hkv, B);
   if (dtype == A3V_BF16)
     hipLaunchKernelGGL(rope_kv_kernel<bf16_t>, g, dim3(256), 0, ST, (const bf16_t*)qkv, ldqkv, (bf16_t*)q_out, ldq, (bf16_t*)k_cache, (bf16_t*)vt_cache, cos_sin, S, H, Hkv, hd, Smax, start_pos, rope_pos0);

@@ -54,6 +54,13 @@ SIGNATURES = {
     "a3v_rows_sum": (I, [P, L, P, I, I, P, I, P]),
 }
 
+class LlamaLayer(ctypes.Structure):
+    """a3v_llama_layer of include/a3vlm_hip.h"""
+    _fields_ = [(n, c_void_p) for n in ("attn_norm_w", "wqkv", "wo", "ffn_norm_w", "w13", "w2", "k_cache", "vt_cache")]
+
+
+SIGNATURES["a3v_llama_decode_step"] = (I, [ctypes.POINTER(LlamaLayer), I, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, F, P])
+
 _lib = None
 
 

@@ -387,6 +387,38 @@ class Transformer(nn.Module):
             self._linear(xn, pk[f"w13.{i}"], act, epilogue=ops.EPI_SWIGLU)
             self._linear(act, lyr.feed_forward.w2.weight, h, residual=h)
 
+    def _decode_step(self, h: torch.Tensor, B: int, pos: int) -> None:
+        """seqlen == 1, bf16: the whole layer stack from one C call (a3v_llama_decode_step)."""
+        import ctypes
+        from ... import lib as _l
+        a = self.args
+        pk = self._pack()
+        key = (self._packed_version, self._cache_shape)
+        if getattr(self, "_layer_tab_key", None) != key:
+            tab = (_l.LlamaLayer * self.n_layers)()
+            for i, lyr in enumerate(self.layers):
+                tab[i].attn_norm_w = lyr.attention_norm.weight.data_ptr()
+                tab[i].wqkv = pk[f"wqkv.{i}"].data_ptr()
+                tab[i].wo = lyr.attention.wo.weight.data_ptr()
+                tab[i].ffn_norm_w = lyr.ffn_norm.weight.data_ptr()
+                tab[i].w13 = pk[f"w13.{i}"].data_ptr()
+                tab[i].w2 = lyr.feed_forward.w2.weight.data_ptr()
+                tab[i].k_cache = self._k_cache[i].data_ptr()
+                tab[i].vt_cache = self._vt_cache[i].data_ptr()
+            self._layer_tab, self._layer_tab_key = tab, key
+        H, Hkv, hd = self.n_heads, self.n_kv_heads, self.head_dim
+        smax = self._k_cache[0].shape[2]
+        xn = self._buf("xn", (B, a.dim))
+        qkv = self._buf("qkv", (B, (H + 2 * Hkv) * hd))
+        att = self._buf("att", (B, H * hd))
+        act = self._buf("act", (B, self.ffn))
+        scratch = self._buf("attn_scratch", (2 * ops.attention_scratch_floats(B, H, hd, a.max_seq_len + 64),), torch.float32)
+        rc = _l.load().a3v_llama_decode_step(self._layer_tab, self.n_layers, h.data_ptr(), xn.data_ptr(), qkv.data_ptr(),
+                                             att.data_ptr(), act.data_ptr(), scratch.data_ptr(), self._cos_sin_dev().data_ptr(),
+                                             B, a.dim, H, Hkv, hd, self.ffn, smax, pos, a.norm_eps,
+                                             torch.cuda.current_stream().cuda_stream)
+        _l.check(rc, "a3v_llama_decode_step")
+
     # ------------------------------------------------------------------ vision
     def _vit_geometry(self):
         a = self.args
@@ -572,7 +604,10 @@ class Transformer(nn.Module):
         ops.embed_assemble(tokens.contiguous(), self.tok_embeddings.weight, h, B, T, W, a.dim)
         if image is not None:
             self.encode_image_into(h, image, B, S, qformer_feats, extra_feats)
-        self._decoder_layers(h, B, S, start_pos, rope0, self._k_cache, self._vt_cache, True)
+        if S == 1 and B <= 16 and self._dtype == torch.bfloat16 and self.head_dim in (64, 128) and a.dim % 32 == 0 and self.ffn % 32 == 0:
+            self._decode_step(h, B, start_pos)
+        else:
+            self._decoder_layers(h, B, S, start_pos, rope0, self._k_cache, self._vt_cache, True)
         last = h.view(B, S, a.dim)[:, -1, :]            # strided rows, no copy
         xn = self._buf("xn_last", (B, a.dim))
         ops.rmsnorm(last, self.norm.weight, xn, a.norm_eps)

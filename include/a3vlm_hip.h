@@ -156,6 +156,26 @@ int a3v_cross_entropy(const void* logits, int64_t ld, const int64_t* labels, flo
                       void* dlogits, int64_t ldd, const int32_t* n_valid_dev, float grad_scale,
                       int rows, int V, int dtype, void* stream);
 
+/* One decode step (seqlen == 1) of the whole decoder stack from a single host call: per layer
+ * RMSNorm -> fused QKV (skinny GEMM) -> RoPE + KV-cache write at `pos` -> split-KV attention over
+ * pos+1 keys -> WO (+residual) -> RMSNorm -> W1|W3 SwiGLU -> W2 (+residual)  (LLM/llama_ens5.py:
+ * 220-249, 490-531).  h [B,dim] bf16 is updated in place; xn/qkv/att/act are caller workspaces of
+ * [B,dim], [B,(H+2Hkv)hd], [B,H*hd], [B,ffn]; attn_scratch as for a3v_attention at Sk = Smax. */
+typedef struct a3v_llama_layer {
+  const void* attn_norm_w;
+  const void* wqkv;     /* [wq;wk;wv] rows */
+  const void* wo;
+  const void* ffn_norm_w;
+  const void* w13;      /* w1/w3 interleaved in 16-row blocks */
+  const void* w2;
+  void* k_cache;        /* [B,Hkv,Smax,hd] */
+  void* vt_cache;       /* [B,Hkv,hd,Smax] */
+} a3v_llama_layer;
+int a3v_llama_decode_step(const a3v_llama_layer* layers, int n_layers, void* h, void* xn, void* qkv,
+                          void* att, void* act, float* attn_scratch, const float* cos_sin, int B,
+                          int dim, int H, int Hkv, int hd, int ffn, int Smax, int pos, float eps,
+                          void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Training (backward) entry points.  Reference: autograd through the same modules under
  * autocast(bf16) with fp32 master weights (engine_finetune.py:44-68, main_finetune.py:212-217).

@@ -102,8 +102,12 @@ def meta_model(gold, dtype=torch.float32):
 
 def test_g5_meta_forward_loss_fp32(gold):
     mm = meta_model(gold)
+    mm.train_compute_dtype = torch.float32      # grad mode on: this goes through the training engine's forward
     g = gold["meta"]
     ex = torch.from_numpy(g["g5_examples"]).to(DEV)
+    with torch.no_grad():                        # inference-path loss
+        l0, _ = mm(ex, torch.from_numpy(g["g5_labels_a"]).to(DEV))
+    assert abs(float(l0) - float(g["g5_loss_a"])) < REL * float(g["g5_loss_a"])
     la, _ = mm(ex, torch.from_numpy(g["g5_labels_a"]).to(DEV))
     assert abs(float(la) - float(g["g5_loss_a"])) < REL * float(g["g5_loss_a"])
     lb, _ = mm(torch.from_numpy(g["g5_examples_b"]).to(DEV), torch.from_numpy(g["g5_labels_b"]).to(DEV))
@@ -204,7 +208,8 @@ def test_decoder_bf16_vs_oracle(gold):
 def test_loss_bf16_within_1e2(gold):
     mm = meta_model(gold, BF)
     g = gold["meta"]
-    la, _ = mm(torch.from_numpy(g["g5_examples"]).to(DEV), torch.from_numpy(g["g5_labels_a"]).to(DEV))
+    with torch.no_grad():      # evaluation of the loss with bf16 weights (training wants fp32 masters: tests/test_gpu_train.py)
+        la, _ = mm(torch.from_numpy(g["g5_examples"]).to(DEV), torch.from_numpy(g["g5_labels_a"]).to(DEV))
     assert abs(float(la) - float(g["g5_loss_a"])) < 1e-2 * float(g["g5_loss_a"])
 
 
