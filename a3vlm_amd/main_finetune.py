@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Fine-tuning entry point with the CLI surface of the reference's ``main_finetune.py`` (flags of
+model/accessory/main_finetune.py:57-136 as used by scripts/a3vlm_train.sh:46-55), running on pure DP replicas:
+
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m a3vlm_amd.main_finetune \
+        --llama_type llama_ens5 --llama_config params.json --tokenizer_path tokenizer.model \
+        --pretrained_path /ckpt --batch_size 2 --accum_iter 8 --epochs 3 --warmup_epochs 0.03 --lr 2e-5 --min_lr 0 \
+        --clip_grad 8 --weight_decay 0 --max_words 2048 --precision bf16 --output_dir out [--synthetic 256]
+
+Call order follows main_finetune.py:141-362: dist init (one process per GPU, backend "nccl" = RCCL) -> MetaModel in
+bf16 on the GPU -> trainables promoted to fp32 -> checkpoint load -> identical weights on all ranks (broadcast) ->
+AdamW(add_weight_decay, betas 0.9/0.95) -> FinetuneDistSampler -> epochs of train_one_epoch -> save_checkpoint.
+FSDP / tensor parallelism / ``--checkpointing`` / ``--quant`` are accepted and ignored or rejected as documented
+in DESIGN.md (DP replicas, activations kept in HBM).  ``--synthetic N`` substitutes a seeded synthetic dataset of N
+items of the dialog dataset's output shape (the real dataset classes are the next host-side row).
+"""
+from __future__ import annotations
+
+import argparse
+import datetime
+import json
+import os
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .checkpoint import latest_checkpoint_dir, load_tensor_parallel_model_list, save_checkpoint
+from .dp import FinetuneDistSampler, GradReducer
+from .engine_finetune import train_one_epoch
+from .model.meta import MetaModel
+from .util import add_weight_decay, promote_trainable_params_to_fp32
+
+
+def get_args_parser():
+    p = argparse.ArgumentParser("LLaMA2-Accessory style fine-tuning on MI355X (DP replicas)", add_help=False)
+    p.add_argument("--batch_size", default=16, type=int)
+    p.add_argument("--accum_iter", default=4, type=int)
+    p.add_argument("--llama_type", default="llama_ens5", type=str)
+    p.add_argument("--llama_config", default=[], nargs="*")
+    p.add_argument("--no_visual", action="store_true")
+    p.add_argument("--tokenizer_path", type=str, default="../tokenizer.model")
+    p.add_argument("--pretrained_path", default=[], type=str, nargs="*")
+    p.add_argument("--pretrained_type", type=str, default=None, choices=["consolidated", "meta_ori"])
+    p.add_argument("--weight_decay", type=float, default=0.02)
+    p.add_argument("--lr", type=float, default=0.001)
+    p.add_argument("--min_lr", type=float, default=0.0001)
+    p.add_argument("--epochs", default=400, type=int)
+    p.add_argument("--warmup_epochs", type=float, default=1.0)
+    p.add_argument("--clip_grad", type=int, default=-1)
+    p.add_argument("--max_words", default=1024, type=int)
+    p.add_argument("--dialog", action="store_true", default=False)
+    p.add_argument("--data_config", default=None, type=str)
+    p.add_argument("--image_transform", default="padded_resize", type=str)
+    p.add_argument("--cache_ann_on_disk", action="store_true")
+    p.add_argument("--output_dir", default="./output_dir")
+    p.add_argument("--save_interval", default=1, type=int)
+    p.add_argument("--save_iteration_interval", default=10000, type=int)
+    p.add_argument("--only_save_trainable", default=False, action="store_true")
+    p.add_argument("--seed", default=0, type=int)
+    p.add_argument("--resume", default="")
+    p.add_argument("--num_workers", default=2, type=int)
+    p.add_argument("--pin_mem", action="store_true")
+    p.add_argument("--no_pin_mem", action="store_false", dest="pin_mem")
+    p.add_argument("--dist_on_itp", action="store_true")
+    p.add_argument("--model_parallel_size", type=int, default=1)
+    p.add_argument("--data_parallel", type=str, choices=["sdp", "fsdp"], default="sdp")
+    p.add_argument("--precision", type=str, choices=["fp16", "bf16", "tf32"], default="bf16")
+    p.add_argument("--checkpointing", action="store_true", default=False)
+    p.add_argument("--quant", action="store_true", default=False)
+    p.add_argument("--synthetic", type=int, default=0, help="use a seeded synthetic dataset of this many items")
+    p.add_argument("--max_seq_len", type=int, default=None)
+    return p
+
+
+class SyntheticDialogDataset(torch.utils.data.Dataset):
+    """Items shaped like FinetuneDialogDataset's (data/conversation/dataset.py:210-273): (tokens[T], labels[T],
+    mask[T], image[3,H,W]) with T = max_words - image_words, BOS first, labels on the second half, pad id 0."""
+
+    def __init__(self, n, T, vocab, image_size, with_image=True, seed=0):
+        self.n, self.T, self.vocab, self.size, self.with_image, self.seed = n, T, vocab, image_size, with_image, seed
+
+    def __len__(self):
+        return self.n
+
+    def groups(self):
+        return [list(range(self.n))]
+
+    def __getitem__(self, i):
+        g = torch.Generator().manual_seed(self.seed * 1000003 + i)
+        tok = torch.randint(3, self.vocab, (self.T,), generator=g)
+        tok[0] = 1
+        lab = tok.clone()
+        lab[: self.T // 2] = 0
+        mask = torch.ones(self.T)
+        if not self.with_image:
+            return tok, lab, mask
+        return tok, lab, mask, torch.randn(3, self.size, self.size, generator=g)
+
+
+def main(args):
+    distributed = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if args.model_parallel_size != 1:
+        raise SystemExit("tensor parallelism is not part of this build (DP replicas only, SURVEY 8(e)): use --model_parallel_size 1")
+    if args.quant:
+        raise SystemExit("--quant (bitsandbytes NF4) is CUDA-only and out of scope (SURVEY 8(a) row Q)")
+    torch.cuda.set_device(local)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)     # "nccl" on ROCm is RCCL (util/misc.py:141-145)
+    seed = args.seed + rank                                              # main_finetune.py:152-154
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    dev = torch.device("cuda", local)
+
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.bfloat16)                              # default_tensor_type(bf16, "cuda"), :212-215
+    with torch.device(dev):
+        model = MetaModel(args.llama_type, args.llama_config, args.tokenizer_path, with_visual=not args.no_visual,
+                          max_seq_len=args.max_seq_len or args.max_words)
+    torch.set_default_dtype(old)
+    promote_trainable_params_to_fp32(model)                              # :217
+    if args.pretrained_path and rank == 0:
+        print("load result:", load_tensor_parallel_model_list(model, args.pretrained_path))
+    if distributed:                                                      # :237-239 (every parameter, trainable or frozen)
+        for p in model.parameters():
+            dist.broadcast(p.data, src=0)
+    model.llma.invalidate_packed_weights()
+    if args.precision == "tf32":
+        model.train_compute_dtype = torch.float32
+
+    optimizer = torch.optim.AdamW(add_weight_decay(model, args.weight_decay), lr=args.lr, betas=(0.9, 0.95), fused=True)
+    reducer = GradReducer(model.train_engine(), dist) if distributed else None
+
+    image_words = model.get_image_words()
+    if not args.synthetic:
+        raise SystemExit("only --synthetic N data is wired in this round; the dialog dataset is the next host-side row")
+    dataset = SyntheticDialogDataset(args.synthetic, args.max_words - image_words, model.tokenizer.n_words,
+                                     getattr(model.llma, "image_size", 224), with_image=not args.no_visual, seed=args.seed)
+    sampler = FinetuneDistSampler(dataset, num_replicas=world, rank=rank, shuffle=True, batch_size=args.batch_size,
+                                  acc_grad=args.accum_iter, seed=args.seed)
+    loader = torch.utils.data.DataLoader(dataset, batch_size=args.batch_size, sampler=sampler, num_workers=args.num_workers,
+                                         pin_memory=args.pin_mem, drop_last=True)
+    start_epoch, start_iter = 0, 0
+    if args.resume:
+        d = latest_checkpoint_dir(args.resume) or args.resume
+        print("resume:", load_tensor_parallel_model_list(model, [d]))
+        other = torch.load(os.path.join(d, "consolidated.00-of-01.other.pth"), weights_only=False)
+        opt_path = os.path.join(d, "consolidated.00-of-01.optimizer.pth")
+        if os.path.isfile(opt_path):
+            optimizer.load_state_dict(torch.load(opt_path, weights_only=False)["optimizer"])
+        if other.get("iter") is not None:
+            start_epoch, start_iter = other["epoch"], other["iter"] + 1
+        else:
+            start_epoch = other["epoch"] + 1
+
+    t0 = time.time()
+    for epoch in range(start_epoch, args.epochs):
+        sampler.set_epoch(epoch, start_iter)
+        def _save(step, epoch=epoch):
+            save_checkpoint(args.output_dir, args, model, optimizer, None, None, epoch=epoch, iteration=step, rank=rank, world_size=world)
+        stats = train_one_epoch(model, loader, optimizer, epoch, start_iter, args, reducer=reducer,
+                                log=(print if rank == 0 else (lambda *_: None)), on_save=_save)
+        if args.output_dir and (epoch % args.save_interval == 0 or epoch + 1 == args.epochs):
+            save_checkpoint(args.output_dir, args, model, optimizer, None, None, epoch=epoch, rank=rank, world_size=world)
+        if rank == 0 and args.output_dir:
+            with open(os.path.join(args.output_dir, "log.txt"), "a") as f:
+                f.write(json.dumps({**{f"train_{k}": v for k, v in stats.items()}, "epoch": epoch}) + "\n")
+        start_iter = 0
+    if rank == 0:
+        print("Training time", str(datetime.timedelta(seconds=int(time.time() - t0))))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    a = argparse.ArgumentParser(parents=[get_args_parser()]).parse_args()
+    if a.output_dir:
+        os.makedirs(a.output_dir, exist_ok=True)
+    main(a)

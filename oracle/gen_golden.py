@@ -442,3 +442,47 @@ def gen_host():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "host":
     gen_host()
+
+
+def gen_ckpt():
+    """G11: a 2-shard ``consolidated.*-of-02.model.pth`` checkpoint and a ``meta_ori`` one, merged to MP=1 by the
+    REFERENCE loader (util/tensor_parallel.py) -> checksums of every merged tensor (tests/golden/ckpt_tiny.json)."""
+    refimport.install()
+    refimport.init_dist_ws1()
+    import accessory.model.meta as meta
+    from accessory.util import tensor_parallel as tp
+    tok_path = os.path.join(GOLD, "tokenizer.model")
+    mm = meta.MetaModel("llama_ens5", os.path.join(GOLD, "tiny_params.json"), tok_path, with_visual=False, max_seq_len=64)
+    V = mm.tokenizer.n_words
+    sd = ref_cpu.make_decoder_weights(ref_cpu.OracleArgs(vocab_size=V, **TINY), seed=21, std=0.05)
+    full = {"llma." + k: v for k, v in sd.items()}
+    from a3vlm_amd.checkpoint import merge_dim
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        # split with the reference's own dims (Column 0 / Row 1 / Embedding 1) through torch.chunk
+        for fmt, names in (("consolidated", ["consolidated.00-of-02.model.pth", "consolidated.01-of-02.model.pth"]),
+                           ("meta_ori", ["consolidated.00.pth", "consolidated.01.pth"])):
+            sub = os.path.join(d, fmt)
+            os.makedirs(sub)
+            for r, fn in enumerate(names):
+                shard = {}
+                for k, v in full.items():
+                    dd = merge_dim(k)
+                    t = torch.chunk(v, 2, dd)[r].clone() if dd >= 0 else v.clone()
+                    shard[k if fmt == "consolidated" else k[len("llma."):]] = t
+                torch.save({"model": shard} if fmt == "consolidated" else shard, os.path.join(sub, fn))
+            for p in mm.parameters():
+                p.data.zero_()
+            res = tp.load_tensor_parallel_model_list(mm, [sub])
+            got = mm.state_dict()
+            out[fmt] = {"load_result": res, "sums": {k: float(v.double().sum()) for k, v in got.items()},
+                        "abs_sums": {k: float(v.double().abs().sum()) for k, v in got.items()}}
+            assert all(torch.equal(got[k], full[k]) for k in full), "reference merge must reproduce the unsharded weights"
+    out["seed"] = 21
+    with open(os.path.join(GOLD, "ckpt_tiny.json"), "w") as f:
+        json.dump(out, f)
+    print("ckpt fixture written")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "ckpt":
+    gen_ckpt()
