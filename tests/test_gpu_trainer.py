@@ -1,0 +1,46 @@
+"""-m gpu: the fine-tuning entry point end to end on one GPU (tiny model, synthetic data): epochs, gradient
+accumulation, checkpoint layout on disk, resume."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run(args, env=None):
+    e = dict(os.environ)
+    e["PYTHONPATH"] = ROOT + os.pathsep + e.get("PYTHONPATH", "")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "a3vlm_amd.main_finetune"] + args, cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    return r.stdout
+
+
+@pytest.mark.parametrize("precision", ["tf32", "bf16"])
+def test_main_finetune_synthetic(tmp_path, precision):
+    gd = os.path.join(ROOT, "tests", "golden")
+    extra = tmp_path / "vit.json"
+    extra.write_text(json.dumps(dict(vit_width=64, vit_layers=2, vit_heads=4, vit_crop=112, n_views=1)))
+    out = tmp_path / "out"
+    base = ["--llama_type", "llama_ens5", "--llama_config", os.path.join(gd, "tiny_params.json"), str(extra),
+            "--tokenizer_path", os.path.join(gd, "tokenizer.model"), "--batch_size", "2", "--accum_iter", "2",
+            "--warmup_epochs", "0.5", "--lr", "1e-3", "--min_lr", "0", "--clip_grad", "8", "--weight_decay", "0",
+            "--max_words", "120", "--precision", precision, "--output_dir", str(out), "--synthetic", "24", "--num_workers", "0",
+            "--dialog", "--data_parallel", "sdp", "--model_parallel_size", "1", "--checkpointing"]
+    log = run(base + ["--epochs", "2"])
+    assert "closs" in log
+    for ep in ("epoch0", "epoch1"):
+        files = set(os.listdir(out / ep))
+        assert {"consolidated.00-of-01.model.pth", "consolidated.00-of-01.optimizer.pth", "consolidated.00-of-01.other.pth",
+                "config.json", "meta.json", "tokenizer.model", "rank-specific-00000-of-00001.pth"} <= files
+    lines = [json.loads(x) for x in open(out / "log.txt")]
+    assert [l["epoch"] for l in lines] == [0, 1] and all(0 < l["train_closs"] < 20 for l in lines)
+    log2 = run(base + ["--epochs", "3", "--resume", str(out)])
+    assert "resume:" in log2 and os.path.isdir(out / "epoch2")
+    lines = [json.loads(x) for x in open(out / "log.txt")]
+    assert [l["epoch"] for l in lines] == [0, 1, 2]
