@@ -17,6 +17,7 @@
 //    split-K partials reduced by a second tiny kernel that also applies the epilogue.
 //  * gemm_nt_f32_kernel : fp32 parity path (plain FMA, 64x64x16 tile).
 #include "a3v_common.h"
+#include <algorithm>
 
 namespace {
 
@@ -1032,20 +1033,24 @@ extern "C" int a3v_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ld
     if (cfg > 256 && !desc_ok) return A3V_ERR_SHAPE;
     launch(cfg, p);
   } else {
-    auto last_fill = [](long tiles, long* rounds) {
-      *rounds = (tiles + 255) / 256;
-      return tiles ? (double)(tiles - (*rounds - 1) * 256) / 256.0 : 0.0;
-    };
-    const long tn256 = (N + 255) / 256;
-    long r_all, r_big;
-    const double f_all = last_fill((long)((M + 255) / 256) * tn256, &r_all);
-    const int m_big = (M / 256) * 256;
-    const double f_big = last_fill((long)(m_big / 256) * tn256, &r_big);
+    // Cost model in units of one 256x256 tile's time on one CU (T256): a "round" is 256 concurrent big tiles or
+    // 512 concurrent 128x128 tiles (2 blocks/CU, each ~0.65 T256 at the small kernel's lower rate); a second launch
+    // costs ~0.1.  Candidates: small kernel for everything, big kernel for everything, or big kernel on the M-tile rows
+    // that fill whole rounds + small kernel on the remaining rows.
+    const long tn256 = (N + 255) / 256, tn128 = (N + 127) / 128;
     const bool eligible = desc_ok && M >= 512 && N >= 512;
-    if (eligible && (r_all >= 6 || f_all >= 0.5)) {
-      launch(257, p);                       // ping-pong alone: its own tail is small or well filled
-    } else if (eligible && M > m_big && f_big >= 0.75) {
-      GemmArgs q = p;                       // whole rounds on the big tile, the last < 256 rows on 128x128
+    auto small_cost = [&](long rows) { return rows <= 0 ? 0.0 : 0.65 * std::max(1.0, (double)((rows + 127) / 128) * tn128 / 512.0); };
+    const double c_small = small_cost(M);
+    const double c_big = eligible ? (double)((((long)(M + 255) / 256) * tn256 + 255) / 256) : 1e30;
+    long mt_h = ((long)(M / 256) * tn256 / 256) * 256 / tn256;          // M-tile rows that make whole rounds
+    double c_hyb = 1e30;
+    if (eligible && mt_h >= 1 && mt_h * 256 < M)
+      c_hyb = (double)((mt_h * tn256 + 255) / 256) + small_cost(M - mt_h * 256) + 0.1;
+    if (c_big <= c_small && c_big <= c_hyb) {
+      launch(257, p);
+    } else if (c_hyb < c_small) {
+      const int m_big = (int)(mt_h * 256);
+      GemmArgs q = p;
       q.M = m_big;
       launch(257, q);
       GemmArgs r = p;
