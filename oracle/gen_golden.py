@@ -486,3 +486,40 @@ def gen_ckpt():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "ckpt":
     gen_ckpt()
+
+
+def gen_text():
+    """G9/G12-lite: prompt strings of the reference's Conversation for demo.json, a multi-turn example with label spans,
+    and format_bounding_box / normalize_number outputs (the two functions are exec'd from the reference's eval script,
+    whose module-level imports -- gradio, cv2, torchvision -- are not installable here)."""
+    import ast
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_conv_lib", os.path.join(refimport.REF_ROOT, "accessory/data/conversation/lib.py"))
+    lib = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lib)
+    demo = json.load(open(os.path.join(refimport.REF_ROOT, "accessory/demo_data/demo.json")))
+    out = {"demo_prompts": []}
+    for item in demo:
+        conv = lib.conv_v1_2()
+        conv.load_qas([[item["conversations"][0]["value"], None]])
+        out["demo_prompts"].append(conv.get_prompt())
+    conv = lib.conv_v1_2()
+    conv.load_qas([["Detect all manipulable object parts.", "<box>lid</box>[[0.12,0.34,0.56]]"], ["And the joint?", "<axis>revolute</axis>[0.10,0.20]"], ["Again?", None]])
+    out["multi_turn"] = conv.process()
+    out["response_end_signal"] = conv.response_end_signal
+    src = open(os.path.join(refimport.REF_ROOT, "accessory/eval_affordance_v2.py")).read()
+    tree = ast.parse(src)
+    ns = {"re": __import__("re")}
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in ("normalize_number", "format_bounding_box"):
+            exec(compile(ast.Module([node], []), "ref_eval", "exec"), ns)
+    cases = ["[0.12, 0.34, 0.56, 0.78]", "The box is [123, 456, 789, 999]", "[[0.15,0.20],[0.62,0.90]]", "0.5,12,345,0.0071", "no numbers",
+             "<box>lid</box>[[12.5, 33.1, 0.9], [1234,5678,1,2]]"]
+    out["bbox_cases"] = [{"in": c, "out": ns["format_bounding_box"](c)} for c in cases]
+    with open(os.path.join(GOLD, "text_tiny.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("text fixture written")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "text":
+    gen_text()
