@@ -137,10 +137,17 @@ def main(args):
     reducer = GradReducer(model.train_engine(), dist) if distributed else None
 
     image_words = model.get_image_words()
-    if not args.synthetic:
-        raise SystemExit("only --synthetic N data is wired in this round; the dialog dataset is the next host-side row")
-    dataset = SyntheticDialogDataset(args.synthetic, args.max_words - image_words, model.tokenizer.n_words,
-                                     getattr(model.llma, "image_size", 224), with_image=not args.no_visual, seed=args.seed)
+    if args.synthetic:
+        dataset = SyntheticDialogDataset(args.synthetic, args.max_words - image_words, model.tokenizer.n_words,
+                                         getattr(model.llma, "image_size", 224), with_image=not args.no_visual, seed=args.seed)
+    elif args.data_config:                                               # main_finetune.py:289-293
+        from .data.conversation.dataset import FinetuneDialogDataset
+        from .data.transform import get_transform
+        dataset = FinetuneDialogDataset(args.data_config, get_transform(args.image_transform, getattr(model.llma, "image_size", 224)),
+                                        max_words=args.max_words, image_words=image_words, tokenizer=model.tokenizer,
+                                        cache_on_disk=args.cache_ann_on_disk, rank=rank)
+    else:
+        raise SystemExit("give --data_config <yaml> (dialog dataset) or --synthetic N")
     sampler = FinetuneDistSampler(dataset, num_replicas=world, rank=rank, shuffle=True, batch_size=args.batch_size,
                                   acc_grad=args.accum_iter, seed=args.seed)
     loader = torch.utils.data.DataLoader(dataset, batch_size=args.batch_size, sampler=sampler, num_workers=args.num_workers,

@@ -469,52 +469,78 @@ class Transformer(nn.Module):
         ops.layernorm(x, vis.ln_post.weight, vis.ln_post.bias, feats)
         return feats
 
-    def _image_row_maps(self, B: int, S: int):
+    def _image_slots(self):
+        """(start tag, end tag) parameters per image slot; slot 0 = RGB (llama_ens5.py:338-339)."""
+        return [(self.start_img, self.end_img)]
+
+    @property
+    def words_per_image(self) -> int:
+        _, _, L = self._vit_geometry()
+        return (self.args.qformer_tokens + L + 2) * self.args.n_views
+
+    def _image_row_maps(self, B: int, S: int, slots=(0,)):
         """int32 device maps from projector rows to rows of the [B*S, dim] sequence buffer
-        for the layout of llama_ens5.py:471-479: h = [BOS | per view (start, [qformer], clip, end) | text]."""
-        key = (B, S, str(self._device))
+        for the layout of llama_ens5.py:471-479: h = [BOS | per image: per view (start, [qformer], clip, end) | text].
+        Image j of the call occupies words [j*Wv, (j+1)*Wv); projector rows are ordered (image, view, batch)."""
+        key = (B, S, tuple(slots), str(self._device))
         m = self._row_maps.get(key)
         if m is not None:
             return m
         a = self.args
         _, _, L = self._vit_geometry()
-        Q, V = a.qformer_tokens, a.n_views
+        Q, V, J = a.qformer_tokens, a.n_views, len(slots)
         per_view = Q + L + 2
-        clip_map = torch.empty(V * B * L, dtype=torch.int32)
-        qf_map = torch.empty(V * B * max(Q, 1), dtype=torch.int32)
-        start_rows, end_rows = [], []
-        for v in range(V):
-            for b in range(B):
-                base = b * S + 1 + v * per_view
-                start_rows.append(base)
-                end_rows.append(base + 1 + Q + L)
-                n = v * B + b
-                clip_map[n * L:(n + 1) * L] = torch.arange(base + 1 + Q, base + 1 + Q + L, dtype=torch.int32)
-                if Q:
-                    qf_map[n * Q:(n + 1) * Q] = torch.arange(base + 1, base + 1 + Q, dtype=torch.int32)
+        clip_map = torch.empty(J * V * B * L, dtype=torch.int32)
+        qf_map = torch.empty(J * V * B * max(Q, 1), dtype=torch.int32)
+        start_rows, end_rows = [[] for _ in slots], [[] for _ in slots]
+        for j in range(J):
+            for v in range(V):
+                for b in range(B):
+                    base = b * S + 1 + (j * V + v) * per_view
+                    start_rows[j].append(base)
+                    end_rows[j].append(base + 1 + Q + L)
+                    n = (j * V + v) * B + b
+                    clip_map[n * L:(n + 1) * L] = torch.arange(base + 1 + Q, base + 1 + Q + L, dtype=torch.int32)
+                    if Q:
+                        qf_map[n * Q:(n + 1) * Q] = torch.arange(base + 1, base + 1 + Q, dtype=torch.int32)
         dev = self._device
         m = (clip_map.to(dev), qf_map.to(dev) if Q else None,
-             torch.tensor(start_rows, dtype=torch.int32, device=dev), torch.tensor(end_rows, dtype=torch.int32, device=dev))
+             [torch.tensor(r, dtype=torch.int32, device=dev) for r in start_rows],
+             [torch.tensor(r, dtype=torch.int32, device=dev) for r in end_rows])
         self._row_maps[key] = m
         return m
 
-    def encode_image_into(self, h: torch.Tensor, image: torch.Tensor, B: int, S: int,
+    def _gather_views(self, images, B: int, dtype=None) -> torch.Tensor:
+        """[J*V*B, 3, c, c] crops of the J images of a call (llama_ens5.py:381-392: fp16 bicubic 2x down + quadrants)."""
+        a = self.args
+        c, J = a.vit_crop, len(images)
+        if a.n_views == 5:
+            views = self._buf("views", (J * 5 * B, 3, c, c), dtype)
+            for j, img in enumerate(images):
+                assert img.shape[-1] == 2 * c and img.shape[-2] == 2 * c, img.shape
+                ops.split_views(img.contiguous(), views[j * 5 * B:(j + 1) * 5 * B])
+            return views
+        assert a.n_views == 1
+        if J == 1:
+            return images[0]
+        views = self._buf("views", (J * B, 3, c, c), images[0].dtype)
+        for j, img in enumerate(images):
+            views[j * B:(j + 1) * B].copy_(img)        # data movement only
+        return views
+
+    def encode_image_into(self, h: torch.Tensor, image, B: int, S: int,
                           qformer_feats: Optional[torch.Tensor] = None,
-                          extra_feats: Optional[List[torch.Tensor]] = None) -> None:
+                          extra_feats: Optional[List[torch.Tensor]] = None, slots=(0,)) -> None:
         """llama_ens5.py:377-458 + 471-478, writing the image words straight into rows 1..W of
-        every sequence of ``h`` [B*S, dim]."""
+        every sequence of ``h`` [B*S, dim].  ``image`` is one tensor or a list of len(slots) tensors (the
+        two-image plugin encodes RGB and depth in one ViT/projector pass)."""
         a = self.args
         dtp = self._dtype
         _, _, L = self._vit_geometry()
-        if a.n_views == 5:
-            c = a.vit_crop
-            assert image.shape[-1] == 2 * c and image.shape[-2] == 2 * c, image.shape
-            views = self._buf("views", (5 * B, 3, c, c))
-            ops.split_views(image.contiguous(), views)
-        else:
-            assert a.n_views == 1
-            views = image
-        N = a.n_views * B
+        images = list(image) if isinstance(image, (list, tuple)) else [image]
+        assert len(images) == len(slots)
+        views = self._gather_views(images, B)
+        N = len(images) * a.n_views * B
         feats = self.clip_encode_image(views)
         if extra_feats is None and self.extra_feat_fns:
             extra_feats = [fn(views) for fn in self.extra_feat_fns]
@@ -536,7 +562,7 @@ class Transformer(nn.Module):
         proj = self._buf("proj_out", (N * L, a.dim))
         vp0, vp1 = getattr(self.visual_proj, "0"), getattr(self.visual_proj, "1")
         ops.gemm_nt(feats, pw, proj, bias=vp0.bias)
-        clip_map, qf_map, start_rows, end_rows = self._image_row_maps(B, S)
+        clip_map, qf_map, start_rows, end_rows = self._image_row_maps(B, S, slots)
         ops.layernorm(proj, vp1.weight, vp1.bias, h, row_map=clip_map)
         if a.qformer_tokens:
             assert qformer_feats is not None, "qformer_tokens set but no Q-Former features given"
@@ -546,23 +572,29 @@ class Transformer(nn.Module):
             qout = self._buf("qf_out", (N * Q, a.dim))
             ops.gemm_nt(qin, qp0.weight, qout, bias=qp0.bias)
             ops.layernorm(qout, qp1.weight, qp1.bias, h, row_map=qf_map)
-        ops.fill_rows(self.start_img.view(-1), h, start_rows)
-        ops.fill_rows(self.end_img.view(-1), h, end_rows)
+        tags = self._image_slots()
+        for j, sl in enumerate(slots):
+            ops.fill_rows(tags[sl][0].view(-1), h, start_rows[j])
+            ops.fill_rows(tags[sl][1].view(-1), h, end_rows[j])
 
     # ------------------------------------------------------------------ forward (teacher forced)
     def forward(self, examples: torch.Tensor, image: Optional[torch.Tensor] = None, *,
                 qformer_feats=None, extra_feats=None) -> torch.Tensor:
         """llama_ens5.py:461-487: logits [B, T, V] in the model dtype for all text positions."""
+        return self._forward_images(examples, [] if image is None else [image], (0,) if image is not None else (),
+                                    qformer_feats, extra_feats)
+
+    def _forward_images(self, examples, images, slots, qformer_feats=None, extra_feats=None, out_from=None) -> torch.Tensor:
         self._destroy_kv_cache()
         self._pack(check=True)
         a = self.args
         B, T = examples.shape
-        W = self.image_words if image is not None else 0
+        W = self.words_per_image * len(images) if images else 0
         S = T + W
         h = self._buf("h", (B * S, a.dim))
         ops.embed_assemble(examples.contiguous(), self.tok_embeddings.weight, h, B, T, W, a.dim)
-        if image is not None:
-            self.encode_image_into(h, image, B, S, qformer_feats, extra_feats)
+        if images:
+            self.encode_image_into(h, images, B, S, qformer_feats, extra_feats, slots)
         spad = (S + 63) // 64 * 64
         kc = self._buf("fw_k", (B, self.n_kv_heads, spad, self.head_dim))
         vc = self._buf("fw_vt", (B, self.n_kv_heads, self.head_dim, spad))
@@ -570,10 +602,11 @@ class Transformer(nn.Module):
         self._decoder_layers(h, B, S, 0, 0, [kc] * L, [vc] * L, True)
         xn = self._buf("xn_final", (B * S, a.dim))
         ops.rmsnorm(h, self.norm.weight, xn, a.norm_eps)
-        out = torch.empty(B, T, a.vocab_size, dtype=self._dtype, device=self._device)
+        o0 = W if out_from is None else out_from       # h[:, image_words:] (llama_ens5.py:486)
+        out = torch.empty(B, S - o0, a.vocab_size, dtype=self._dtype, device=self._device)
         xv = xn.view(B, S, a.dim)
         for b in range(B):
-            ops.gemm_nt(xv[b, W:], self.output.weight, out[b])
+            ops.gemm_nt(xv[b, o0:], self.output.weight, out[b])
         return out
 
     # ------------------------------------------------------------------ forward_inference (KV cached)
@@ -581,16 +614,22 @@ class Transformer(nn.Module):
     def forward_inference(self, tokens: torch.Tensor, start_pos: int, image: Optional[torch.Tensor] = None, *,
                           qformer_feats=None, extra_feats=None) -> torch.Tensor:
         """llama_ens5.py:490-531: fp32 logits [B, V] of the last position."""
+        return self._forward_inference_images(tokens, start_pos, [] if image is None else [image],
+                                              (0,) if image is not None else (), qformer_feats, extra_feats)
+
+    def _forward_inference_images(self, tokens, start_pos, images, slots, qformer_feats=None, extra_feats=None) -> torch.Tensor:
         a = self.args
         B, T = tokens.shape
         if start_pos == 0:
             self._allocate_kv_cache(B)
             self._pack(check=True)
         W = 0
+        image = images if images else None
         if image is not None:
             assert start_pos == 0
-            W = self.image_words
+            W = self.words_per_image * len(images)
             self.cache_image_words = W
+            assert self.cache_image_words == self.image_words
             rope0 = 0
         else:
             if start_pos == 0:
@@ -603,7 +642,7 @@ class Transformer(nn.Module):
         h = self._buf("h", (B * S, a.dim))
         ops.embed_assemble(tokens.contiguous(), self.tok_embeddings.weight, h, B, T, W, a.dim)
         if image is not None:
-            self.encode_image_into(h, image, B, S, qformer_feats, extra_feats)
+            self.encode_image_into(h, image, B, S, qformer_feats, extra_feats, slots)
         if S == 1 and B <= 16 and self._dtype == torch.bfloat16 and self.head_dim in (64, 128) and a.dim % 32 == 0 and self.ffn % 32 == 0:
             self._decode_step(h, B, start_pos)
         else:

@@ -196,6 +196,8 @@ class MetaModel(nn.Module):
         dev = self._device
         if images is not None:
             images = images.to(dev)
+        if depth_images is not None:
+            depth_images = depth_images.to(dev)
         bsz = len(prompts)
         args = self.llma.args
         assert bsz <= args.max_batch_size, (bsz, args.max_batch_size)
@@ -226,8 +228,14 @@ class MetaModel(nn.Module):
         next_token = torch.empty(bsz, dtype=torch.long, device=dev)
 
         for cur_pos in range(start_pos, total_len):
-            logits = self.llma.forward_inference(tokens[:, prev_pos:cur_pos], prev_pos,
-                                                 images if prev_pos == 0 else None)
+            if depth_images is not None:                     # two-image plugin (meta.py:447-451)
+                if prev_pos == 0:
+                    logits = self.llma.forward_inference(tokens[:, prev_pos:cur_pos], prev_pos, images, depth_images)
+                else:
+                    logits = self.llma.forward_inference(tokens[:, prev_pos:cur_pos], prev_pos)
+            else:
+                logits = self.llma.forward_inference(tokens[:, prev_pos:cur_pos], prev_pos,
+                                                     images if prev_pos == 0 else None)
             if temperature > 0:
                 probs = torch.softmax(logits / temperature, dim=-1)
                 nt = self.sample_top_p(probs, top_p).reshape(-1)

@@ -79,6 +79,8 @@ class TrainEngine:
             vis = [("visual_proj.0.weight", vp0.weight), ("visual_proj.0.bias", vp0.bias),
                    ("visual_proj.1.weight", vp1.weight), ("visual_proj.1.bias", vp1.bias),
                    ("start_img", m.start_img), ("end_img", m.end_img)]
+            if hasattr(m, "start_depth_img"):                  # two-image plugin (llama_ens5_2images.py:343-344)
+                vis += [("start_depth_img", m.start_depth_img), ("end_depth_img", m.end_depth_img)]
             if m.args.qformer_tokens:
                 q0, q1 = getattr(m.qformer_proj, "0"), getattr(m.qformer_proj, "1")
                 vis += [("qformer_proj.0.weight", q0.weight), ("qformer_proj.0.bias", q0.bias),
@@ -281,7 +283,8 @@ class TrainEngine:
         m, a = self.m, self.m.args
         im = self._images()
         B, T = examples.shape
-        W = m.image_words if image is not None else 0
+        n_img = 0 if image is None else (len(image) if isinstance(image, (list, tuple)) else 1)
+        W = m.words_per_image * n_img if n_img else 0
         S = T + W
         rows = B * S
         dim, V = a.dim, a.vocab_size
@@ -369,12 +372,10 @@ class TrainEngine:
         if a.extra_feat_dim or a.qformer_tokens:
             raise NotImplementedError("training with the hook-fed encoder streams is not wired yet (next: SURVEY 8(f) N4)")
         _, _, L = m._vit_geometry()
-        if a.n_views == 5:
-            views = m._buf("views", (5 * B, 3, a.vit_crop, a.vit_crop), m.clip.visual.conv1.weight.dtype)
-            ops.split_views(image.contiguous(), views)
-        else:
-            views = image
-        N = a.n_views * B
+        images = list(image) if isinstance(image, (list, tuple)) else [image]
+        slots = tuple(range(len(images)))
+        views = m._gather_views(images, B, m.clip.visual.conv1.weight.dtype)
+        N = len(images) * a.n_views * B
         feats = m.clip_encode_image(views)                      # frozen, compute dtype of the clip params
         if feats.dtype != self.act:
             f2 = self._buf("feats_act", tuple(feats.shape))
@@ -383,11 +384,13 @@ class TrainEngine:
         proj = self._buf("proj", (N * L, a.dim))
         ops.gemm_nt(feats, im["vp"], proj, bias=im["vp.b"])
         vp1 = getattr(m.visual_proj, "1")
-        clip_map, _, start_rows, end_rows = m._image_row_maps(B, S)
+        clip_map, _, start_rows, end_rows = m._image_row_maps(B, S, slots)
         ops.layernorm(proj, vp1.weight, vp1.bias, h, row_map=clip_map)
-        ops.fill_rows(m.start_img.view(-1), h, start_rows)
-        ops.fill_rows(m.end_img.view(-1), h, end_rows)
-        return dict(feats=feats, proj=proj, clip_map=clip_map, start_rows=start_rows, end_rows=end_rows, N=N, L=L)
+        tags = m._image_slots()
+        for j, sl in enumerate(slots):
+            ops.fill_rows(tags[sl][0].view(-1), h, start_rows[j])
+            ops.fill_rows(tags[sl][1].view(-1), h, end_rows[j])
+        return dict(feats=feats, proj=proj, clip_map=clip_map, start_rows=start_rows, end_rows=end_rows, N=N, L=L, slots=slots)
 
     def _encode_image_backward(self, dh, vis, B, S):
         m, a = self.m, self.m.args
@@ -398,8 +401,10 @@ class TrainEngine:
                           self._views["visual_proj.1.bias"])
         self._wgrad(dproj, vis["feats"], self._views["visual_proj.0.weight"], "vp")
         ops.rows_sum(dproj, None, rowsv, self._views["visual_proj.0.bias"])
-        ops.rows_sum(dh, vis["start_rows"], vis["start_rows"].numel(), self._views["start_img"].view(-1))
-        ops.rows_sum(dh, vis["end_rows"], vis["end_rows"].numel(), self._views["end_img"].view(-1))
+        names = [("start_img", "end_img"), ("start_depth_img", "end_depth_img")]
+        for j, sl in enumerate(vis["slots"]):
+            ops.rows_sum(dh, vis["start_rows"][j], vis["start_rows"][j].numel(), self._views[names[sl][0]].view(-1))
+            ops.rows_sum(dh, vis["end_rows"][j], vis["end_rows"][j].numel(), self._views[names[sl][1]].view(-1))
 
 
 class _StepLoss(torch.autograd.Function):

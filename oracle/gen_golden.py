@@ -523,3 +523,111 @@ def gen_text():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "text":
     gen_text()
+
+
+def dialog_yaml(tmpdir):
+    """The dataset config used by the G9 fixture and its test (paths are machine-specific, so it is written on the fly)."""
+    d = os.path.join(GOLD, "dialog")
+    p = os.path.join(tmpdir, "dialog.yaml")
+    with open(p, "w") as f:
+        f.write("META:\n"
+                f"  - path: '{d}/mm.json'\n    type: 'image_text'\n    root: '{os.path.join(GOLD, 'demo')}'\n"
+                f"  - path: '{d}/text.jsonl'\n    type: 'text'\n    ratio: 0.9\n")
+    return p
+
+
+def dialog_transform(img):
+    """Stand-in transform for the fixture: a tiny deterministic function of the decoded PIL image."""
+    a = np.asarray(img.resize((4, 4)), dtype=np.float32) / 255.0
+    return torch.from_numpy(a).permute(2, 0, 1).contiguous()
+
+
+def gen_dialog():
+    """G9: items of the reference's FinetuneDialogDataset (tokens, assistant-span labels, masks, group layout) over
+    tests/golden/dialog/* with the fixture tokenizer -> tests/golden/dialog/items.json."""
+    import builtins
+    import tempfile
+    refimport.install(data_stubs=True)
+    import pandas  # noqa: F401
+    from accessory.data.conversation.dataset import FinetuneDialogDataset
+    real_print = builtins.print
+    builtins.print = lambda *a, force=False, **k: real_print(*a, **k)      # the reference prints with force= (misc.py patch)
+    with tempfile.TemporaryDirectory() as td:
+        ds = FinetuneDialogDataset(dialog_yaml(td), dialog_transform, max_words=150, image_words=30,
+                                   tokenizer=os.path.join(GOLD, "tokenizer.model"))
+        out = {"len": len(ds), "groups": ds.groups(), "items": []}
+        for i in range(len(ds)):
+            it = ds[i]
+            rec = {"tokens": it[0].tolist(), "labels": it[1].tolist(), "mask_sum": float(it[2].sum())}
+            if len(it) == 4:
+                rec["image_sum"] = float(it[3].double().sum())
+            out["items"].append(rec)
+    builtins.print = real_print
+    with open(os.path.join(GOLD, "dialog", "items.json"), "w") as f:
+        json.dump(out, f)
+    print("dialog fixture written:", out["len"], "items, groups", [len(g) for g in out["groups"]])
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "dialog":
+    gen_dialog()
+
+
+def depth_tags(dim: int = 64, seed: int = 21):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(1, 1, dim, generator=g), torch.rand(1, 1, dim, generator=g)
+
+
+def gen_2img():
+    """G8b: the reference's two-image plugin (llama_ens5_2images): RGB + depth image words with their own tags,
+    teacher-forced logits and cached prefill + 2 decode steps -> tests/golden/vision2_tiny.npz."""
+    refimport.install()
+    refimport.init_dist_ws1()
+    torch.manual_seed(0)
+    import sentencepiece as spm
+    import accessory.model.LLM.llama_ens5_2images as ens2
+    V = spm.SentencePieceProcessor(model_file=os.path.join(GOLD, "tokenizer.model")).vocab_size()
+    args = ens2.ModelArgs(vocab_size=V, max_batch_size=32, **{**TINY, "max_seq_len": 3200})
+    sd = ref_cpu.make_decoder_weights(ref_cpu.OracleArgs(vocab_size=V, **TINY), seed=0, std=0.08)
+    vsd = ref_cpu.make_vision_weights(64, width=VIT["width"], layers=VIT["layers"], patch=VIT["patch"], grid=VIT["grid"],
+                                      in_feat=VIT["width"] + 3072 + 1536, with_qformer=True, seed=1, std=0.05)
+    vm = ens2.Transformer(args, with_visual=False)
+    vm.load_state_dict(sd)
+    vm.clip = _Clip(w=VIT["width"], layers=VIT["layers"], h=VIT["heads"], patch=VIT["patch"], grid=VIT["grid"])
+    vm.qformer_proj = nn.Sequential(nn.Linear(768, 64), nn.LayerNorm(64))
+    vm.visual_proj = nn.Sequential(nn.Linear(3072 + VIT["width"] + 1536, 64), nn.LayerNorm(64))
+    vm.start_img = nn.Parameter(torch.zeros(1, 1, 64))
+    vm.end_img = nn.Parameter(torch.zeros(1, 1, 64))
+    sdi, edi = depth_tags()
+    vm.start_depth_img, vm.end_depth_img = nn.Parameter(sdi), nn.Parameter(edi)
+    vm.visual_image_words = (32 + 257 + 2) * 5
+    vm.image_words = vm.visual_image_words * 2
+    vm.image_size = 448
+    res = vm.load_state_dict(vsd, strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys
+    B = 2
+    qf, cnx, dino = extra_feature_inputs(5 * B)       # the three out-of-scope streams: same features for both images
+    vm.qformer, vm.openclip_convnext_xxl, vm.dinov2_vitg14 = _QF(qf), _FixedFeat(cnx), _Dino(dino)
+    vm.eval()
+    img, depth = synth_image(B, seed=5), synth_image(B, seed=6)
+    g = torch.Generator().manual_seed(31)
+    ex = torch.randint(3, V, (B, 9), generator=g)
+    ex[:, 0] = 1
+    vo = {"examples": ex.numpy(), "depth_checksum": np.float64(depth.double().abs().sum().item())}
+    with torch.no_grad():
+        full = vm(ex, img, depth)                  # reference quirk (:505): rows from visual_image_words on = depth words + text
+        vo["logits_2img_shape"] = np.array(full.shape)
+        vo["logits_2img_tail"] = np32(full[:, -12:])
+        vo["logits_2img_rowsum"] = np32(full.sum(-1))
+        vo["logits_rgb_only"] = np32(vm(ex, img))
+        l0 = np32(vm.forward_inference(ex[:, :6], 0, img, depth))
+        vo["cache_image_words"] = np.int64(vm.cache_image_words)
+        l1 = np32(vm.forward_inference(ex[:, 6:7], 6))
+        l2 = np32(vm.forward_inference(ex[:, 7:8], 7))
+        vo["inf_logits"] = np.stack([l0, l1, l2])
+        vo["inf_logits_rgb_dropped"] = np32(vm.forward_inference(ex[:, :6], 0, img, None))   # image ignored without depth (:517)
+    np.savez_compressed(os.path.join(GOLD, "vision2_tiny.npz"), **vo)
+    print("two-image fixture written", {k: getattr(v, "shape", None) for k, v in vo.items()})
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "2img":
+    gen_2img()

@@ -215,7 +215,9 @@ class OracleDecoder:
         self.v_cache = [None] * self.args.n_layers
 
     # LLM/llama_ens5.py:461-487
-    def forward(self, examples: Tensor, image_tokens: Optional[Tensor] = None) -> Tensor:
+    def forward(self, examples: Tensor, image_tokens: Optional[Tensor] = None, out_from: Optional[int] = None) -> Tensor:
+        """``out_from``: first sequence row fed to the LM head when it is not the number of image words (the
+        two-image plugin slices from ``visual_image_words``, LLM/llama_ens5_2images.py:505)."""
         self.destroy_kv_cache()
         h = self.embed(examples)
         image_words = 0
@@ -227,7 +229,7 @@ class OracleDecoder:
         for i in range(self.args.n_layers):
             h = self.block(i, h, 0, freqs_cis, "causal")
         h = rmsnorm(h, self.sd["norm.weight"], self.args.norm_eps)
-        return F.linear(h[:, image_words:, :], self.sd["output.weight"])
+        return F.linear(h[:, image_words if out_from is None else out_from:, :], self.sd["output.weight"])
 
     # LLM/llama_ens5.py:490-531
     def forward_inference(self, tokens: Tensor, start_pos: int,

@@ -44,3 +44,20 @@ def test_main_finetune_synthetic(tmp_path, precision):
     assert "resume:" in log2 and os.path.isdir(out / "epoch2")
     lines = [json.loads(x) for x in open(out / "log.txt")]
     assert [l["epoch"] for l in lines] == [0, 1, 2]
+
+
+def test_main_finetune_dialog_dataset(tmp_path):
+    """--data_config: the dialog dataset (image_text + text groups), PIL transform and FinetuneDistSampler feed the trainer."""
+    from oracle.gen_golden import dialog_yaml
+    gd = os.path.join(ROOT, "tests", "golden")
+    extra = tmp_path / "vit.json"
+    extra.write_text(json.dumps(dict(vit_width=64, vit_layers=2, vit_heads=4, vit_crop=112, n_views=1)))
+    out = tmp_path / "out"
+    log = run(["--llama_type", "llama_ens5", "--llama_config", os.path.join(gd, "tiny_params.json"), str(extra),
+               "--tokenizer_path", os.path.join(gd, "tokenizer.model"), "--batch_size", "2", "--accum_iter", "1", "--epochs", "1",
+               "--warmup_epochs", "0.5", "--lr", "1e-3", "--min_lr", "0", "--clip_grad", "8", "--weight_decay", "0.02",
+               "--max_words", "220", "--precision", "bf16", "--output_dir", str(out), "--data_config", dialog_yaml(str(tmp_path)),
+               "--image_transform", "padded_resize", "--num_workers", "0", "--dialog", "--model_parallel_size", "1"])
+    assert "closs" in log and "total length: 13" in log
+    line = json.loads(open(out / "log.txt").read().strip().splitlines()[-1])
+    assert 0 < line["train_closs"] < 20

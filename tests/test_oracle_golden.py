@@ -167,3 +167,35 @@ def test_g7_g8_vision(golden_dir, tiny):
     l1 = d.forward_inference(ex[:, 6:7], 6)
     l2 = d.forward_inference(ex[:, 7:8], 7)
     close(torch.stack([l0, l1, l2]), v["g8_inf_logits"], atol=1e-4)
+
+
+def test_g8b_two_image_plugin(golden_dir, tiny):
+    """llama_ens5_2images: [BOS | RGB words | depth words (own tags) | text]; LM head from visual_image_words on;
+    cached inference inserts image words only when both images are given."""
+    from oracle.gen_golden import depth_tags
+    v = np.load(os.path.join(golden_dir, "vision2_tiny.npz"))
+    args, sd = tiny
+    vsd = ref_cpu.make_vision_weights(64, width=VIT["width"], layers=VIT["layers"], patch=VIT["patch"],
+                                      grid=VIT["grid"], in_feat=VIT["width"] + 3072 + 1536, with_qformer=True, seed=1, std=0.05)
+    B = 2
+    img, depth = synth_image(B, seed=5), synth_image(B, seed=6)
+    assert abs(depth.double().abs().sum().item() - float(v["depth_checksum"])) < 1e-3
+    qf, cnx, dino = extra_feature_inputs(5 * B)
+    kw = dict(vit_layers=VIT["layers"], vit_heads=VIT["heads"], n_views=5, qformer_feats=qf, extra_feats=[convnext_tokens(cnx), dino])
+    sdi, edi = depth_tags()
+    t_rgb = ref_cpu.assemble_image_tokens(ref_cpu.encode_image(img, vsd, **kw), vsd["start_img"], vsd["end_img"])
+    t_dep = ref_cpu.assemble_image_tokens(ref_cpu.encode_image(depth, vsd, **kw), sdi, edi)
+    itok = torch.cat([t_rgb, t_dep], dim=1)
+    assert itok.shape[1] == 2910 == int(v["cache_image_words"])
+    d = ref_cpu.OracleDecoder(ref_cpu.OracleArgs(vocab_size=args.vocab_size, **{**TINY, "max_seq_len": 3200}), sd)
+    ex = torch.from_numpy(v["examples"])
+    full = d.forward(ex, itok, out_from=1455)
+    assert list(full.shape) == list(v["logits_2img_shape"])
+    close(full[:, -12:], v["logits_2img_tail"], atol=1e-4)
+    close(full.sum(-1), v["logits_2img_rowsum"], atol=2e-3)
+    close(d.forward(ex, t_rgb), v["logits_rgb_only"], atol=1e-4)
+    l0 = d.forward_inference(ex[:, :6], 0, itok)
+    l1 = d.forward_inference(ex[:, 6:7], 6)
+    l2 = d.forward_inference(ex[:, 7:8], 7)
+    close(torch.stack([l0, l1, l2]), v["inf_logits"], atol=1e-4)
+    close(d.forward_inference(ex[:, :6], 0), v["inf_logits_rgb_dropped"], atol=1e-4)

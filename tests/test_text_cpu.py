@@ -62,4 +62,44 @@ def test_padded_resize_transform(golden_dir):
     t2 = get_transform("padded_resize", 448)(img)
     assert t2.shape == (3, 448, 448) and torch.isfinite(t2).all()
     with pytest.raises(ValueError):
-        get_transform("random_resized_crop")
+        get_transform("no_such_transform")
+    # the other two reference transforms: output geometry, determinism under torch's RNG, crop parameters in range
+    c = get_transform("resized_center_crop", 224)(img)
+    assert c.shape == (3, 224, 224)
+    rrc = get_transform("random_resized_crop", 224)
+    torch.manual_seed(3)
+    r1 = rrc(img)
+    torch.manual_seed(3)
+    r2 = rrc(img)
+    assert r1.shape == (3, 224, 224) and torch.equal(r1, r2)
+    for _ in range(20):
+        top, left, ch, cw = rrc.get_params(336, 300)
+        assert 0 <= top and top + ch <= 300 and 0 <= left and left + cw <= 336
+        assert 0.9 * 336 * 300 * 0.98 <= ch * cw <= 336 * 300 and 0.74 <= cw / ch <= 1.35
+
+
+def test_dialog_dataset_matches_reference_items(tmp_path, capsys):
+    """G9: FinetuneDialogDataset items (tokens, assistant-span labels, pad mask, image pass-through, group layout incl.
+    ratio sub-sampling, length sort, str() of non-string turns, nothing-to-predict fallback) equal the reference's."""
+    import json
+    import os
+    from a3vlm_amd.data.conversation.dataset import FinetuneDialogDataset, find_sublist
+    from oracle.gen_golden import GOLD, dialog_transform, dialog_yaml
+    want = json.load(open(os.path.join(GOLD, "dialog", "items.json")))
+    ds = FinetuneDialogDataset(dialog_yaml(str(tmp_path)), dialog_transform, max_words=150, image_words=30,
+                               tokenizer=os.path.join(GOLD, "tokenizer.model"))
+    assert len(ds) == want["len"] and ds.groups() == want["groups"]
+    n_img = 0
+    for i, w in enumerate(want["items"]):
+        it = ds[i]
+        assert it[0].tolist() == w["tokens"] and it[1].tolist() == w["labels"], i
+        assert float(it[2].sum()) == w["mask_sum"]
+        assert (len(it) == 4) == ("image_sum" in w)
+        if len(it) == 4:
+            n_img += 1
+            assert it[0].numel() == 150 - 30 and abs(float(it[3].double().sum()) - w["image_sum"]) < 1e-6
+        else:
+            assert it[0].numel() == 150
+        assert it[1].count_nonzero() > 0 and set(it[1][it[1] != 0].tolist()) <= set(it[0].tolist())
+    assert n_img == 6
+    assert find_sublist([1, 2, 3, 4], [3, 4]) == 2 and find_sublist([1, 2], [3]) == -1
