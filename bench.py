@@ -261,6 +261,18 @@ def cpu_baseline(args, T, W, seconds):
                 seconds=round(el, 1))
 
 
+def pmc_traffic():
+    """HBM-side bytes per launch of the dominant GEMM from the committed rocprofv3 PMC passes (counters cannot be read
+    from inside the process); None when the summary is absent."""
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01e_pmc_traffic.json")) as f:
+            d = json.load(f)
+        return {"bytes_per_launch": d["traffic_bytes_per_launch"], "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
+                "shape": d["shape"], "source": d["source"]}
+    except Exception:
+        return None
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -369,10 +381,14 @@ def main():
                        "global_batch": B * world, "seq_len": S, "parallelism": f"dp{world} replicas (no data-path collective)"},
             "forward_tflops": round(fl["total"] * world / (ms_step * 1e-3) / 1e12, 1),
             "forward_mfma_frac": round(fl["total"] / (ms_step * 1e-3) / MFMA_PEAK_BF16, 4),
-            "roofline": {"kernel": "gemm_nt_bf16_kernel", "bound": "mfma", "achieved": round(gf / gt / 1e12, 1), "peak": MFMA_PEAK_BF16 / 1e12,
-                         "unit": "TFLOP/s", "frac": round(gf / gt / MFMA_PEAK_BF16, 4), "traffic": None,
-                         "note": "algorithmic 2MNK per launch / HIP-event duration, FLOP-weighted over the step's GEMM shapes",
-                         "gemm_ms_per_step": round(gt * 1e3, 2), "shapes": table},
+            "roofline": {"kernel": "gemm_nt_bf16_pp_kernel (256x256x64 ping-pong; gemm_nt_bf16_kernel<128,128> on tail rows / small shapes)",
+                         "bound": "mfma", "achieved": round(gf / gt / 1e12, 1), "peak": MFMA_PEAK_BF16 / 1e12,
+                         "unit": "TFLOP/s", "frac": round(gf / gt / MFMA_PEAK_BF16, 4), "traffic": pmc_traffic(),
+                         "note": "algorithmic 2MNK per GEMM call / HIP-event duration on the launch stream, FLOP-weighted over the step's GEMM "
+                                 "shapes (= total GEMM FLOP / total GEMM time of one step); traffic = rocprofv3 PMC bytes per launch of the "
+                                 "dominant w1|w3 shape (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction), from profiles/",
+                         "gemm_ms_per_step": round(gt * 1e3, 2), "gemm_calls_per_step": sum(r["count"] for r in table),
+                         "avg_call_us": round(gt * 1e6 / max(1, sum(r["count"] for r in table)), 1), "shapes": table},
             "decode_tok_s": round(dec_tok_s, 1), "decode_ms_per_step": round(dec_ms, 3), "decode_steps": a.decode_steps,
             "decode_roofline": {"bound": "hbm", "achieved": round(dec_bytes / (dec_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                                 "frac": round(dec_bytes / (dec_ms * 1e-3) / HBM_PEAK, 4), "bytes_per_step": dec_bytes,
