@@ -16,6 +16,7 @@
 //    K rows / V^T rows with 16-byte loads, + combine kernel.
 //  * attn_f32_kernel: fp32 parity path (any Sq), one wave per (b, h, q).
 #include "a3v_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -407,6 +408,9 @@ __global__ __launch_bounds__(64) void attn_generic_kernel(AttnArgs p, int hd, in
 
 inline void decode_plan(int B, int H, int Sk, int* nsplit, int* chunk) {
   int want = (1024 + B * H - 1) / (B * H);
+#ifdef A3V_ABLATION
+  { static const char* e = getenv("A3V_DECODE_WANT"); if (e) want = atoi(e); }
+#endif
   int maxs = (Sk + 127) / 128;
   int ns = want < maxs ? want : maxs;
   if (ns < 1) ns = 1;

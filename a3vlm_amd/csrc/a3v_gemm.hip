@@ -12,9 +12,9 @@
 //    (bias, GELU, residual, SwiGLU on interleaved w1/w3 row blocks).
 //    blockIdx -> tile map is XCD-aware (8 XCDs, private L2s): each XCD walks a
 //    contiguous range of GROUP_M-tall tile groups.
-//  * gemm_skinny_bf16_kernel : M <= 16 (decode).  One wave per 16 W-rows x K-slice,
-//    W streamed straight from HBM into MFMA operand registers (no LDS round trip),
-//    split-K partials reduced by a second tiny kernel that also applies the epilogue.
+//  * gemv_dma_bf16_kernel : M <= 16 (decode), K % 128 == 0.  W streamed once from HBM by coalesced LDS-DMA
+//    through wave-private rings, A slice shared per block in LDS, split-K across blocks with an in-kernel
+//    last-block fix-up (one launch).  gemm_skinny1_bf16_kernel is the direct-to-VGPR form for other K.
 //  * gemm_nt_f32_kernel : fp32 parity path (plain FMA, 64x64x16 tile).
 #include "a3v_common.h"
 #include <algorithm>
@@ -667,110 +667,6 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_pp32_kernel(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------
-// Skinny GEMM (M <= 16): HBM-bound weight streaming.
-// ------------------------------------------------------------------------------------
-struct SkinnyArgs {
-  const bf16_t* A;
-  const bf16_t* W;
-  float* part;
-  int64_t lda, ldw;
-  int M, N, K, split, kslice, n_tiles;
-};
-
-__global__ __launch_bounds__(256) void gemm_skinny_bf16_kernel(SkinnyArgs p) {
-  const int lane = threadIdx.x & 63;
-  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (wid >= p.n_tiles * p.split) return;
-  const int nt = wid % p.n_tiles, ks = wid / p.n_tiles;
-  const int n0 = nt * 16;
-  const int row = lane & 15, kq = (lane >> 4) * 8;
-  int wr = n0 + row;
-  wr = wr < p.N ? wr : p.N - 1;
-  const int ar = row < p.M ? row : p.M - 1;
-  const bf16_t* wp = p.W + (int64_t)wr * p.ldw + ks * p.kslice + kq;
-  const bf16_t* ap = p.A + (int64_t)ar * p.lda + ks * p.kslice + kq;
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-  int k = 0;
-  for (; k + 256 <= p.kslice; k += 256) {
-    bf16x8 w[8], a[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) w[q] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + k + q * 32));
-#pragma unroll
-    for (int q = 0; q < 8; ++q) a[q] = *reinterpret_cast<const bf16x8*>(ap + k + q * 32);
-#pragma unroll
-    for (int q = 0; q < 8; q += 2) {
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[q], a[q], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[q + 1], a[q + 1], acc1, 0, 0, 0);
-    }
-  }
-  for (; k < p.kslice; k += 32) {
-    const bf16x8 w = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + k));
-    const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap + k);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a, acc0, 0, 0, 0);
-  }
-  // D[n = (lane>>4)*4 + r][m = lane&15]
-  const int m = lane & 15;
-  const int n = n0 + (lane >> 4) * 4;
-  if (m < p.M && n < p.N) {
-    f32x4 o;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) o[r] = acc0[r] + acc1[r];
-    *reinterpret_cast<f32x4*>(p.part + ((int64_t)ks * p.M + m) * p.N + n) = o;
-  }
-}
-
-struct SkinnyEpiArgs {
-  const float* part;
-  void* C;
-  const void* res;
-  int64_t ldc, ldr;
-  int M, N, split, epi;
-};
-
-__global__ __launch_bounds__(256) void gemm_skinny_epilogue_kernel(SkinnyEpiArgs p) {
-  // one thread per 4 output columns
-  const int ncols = (p.epi & A3V_EPI_SWIGLU) ? p.N / 2 : p.N;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  const int per_row = ncols / 4;
-  if (idx >= p.M * per_row) return;
-  const int m = idx / per_row, c = (idx % per_row) * 4;
-  float v[4];
-  if (p.epi & A3V_EPI_SWIGLU) {
-    const int ng = (c >> 4) * 32 + (c & 15);
-    f32x4 g = {0.f, 0.f, 0.f, 0.f}, u = {0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < p.split; ++s) {
-      const float* base = p.part + ((int64_t)s * p.M + m) * p.N;
-      g += *reinterpret_cast<const f32x4*>(base + ng);
-      u += *reinterpret_cast<const f32x4*>(base + ng + 16);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = rbf(silu(rbf(g[r]))) * rbf(u[r]);
-  } else {
-    f32x4 a = {0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < p.split; ++s)
-      a += *reinterpret_cast<const f32x4*>(p.part + ((int64_t)s * p.M + m) * p.N + c);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = rbf(a[r]);
-    if (p.epi & A3V_EPI_RESIDUAL) {
-      const bf16x4 rr = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(p.res) + (int64_t)m * p.ldr + c);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] += bf2f(rr[r]);
-    }
-  }
-  if (p.epi & A3V_EPI_OUT_F32) {
-    f32x4 o;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) o[r] = v[r];
-    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + c) = o;
-  } else {
-    bf16x4 o;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) o[r] = f2bf(v[r]);
-    *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + c) = o;
-  }
-}
-
-// ------------------------------------------------------------------------------------
 // Skinny GEMM, single launch: one 8-wave block per 16 (or 32 with SwiGLU: gate block + up block)
 // rows of W.  The block's waves split K, each streams its slice of the W rows straight into MFMA
 // operand registers (8 independent 16-B non-temporal loads in flight per lane), the eight partial
@@ -861,6 +757,194 @@ __global__ __launch_bounds__(512) void gemm_skinny1_bf16_kernel(Skinny1Args p) {
   float o4[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) o4[r] = rbf(v[0][r]);
+  if (p.epi & A3V_EPI_RESIDUAL) {
+    const bf16x4 rr = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(p.res) + (int64_t)m * p.ldr + n);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o4[r] += bf2f(rr[r]);
+  }
+  if (p.epi & A3V_EPI_OUT_F32) {
+    f32x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = o4[r];
+    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n) = o;
+  } else {
+    bf16x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = f2bf(o4[r]);
+    *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + n) = o;
+  }
+}
+
+
+// ------------------------------------------------------------------------------------
+// Decode GEMV, M <= 16, K % 128 == 0: W streamed ONCE from HBM by LDS-DMA.
+//   * block = 4 waves, all on K-slice `sl` of row group `tg` (64 W rows); wave w owns the 16-row tile tg*4 + w.
+//   * the A slice [AROWS][slice] is DMA'd once per block into LDS and shared by the 4 waves (AROWS = 8 when
+//     M <= 8: MFMA columns m >= 8 read row m & 7 and are never stored), so activations cost no VGPR traffic.
+//   * each wave streams its 16 rows through a private 2-stage ring of 16 rows x 128 k (4 KB = 4 DMA instructions
+//     of 4 rows x 256 contiguous bytes); MFMA fragments by ds_read_b128, slot XOR row swizzle applied on the DMA
+//     source side (conflict-free).  No block barrier in the K loop (the ring is wave-private).
+//   * split-K across blocks: partial accumulators go to the workspace; the WAVE that arrives last at its tile's
+//     (agent-scope) counter sums the S partials in slice order (deterministic), runs the epilogue and leaves the
+//     counter at zero -- no block barrier, no second launch.  Blocks of one row group share an XCD (same L2).
+// Measured (tools/ubench/skinny.hip, weights rotating through 3 GB): 5.0-5.5 TB/s vs 3.5-4.3 for the direct-to-VGPR form.
+// ------------------------------------------------------------------------------------
+struct GemvArgs {
+  const bf16_t* A;
+  const bf16_t* W;
+  void* C;
+  const void* res;
+  float* part;
+  int* counters;
+  int64_t lda, ldw, ldc, ldr;
+  int M, N, K, epi, S, nkb, tgs, maxkb;
+};
+
+template <int AROWS>
+__global__ __launch_bounds__(256) void gemv_dma_bf16_kernel(GemvArgs p) {
+  extern __shared__ __attribute__((aligned(1024))) char gemv_lds[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // block -> (row group, slice): all slices of a row group on one XCD (blockIdx % 8)
+  const int xq = blockIdx.x >> 3;
+  const int sl = xq % p.S;
+  const int tg = (xq / p.S) * 8 + (blockIdx.x & 7);
+  if (tg >= p.tgs) return;
+  const int kb0 = (int)(((int64_t)sl * p.nkb) / p.S), kb1 = (int)(((int64_t)(sl + 1) * p.nkb) / p.S);
+  const int nkb = kb1 - kb0;
+  constexpr int ABLK = AROWS * 256;                    // bytes of A per 128-k block
+  char* Alds = gemv_lds;
+  char* Wring = gemv_lds + p.maxkb * ABLK + wave * 2 * 4096;
+  const int n0 = (tg * 4 + wave) * 16;
+  const int dr = lane >> 4, dslot = lane & 15;
+  {
+    constexpr int IPB = AROWS / 4;                     // DMA instructions per k-block
+    for (int j = wave; j < nkb * IPB; j += 4) {
+      const int kb = j / IPB, i = j % IPB;
+      const int row = 4 * i + dr;
+      const int ar = row < p.M ? row : p.M - 1;
+      const bf16_t* src = p.A + (int64_t)ar * p.lda + (int64_t)(kb0 + kb) * 128 + ((dslot ^ row) & 15) * 8;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(Alds + kb * ABLK + i * 1024), 16, 0, 0);
+    }
+  }
+  const bf16_t* wrow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 4 * i + dr;
+    int wr = n0 + row;
+    wr = wr < p.N ? wr : p.N - 1;
+    wrow[i] = p.W + (int64_t)wr * p.ldw + (int64_t)kb0 * 128 + ((dslot ^ row) & 15) * 8;
+  }
+  auto dma_stage = [&](int kb, int slot) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wrow[i] + kb * 128),
+                                       (__attribute__((address_space(3))) void*)(Wring + slot * 4096 + i * 1024), 16, 0, 0);
+  };
+  dma_stage(0, 0);
+  if (nkb > 1) {
+    dma_stage(1, 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // in-order completion: the A pieces issued before the ring prologue
+  } else {
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  }
+  __syncthreads();
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fg = lane >> 4;
+  const int arow = AROWS == 8 ? (fr & 7) : fr;
+  int foff[4];
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) foff[s4] = (((4 * s4 + fg) ^ fr) & 15) * 16;
+  int aoff[4];
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) aoff[s4] = (((4 * s4 + fg) ^ arow) & 15) * 16;
+  for (int kb = 0; kb < nkb; ++kb) {
+    const int slot = kb & 1;
+    if (kb + 2 <= nkb) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const char* Ws = Wring + slot * 4096 + fr * 256;
+    const char* As = Alds + kb * ABLK + arow * 256;
+    bf16x8 wf[4], af[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      wf[s4] = *reinterpret_cast<const bf16x8*>(Ws + foff[s4]);
+      af[s4] = *reinterpret_cast<const bf16x8*>(As + aoff[s4]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragments are in registers: the slot may be overwritten
+    if (kb + 2 < nkb) dma_stage(kb + 2, slot);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      if (s4 & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s4], af[s4], acc1, 0, 0, 0);
+      else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s4], af[s4], acc0, 0, 0, 0);
+    }
+  }
+  f32x4 v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = acc0[r] + acc1[r];
+  const bool swiglu = (p.epi & A3V_EPI_SWIGLU) != 0;     // launcher guarantees S > 1 with SwiGLU
+  f32x4 u = {0.f, 0.f, 0.f, 0.f};
+  int nt0 = n0;                                          // first W row of the tile this wave finishes
+  if (p.S > 1) {
+    // Wave-granular split-K fix-up, no block barrier: the wave writes its partial accumulator (sc0 sc1 = agent-coherent
+    // access, no cache-wide write-back / invalidate), waits for the acknowledge, then bumps the arrival counter of its
+    // tile (of its gate/up tile PAIR with SwiGLU).  The wave that arrives last reloads all partials in one round trip,
+    // sums them in slice order (bit-identical whichever wave is last), resets the counter and runs the epilogue.
+    float* mine = p.part + (((int64_t)(tg * p.S + sl) * 4 + wave) * 64 + lane) * 4;
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(mine), "v"(v) : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int* ctr = p.counters + (swiglu ? tg * 2 + (wave >> 1) : tg * 4 + wave);
+    const int expect = swiglu ? 2 * p.S : p.S;
+    int old = 0;
+    if (lane == 0) old = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (old != expect - 1) return;
+    if (lane == 0) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int w0 = swiglu ? (wave & ~1) : wave;          // gate tile (or own tile)
+    nt0 = (tg * 4 + w0) * 16;
+    const float* base = p.part + (((int64_t)tg * p.S * 4 + w0) * 64 + lane) * 4;
+    f32x4 x[8], y[8];
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) {
+      const float* src = base + (int64_t)(s8 < p.S ? s8 : p.S - 1) * 4 * 64 * 4;
+      asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(x[s8]) : "v"(src) : "memory");
+    }
+    if (swiglu) {
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) {
+        const float* src = base + 64 * 4 + (int64_t)(s8 < p.S ? s8 : p.S - 1) * 4 * 64 * 4;
+        asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(y[s8]) : "v"(src) : "memory");
+      }
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]), "+v"(y[4]), "+v"(y[5]), "+v"(y[6]), "+v"(y[7])::"memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7])::"memory");
+    v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8)
+      if (s8 < p.S) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += x[s8][r];
+        if (swiglu) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) u[r] += y[s8][r];
+        }
+      }
+  }
+  // v[r] = D[n = nt0 + 4 (lane>>4) + r][m = lane & 15]   (u: the matching up-projection rows with SwiGLU)
+  const int m = lane & 15;
+  if (swiglu) {
+    if (m >= p.M || nt0 >= p.N) return;
+    const int oc = (nt0 >> 1) + (lane >> 4) * 4;
+    bf16x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = f2bf(rbf(silu(rbf(v[r]))) * rbf(u[r]));
+    *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + oc) = o;
+    return;
+  }
+  const int n = nt0 + (lane >> 4) * 4;
+  if (m >= p.M || n >= p.N) return;
+  float o4[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) o4[r] = rbf(v[r]);
   if (p.epi & A3V_EPI_RESIDUAL) {
     const bf16x4 rr = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(p.res) + (int64_t)m * p.ldr + n);
 #pragma unroll
@@ -1068,16 +1152,24 @@ extern "C" int a3v_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ld
   return A3V_OK;
 }
 
+// split-K factor of the DMA GEMV: enough blocks (row groups x S >= 1024) for 256 CUs, S <= 8, S <= K/128
+static int gemv_split(int N, int K) {
+  const int tgs = (N + 63) / 64, nkb = K / 128;
+  int S = 1;
+  while (S < 8 && tgs * S < 1024 && S * 2 <= nkb) S *= 2;
+  return S;
+}
+
 extern "C" int a3v_gemm_skinny_split(int M, int N, int K) {
   (void)M;
-  const int n_tiles = (N + 15) / 16;
-  int want = (2048 + n_tiles - 1) / n_tiles;
-  if (want > 8) want = 8;
-  if (want < 1) want = 1;
-  int split = 1;
-  for (int s = want; s >= 1; --s)
-    if (K % (32 * s) == 0) { split = s; break; }
-  return split;
+  return (K % 128 == 0 && K >= 128) ? gemv_split(N, K) : 1;
+}
+
+extern "C" int64_t a3v_gemm_skinny_ws_bytes(int M, int N, int K) {
+  (void)M;
+  if (K % 128 || K < 128) return 16384;
+  const int64_t tgs = (N + 63) / 64;
+  return 16384 + tgs * gemv_split(N, K) * 4 * 1024;
 }
 
 extern "C" int a3v_gemm_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
@@ -1089,31 +1181,39 @@ extern "C" int a3v_gemm_skinny(const void* A, int64_t lda, const void* W, int64_
   if (epilogue & ~(A3V_EPI_RESIDUAL | A3V_EPI_SWIGLU | A3V_EPI_OUT_F32)) return A3V_ERR_ARG;
   if ((epilogue & A3V_EPI_RESIDUAL) && (!residual || (ldr % 4))) return A3V_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  {
-    // single-launch path (partial scratch unused): 8 waves split K in 32-element granules
-    Skinny1Args q;
-    q.A = (const bf16_t*)A; q.W = (const bf16_t*)W; q.C = C; q.res = residual;
-    q.lda = lda; q.ldw = ldw; q.ldc = ldc; q.ldr = ldr;
-    q.M = M; q.N = N; q.K = K; q.epi = epilogue;
-    q.kslice = ((K / 32 + 7) / 8) * 32;
-    if (epilogue & A3V_EPI_SWIGLU) hipLaunchKernelGGL(gemm_skinny1_bf16_kernel<2>, dim3((N + 31) / 32), dim3(512), 0, st, q);
-    else hipLaunchKernelGGL(gemm_skinny1_bf16_kernel<1>, dim3((N + 15) / 16), dim3(512), 0, st, q);
-    A3V_LAUNCH_CHECK();
-    return A3V_OK;
+  if (K % 128 == 0 && N <= 65536) {
+    GemvArgs g;
+    g.A = (const bf16_t*)A; g.W = (const bf16_t*)W; g.C = C; g.res = residual;
+    g.counters = (int*)partial; g.part = (float*)((char*)partial + 16384);
+    g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.ldr = ldr;
+    g.M = M; g.N = N; g.K = K; g.epi = epilogue;
+    g.S = gemv_split(N, K); g.nkb = K / 128; g.tgs = (N + 63) / 64;
+    g.maxkb = (g.nkb + g.S - 1) / g.S;
+    const int arows = M <= 8 ? 8 : 16;
+    const size_t ldsb = (size_t)g.maxkb * arows * 256 + 4 * 2 * 4096;
+    if (ldsb <= 150 * 1024 && !((epilogue & A3V_EPI_SWIGLU) && g.S == 1)) {
+      const int blocks = ((g.tgs + 7) / 8) * 8 * g.S;
+      if (arows == 8) {
+        static bool once8 = false;
+        if (!once8) { (void)hipFuncSetAttribute((const void*)gemv_dma_bf16_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); once8 = true; }
+        hipLaunchKernelGGL(gemv_dma_bf16_kernel<8>, dim3(blocks), dim3(256), ldsb, st, g);
+      } else {
+        static bool once16 = false;
+        if (!once16) { (void)hipFuncSetAttribute((const void*)gemv_dma_bf16_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); once16 = true; }
+        hipLaunchKernelGGL(gemv_dma_bf16_kernel<16>, dim3(blocks), dim3(256), ldsb, st, g);
+      }
+      A3V_LAUNCH_CHECK();
+      return A3V_OK;
+    }
   }
-  SkinnyArgs p;
-  p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.part = (float*)partial;
-  p.lda = lda; p.ldw = ldw; p.M = M; p.N = N; p.K = K;
-  p.split = a3v_gemm_skinny_split(M, N, K);
-  p.kslice = K / p.split;
-  p.n_tiles = (N + 15) / 16;
-  const int waves = p.n_tiles * p.split;
-  hipLaunchKernelGGL(gemm_skinny_bf16_kernel, dim3((waves + 3) / 4), dim3(256), 0, st, p);
-  A3V_LAUNCH_CHECK();
-  SkinnyEpiArgs e{(const float*)partial, C, residual, ldc, ldr, M, N, p.split, epilogue};
-  const int ncols = (epilogue & A3V_EPI_SWIGLU) ? N / 2 : N;
-  const int threads = M * (ncols / 4);
-  hipLaunchKernelGGL(gemm_skinny_epilogue_kernel, dim3((threads + 255) / 256), dim3(256), 0, st, e);
+  // direct-to-VGPR form (any K % 32 == 0): 8 waves split K in 32-element granules, LDS reduction (workspace unused)
+  Skinny1Args q;
+  q.A = (const bf16_t*)A; q.W = (const bf16_t*)W; q.C = C; q.res = residual;
+  q.lda = lda; q.ldw = ldw; q.ldc = ldc; q.ldr = ldr;
+  q.M = M; q.N = N; q.K = K; q.epi = epilogue;
+  q.kslice = ((K / 32 + 7) / 8) * 32;
+  if (epilogue & A3V_EPI_SWIGLU) hipLaunchKernelGGL(gemm_skinny1_bf16_kernel<2>, dim3((N + 31) / 32), dim3(512), 0, st, q);
+  else hipLaunchKernelGGL(gemm_skinny1_bf16_kernel<1>, dim3((N + 15) / 16), dim3(512), 0, st, q);
   A3V_LAUNCH_CHECK();
   return A3V_OK;
 }

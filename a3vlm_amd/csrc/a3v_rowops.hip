@@ -328,16 +328,30 @@ __global__ __launch_bounds__(256) void split_views_kernel(const TI* __restrict__
 }
 
 // ---------------------------------------------------------------- argmax / CE
-__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ logits, int64_t ld, int64_t* __restrict__ out, int V) {
-  __shared__ float bv[4];
-  __shared__ int bi[4];
+// one 1024-thread block per row; 4 independent 16-B loads in flight per thread (the decode loop calls this every step:
+// a 256-thread scalar loop took 39 us on a [8, 32000] fp32 row set, latency-bound)
+__global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ logits, int64_t ld, int64_t* __restrict__ out, int V) {
+  __shared__ float bv[16];
+  __shared__ int bi[16];
   const float* r = logits + (int64_t)blockIdx.x * ld;
   float best = -INFINITY;
   int idx = 0x7fffffff;
-  for (int i = threadIdx.x; i < V; i += 256) {
-    const float v = r[i];
-    if (v > best || (v == best && i < idx)) { best = v; idx = i; }
+  auto take = [&](float v, int i) { if (v > best || (v == best && i < idx)) { best = v; idx = i; } };
+  const bool vec = ((reinterpret_cast<uintptr_t>(r) & 15) == 0);
+  const int V4 = vec ? V / 4 : 0;
+  for (int i0 = threadIdx.x; i0 < V4; i0 += 4 * 1024) {
+    f32x4 x[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = i0 + q * 1024;
+      x[q] = i < V4 ? reinterpret_cast<const f32x4*>(r)[i] : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) take(x[q][e], (i0 + q * 1024) * 4 + e);
   }
+  for (int i = V4 * 4 + threadIdx.x; i < V; i += 1024) take(r[i], i);
   // NaN handling follows torch only for finite rows (the path never produces NaN logits)
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -348,7 +362,7 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ l
   if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = idx; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int w = 1; w < 4; ++w)
+    for (int w = 1; w < 16; ++w)
       if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
     out[blockIdx.x] = idx == 0x7fffffff ? 0 : idx;
   }
@@ -555,7 +569,7 @@ extern "C" int a3v_split_views(const void* img, void* out, int B, int crop, int 
 
 extern "C" int a3v_argmax(const float* logits, int64_t ld, int64_t* out, int B, int V, void* stream) {
   if (!logits || !out || B <= 0 || V <= 0) return A3V_ERR_ARG;
-  hipLaunchKernelGGL(argmax_kernel, dim3(B), dim3(256), 0, ST, logits, ld, out, V);
+  hipLaunchKernelGGL(argmax_kernel, dim3(B), dim3(1024), 0, ST, logits, ld, out, V);
   A3V_LAUNCH_CHECK();
   return A3V_OK;
 }

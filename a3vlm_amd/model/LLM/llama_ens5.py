@@ -346,11 +346,19 @@ class Transformer(nn.Module):
         self._k_cache, self._vt_cache, self._cache_shape = [], [], None
 
     # ------------------------------------------------------------------ linear dispatch
+    def _skinny_ws(self, M: int, N: int, K: int) -> torch.Tensor:
+        """One zero-initialised GEMV workspace (grown on demand; the kernels leave its counters zero)."""
+        need = ops.gemm_skinny_ws_bytes(M, N, K)
+        ws = self._ws.get("skinny_ws")
+        if ws is None or ws.numel() * 4 < need:
+            ws = torch.zeros((need + 3) // 4, dtype=torch.float32, device=self._device)
+            self._ws["skinny_ws"] = ws
+        return ws
+
     def _linear(self, x, w, out, **kw):
         if x.shape[0] <= 16 and x.dtype == torch.bfloat16 and "bias" not in kw and w.shape[1] % 32 == 0:
             ep = kw.get("epilogue", 0)
-            part = self._buf("skinny_part", (8 * 16 * max(w.shape[0], 1),), torch.float32)
-            return ops.gemm_skinny(x, w, out, part, residual=kw.get("residual"), epilogue=ep)
+            return ops.gemm_skinny(x, w, out, self._skinny_ws(x.shape[0], w.shape[0], w.shape[1]), residual=kw.get("residual"), epilogue=ep)
         return ops.gemm_nt(x, w, out, **kw)
 
     # ------------------------------------------------------------------ decoder stack
@@ -413,8 +421,11 @@ class Transformer(nn.Module):
         att = self._buf("att", (B, H * hd))
         act = self._buf("act", (B, self.ffn))
         scratch = self._buf("attn_scratch", (2 * ops.attention_scratch_floats(B, H, hd, a.max_seq_len + 64),), torch.float32)
+        sws = self._skinny_ws(B, max((H + 2 * Hkv) * hd, 2 * self.ffn, a.dim), max(a.dim, self.ffn))
+        for (n_, k_) in (((H + 2 * Hkv) * hd, a.dim), (a.dim, H * hd), (2 * self.ffn, a.dim), (a.dim, self.ffn)):
+            sws = self._skinny_ws(B, n_, k_)
         rc = _l.load().a3v_llama_decode_step(self._layer_tab, self.n_layers, h.data_ptr(), xn.data_ptr(), qkv.data_ptr(),
-                                             att.data_ptr(), act.data_ptr(), scratch.data_ptr(), self._cos_sin_dev().data_ptr(),
+                                             att.data_ptr(), act.data_ptr(), scratch.data_ptr(), sws.data_ptr(), self._cos_sin_dev().data_ptr(),
                                              B, a.dim, H, Hkv, hd, self.ffn, smax, pos, a.norm_eps,
                                              torch.cuda.current_stream().cuda_stream)
         _l.check(rc, "a3v_llama_decode_step")

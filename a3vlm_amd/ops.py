@@ -60,10 +60,22 @@ def gemm_skinny_split(M: int, N: int, K: int) -> int:
     return _l.load().a3v_gemm_skinny_split(M, N, K)
 
 
+def gemm_skinny_ws_bytes(M: int, N: int, K: int) -> int:
+    return int(_l.load().a3v_gemm_skinny_ws_bytes(M, N, K))
+
+
+def gemm_skinny_workspace(M: int, N: int, K: int, device) -> "torch.Tensor":
+    """Zero-filled workspace for gemm_skinny (arrival counters first; every call leaves them zero)."""
+    import torch
+    return torch.zeros((gemm_skinny_ws_bytes(M, N, K) + 3) // 4, dtype=torch.float32, device=device)
+
+
 def gemm_skinny(a, w, out, partial, *, residual=None, epilogue: int = 0):
     _dev(a, w, out, partial, residual)
     M, K = a.shape
     N = w.shape[0]
+    if partial.numel() * partial.element_size() < gemm_skinny_ws_bytes(M, N, K):
+        raise ValueError("gemm_skinny workspace too small (a3v_gemm_skinny_ws_bytes)")
     ep = epilogue | (EPI_RESIDUAL if residual is not None else 0)
     rc = _l.load().a3v_gemm_skinny(_p(a), a.stride(0), _p(w), w.stride(0), _p(out), out.stride(0), M, N, K,
                                    _p(residual), residual.stride(0) if residual is not None else 0, ep,

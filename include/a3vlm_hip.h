@@ -68,10 +68,13 @@ int a3v_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ldw, void* C,
                 int M, int N, int K, const void* bias, const void* residual, int64_t ldr,
                 int epilogue, int dtype, void* stream);
 
-/* Skinny-M (decode) form of the same contract, M <= 16: streams W once from HBM.
- * `partial` is an fp32 scratch of split*M*N floats (split returned by
- * a3v_gemm_skinny_split).  Epilogues: NONE, RESIDUAL, SWIGLU, OUT_F32. */
+/* Skinny-M (decode) form of the same contract, M <= 16: streams W once from HBM (one launch).
+ * `partial` is a workspace of a3v_gemm_skinny_ws_bytes(M, N, K) bytes: the first 16384 bytes are
+ * split-K arrival counters that the caller zero-fills ONCE; every call leaves them zero.  The
+ * workspace must not be shared by calls that can run concurrently (different streams).
+ * a3v_gemm_skinny_split reports the split-K factor used.  Epilogues: NONE, RESIDUAL, SWIGLU, OUT_F32. */
 int a3v_gemm_skinny_split(int M, int N, int K);
+int64_t a3v_gemm_skinny_ws_bytes(int M, int N, int K);
 int a3v_gemm_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
                     int M, int N, int K, const void* residual, int64_t ldr, int epilogue,
                     void* partial, void* stream);
@@ -160,7 +163,8 @@ int a3v_cross_entropy(const void* logits, int64_t ld, const int64_t* labels, flo
  * RMSNorm -> fused QKV (skinny GEMM) -> RoPE + KV-cache write at `pos` -> split-KV attention over
  * pos+1 keys -> WO (+residual) -> RMSNorm -> W1|W3 SwiGLU -> W2 (+residual)  (LLM/llama_ens5.py:
  * 220-249, 490-531).  h [B,dim] bf16 is updated in place; xn/qkv/att/act are caller workspaces of
- * [B,dim], [B,(H+2Hkv)hd], [B,H*hd], [B,ffn]; attn_scratch as for a3v_attention at Sk = Smax. */
+ * [B,dim], [B,(H+2Hkv)hd], [B,H*hd], [B,ffn]; attn_scratch as for a3v_attention at Sk = Smax;
+ * skinny_ws as for a3v_gemm_skinny, sized for the largest of the four linears. */
 typedef struct a3v_llama_layer {
   const void* attn_norm_w;
   const void* wqkv;     /* [wq;wk;wv] rows */
@@ -172,7 +176,7 @@ typedef struct a3v_llama_layer {
   void* vt_cache;       /* [B,Hkv,hd,Smax] */
 } a3v_llama_layer;
 int a3v_llama_decode_step(const a3v_llama_layer* layers, int n_layers, void* h, void* xn, void* qkv,
-                          void* att, void* act, float* attn_scratch, const float* cos_sin, int B,
+                          void* att, void* act, float* attn_scratch, void* skinny_ws, const float* cos_sin, int B,
                           int dim, int H, int Hkv, int hd, int ffn, int Smax, int pos, float eps,
                           void* stream);
 

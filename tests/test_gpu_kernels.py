@@ -143,18 +143,21 @@ def test_gemm_bf16_swiglu(M):
     want = rt(rt(F.silu(rt(a @ w1.t()))) * rt(a @ w3.t()))
     assert_close(out, want, rtol=2 ** -6, atol=4e-3, what="swiglu")
     if M <= 16:
-        part = torch.empty(8 * 16 * 2 * F_, dtype=torch.float32, device=DEV)
+        part = ops.gemm_skinny_workspace(M, 2 * F_, K, DEV)
         out2 = torch.empty(M, F_, dtype=BF, device=DEV)
         ops.gemm_skinny(a.to(BF).to(DEV), w13, out2, part, epilogue=ops.EPI_SWIGLU)
         assert_close(out2, want, rtol=2 ** -6, atol=4e-3, what="skinny swiglu")
 
 
-@pytest.mark.parametrize("M,N,K", [(1, 256, 128), (8, 4096, 4096), (16, 1000, 1376), (5, 32000, 512)])
+@pytest.mark.parametrize("M,N,K", [(1, 256, 128), (8, 4096, 4096), (16, 1000, 1376), (5, 32000, 512), (8, 12288, 4096),
+                                   (16, 1000, 1024), (9, 4096, 4096), (8, 4096, 11008), (2, 132, 256), (7, 64, 2048)])
 def test_gemm_skinny(M, N, K):
+    """K % 128 == 0 -> LDS-DMA split-K GEMV (uneven slices at K = 11008, 16-row A image at M > 8, ragged N);
+    otherwise the direct-to-VGPR kernel.  The workspace counters are left zero, so it is reused across calls."""
     a, w = rt(gen(M, K, seed=13)), rt(gen(N, K, seed=14, scale=0.05))
     res = rt(gen(M, N, seed=15))
     ad, wd = a.to(BF).to(DEV), w.to(BF).to(DEV)
-    part = torch.empty(8 * 16 * N, dtype=torch.float32, device=DEV)
+    part = ops.gemm_skinny_workspace(M, N, K, DEV)
     lin = a @ w.t()
     out = torch.empty(M, N, dtype=BF, device=DEV)
     ops.gemm_skinny(ad, wd, out, part)
@@ -165,6 +168,23 @@ def test_gemm_skinny(M, N, K):
     o32 = torch.empty(M, N, dtype=torch.float32, device=DEV)
     ops.gemm_skinny(ad, wd, o32, part, epilogue=ops.EPI_OUT_F32)
     assert_close(o32, rt(lin), rtol=2 ** -7, atol=2e-3 * math.sqrt(K) * 0.05 + 1e-3, what="skinny f32 out")
+    # split-K partials are summed in slice order by whichever block arrives last: bit-identical across runs
+    o32b = torch.empty_like(o32)
+    for _ in range(3):
+        ops.gemm_skinny(ad, wd, o32b, part, epilogue=ops.EPI_OUT_F32)
+        assert torch.equal(o32, o32b)
+    assert int(part[:4096].view(torch.int32).abs().sum()) == 0
+
+
+@pytest.mark.parametrize("M,F_,K", [(8, 11008, 4096), (3, 96, 512), (16, 2048, 1024)])
+def test_gemm_skinny_swiglu_large(M, F_, K):
+    a, w1, w3 = rt(gen(M, K, seed=20)), rt(gen(F_, K, seed=21, scale=0.03)), rt(gen(F_, K, seed=22, scale=0.03))
+    w13 = pack_w13(w1, w3).to(BF).to(DEV)
+    part = ops.gemm_skinny_workspace(M, 2 * F_, K, DEV)
+    out = torch.empty(M, F_, dtype=BF, device=DEV)
+    ops.gemm_skinny(a.to(BF).to(DEV), w13, out, part, epilogue=ops.EPI_SWIGLU)
+    want = rt(rt(F.silu(rt(a @ w1.t()))) * rt(a @ w3.t()))
+    assert_close(out, want, rtol=2 ** -6, atol=4e-3, what="skinny swiglu large")
 
 
 @pytest.mark.parametrize("M,N,K", [(70, 96, 64), (64, 64, 16), (130, 200, 640)])
