@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_bf16_kernel(AttnArgs p) {
 // Decode (Sq == 1): grid (nsplit, H, B); block 256.  part[b][h][split] = {o[HD], m, l}
 // ------------------------------------------------------------------------------------
 template <int HD>
-__global__ __launch_bounds__(256) void attn_decode_bf16_kernel(AttnArgs p, float* part, int nsplit, int chunk) {
+__global__ __launch_bounds__(256) void attn_decode_bf16_kernel(AttnArgs p, float* part, int nsplit, int chunk, int* counters) {
   constexpr int LPR = HD / 8;            // lanes per K row (16-B each)
   constexpr int RPW = 64 / LPR;          // K rows per wave-load
   extern __shared__ __attribute__((aligned(16))) char dsm[];
@@ -241,15 +241,15 @@ __global__ __launch_bounds__(256) void attn_decode_bf16_kernel(AttnArgs p, float
   const int kv_hi = min(p.Sk, kv_lo + chunk);
   const int n = kv_hi - kv_lo;
   float* po = part + ((int64_t)(b * p.H + h) * nsplit + sp) * (HD + 2);
-  if (n <= 0) {
+  if (n <= 0) {          // cannot happen with decode_plan's splits (every split owns >= 1 key); kept for safety
     if (tid < HD) po[tid] = 0.f;
     if (tid == 0) { po[HD] = -INFINITY; po[HD + 1] = 0.f; }
-    return;
+    if (!counters) return;
   }
   const bf16_t* Q = (const bf16_t*)p.q + b * p.q_sb + h * p.q_sh;
   const bf16_t* K = (const bf16_t*)p.k + b * p.k_sb + hk * p.k_sh;
   const bf16_t* VT = (const bf16_t*)p.vt + b * p.v_sb + hk * p.v_sh;
-
+  if (n > 0) {
   // phase 1: scores.  lane -> (row-in-group, 8 d's); U independent row groups in flight per wave
   float qv[8];
   load8(Q + (lane % LPR) * 8, qv);
@@ -327,6 +327,63 @@ __global__ __launch_bounds__(256) void attn_decode_bf16_kernel(AttnArgs p, float
     }
   }
   if (tid == 0) { po[HD] = mx; po[HD + 1] = ls; }
+  }  // n > 0
+  if (!counters) return;
+  // Fused combine (decode step): the block that arrives last at the (batch, head) counter merges the nsplit partials.
+  // The splits of a head may run on different XCDs (private L2s), so the hand-off uses agent-coherent accesses: this
+  // block re-writes its HD+2 partial values with sc0 sc1 stores (write-through), waits for the acknowledgement, bumps
+  // the counter; the last block reads all partials with sc0 sc1 loads.  (An agent-scope fence instead = L2 write-back
+  // + invalidate per wave: measured 5x slower on the GEMV that uses the same scheme.)
+  __shared__ int last_s;
+  __syncthreads();                                    // po[] of this block is complete (plain stores, same CU)
+  if (tid < HD + 2) st_agent(po + tid, po[tid]);      // L1 is write-through: the value read back is this block's own
+  agent_wait();
+  __syncthreads();
+  if (tid == 0) {
+    int* ctr = counters + b * p.H + h;
+    const int old = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last_s = old == nsplit - 1;
+    if (old == nsplit - 1) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!last_s || tid >= HD) return;
+  const float* pp = part + (int64_t)(b * p.H + h) * nsplit * (HD + 2);
+  float acc = 0.f, l = 0.f;
+  if (nsplit <= 8) {                                  // all loads in flight at once: one memory round trip
+    float mv[8], av[8], lv[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const float* q = pp + (s < nsplit ? s : nsplit - 1) * (HD + 2);
+      mv[s] = ld_agent_issue(q + HD);
+      av[s] = ld_agent_issue(q + tid);
+      lv[s] = ld_agent_issue(q + HD + 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(mv[0]), "+v"(mv[1]), "+v"(mv[2]), "+v"(mv[3]), "+v"(mv[4]), "+v"(mv[5]), "+v"(mv[6]), "+v"(mv[7])::"memory");
+    asm volatile("" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]), "+v"(av[4]), "+v"(av[5]), "+v"(av[6]), "+v"(av[7]));
+    asm volatile("" : "+v"(lv[0]), "+v"(lv[1]), "+v"(lv[2]), "+v"(lv[3]), "+v"(lv[4]), "+v"(lv[5]), "+v"(lv[6]), "+v"(lv[7]));
+    float m = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) if (s < nsplit) m = fmaxf(m, mv[s]);
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+      if (s < nsplit) {
+        const float w = (mv[s] == -INFINITY) ? 0.f : __expf(mv[s] - m);
+        acc += w * av[s];
+        l += w * lv[s];
+      }
+  } else {
+    float m = -INFINITY;
+    for (int s = 0; s < nsplit; ++s) m = fmaxf(m, ld_agent(pp + s * (HD + 2) + HD));
+    for (int s = 0; s < nsplit; ++s) {
+      const float ms = ld_agent(pp + s * (HD + 2) + HD);
+      const float a1 = ld_agent(pp + s * (HD + 2) + tid);
+      const float l1 = ld_agent(pp + s * (HD + 2) + HD + 1);
+      const float w = (ms == -INFINITY) ? 0.f : __expf(ms - m);
+      acc += w * a1;
+      l += w * l1;
+    }
+  }
+  ((bf16_t*)p.out)[b * p.o_sb + h * p.o_sh + tid] = f2bf(acc / l);
 }
 
 template <int HD>
@@ -469,11 +526,11 @@ static int attention_impl(const void* q, const void* k, const void* vt, void* ou
     decode_plan(B, H, Sk, &ns, &ch);
     const size_t shm = (size_t)(ch + 8) * sizeof(float);
     if (hd == 128) {
-      hipLaunchKernelGGL(attn_decode_bf16_kernel<128>, dim3(ns, H, B), dim3(256), shm, st, p, scratch, ns, ch);
+      hipLaunchKernelGGL(attn_decode_bf16_kernel<128>, dim3(ns, H, B), dim3(256), shm, st, p, scratch, ns, ch, (int*)nullptr);
       A3V_LAUNCH_CHECK();
       hipLaunchKernelGGL(attn_decode_combine_kernel<128>, dim3(H, B), dim3(128), 0, st, scratch, out, p.o_sb, p.o_sh, H, ns, dtype);
     } else {
-      hipLaunchKernelGGL(attn_decode_bf16_kernel<64>, dim3(ns, H, B), dim3(256), shm, st, p, scratch, ns, ch);
+      hipLaunchKernelGGL(attn_decode_bf16_kernel<64>, dim3(ns, H, B), dim3(256), shm, st, p, scratch, ns, ch, (int*)nullptr);
       A3V_LAUNCH_CHECK();
       hipLaunchKernelGGL(attn_decode_combine_kernel<64>, dim3(H, B), dim3(64), 0, st, scratch, out, p.o_sb, p.o_sh, H, ns, dtype);
     }
@@ -504,3 +561,30 @@ extern "C" int a3v_attention_lse(const void* q, const void* k, const void* vt, v
   if (!lse) return A3V_ERR_ARG;
   return attention_impl(q, k, vt, out, B, Sq, Sk, H, Hkv, hd, strides, causal, nullptr, lse, dtype, stream);
 }
+
+// Decode attention with the split combine folded into the same launch (see attn_decode_bf16_kernel); `counters` are
+// B*H zero-initialised ints that the kernel leaves zero.  bf16, hd in {64, 128}.
+int a3v_attention_decode_fused(const void* q, const void* k, const void* vt, void* out, int B, int Sk, int H, int Hkv, int hd,
+                               const int64_t* strides, float* scratch, int* counters, void* stream) {
+  if (!q || !k || !vt || !out || !strides || !scratch || !counters || B <= 0 || Sk <= 0 || H <= 0 || Hkv <= 0) return A3V_ERR_ARG;
+  if (H % Hkv || (hd != 64 && hd != 128)) return A3V_ERR_SHAPE;
+  AttnArgs p;
+  p.q = q; p.k = k; p.vt = vt; p.out = out;
+  p.q_sb = strides[0]; p.q_ss = strides[1]; p.q_sh = strides[2];
+  p.k_sb = strides[3]; p.k_sh = strides[4]; p.k_ss = strides[5];
+  p.v_sb = strides[6]; p.v_sh = strides[7]; p.v_sd = strides[8];
+  p.o_sb = strides[9]; p.o_ss = strides[10]; p.o_sh = strides[11];
+  p.B = B; p.Sq = 1; p.Sk = Sk; p.H = H; p.Hkv = Hkv;
+  p.scale = 1.0f / sqrtf((float)hd);
+  p.scale_log2 = p.scale * 1.4426950408889634f;
+  p.lse = nullptr;
+  int ns, ch;
+  decode_plan(B, H, Sk, &ns, &ch);
+  const size_t shm = (size_t)(ch + 8) * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  if (hd == 128) hipLaunchKernelGGL(attn_decode_bf16_kernel<128>, dim3(ns, H, B), dim3(256), shm, st, p, scratch, ns, ch, counters);
+  else hipLaunchKernelGGL(attn_decode_bf16_kernel<64>, dim3(ns, H, B), dim3(256), shm, st, p, scratch, ns, ch, counters);
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}
+

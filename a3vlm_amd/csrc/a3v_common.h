@@ -88,3 +88,36 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     hipError_t e_ = hipGetLastError();             \
     if (e_ != hipSuccess) return (int)e_;          \
   } while (0)
+
+// Agent-coherent (sc0 sc1) scalar accesses for in-kernel hand-offs between workgroups that may sit on different XCDs
+// (L2 is per XCD): the store is written through, the load bypasses stale lines; no cache-wide write-back / invalidate.
+// ld_agent_issue only ISSUES the load: the caller must `s_waitcnt vmcnt(0)` (agent_wait) before using the value.
+__device__ __forceinline__ void st_agent(float* p, float v) { asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ float ld_agent_issue(const float* p) {
+  float v;
+  asm volatile("global_load_dword %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ void agent_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ float ld_agent(const float* p) {          // issue + wait (the value is tied to the wait)
+  float v = ld_agent_issue(p);
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(v)::"memory");
+  return v;
+}
+
+// Layout of the decode workspace (a3v_gemm_skinny `partial` / a3v_llama_decode_step `skinny_ws`): zero-filled once by the
+// caller; every kernel leaves the counter areas zero.
+//   [0, 16 KB)      GEMV split-K arrival counters (one per 16-row tile, N <= 65536)
+//   [16 KB, 32 KB)  decode-attention arrival counters (one per (batch, head))
+//   [32 KB, 48 KB)  per-tile sums of squares of the residual rows (RMSNorm fused into the consuming GEMV)
+//   [48 KB, ...)    split-K partial accumulators
+constexpr int A3V_WS_ATTN_COUNTERS = 16384;
+constexpr int A3V_WS_SSQ = 32768;
+constexpr int A3V_WS_PARTIALS = 49152;
+int a3v_gemv_fused(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int M, int N, int K,
+                   const void* residual, int64_t ldr, int epilogue, const void* norm_w, const float* ssq_in, float eps,
+                   float* ssq_out, int rope, const float* cos_sin, void* k_cache, void* vt_cache, int H, int Hkv, int hd,
+                   int Smax, int pos, void* ws, void* stream);
+int a3v_attention_decode_fused(const void* q, const void* k, const void* vt, void* out, int B, int Sk, int H, int Hkv, int hd,
+                               const int64_t* strides, float* scratch, int* counters, void* stream);
+

@@ -2,7 +2,31 @@
 // mask == None) issued from ONE host call: every kernel of every layer is enqueued back to back on
 // the caller's stream, so the per-kernel host cost is a C++ launch (~2-3 us) instead of a Python
 // ctypes round trip -- at batch 8 the step is HBM-bound on the GPU only if the host keeps up.
+//
+// Fused form (dim, ffn, H*hd multiples of 128; hd in {64, 128}): FIVE launches per layer instead of ten --
+//   qkv GEMV  [RMSNorm prologue | RoPE + KV-cache epilogue]      (was rmsnorm, GEMV, rope)
+//   attention [split-KV, combine folded in by the last-arriving block]   (was attention, combine)
+//   wo GEMV   [+residual, emits per-tile sums of squares of the new h]
+//   w1|w3 GEMV [RMSNorm prologue from those sums | SwiGLU]       (was rmsnorm, GEMV)
+//   w2 GEMV   [+residual, sums of squares for the next layer's prologue]
+// The small kernels were ~5-7 us each of pure launch + latency: 24 of ~146 us per 7B layer.
 #include "a3v_common.h"
+
+namespace {
+// sums of squares of the rows of h [B, dim] in the producer layout ([dim/16][16]) for the first layer's prologue
+__global__ __launch_bounds__(256) void rows_ssq_kernel(const bf16_t* __restrict__ h, int64_t ld, int B, int dim, float* __restrict__ ssq) {
+  const int t = blockIdx.x * 256 + threadIdx.x;         // (tile, m)
+  const int tile = t >> 4, m = t & 15;
+  if (tile * 16 >= dim) return;
+  float s = 0.f;
+  if (m < B) {
+    const bf16_t* r = h + (int64_t)m * ld + tile * 16;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { const float x = (float)r[e]; s = fmaf(x, x, s); }
+  }
+  ssq[t] = s;
+}
+}  // namespace
 
 extern "C" int a3v_llama_decode_step(const a3v_llama_layer* layers, int n_layers, void* h, void* xn, void* qkv, void* att,
                                      void* act, float* attn_scratch, void* skinny_ws, const float* cos_sin, int B, int dim, int H, int Hkv,
@@ -15,6 +39,28 @@ extern "C" int a3v_llama_decode_step(const a3v_llama_layer* layers, int n_layers
                                (int64_t)Hkv * hd * Smax, (int64_t)hd * Smax, Smax,
                                (int64_t)H * hd, (int64_t)H * hd, hd};
   int rc;
+  const bool fused = dim % 128 == 0 && ffn % 128 == 0 && (H * hd) % 128 == 0 && (hd == 64 || hd == 128) && ldq <= 65536 &&
+                     2 * ffn <= 65536 && dim / 16 * 16 * 4 <= A3V_WS_PARTIALS - A3V_WS_SSQ;
+  if (fused) {
+    float* ssq = (float*)((char*)skinny_ws + A3V_WS_SSQ);
+    int* actr = (int*)((char*)skinny_ws + A3V_WS_ATTN_COUNTERS);
+    if (B * H * (int)sizeof(int) > A3V_WS_SSQ - A3V_WS_ATTN_COUNTERS) return A3V_ERR_SHAPE;
+    hipLaunchKernelGGL(rows_ssq_kernel, dim3((dim / 16 * 16 + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h, (int64_t)dim, B, dim, ssq);
+    A3V_LAUNCH_CHECK();
+    for (int i = 0; i < n_layers; ++i) {
+      const a3v_llama_layer& L = layers[i];
+      if ((rc = a3v_gemv_fused(h, dim, L.wqkv, dim, qkv, ldq, B, (int)ldq, dim, nullptr, 0, 0, L.attn_norm_w, ssq, eps, nullptr, 1, cos_sin,
+                               L.k_cache, L.vt_cache, H, Hkv, hd, Smax, pos, skinny_ws, stream))) return rc;
+      if ((rc = a3v_attention_decode_fused(qkv, L.k_cache, L.vt_cache, att, B, pos + 1, H, Hkv, hd, strides, attn_scratch, actr, stream))) return rc;
+      if ((rc = a3v_gemv_fused(att, (int64_t)H * hd, L.wo, (int64_t)H * hd, h, dim, B, dim, H * hd, h, dim, A3V_EPI_RESIDUAL, nullptr, nullptr, eps,
+                               ssq, 0, nullptr, nullptr, nullptr, H, Hkv, hd, Smax, pos, skinny_ws, stream))) return rc;
+      if ((rc = a3v_gemv_fused(h, dim, L.w13, dim, act, ffn, B, 2 * ffn, dim, nullptr, 0, A3V_EPI_SWIGLU, L.ffn_norm_w, ssq, eps, nullptr, 0, nullptr,
+                               nullptr, nullptr, H, Hkv, hd, Smax, pos, skinny_ws, stream))) return rc;
+      if ((rc = a3v_gemv_fused(act, ffn, L.w2, ffn, h, dim, B, dim, ffn, h, dim, A3V_EPI_RESIDUAL, nullptr, nullptr, eps, ssq, 0, nullptr, nullptr,
+                               nullptr, H, Hkv, hd, Smax, pos, skinny_ws, stream))) return rc;
+    }
+    return A3V_OK;
+  }
   for (int i = 0; i < n_layers; ++i) {
     const a3v_llama_layer& L = layers[i];
     if ((rc = a3v_rmsnorm(h, dim, L.attn_norm_w, xn, dim, B, dim, eps, A3V_BF16, A3V_BF16, A3V_BF16, stream))) return rc;

@@ -798,11 +798,24 @@ struct GemvArgs {
   int* counters;
   int64_t lda, ldw, ldc, ldr;
   int M, N, K, epi, S, nkb, tgs, maxkb;
+  // fused decode-step forms (a3v_gemv_fused): RMSNorm prologue, RoPE + KV-cache epilogue, sum-of-squares side output
+  const bf16_t* norm_w;     // PRO: A holds the un-normalised rows h; the block normalises its K slice while staging it
+  const float* ssq_in;      // PRO: [ssq_tiles][16] per-16-column partial sums of squares of the rows of A
+  float* ssq_out;           // GEMV_EPI_SSQ: the same quantity for the rows this GEMV writes (residual stream)
+  const float* cos_sin;     // GEMV_EPI_ROPEKV: fp32 [pos][hd/2][2]
+  bf16_t* k_cache;          //   [M, Hkv, Smax, hd]
+  bf16_t* vt_cache;         //   [M, Hkv, hd, Smax]
+  float eps;
+  int ssq_tiles, H, Hkv, hd, Smax, pos;
 };
 
-template <int AROWS>
+constexpr int GEMV_EPI_ROPEKV = 1 << 24;
+constexpr int GEMV_EPI_SSQ = 1 << 25;
+
+template <int AROWS, bool PRO>
 __global__ __launch_bounds__(256) void gemv_dma_bf16_kernel(GemvArgs p) {
   extern __shared__ __attribute__((aligned(1024))) char gemv_lds[];
+  __shared__ float rinv_s[16];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // block -> (row group, slice): all slices of a row group on one XCD (blockIdx % 8)
   const int xq = blockIdx.x >> 3;
@@ -816,7 +829,7 @@ __global__ __launch_bounds__(256) void gemv_dma_bf16_kernel(GemvArgs p) {
   char* Wring = gemv_lds + p.maxkb * ABLK + wave * 2 * 4096;
   const int n0 = (tg * 4 + wave) * 16;
   const int dr = lane >> 4, dslot = lane & 15;
-  {
+  if (!PRO) {
     constexpr int IPB = AROWS / 4;                     // DMA instructions per k-block
     for (int j = wave; j < nkb * IPB; j += 4) {
       const int kb = j / IPB, i = j % IPB;
@@ -841,12 +854,79 @@ __global__ __launch_bounds__(256) void gemv_dma_bf16_kernel(GemvArgs p) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wrow[i] + kb * 128),
                                        (__attribute__((address_space(3))) void*)(Wring + slot * 4096 + i * 1024), 16, 0, 0);
   };
-  dma_stage(0, 0);
-  if (nkb > 1) {
-    dma_stage(1, 1);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // in-order completion: the A pieces issued before the ring prologue
+  if (PRO) {
+    // RMSNorm of the block's K slice of A (model/components.py:39,52-53 rounding: fp32 x*rinv -> bf16 -> * weight -> bf16),
+    // 1/rms from the producer's per-tile sums of squares.  All prologue loads (L2 hits) are issued BEFORE the weight
+    // ring's first DMAs: memory returns in order, so the normalisation runs while the first weight stages are in flight.
+    __shared__ float ssq_w[4][16];
+    constexpr int NQ = AROWS / 4;                      // float4 per tile row of the ssq table
+    f32x4 sq[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) sq[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = threadIdx.x; t < p.ssq_tiles; t += 256) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(p.ssq_in + t * 16 + q * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sq[q][r] += x[r];
+      }
+    }
+    const int per_row = nkb * 16, total = p.M * per_row;
+    constexpr int CH = 4;                              // items (16-B chunks of A) per thread per pass
+    bf16x8 xa[CH], ga[CH];
+    auto issue = [&](int base) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        int it = base + j * 256 + threadIdx.x;
+        it = it < total ? it : total - 1;
+        const int m = it / per_row, cc = it % per_row;
+        const int64_t k = (int64_t)(kb0 + (cc >> 4)) * 128 + (cc & 15) * 8;
+        xa[j] = *reinterpret_cast<const bf16x8*>(p.A + (int64_t)m * p.lda + k);
+        ga[j] = *reinterpret_cast<const bf16x8*>(p.norm_w + k);
+      }
+    };
+    auto finish = [&](int base) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const int it = base + j * 256 + threadIdx.x;
+        if (it < total) {
+          const int m = it / per_row, cc = it % per_row;
+          const int kb = cc >> 4, c = cc & 15;
+          const float ri = rinv_s[m];
+          bf16x8 y;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) y[e] = f2bf(rbf((float)xa[j][e] * ri) * (float)ga[j][e]);
+          *reinterpret_cast<bf16x8*>(Alds + kb * ABLK + m * 256 + ((c ^ m) & 15) * 16) = y;
+        }
+      }
+    };
+    issue(0);
+    dma_stage(0, 0);
+    if (nkb > 1) dma_stage(1, 1);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float t = wave_sum(sq[q][r]);
+        if (lane == 0) ssq_w[wave][q * 4 + r] = t;
+      }
+    __syncthreads();
+    if (threadIdx.x < AROWS)
+      rinv_s[threadIdx.x] = rsqrtf((ssq_w[0][threadIdx.x] + ssq_w[1][threadIdx.x] + ssq_w[2][threadIdx.x] + ssq_w[3][threadIdx.x]) / (float)p.K + p.eps);
+    __syncthreads();
+    finish(0);
+    for (int base = CH * 256; base < total; base += CH * 256) {
+      issue(base);
+      finish(base);
+    }
   } else {
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    dma_stage(0, 0);
+    if (nkb > 1) {
+      dma_stage(1, 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // in-order completion: the A pieces issued before the ring prologue
+    } else {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    }
   }
   __syncthreads();
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -941,15 +1021,49 @@ __global__ __launch_bounds__(256) void gemv_dma_bf16_kernel(GemvArgs p) {
     return;
   }
   const int n = nt0 + (lane >> 4) * 4;
-  if (m >= p.M || n >= p.N) return;
   float o4[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) o4[r] = rbf(v[r]);
-  if (p.epi & A3V_EPI_RESIDUAL) {
+  if (p.epi & GEMV_EPI_ROPEKV) {
+    // fused apply_rotary_emb + KV-cache write of the decode step (llama_ens5.py:118,124-129; a3v_rope_kvcache at S == 1):
+    // rows n are [q heads | k heads | v heads] x hd; a lane holds two interleaved pairs of one head, batch row m.
+    if (m >= p.M || n >= p.N) return;
+    const int slot = n / p.hd, d = n % p.hd, half = p.hd >> 1;
+    if (slot < p.H + p.Hkv) {
+      const float* cs = p.cos_sin + ((int64_t)p.pos * half + (d >> 1)) * 2;
+      const f32x4 t = *reinterpret_cast<const f32x4*>(cs);          // (cos, sin) of the two pairs
+      bf16x4 o;
+      o[0] = f2bf(o4[0] * t[0] - o4[1] * t[1]);
+      o[1] = f2bf(o4[0] * t[1] + o4[1] * t[0]);
+      o[2] = f2bf(o4[2] * t[2] - o4[3] * t[3]);
+      o[3] = f2bf(o4[2] * t[3] + o4[3] * t[2]);
+      bf16_t* dst = slot < p.H ? reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + n
+                               : p.k_cache + (((int64_t)m * p.Hkv + (slot - p.H)) * p.Smax + p.pos) * p.hd + d;
+      *reinterpret_cast<bf16x4*>(dst) = o;
+    } else {
+      bf16_t* dst = p.vt_cache + (((int64_t)m * p.Hkv + (slot - p.H - p.Hkv)) * p.hd + d) * (int64_t)p.Smax + p.pos;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst[(int64_t)r * p.Smax] = f2bf(o4[r]);
+    }
+    return;
+  }
+  const bool live = m < p.M && n < p.N;
+  if (live && (p.epi & A3V_EPI_RESIDUAL)) {
     const bf16x4 rr = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(p.res) + (int64_t)m * p.ldr + n);
 #pragma unroll
     for (int r = 0; r < 4; ++r) o4[r] += bf2f(rr[r]);
   }
+  if (p.epi & GEMV_EPI_SSQ) {
+    // sum of squares of the 16 bf16 values this tile contributes to row m (consumed by the next GEMV's RMSNorm prologue)
+    float sq = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const float hb = rbf(o4[r]); sq = fmaf(hb, hb, sq); }
+    if (!live) sq = 0.f;
+    sq += __shfl_xor(sq, 16, 64);
+    sq += __shfl_xor(sq, 32, 64);
+    if (lane < 16 && nt0 < p.N) p.ssq_out[(nt0 >> 4) * 16 + lane] = sq;
+  }
+  if (!live) return;
   if (p.epi & A3V_EPI_OUT_F32) {
     f32x4 o;
 #pragma unroll
@@ -1160,6 +1274,26 @@ static int gemv_split(int N, int K) {
   return S;
 }
 
+// fills the split-K plan + workspace pointers of `g` and launches; false when the shape needs the direct-to-VGPR kernel
+static bool gemv_launch(GemvArgs& g, void* ws, hipStream_t st) {
+  g.counters = (int*)ws;
+  g.part = (float*)((char*)ws + A3V_WS_PARTIALS);
+  g.S = gemv_split(g.N, g.K); g.nkb = g.K / 128; g.tgs = (g.N + 63) / 64;
+  g.maxkb = (g.nkb + g.S - 1) / g.S;
+  const int arows = g.M <= 8 ? 8 : 16;
+  const size_t ldsb = (size_t)g.maxkb * arows * 256 + 4 * 2 * 4096;
+  if (ldsb > 150 * 1024 || ((g.epi & A3V_EPI_SWIGLU) && g.S == 1)) return false;
+  const int blocks = ((g.tgs + 7) / 8) * 8 * g.S;
+  const bool pro = g.norm_w != nullptr;
+  void (*kern)(GemvArgs) = arows == 8 ? (pro ? gemv_dma_bf16_kernel<8, true> : gemv_dma_bf16_kernel<8, false>)
+                                      : (pro ? gemv_dma_bf16_kernel<16, true> : gemv_dma_bf16_kernel<16, false>);
+  static bool attr_done[4] = {false, false, false, false};
+  const int ki = (arows == 16 ? 2 : 0) + (pro ? 1 : 0);
+  if (!attr_done[ki]) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_done[ki] = true; }
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), ldsb, st, g);
+  return true;
+}
+
 extern "C" int a3v_gemm_skinny_split(int M, int N, int K) {
   (void)M;
   return (K % 128 == 0 && K >= 128) ? gemv_split(N, K) : 1;
@@ -1167,9 +1301,9 @@ extern "C" int a3v_gemm_skinny_split(int M, int N, int K) {
 
 extern "C" int64_t a3v_gemm_skinny_ws_bytes(int M, int N, int K) {
   (void)M;
-  if (K % 128 || K < 128) return 16384;
+  if (K % 128 || K < 128) return A3V_WS_PARTIALS;
   const int64_t tgs = (N + 63) / 64;
-  return 16384 + tgs * gemv_split(N, K) * 4 * 1024;
+  return A3V_WS_PARTIALS + tgs * gemv_split(N, K) * 4 * 1024;
 }
 
 extern "C" int a3v_gemm_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
@@ -1182,29 +1316,11 @@ extern "C" int a3v_gemm_skinny(const void* A, int64_t lda, const void* W, int64_
   if ((epilogue & A3V_EPI_RESIDUAL) && (!residual || (ldr % 4))) return A3V_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (K % 128 == 0 && N <= 65536) {
-    GemvArgs g;
+    GemvArgs g{};
     g.A = (const bf16_t*)A; g.W = (const bf16_t*)W; g.C = C; g.res = residual;
-    g.counters = (int*)partial; g.part = (float*)((char*)partial + 16384);
     g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.ldr = ldr;
     g.M = M; g.N = N; g.K = K; g.epi = epilogue;
-    g.S = gemv_split(N, K); g.nkb = K / 128; g.tgs = (N + 63) / 64;
-    g.maxkb = (g.nkb + g.S - 1) / g.S;
-    const int arows = M <= 8 ? 8 : 16;
-    const size_t ldsb = (size_t)g.maxkb * arows * 256 + 4 * 2 * 4096;
-    if (ldsb <= 150 * 1024 && !((epilogue & A3V_EPI_SWIGLU) && g.S == 1)) {
-      const int blocks = ((g.tgs + 7) / 8) * 8 * g.S;
-      if (arows == 8) {
-        static bool once8 = false;
-        if (!once8) { (void)hipFuncSetAttribute((const void*)gemv_dma_bf16_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); once8 = true; }
-        hipLaunchKernelGGL(gemv_dma_bf16_kernel<8>, dim3(blocks), dim3(256), ldsb, st, g);
-      } else {
-        static bool once16 = false;
-        if (!once16) { (void)hipFuncSetAttribute((const void*)gemv_dma_bf16_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); once16 = true; }
-        hipLaunchKernelGGL(gemv_dma_bf16_kernel<16>, dim3(blocks), dim3(256), ldsb, st, g);
-      }
-      A3V_LAUNCH_CHECK();
-      return A3V_OK;
-    }
+    if (gemv_launch(g, partial, st)) return A3V_OK;
   }
   // direct-to-VGPR form (any K % 32 == 0): 8 waves split K in 32-element granules, LDS reduction (workspace unused)
   Skinny1Args q;
@@ -1214,6 +1330,29 @@ extern "C" int a3v_gemm_skinny(const void* A, int64_t lda, const void* W, int64_
   q.kslice = ((K / 32 + 7) / 8) * 32;
   if (epilogue & A3V_EPI_SWIGLU) hipLaunchKernelGGL(gemm_skinny1_bf16_kernel<2>, dim3((N + 31) / 32), dim3(512), 0, st, q);
   else hipLaunchKernelGGL(gemm_skinny1_bf16_kernel<1>, dim3((N + 15) / 16), dim3(512), 0, st, q);
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}
+
+// Decode-step forms of the GEMV (internal to the library, used by a3v_llama_decode_step):
+//   norm_w != NULL : A is the un-normalised residual rows h; RMSNorm(h) is applied while the A slice is staged (ssq_in)
+//   rope != 0      : [q|k|v] rows get RoPE and go to C (q) / the KV cache at `pos` (no separate rope kernel)
+//   ssq_out != NULL: with a residual epilogue, also emit the per-tile sums of squares of the new rows
+int a3v_gemv_fused(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int M, int N, int K,
+                   const void* residual, int64_t ldr, int epilogue, const void* norm_w, const float* ssq_in, float eps,
+                   float* ssq_out, int rope, const float* cos_sin, void* k_cache, void* vt_cache, int H, int Hkv, int hd,
+                   int Smax, int pos, void* ws, void* stream) {
+  if (M <= 0 || M > 16 || K % 128 || N % 16 || N > 65536 || !ws) return A3V_ERR_SHAPE;
+  GemvArgs g{};
+  g.A = (const bf16_t*)A; g.W = (const bf16_t*)W; g.C = C; g.res = residual;
+  g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.ldr = ldr;
+  g.M = M; g.N = N; g.K = K;
+  g.epi = epilogue | (rope ? GEMV_EPI_ROPEKV : 0) | (ssq_out ? GEMV_EPI_SSQ : 0);
+  g.norm_w = (const bf16_t*)norm_w; g.ssq_in = ssq_in; g.eps = eps; g.ssq_tiles = K / 16; g.ssq_out = ssq_out;
+  g.cos_sin = cos_sin; g.k_cache = (bf16_t*)k_cache; g.vt_cache = (bf16_t*)vt_cache;
+  g.H = H; g.Hkv = Hkv; g.hd = hd; g.Smax = Smax; g.pos = pos;
+  if (rope && (hd % 16 || !cos_sin || !k_cache || !vt_cache)) return A3V_ERR_ARG;
+  if (!gemv_launch(g, ws, (hipStream_t)stream)) return A3V_ERR_SHAPE;
   A3V_LAUNCH_CHECK();
   return A3V_OK;
 }

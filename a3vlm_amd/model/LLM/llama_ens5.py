@@ -654,7 +654,8 @@ class Transformer(nn.Module):
         ops.embed_assemble(tokens.contiguous(), self.tok_embeddings.weight, h, B, T, W, a.dim)
         if image is not None:
             self.encode_image_into(h, image, B, S, qformer_feats, extra_feats, slots)
-        if S == 1 and B <= 16 and self._dtype == torch.bfloat16 and self.head_dim in (64, 128) and a.dim % 32 == 0 and self.ffn % 32 == 0:
+        if (S == 1 and B <= 16 and self._dtype == torch.bfloat16 and self.head_dim in (64, 128) and a.dim % 32 == 0 and self.ffn % 32 == 0
+                and not getattr(self, "_per_kernel_decode", False)):     # test hook: run the step kernel by kernel
             self._decode_step(h, B, start_pos)
         else:
             self._decoder_layers(h, B, S, start_pos, rope0, self._k_cache, self._vt_cache, True)

@@ -267,3 +267,44 @@ def test_vit_single_crop_geometry_bf16():
     m.to(BF)
     outb = m(ex.to(DEV), img.to(DEV))
     assert rel_err(outb, want.numpy()) < 5e-2
+
+
+@pytest.mark.parametrize("heads,kv,dim,B", [(4, 4, 256, 5), (4, 2, 512, 8), (2, 1, 256, 1), (8, 8, 512, 11)])
+def test_fused_decode_step_matches_per_kernel_path(heads, kv, dim, B):
+    """a3v_llama_decode_step's fused form (RMSNorm folded into the consuming GEMV, RoPE + KV write in the QKV epilogue,
+    attention combine in-kernel) vs the same step run kernel by kernel: same rounding points, so logits agree to bf16
+    accumulation-order noise, the KV cache rows written at the decode positions included; and vs the bf16 oracle."""
+    args = plugin.ModelArgs(dim=dim, n_layers=3, n_heads=heads, n_kv_heads=kv, vocab_size=640, multiple_of=128, max_seq_len=192)
+    oargs = ref_cpu.OracleArgs(dim=dim, n_layers=3, n_heads=heads, n_kv_heads=kv, vocab_size=640, multiple_of=128, max_seq_len=192)
+    sd = ref_cpu.make_decoder_weights(oargs, seed=11, std=0.06)
+    m = plugin.Transformer(args)
+    m.load_state_dict(sd)
+    m.to(BF).to(DEV)
+    g = torch.Generator().manual_seed(2)
+    T0, steps = 37, 6
+    ex = torch.randint(3, 640, (B, T0 + steps), generator=g)
+    ex[:, 0] = 1
+    dec = ref_cpu.OracleDecoder(oargs, {k: v.to(BF) for k, v in sd.items()})
+    want = [dec.forward_inference(ex[:, :T0], 0).float()]
+    for t in range(T0, T0 + steps):
+        want.append(dec.forward_inference(ex[:, t:t + 1], t).float())
+    exd = ex.to(DEV)
+    outs = {}
+    for mode in (False, True):
+        m._per_kernel_decode = mode
+        lg = [m.forward_inference(exd[:, :T0], 0).float().clone()]
+        for t in range(T0, T0 + steps):
+            lg.append(m.forward_inference(exd[:, t:t + 1], t).float().clone())
+        outs[mode] = (lg, [k[:, :, :T0 + steps].clone() for k in m._k_cache], [v[:, :, :, :T0 + steps].clone() for v in m._vt_cache])
+    scale = max(float(w.abs().max()) for w in want)
+    for i in range(steps + 1):
+        assert float((outs[False][0][i] - outs[True][0][i]).abs().max()) / scale < 2e-2, i
+        assert float((outs[False][0][i].cpu() - want[i]).abs().max()) / scale < 4e-2, i
+    for l in range(3):
+        ks = float(outs[True][1][l].float().abs().max())
+        assert float((outs[False][1][l].float() - outs[True][1][l].float()).abs().max()) / ks < 2e-2
+        vs = float(outs[True][2][l].float().abs().max())
+        assert float((outs[False][2][l].float() - outs[True][2][l].float()).abs().max()) / vs < 2e-2
+    # the arrival counters are left at zero
+    ws = m._ws["skinny_ws"]
+    assert int(ws[:8192].view(torch.int32).abs().sum()) == 0
