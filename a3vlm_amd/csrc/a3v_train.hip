@@ -87,6 +87,88 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
   }
 }
 
+
+// Vector form (dim % 4 == 0, 16-B aligned rows): a thread keeps its float4 slices of x and dy in registers across the two
+// passes of a row (one HBM read each), RPB rows per block for the weight-gradient partials.
+template <typename TA, int RPB, int MAXV>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_vec_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ w,
+                                                              const TA* __restrict__ dy, int64_t lddy, float* __restrict__ dh,
+                                                              int64_t lddh, float* __restrict__ dw, int rows, int dim, float eps) {
+  __shared__ float red[2][8];
+  const int tid = threadIdx.x;
+  const int nv = dim >> 2;
+  f32x4 wv[MAXV], dwp[MAXV];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = tid + i * 256;
+    wv[i] = c < nv ? reinterpret_cast<const f32x4*>(w)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+    dwp[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int row0 = blockIdx.x * RPB;
+  for (int rr = 0; rr < RPB; ++rr) {
+    const int row = row0 + rr;
+    if (row >= rows) break;
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + (int64_t)row * ldx);
+    const TA* dyr = dy + (int64_t)row * lddy;
+    f32x4 xv[MAXV], gv[MAXV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = tid + i * 256;
+      if (c < nv) {
+        xv[i] = xr[c];
+        if constexpr (sizeof(TA) == 2) {
+          const bf16x4 d = *reinterpret_cast<const bf16x4*>(dyr + 4 * c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) gv[i][e] = (float)d[e];
+        } else {
+          gv[i] = *reinterpret_cast<const f32x4*>(dyr + 4 * c);
+        }
+      } else {
+        xv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        gv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s1 = fmaf(xv[i][e], xv[i][e], s1);
+        s2 = fmaf(gv[i][e] * wv[i][e], xv[i][e], s2);
+      }
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    const int pb = rr & 1;                    // double-buffered: one barrier per row
+    if ((tid & 63) == 0) { red[pb][tid >> 6] = s1; red[pb][4 + (tid >> 6)] = s2; }
+    __syncthreads();
+    s1 = red[pb][0] + red[pb][1] + red[pb][2] + red[pb][3];
+    s2 = red[pb][4] + red[pb][5] + red[pb][6] + red[pb][7];
+    const float r = rsqrtf(s1 / (float)dim + eps);
+    const float k2 = r * r * r * s2 / (float)dim;
+    f32x4* dhr = reinterpret_cast<f32x4*>(dh + (int64_t)row * lddh);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = tid + i * 256;
+      if (c < nv) {
+        f32x4 o = dhr[c];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[e] += r * gv[i][e] * wv[i][e] - xv[i][e] * k2;
+          dwp[i][e] += gv[i][e] * xv[i][e] * r;
+        }
+        dhr[c] = o;
+      }
+    }
+  }
+  if (dw) {
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = tid + i * 256;
+      if (c < nv) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(dw + 4 * c + e, dwp[i][e]);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ LayerNorm backward (projector LN)
 // y = (x-mean)*rstd*w + b (fp32 math); dy rows are gathered through row_map from the fp32 stream.
 template <typename TA, int RPB>
@@ -343,9 +425,35 @@ __global__ __launch_bounds__(256) void cast2d_kernel(const TS* __restrict__ src,
   }
 }
 
+// dst[r, c] += src[r, c]  (scatter-accumulate of the block-diagonal LoRA gradient GEMMs into the adapter grads; the
+// adapter path's residual add h += o)
+template <typename T>
+__global__ __launch_bounds__(256) void add2d_kernel(T* __restrict__ dst, int64_t ldd, const T* __restrict__ src, int64_t lds_, int rows, int cols) {
+  const int64_t n = (int64_t)rows * (cols / 4);
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int r = i / (cols / 4), c = (i % (cols / 4)) * 4;
+    T* d = dst + (int64_t)r * ldd + c;
+    const T* s2 = src + (int64_t)r * lds_ + c;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) Cvt<T>::st(d + e, Cvt<T>::ld(d + e) + Cvt<T>::ld(s2 + e));
+  }
+}
+
 }  // namespace
 
 #define ST ((hipStream_t)stream)
+
+extern "C" int a3v_add2d(void* dst, int64_t ld_dst, const void* src, int64_t ld_src, int rows, int cols, int dtype, void* stream) {
+  if (!dst || !src || rows <= 0 || cols <= 0) return A3V_ERR_ARG;
+  if (cols % 4) return A3V_ERR_SHAPE;
+  const int64_t n = (int64_t)rows * (cols / 4);
+  const int blocks = (int)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
+  if (dtype == A3V_F32) hipLaunchKernelGGL(add2d_kernel<float>, dim3(blocks), dim3(256), 0, ST, (float*)dst, ld_dst, (const float*)src, ld_src, rows, cols);
+  else if (dtype == A3V_BF16) hipLaunchKernelGGL(add2d_kernel<bf16_t>, dim3(blocks), dim3(256), 0, ST, (bf16_t*)dst, ld_dst, (const bf16_t*)src, ld_src, rows, cols);
+  else return A3V_ERR_DTYPE;
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}
 
 extern "C" int a3v_cast(const void* src, int64_t ld_src, int src_dtype, void* dst, int64_t ld_dst, int dst_dtype, int rows, int cols, void* stream) {
   if (!src || !dst || rows <= 0 || cols <= 0) return A3V_ERR_ARG;
@@ -379,6 +487,21 @@ extern "C" int a3v_rmsnorm_bwd(const float* x, int64_t ldx, const float* w, cons
                                float* dw, int rows, int dim, float eps, int act_dtype, void* stream) {
   if (!x || !w || !dy || !dh || rows <= 0) return A3V_ERR_ARG;
   if (dim > 8192) return A3V_ERR_SHAPE;
+  if (dim % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && lddh % 4 == 0 && (act_dtype == A3V_BF16 || act_dtype == A3V_F32) &&
+      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dh) | reinterpret_cast<uintptr_t>(w)) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(dy) & (act_dtype == A3V_BF16 ? 7 : 15)) == 0) {
+    constexpr int RV = 8;
+    dim3 gv((rows + RV - 1) / RV);
+    if (dim <= 4096) {
+      if (act_dtype == A3V_BF16) hipLaunchKernelGGL((rmsnorm_bwd_vec_kernel<bf16_t, RV, 4>), gv, dim3(256), 0, ST, x, ldx, w, (const bf16_t*)dy, lddy, dh, lddh, dw, rows, dim, eps);
+      else hipLaunchKernelGGL((rmsnorm_bwd_vec_kernel<float, RV, 4>), gv, dim3(256), 0, ST, x, ldx, w, (const float*)dy, lddy, dh, lddh, dw, rows, dim, eps);
+    } else {
+      if (act_dtype == A3V_BF16) hipLaunchKernelGGL((rmsnorm_bwd_vec_kernel<bf16_t, RV, 8>), gv, dim3(256), 0, ST, x, ldx, w, (const bf16_t*)dy, lddy, dh, lddh, dw, rows, dim, eps);
+      else hipLaunchKernelGGL((rmsnorm_bwd_vec_kernel<float, RV, 8>), gv, dim3(256), 0, ST, x, ldx, w, (const float*)dy, lddy, dh, lddh, dw, rows, dim, eps);
+    }
+    A3V_LAUNCH_CHECK();
+    return A3V_OK;
+  }
   constexpr int RPB = 16;
   dim3 g((rows + RPB - 1) / RPB);
   if (act_dtype == A3V_BF16) hipLaunchKernelGGL((rmsnorm_bwd_kernel<bf16_t, RPB>), g, dim3(256), 0, ST, x, ldx, w, (const bf16_t*)dy, lddy, dh, lddh, dw, rows, dim, eps);

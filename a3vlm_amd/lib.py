@@ -47,6 +47,7 @@ SIGNATURES = {
     "a3v_swiglu_fwd": (I, [P, L, P, L, I, I, I, I, P]),
     "a3v_swiglu_bwd": (I, [P, L, P, L, P, L, I, I, I, I, P]),
     "a3v_cast": (I, [P, L, I, P, L, I, I, I, P]),
+    "a3v_add2d": (I, [P, L, P, L, I, I, I, P]),
     "a3v_rope_bwd_pack": (I, [P, P, P, P, L, P, I, I, I, I, I, I, I, P]),
     "a3v_attention_bwd": (I, [P, P, L, L, P, L, L, L, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
     "a3v_attention_bwd_workspace_bytes": (L, [I, I, I, I, I]),

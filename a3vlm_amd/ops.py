@@ -218,6 +218,16 @@ def cast(src, dst):
     return dst
 
 
+def add2d(dst, src):
+    """dst += src (2-D blocks of one dtype, arbitrary row strides)."""
+    _dev(dst, src)
+    assert dst.dtype == src.dtype and dst.shape == src.shape
+    rows, cols = dst.shape
+    rc = _l.load().a3v_add2d(_p(dst), dst.stride(0), _p(src), src.stride(0), rows, cols, dt(dst), _stream())
+    _l.check(rc, "a3v_add2d")
+    return dst
+
+
 def rmsnorm_bwd(x, w, dy, dh, dw, eps):
     _dev(x, w, dy, dh, dw)
     assert x.dtype == torch.float32 and w.dtype == torch.float32 and dh.dtype == torch.float32

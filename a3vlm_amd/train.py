@@ -30,6 +30,7 @@ class TrainEngine:
         1.15 GB per 7B layer at 8 x 1091 tokens -- affordable in 288 GB of HBM and ~1/4 fewer GEMM FLOPs per step).
         None = decide from free HBM at the first step."""
         self.m = model
+        self.lora = int(getattr(model, "lora_rank", 0) or 0) > 0
         self.act = compute_dtype
         self.recompute = recompute
         self._img: Dict[str, torch.Tensor] = {}
@@ -55,7 +56,7 @@ class TrainEngine:
 
     def _check_dtypes(self):
         for n, p in self.m.get_trainable_params().items():
-            if p.dtype != torch.float32:
+            if p.requires_grad and p.dtype != torch.float32:
                 raise TypeError(f"trainable parameter {n} must be fp32 (promote_trainable_params_to_fp32, "
                                 f"util/tensor_type.py:60-66); got {p.dtype}")
 
@@ -73,6 +74,12 @@ class TrainEngine:
                 (p + "feed_forward.w1.weight", l.feed_forward.w1.weight), (p + "feed_forward.w3.weight", l.feed_forward.w3.weight),
                 (p + "feed_forward.w2.weight", l.feed_forward.w2.weight),
                 (p + "attention_norm.weight", l.attention_norm.weight), (p + "ffn_norm.weight", l.ffn_norm.weight)]))
+            if self.lora:
+                for sub, mod in (("attention.wq", l.attention.wq), ("attention.wk", l.attention.wk), ("attention.wv", l.attention.wv),
+                                 ("attention.wo", l.attention.wo), ("feed_forward.w1", l.feed_forward.w1),
+                                 ("feed_forward.w3", l.feed_forward.w3), ("feed_forward.w2", l.feed_forward.w2)):
+                    items[-1][1].append((p + sub + ".lora_a.weight", mod.lora_a.weight))
+                    items[-1][1].append((p + sub + ".lora_b.weight", mod.lora_b.weight))
         items.append(("head", [("norm.weight", m.norm.weight), ("output.weight", m.output.weight)]))
         if m.with_visual:
             vp0, vp1 = getattr(m.visual_proj, "0"), getattr(m.visual_proj, "1")
@@ -86,7 +93,8 @@ class TrainEngine:
                 vis += [("qformer_proj.0.weight", q0.weight), ("qformer_proj.0.bias", q0.bias),
                         ("qformer_proj.1.weight", q1.weight), ("qformer_proj.1.bias", q1.bias)]
             items.append(("vision_proj", vis))
-        return items
+        # frozen parameters get no gradient storage (LoRA / partial fine-tuning)
+        return [(b, [(n, q) for n, q in plist if q.requires_grad]) for b, plist in items]
 
     def ensure_grads(self):
         """Allocate the flat fp32 gradient buffer once; (re)attach zeroed views where .grad is None."""
@@ -107,6 +115,8 @@ class TrainEngine:
             self._params = {name: p for name, (o, p) in offs.items()}
         for name, p in self._params.items():
             if not p.requires_grad:
+                if p.grad is not None and p.grad.data_ptr() == self._views[name].data_ptr():
+                    p.grad = None
                 continue
             v = self._views[name]
             if p.grad is None:
@@ -121,6 +131,9 @@ class TrainEngine:
     def flat_grads(self) -> torch.Tensor:
         return self._flat
 
+    def _has(self, *names: str) -> bool:
+        return all(n in self._views for n in names)
+
     def _gview(self, first: str, last: str) -> torch.Tensor:
         """Fused [rows, cols] view over consecutive parameters (wq|wk|wv, w1|w3)."""
         a, b = self._views[first], self._views[last]
@@ -133,7 +146,8 @@ class TrainEngine:
     # ------------------------------------------------------------------ weight images in the compute dtype
     def _images(self):
         m = self.m
-        ver = m._weights_version()
+        base = [q for n, q in m.named_parameters() if "lora_" not in n and not n.startswith("clip.")]
+        ver = tuple(q._version for q in base) + (self.act, str(m._device))
         if self._img_version == ver:
             return self._img
         act = self.act
@@ -189,6 +203,66 @@ class TrainEngine:
             dy = dyp
         ops.gemm_nt(dy, wt, out)
 
+    # ------------------------------------------------------------------ LoRA adapters (model/peft.py semantics)
+    def _lora_step_images(self):
+        """A [Rp,in], B [N,Rp] (+ transposes for the backward GEMMs) of every adapter group in the compute dtype."""
+        m = self.m
+        ver = tuple(q._version for n, q in m.named_parameters() if "lora_" in n)
+        if getattr(self, "_li_ver", None) == ver:
+            return self._li
+        src = m.lora_images(dtype=self.act, interleave_w13=False)
+        li = {}
+        for k, v in src.items():
+            li[k] = v
+            R, C = v.shape
+            vt = torch.empty(C, _pad64(R), dtype=v.dtype, device=v.device)
+            if _pad64(R) != R:
+                vp = torch.zeros(_pad64(R), C, dtype=v.dtype, device=v.device)
+                vp[:R] = v
+            else:
+                vp = v
+            ops.transpose(vp, vt, _pad64(R), C, _pad64(R))
+            li[k + "t"] = vt
+        self._li, self._li_ver = li, ver
+        return li
+
+    def _lora_fwd(self, key: str, x: torch.Tensor, y: torch.Tensor, tag: str) -> torch.Tensor:
+        """y += lora_b(lora_a(x)) for a fused adapter group; returns t = lora_a(x) (kept for the backward)."""
+        li = self._lora_step_images()
+        A, Bm = li[key + ".A"], li[key + ".B"]
+        t = self._buf("lora_t." + key.split(".")[0] + tag, (x.shape[0], A.shape[0]))
+        ops.gemm_nt(x, A, t)
+        f32 = y.dtype == torch.float32 and self.act == torch.bfloat16
+        ops.gemm_nt(t, Bm, y, residual=y, epilogue=ops.EPI_RES_F32 if f32 else 0)
+        return t
+
+    def _lora_bwd(self, i: int, key: str, dy: torch.Tensor, x: torch.Tensor, t: torch.Tensor, dx: Optional[torch.Tensor]):
+        """Adapter gradients of a fused group and the adapter term of the input gradient (dx += (dy B) A)."""
+        m = self.m
+        li = self._lora_step_images()
+        r = m.lora_rank
+        Bt, At = li[key + ".Bt"], li[key + ".At"]          # [Rp, Npad], [in, Rp]
+        M, N = dy.shape
+        Rp = t.shape[1]
+        dt = self._buf("lora_dt", (M, Rp))
+        self._dgrad(dy, Bt, dt)                              # dt = dy @ B
+        g = key.split(".")[0]
+        gB = self._buf("lora_gB." + g, (N, Rp), torch.float32, zero=True)
+        gA = self._buf("lora_gA." + g, (Rp, x.shape[1]), torch.float32, zero=True)
+        self._wgrad(dy, t, gB, "lb")
+        self._wgrad(dt, x, gA, "la")
+        names = {"qkv": ["attention.wq", "attention.wk", "attention.wv"], "wo": ["attention.wo"],
+                 "w13": ["feed_forward.w1", "feed_forward.w3"], "w2": ["feed_forward.w2"]}[g]
+        row = 0
+        for j, nm in enumerate(names):
+            vb = self._views[f"layers.{i}.{nm}.lora_b.weight"]
+            va = self._views[f"layers.{i}.{nm}.lora_a.weight"]
+            ops.add2d(vb, gB[row:row + vb.shape[0], j * r:(j + 1) * r])
+            ops.add2d(va, gA[j * r:(j + 1) * r])
+            row += vb.shape[0]
+        if dx is not None:
+            ops.gemm_nt(dt, At, dx, residual=dx)             # dx += dt @ A
+
     # ------------------------------------------------------------------ one decoder block (forward / recompute)
     def _block_forward(self, i: int, h: torch.Tensor, B: int, S: int, keep: bool, tag: str = "", h_out: Optional[torch.Tensor] = None):
         """One decoder block on the fp32 stream h [B*S, dim].
@@ -210,6 +284,9 @@ class TrainEngine:
         lse = self._buf("lse" + tag, (B, H, S), torch.float32)
         ops.rmsnorm(h, l.attention_norm.weight, xn, a.norm_eps)
         ops.gemm_nt(xn, im[f"qkv.{i}"], qkv)
+        lt = {}
+        if self.lora:
+            lt["qkv"] = self._lora_fwd(f"qkv.{i}", xn, qkv, tag)
         ops.rope_kvcache(qkv, qrot, kc, vc, m._cos_sin_dev(), B, S, H, Hkv, hd, 0, 0)
         strides = (S * H * hd, H * hd, hd, Hkv * spad * hd, spad * hd, hd, Hkv * hd * spad, hd * spad, spad, S * H * hd, H * hd, hd)
         ops.attention_lse(qrot, kc, vc, att, lse, B, S, S, H, Hkv, hd, strides, True)
@@ -220,16 +297,28 @@ class TrainEngine:
         else:
             h_mid = h
             ops.gemm_nt(att, im[f"wo.{i}"], h, residual=h, epilogue=res_flag)
+        if self.lora:
+            lt["wo"] = self._lora_fwd(f"wo.{i}", att, h_mid, tag)
         xn2 = self._buf("xn2" + tag, (rows, dim))
         gu = self._buf("gu" + tag, (rows, 2 * F))
         actb = self._buf("act" + tag, (rows, F))
         ops.rmsnorm(h_mid, l.ffn_norm.weight, xn2, a.norm_eps)
         ops.gemm_nt(xn2, im[f"w13.{i}"], gu)
+        if self.lora:
+            lt["w13"] = self._lora_fwd(f"w13.{i}", xn2, gu, tag)
         ops.swiglu_fwd(gu, actb, F, interleaved=False)
-        kept = dict(xn=xn, qkv=qkv, qrot=qrot, kc=kc, att=att, lse=lse, h_mid=h_mid, xn2=xn2, gu=gu, act=actb, spad=spad)
+        if self.lora:                                     # t = lora_a(act) of w2 is needed by the backward even without the output
+            li = self._lora_step_images()
+            lt["w2"] = self._buf("lora_t.w2" + tag, (rows, li[f"w2.{i}.A"].shape[0]))
+            ops.gemm_nt(actb, li[f"w2.{i}.A"], lt["w2"])
+        kept = dict(xn=xn, qkv=qkv, qrot=qrot, kc=kc, att=att, lse=lse, h_mid=h_mid, xn2=xn2, gu=gu, act=actb, spad=spad, lt=lt)
         if keep and h_out is None:
             return kept                                   # recompute inside backward: the block output is not needed
-        ops.gemm_nt(actb, im[f"w2.{i}"], h_out if keep else h, residual=h_mid, epilogue=res_flag)
+        out = h_out if keep else h
+        ops.gemm_nt(actb, im[f"w2.{i}"], out, residual=h_mid, epilogue=res_flag)
+        if self.lora:
+            f32 = out.dtype == torch.float32 and self.act == torch.bfloat16
+            ops.gemm_nt(lt["w2"], self._lora_step_images()[f"w2.{i}.B"], out, residual=out, epilogue=ops.EPI_RES_F32 if f32 else 0)
         return kept
 
     def _block_backward(self, i: int, h_in: torch.Tensor, dh: torch.Tensor, B: int, S: int):
@@ -242,20 +331,30 @@ class TrainEngine:
         # ---- FFN: out = h_mid + w2(silu(g) * u)
         dha = self._buf("dh_act", (rows, dim))
         ops.cast(dh, dha)
-        self._wgrad(dha, k["act"], self._views[pre + "feed_forward.w2.weight"], "w2")
+        lt = k.get("lt", {})
+        if self._has(pre + "feed_forward.w2.weight"):
+            self._wgrad(dha, k["act"], self._views[pre + "feed_forward.w2.weight"], "w2")
         dact = self._buf("dact", (rows, F))
         self._dgrad(dha, im[f"w2.{i}.t"], dact)
+        if self.lora:
+            self._lora_bwd(i, f"w2.{i}", dha, k["act"], lt["w2"], dact)
         dgu = self._buf("dgu", (rows, 2 * F))
         ops.swiglu_bwd(k["gu"], dact, dgu, F, interleaved=False)
-        self._wgrad(dgu, k["xn2"], self._gview(pre + "feed_forward.w1.weight", pre + "feed_forward.w3.weight"), "w13")
+        if self._has(pre + "feed_forward.w1.weight", pre + "feed_forward.w3.weight"):
+            self._wgrad(dgu, k["xn2"], self._gview(pre + "feed_forward.w1.weight", pre + "feed_forward.w3.weight"), "w13")
         dxn = self._buf("dxn", (rows, dim))
         self._dgrad(dgu, im[f"w13.{i}.t"], dxn)
-        ops.rmsnorm_bwd(k["h_mid"], l.ffn_norm.weight, dxn, dh, self._views[pre + "ffn_norm.weight"], a.norm_eps)
+        if self.lora:
+            self._lora_bwd(i, f"w13.{i}", dgu, k["xn2"], lt["w13"], dxn)
+        ops.rmsnorm_bwd(k["h_mid"], l.ffn_norm.weight, dxn, dh, self._views.get(pre + "ffn_norm.weight"), a.norm_eps)
         # ---- attention: h_mid = h_in + wo(attn(rope(qkv(norm(h_in)))))
         ops.cast(dh, dha)
-        self._wgrad(dha, k["att"], self._views[pre + "attention.wo.weight"], "wo")
+        if self._has(pre + "attention.wo.weight"):
+            self._wgrad(dha, k["att"], self._views[pre + "attention.wo.weight"], "wo")
         datt = self._buf("datt", (rows, H * hd))
         self._dgrad(dha, im[f"wo.{i}.t"], datt)
+        if self.lora:
+            self._lora_bwd(i, f"wo.{i}", dha, k["att"], lt["wo"], datt)
         dq = self._buf("dq", (rows, H * hd))
         dk = self._buf("dk", (B, Hkv, S, hd))
         dv = self._buf("dv", (B, Hkv, S, hd))
@@ -271,9 +370,12 @@ class TrainEngine:
                           dq, dk, dv, B, S, H, Hkv, hd, True, workspace=wsp)
         dqkv = self._buf("dqkv", (rows, (H + 2 * Hkv) * hd))
         ops.rope_bwd_pack(dq, dk, dv, dqkv, m._cos_sin_dev(), B, S, H, Hkv, hd, 0)
-        self._wgrad(dqkv, k["xn"], self._gview(pre + "attention.wq.weight", pre + "attention.wv.weight"), "qkv")
+        if self._has(pre + "attention.wq.weight", pre + "attention.wk.weight", pre + "attention.wv.weight"):
+            self._wgrad(dqkv, k["xn"], self._gview(pre + "attention.wq.weight", pre + "attention.wv.weight"), "qkv")
         self._dgrad(dqkv, im[f"qkv.{i}.t"], dxn)
-        ops.rmsnorm_bwd(h_in, l.attention_norm.weight, dxn, dh, self._views[pre + "attention_norm.weight"], a.norm_eps)
+        if self.lora:
+            self._lora_bwd(i, f"qkv.{i}", dqkv, k["xn"], lt["qkv"], dxn)
+        ops.rmsnorm_bwd(h_in, l.attention_norm.weight, dxn, dh, self._views.get(pre + "attention_norm.weight"), a.norm_eps)
 
     # ------------------------------------------------------------------ forward (loss) and backward
     @torch.no_grad()
@@ -338,20 +440,22 @@ class TrainEngine:
         # ---- CE + LM head + final norm
         dlog = self._buf("dlogits", (B * T, V))
         ops.cross_entropy(s["logits"], s["lab"], self._buf("row_loss", (B * T,), torch.float32), dlog, s["n_valid"], grad_scale)
-        self._wgrad(dlog, s["xt"], self._views["output.weight"], "out")
+        if self._has("output.weight"):
+            self._wgrad(dlog, s["xt"], self._views["output.weight"], "out")
         dxt = self._buf("dxn_text", (B * T, dim))
         self._dgrad(dlog, im["out.t"], dxt)
         dh = self._buf("dh", (rows, dim), torch.float32, zero=True)
         hv, dhv = s["h"].view(B, S, dim), dh.view(B, S, dim)
         for b in range(B):
-            ops.rmsnorm_bwd(hv[b, W:], m.norm.weight, dxt[b * T:(b + 1) * T], dhv[b, W:], self._views["norm.weight"], a.norm_eps)
+            ops.rmsnorm_bwd(hv[b, W:], m.norm.weight, dxt[b * T:(b + 1) * T], dhv[b, W:], self._views.get("norm.weight"), a.norm_eps)
         self._notify("head")
         # ---- decoder blocks, last to first (recompute from the saved block input)
         for i in range(m.n_layers - 1, -1, -1):
             self._block_backward(i, s["hs"][i], dh, B, S)
             self._notify(f"layer{i}")
         # ---- embeddings and projector
-        ops.embed_bwd(s["tokens"], dh, self._views["tok_embeddings.weight"], B, T, W, dim)
+        if self._has("tok_embeddings.weight"):
+            ops.embed_bwd(s["tokens"], dh, self._views["tok_embeddings.weight"], B, T, W, dim)
         self._notify("embed")
         if s["vis"] is not None:
             self._encode_image_backward(dh, s["vis"], B, S)

@@ -199,6 +199,76 @@ def train_leg(m, args, B, T, image, tokens, steps, dist, dev):
     return el / steps, float(loss), torch.cuda.max_memory_allocated() / 2 ** 30
 
 
+def lora_leg(m, args, B, T, image, tokens, steps, dist, dev, rank=16):
+    """configs[2]: LoRA fine-tune step (rank-16 adapters on the seven decoder linears of every block + norms + projector
+    trainable, base matrices frozen in bf16) on this rank's micro-batch.  The adapter plugin is built around the SAME base
+    parameter tensors as ``m`` (no second copy of the 7B weights)."""
+    import dataclasses
+    from a3vlm_amd.model.LLM import llama_ens5_peft as peft
+    from a3vlm_amd.train import TrainEngine
+    from a3vlm_amd.util import promote_trainable_params_to_fp32
+    from a3vlm_amd.dp import GradReducer
+    pargs = peft.ModelArgs(**dataclasses.asdict(args), lora_rank=rank)
+    with torch.device("meta"):
+        pm = peft.Transformer(pargs, with_visual=True)
+    base = dict(m.named_parameters())
+    g = torch.Generator(device=dev).manual_seed(7)
+    for name, p in list(pm.named_parameters()):
+        mod = pm
+        parts = name.split(".")
+        for q in parts[:-1]:
+            mod = getattr(mod, q)
+        if name in base:
+            setattr(mod, parts[-1], base[name])                      # shared storage
+        else:
+            t = torch.empty(p.shape, dtype=torch.bfloat16, device=dev)
+            t.normal_(0.0, 0.02, generator=g)                        # B != 0 so that every adapter GEMM does real work
+            setattr(mod, parts[-1], torch.nn.Parameter(t))
+    pm._cos_sin_cpu = m._cos_sin_cpu
+    train = pm.get_trainable_params()
+    for n, p in pm.named_parameters():
+        p.requires_grad = n in train
+    promote_trainable_params_to_fp32(pm)
+    n_train = sum(p.numel() for p in pm.parameters() if p.requires_grad)
+    eng = TrainEngine(pm, torch.bfloat16)
+    opt = torch.optim.AdamW([p for p in pm.parameters() if p.requires_grad], lr=2e-5, betas=(0.9, 0.95), weight_decay=0.0, fused=True)
+    red = GradReducer(eng, dist) if dist is not None else None
+    labels = tokens.clone()
+    labels[:, :T // 2] = 0
+
+    def one():
+        loss = eng.forward_loss(tokens, labels, image)
+        eng.backward(1.0)
+        if red is not None:
+            red.finish()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return loss
+
+    one()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = one()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    mem = torch.cuda.max_memory_allocated() / 2 ** 30
+    # restore the shared parameters' state for the legs that follow
+    for n, p in m.named_parameters():
+        p.grad = None
+    del eng, opt, red, pm
+    torch.cuda.empty_cache()
+    return el / steps, float(loss), mem, n_train
+
+
 def cpu_baseline(args, T, W, seconds):
     """The CPU oracle (oracle/ref_cpu.py, kind "port") on the host cores, bf16, ONE sample of the same
     workload: full ViT-L/14@336 + projector + all decoder layers over 1091 positions + LM head.  To keep
@@ -351,6 +421,18 @@ def main():
     ctx = S + 2 + a.decode_steps // 2
     dec_bytes = bytes_decode_step(args, B, ctx)
 
+    lora = None
+    if not a.no_train and a.model != "13b":
+        try:
+            sec, tl, mem, ntr = lora_leg(m, args, B, T, image, tokens, a.train_steps, dist, dev)
+            fl_t = flops_forward(args, B, T, W)
+            lora = {"samples_s": round(B * world / sec, 2), "ms_per_step": round(sec * 1e3, 1), "loss": round(tl, 4), "hbm_gib": round(mem, 1),
+                    "trainable_params": ntr, "tflops": round(2 * fl_t["total"] * world / sec / 1e12, 1),
+                    "mfma_frac": round(2 * fl_t["total"] / sec / MFMA_PEAK_BF16, 4),
+                    "config": f"configs[2]: LoRA r=16 on all 7 decoder linears + norms + projector trainable, base frozen bf16, bs={B}/GPU, dp{world}",
+                    "flop_convention": "2 x forward FLOPs (forward + input-gradient GEMMs; no weight-gradient GEMMs for frozen matrices)"}
+        except Exception as e:
+            lora = {"samples_s": None, "error": repr(e)[:300]}
     train = None
     if not a.no_train and a.model != "13b":
         try:
@@ -395,6 +477,7 @@ def main():
                                 "note": "bf16 weights once per step + KV of all sequences (SURVEY 8(d)); whole step incl. host launch gaps"},
         }
         out["train"] = train
+        out["train_lora"] = lora
         if not a.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, T, W, a.cpu_seconds)

@@ -240,6 +240,10 @@ int a3v_attention_bwd_mfma(const void* q, const void* k, int64_t k_sb, int64_t k
                            int H, int Hkv, int hd, int causal, void* stream);
 
 /* dst = (dst_dtype) src, 2-D with leading dimensions (fp32 grad stream -> bf16 GEMM operand). */
+/* dst[r, c] += src[r, c] (fp32 or bf16, cols % 4 == 0): accumulates the diagonal blocks of the fused LoRA gradient GEMMs
+ * into lora_a.weight.grad / lora_b.weight.grad (model/peft.py adapters) and performs the block's residual add
+ * `h + out` (LLM/llama_ens5.py:238,241) when the adapter sum must be rounded before it (peft.py:95). */
+int a3v_add2d(void* dst, int64_t ld_dst, const void* src, int64_t ld_src, int rows, int cols, int dtype, void* stream);
 int a3v_cast(const void* src, int64_t ld_src, int src_dtype, void* dst, int64_t ld_dst, int dst_dtype,
              int rows, int cols, void* stream);
 

@@ -631,3 +631,38 @@ def gen_2img():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "2img":
     gen_2img()
+
+
+def gen_lora():
+    """G13: the reference's LoRA linears (model/peft.py LoraLinear / LoraColumnParallelLinear / LoraRowParallelLinear at
+    MP=1) on seeded inputs -> tests/golden/lora_tiny.npz; pins y = W x (+ b) + B (A x) with no alpha/r scaling."""
+    refimport.install(data_stubs=True)
+    refimport.init_dist_ws1()
+    import sys as _sys
+    fs = _sys.modules["fairscale.nn.model_parallel.layers"]
+    import accessory.model.peft as peft
+    g = torch.Generator().manual_seed(41)
+    out = {}
+    for name, cls, kw in [("plain", peft.LoraLinear, dict(bias=True)), ("col", peft.LoraColumnParallelLinear, dict(bias=False, gather_output=False)),
+                          ("row", peft.LoraRowParallelLinear, dict(bias=False, input_is_parallel=True))]:
+        m = cls(48, 80, lora_rank=8, **kw)
+        w = torch.randn(80, 48, generator=g) * 0.1
+        a = torch.randn(8, 48, generator=g) * 0.1
+        b = torch.randn(80, 8, generator=g) * 0.1
+        x = torch.randn(5, 48, generator=g)
+        with torch.no_grad():
+            m.weight.copy_(w)
+            if getattr(m, "bias", None) is not None:
+                m.bias.zero_()
+            assert float(m.lora_b.weight.abs().sum()) == 0.0          # reference init: B = 0
+            m.lora_a.weight.copy_(a)
+            m.lora_b.weight.copy_(b)
+            y = m(x)
+        out[name + "_w"], out[name + "_a"], out[name + "_b"], out[name + "_x"], out[name + "_y"] = np32(w), np32(a), np32(b), np32(x), np32(y)
+        out[name + "_keys"] = np.array(sorted(m.state_dict().keys()))
+    np.savez_compressed(os.path.join(GOLD, "lora_tiny.npz"), **out)
+    print("lora fixture written", list(out["col_keys"]))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "lora":
+    gen_lora()

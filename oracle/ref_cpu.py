@@ -162,12 +162,19 @@ class OracleDecoder:
         self.cache_image_words = 0
 
     # LLM/llama_ens5.py:97-169
+    def lin(self, x: Tensor, name: str) -> Tensor:
+        """F.linear with the optional LoRA branch of model/peft.py:84-99: y = W x + lora_b(lora_a(x)), no alpha/r scale."""
+        y = F.linear(x, self.sd[name + ".weight"])
+        if name + ".lora_a.weight" in self.sd:
+            y = y + F.linear(F.linear(x, self.sd[name + ".lora_a.weight"]), self.sd[name + ".lora_b.weight"])
+        return y
+
     def attention(self, i: int, x: Tensor, start_pos: int, freqs_cis: Tensor, mask) -> Tensor:
         sd, p = self.sd, f"layers.{i}.attention."
         bsz, seqlen, _ = x.shape
-        xq = F.linear(x, sd[p + "wq.weight"]).view(bsz, seqlen, self.args.n_heads, self.head_dim)
-        xk = F.linear(x, sd[p + "wk.weight"]).view(bsz, seqlen, self.n_kv_heads, self.head_dim)
-        xv = F.linear(x, sd[p + "wv.weight"]).view(bsz, seqlen, self.n_kv_heads, self.head_dim)
+        xq = self.lin(x, p + "wq").view(bsz, seqlen, self.args.n_heads, self.head_dim)
+        xk = self.lin(x, p + "wk").view(bsz, seqlen, self.n_kv_heads, self.head_dim)
+        xv = self.lin(x, p + "wv").view(bsz, seqlen, self.n_kv_heads, self.head_dim)
         xq, xk = apply_rotary_emb(xq, xk, freqs_cis)
         if self.k_cache[i] is None:
             keys, values = xk, xv
@@ -183,13 +190,12 @@ class OracleDecoder:
         xq = xq.transpose(1, 2)
         m = make_causal_mask(xq.size(2), keys.size(2)) if mask == "causal" else None
         out = sdpa(xq, keys, values, m).transpose(1, 2).contiguous().view(bsz, seqlen, -1)
-        return F.linear(out, sd[p + "wo.weight"])
+        return self.lin(out, p + "wo")
 
     # LLM/llama_ens5.py:213-217
     def feed_forward(self, i: int, x: Tensor) -> Tensor:
-        sd, p = self.sd, f"layers.{i}.feed_forward."
-        return F.linear(F.silu(F.linear(x, sd[p + "w1.weight"])) * F.linear(x, sd[p + "w3.weight"]),
-                        sd[p + "w2.weight"])
+        p = f"layers.{i}.feed_forward."
+        return self.lin(F.silu(self.lin(x, p + "w1")) * self.lin(x, p + "w3"), p + "w2")
 
     # LLM/llama_ens5.py:237-249
     def block(self, i: int, x: Tensor, start_pos: int, freqs_cis: Tensor, mask) -> Tensor:
@@ -499,3 +505,23 @@ def make_vision_weights(dim: int, *, width: int, layers: int, patch: int, grid: 
     sd["start_img"] = torch.rand(1, 1, dim, generator=g).to(dtype)
     sd["end_img"] = torch.rand(1, 1, dim, generator=g).to(dtype)
     return sd
+
+
+def make_lora_weights(args, rank: int, seed: int = 0, std_a: float = 0.02, std_b: float = 0.02) -> Dict[str, Tensor]:
+    """LoRA adapters for the seven decoder linears of every layer (model/peft.py key names ``<linear>.lora_a.weight`` [r, in],
+    ``<linear>.lora_b.weight`` [out, r]).  The reference initialises lora_b to zero (:76); tests use a non-zero B so the
+    branch is exercised."""
+    g = torch.Generator().manual_seed(seed)
+    hd = args.dim // args.n_heads
+    n_kv = args.n_heads if args.n_kv_heads is None else args.n_kv_heads
+    ffn = ffn_hidden_dim(args.dim, args.multiple_of, args.ffn_dim_multiplier)
+    shapes = {"attention.wq": (args.n_heads * hd, args.dim), "attention.wk": (n_kv * hd, args.dim), "attention.wv": (n_kv * hd, args.dim),
+              "attention.wo": (args.dim, args.n_heads * hd), "feed_forward.w1": (ffn, args.dim), "feed_forward.w2": (args.dim, ffn),
+              "feed_forward.w3": (ffn, args.dim)}
+    sd = {}
+    for i in range(args.n_layers):
+        for name, (o, k) in shapes.items():
+            sd[f"layers.{i}.{name}.lora_a.weight"] = torch.randn(rank, k, generator=g) * std_a
+            sd[f"layers.{i}.{name}.lora_b.weight"] = torch.randn(o, rank, generator=g) * std_b
+    return sd
+

@@ -46,8 +46,9 @@ def test_transpose_and_cast(dtype):
 
 
 @pytest.mark.parametrize("act", [torch.float32, BF])
-def test_rmsnorm_bwd(act):
-    rows, dim = 45, 512
+@pytest.mark.parametrize("rows,dim", [(45, 512), (19, 4096), (9, 6144), (33, 130), (8, 1028)])
+def test_rmsnorm_bwd(act, rows, dim):
+    """vector kernel (dim % 4 == 0; 4 or 8 float4 per thread) and the scalar fallback (dim = 130)"""
     x = gen(rows, dim, seed=3, scale=2.0).requires_grad_(True)
     w = (1 + 0.1 * gen(dim, seed=4)).requires_grad_(True)
     dy = gen(rows, dim, seed=5).to(act)

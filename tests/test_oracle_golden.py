@@ -199,3 +199,15 @@ def test_g8b_two_image_plugin(golden_dir, tiny):
     l2 = d.forward_inference(ex[:, 7:8], 7)
     close(torch.stack([l0, l1, l2]), v["inf_logits"], atol=1e-4)
     close(d.forward_inference(ex[:, :6], 0), v["inf_logits_rgb_dropped"], atol=1e-4)
+
+
+def test_g13_lora_linear(golden_dir):
+    """model/peft.py: y = W x + lora_b(lora_a(x)) (no alpha / rank scaling), key names <linear>.lora_{a,b}.weight."""
+    v = np.load(os.path.join(golden_dir, "lora_tiny.npz"))
+    for name in ("plain", "col", "row"):
+        sd = {"l.weight": torch.from_numpy(v[name + "_w"]), "l.lora_a.weight": torch.from_numpy(v[name + "_a"]),
+              "l.lora_b.weight": torch.from_numpy(v[name + "_b"])}
+        d = ref_cpu.OracleDecoder.__new__(ref_cpu.OracleDecoder)
+        d.sd = sd
+        close(d.lin(torch.from_numpy(v[name + "_x"]), "l"), v[name + "_y"], atol=1e-5)
+        assert {"lora_a.weight", "lora_b.weight", "weight"} <= set(v[name + "_keys"].tolist())
