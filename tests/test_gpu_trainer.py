@@ -61,3 +61,24 @@ def test_main_finetune_dialog_dataset(tmp_path):
     assert "closs" in log and "total length: 13" in log
     line = json.loads(open(out / "log.txt").read().strip().splitlines()[-1])
     assert 0 < line["train_closs"] < 20
+
+
+def test_main_finetune_lora_only_save_trainable(tmp_path):
+    """--llama_type llama_ens5_peft: adapters + norms train, the base is frozen; --only_save_trainable writes just those keys
+    (util/misc.py:340-350) and the run resumes / reloads on top of a base checkpoint by name."""
+    import torch
+    gd = os.path.join(ROOT, "tests", "golden")
+    extra = tmp_path / "peft.json"
+    extra.write_text(json.dumps(dict(vit_width=64, vit_layers=2, vit_heads=4, vit_crop=112, n_views=1, lora_rank=8)))
+    out = tmp_path / "out"
+    log = run(["--llama_type", "llama_ens5_peft", "--llama_config", os.path.join(gd, "tiny_params.json"), str(extra),
+               "--tokenizer_path", os.path.join(gd, "tokenizer.model"), "--batch_size", "2", "--accum_iter", "1", "--epochs", "1",
+               "--warmup_epochs", "0.5", "--lr", "1e-3", "--min_lr", "0", "--clip_grad", "8", "--weight_decay", "0.0",
+               "--max_words", "120", "--precision", "bf16", "--output_dir", str(out), "--synthetic", "16", "--num_workers", "0",
+               "--dialog", "--model_parallel_size", "1", "--only_save_trainable"])
+    assert "closs" in log
+    sd = torch.load(out / "epoch0" / "consolidated.00-of-01.model.pth", weights_only=False)["model"]
+    keys = set(sd)
+    assert any("lora_a" in k for k in keys) and any("attention_norm" in k for k in keys) and "llma.visual_proj.0.weight" in keys
+    assert not any(k.endswith("attention.wq.weight") for k in keys) and "llma.tok_embeddings.weight" not in keys
+    assert json.load(open(out / "epoch0" / "meta.json"))["llama_type"] == "llama_ens5_peft"
