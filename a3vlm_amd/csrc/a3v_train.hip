@@ -30,6 +30,43 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ sr
   }
 }
 
+// bf16 fast path: 16-B global loads and stores, the 64 x 64 tile is transposed through LDS (row pitch 66 elements: the
+// eight 2-B column reads of a lane and the lanes of a wave fall on distinct banks).  C % 8 == 0, Rpad % 8 == 0, 16-B aligned.
+__global__ __launch_bounds__(256) void transpose_bf16_vec_kernel(const bf16_t* __restrict__ src, int64_t lds_, int64_t bs_s,
+                                                                 bf16_t* __restrict__ dst, int64_t ldd, int64_t bs_d, int R, int C, int Rpad) {
+  __shared__ uint32_t tile[64][33];                  // [row][column pair]: 66 bf16 per row
+  const bf16_t* s = src + blockIdx.z * bs_s;
+  bf16_t* d = dst + blockIdx.z * bs_d;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int idx = threadIdx.x + j * 256;
+    const int row = idx >> 3, c8 = (idx & 7) * 8;
+    const int r = r0 + row, c = c0 + c8;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (r < R && c < C) v = *reinterpret_cast<const u32x4*>(s + (int64_t)r * lds_ + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tile[row][(c8 >> 1) + e] = v[e];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int idx = threadIdx.x + j * 256;
+    const int c = idx >> 3, r8 = (idx & 7) * 8;
+    if (c0 + c < C && r0 + r8 < Rpad) {
+      const int sh = (c & 1) * 16;
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t lo = (tile[r8 + 2 * e][c >> 1] >> sh) & 0xffffu;
+        const uint32_t hi = (tile[r8 + 2 * e + 1][c >> 1] >> sh) & 0xffffu;
+        o[e] = lo | (hi << 16);
+      }
+      *reinterpret_cast<u32x4*>(d + (int64_t)(c0 + c) * ldd + r0 + r8) = o;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ RMSNorm backward
 // y = w * x * r, r = rsqrt(mean(x^2)+eps).  dx = r*dy*w - x * r^3 * sum(dy*w*x)/dim  (added into dh);
 // dw[j] += sum_rows dy*x*r  (thread-private partial over the block's rows, one atomic per column per block)
@@ -476,6 +513,12 @@ extern "C" int a3v_transpose(const void* src, int64_t ld_src, int64_t bs_src, vo
                              int R, int C, int Rpad, int batch, int dtype, void* stream) {
   if (!src || !dst || R <= 0 || C <= 0 || Rpad < R || batch <= 0) return A3V_ERR_ARG;
   dim3 g((C + 63) / 64, (Rpad + 63) / 64, batch);
+  if (dtype == A3V_BF16 && C % 8 == 0 && Rpad % 8 == 0 && ld_src % 8 == 0 && ld_dst % 8 == 0 && bs_src % 8 == 0 && bs_dst % 8 == 0 &&
+      ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0) {
+    hipLaunchKernelGGL(transpose_bf16_vec_kernel, g, dim3(256), 0, ST, (const bf16_t*)src, ld_src, bs_src, (bf16_t*)dst, ld_dst, bs_dst, R, C, Rpad);
+    A3V_LAUNCH_CHECK();
+    return A3V_OK;
+  }
   if (dtype == A3V_BF16) hipLaunchKernelGGL(transpose_kernel<bf16_t>, g, dim3(256), 0, ST, (const bf16_t*)src, ld_src, bs_src, (bf16_t*)dst, ld_dst, bs_dst, R, C, Rpad);
   else if (dtype == A3V_F32) hipLaunchKernelGGL(transpose_kernel<float>, g, dim3(256), 0, ST, (const float*)src, ld_src, bs_src, (float*)dst, ld_dst, bs_dst, R, C, Rpad);
   else return A3V_ERR_DTYPE;

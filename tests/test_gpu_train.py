@@ -39,6 +39,13 @@ def test_transpose_and_cast(dtype):
     ops.transpose(xd, out, 70, 130, 128, batch=3, bs_src=70 * 130, bs_dst=130 * 128)
     assert torch.equal(out[:, :, :70].cpu(), x.transpose(1, 2))
     assert float(out[:, :, 70:].float().abs().sum()) == 0
+    # vector path (bf16, C % 8 == 0, Rpad % 8 == 0): ragged R, strided source rows, several tiles
+    for (R, C, Rp, ld) in [(70, 136, 128, 136), (8728 // 8, 256, 1152, 320), (5, 64, 64, 64), (200, 4096, 256, 4096)]:
+        z = gen(R, ld, seed=7).to(dtype)
+        zd = z.to(DEV)
+        o2 = torch.full((C, Rp), 3.0, dtype=dtype, device=DEV)
+        ops.transpose(zd[:, :C], o2, R, C, Rp)
+        assert torch.equal(o2[:, :R].cpu(), z[:, :C].t()) and float(o2[:, R:].float().abs().sum()) == 0
     y = gen(37, 64, seed=2)
     yb = torch.empty(37, 64, dtype=BF, device=DEV)
     ops.cast(y.to(DEV), yb)
