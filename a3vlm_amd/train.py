@@ -39,6 +39,8 @@ class TrainEngine:
         self._flat: Optional[torch.Tensor] = None
         self._views: Dict[str, torch.Tensor] = {}
         self._ranges: List[Tuple[str, int, int]] = []       # (bucket name, start, end) in the flat grad buffer
+        self._fresh: set = set()                            # grads attached this step whose storage is still undefined
+        self._gemm_written: set = set()                     # names whose gradient comes from exactly one wgrad GEMM per micro-step
         self.on_layer_grads_ready: Optional[Callable[[str, int, int], None]] = None
         self._saved = None
 
@@ -113,6 +115,8 @@ class TrainEngine:
             for name, (o, p) in offs.items():
                 self._views[name] = self._flat[o:o + p.numel()].view(p.shape)
             self._params = {name: p for name, (o, p) in offs.items()}
+            self._gemm_written = {n for n in self._params if n == "output.weight" or (n.startswith("layers.") and n.endswith(
+                ("wq.weight", "wk.weight", "wv.weight", "wo.weight", "w1.weight", "w2.weight", "w3.weight")) and "lora_" not in n)}
         for name, p in self._params.items():
             if not p.requires_grad:
                 if p.grad is not None and p.grad.data_ptr() == self._views[name].data_ptr():
@@ -120,7 +124,12 @@ class TrainEngine:
                 continue
             v = self._views[name]
             if p.grad is None:
-                v.zero_()
+                # big decoder / head matrices are written (not accumulated) by their first weight-gradient GEMM of the
+                # step: no 27 GB zero-fill and no read of the old value.  Everything else is zeroed here.
+                if name in self._gemm_written:
+                    self._fresh.add(name)
+                else:
+                    v.zero_()
                 p.grad = v
             elif p.grad.data_ptr() != v.data_ptr():
                 raise RuntimeError(f"{name}.grad was replaced by a foreign tensor; use zero_grad(set_to_none=True) or keep the views")
@@ -182,8 +191,8 @@ class TrainEngine:
         return im
 
     # ------------------------------------------------------------------ GEMM helpers
-    def _wgrad(self, dy: torch.Tensor, x: torch.Tensor, grad: torch.Tensor, tag: str):
-        """grad[N,K] (fp32) += dy[M,N]^T @ x[M,K]."""
+    def _wgrad(self, dy: torch.Tensor, x: torch.Tensor, grad: torch.Tensor, tag: str, names=()):
+        """grad[N,K] (fp32) += dy[M,N]^T @ x[M,K]; plain store when every parameter in ``names`` is fresh this step."""
         M, N = dy.shape
         K = x.shape[1]
         Mp = _pad64(M)
@@ -191,7 +200,12 @@ class TrainEngine:
         xt = self._buf("wg_xt" + tag, (K, Mp))
         ops.transpose(dy, dyt, M, N, Mp)
         ops.transpose(x, xt, M, K, Mp)
-        ops.gemm_nt(dyt, xt, grad, residual=grad, epilogue=ops.EPI_RES_F32 if self.act == torch.bfloat16 else 0)
+        if names and all(n in self._fresh for n in names):
+            self._fresh.difference_update(names)
+            ops.gemm_nt(dyt, xt, grad, epilogue=ops.EPI_OUT_F32 if self.act == torch.bfloat16 else 0)
+        else:
+            assert not any(n in self._fresh for n in names), "partially fresh fused gradient view"
+            ops.gemm_nt(dyt, xt, grad, residual=grad, epilogue=ops.EPI_RES_F32 if self.act == torch.bfloat16 else 0)
 
     def _dgrad(self, dy: torch.Tensor, wt: torch.Tensor, out: torch.Tensor):
         """out[M,K] = dy[M,N] @ W[N,K] with wt = W^T [K, Np]; dy may have N < Np columns -> padded copy."""
@@ -333,7 +347,7 @@ class TrainEngine:
         ops.cast(dh, dha)
         lt = k.get("lt", {})
         if self._has(pre + "feed_forward.w2.weight"):
-            self._wgrad(dha, k["act"], self._views[pre + "feed_forward.w2.weight"], "w2")
+            self._wgrad(dha, k["act"], self._views[pre + "feed_forward.w2.weight"], "w2", (pre + "feed_forward.w2.weight",))
         dact = self._buf("dact", (rows, F))
         self._dgrad(dha, im[f"w2.{i}.t"], dact)
         if self.lora:
@@ -341,7 +355,8 @@ class TrainEngine:
         dgu = self._buf("dgu", (rows, 2 * F))
         ops.swiglu_bwd(k["gu"], dact, dgu, F, interleaved=False)
         if self._has(pre + "feed_forward.w1.weight", pre + "feed_forward.w3.weight"):
-            self._wgrad(dgu, k["xn2"], self._gview(pre + "feed_forward.w1.weight", pre + "feed_forward.w3.weight"), "w13")
+            self._wgrad(dgu, k["xn2"], self._gview(pre + "feed_forward.w1.weight", pre + "feed_forward.w3.weight"), "w13",
+                        (pre + "feed_forward.w1.weight", pre + "feed_forward.w3.weight"))
         dxn = self._buf("dxn", (rows, dim))
         self._dgrad(dgu, im[f"w13.{i}.t"], dxn)
         if self.lora:
@@ -350,7 +365,7 @@ class TrainEngine:
         # ---- attention: h_mid = h_in + wo(attn(rope(qkv(norm(h_in)))))
         ops.cast(dh, dha)
         if self._has(pre + "attention.wo.weight"):
-            self._wgrad(dha, k["att"], self._views[pre + "attention.wo.weight"], "wo")
+            self._wgrad(dha, k["att"], self._views[pre + "attention.wo.weight"], "wo", (pre + "attention.wo.weight",))
         datt = self._buf("datt", (rows, H * hd))
         self._dgrad(dha, im[f"wo.{i}.t"], datt)
         if self.lora:
@@ -371,7 +386,8 @@ class TrainEngine:
         dqkv = self._buf("dqkv", (rows, (H + 2 * Hkv) * hd))
         ops.rope_bwd_pack(dq, dk, dv, dqkv, m._cos_sin_dev(), B, S, H, Hkv, hd, 0)
         if self._has(pre + "attention.wq.weight", pre + "attention.wk.weight", pre + "attention.wv.weight"):
-            self._wgrad(dqkv, k["xn"], self._gview(pre + "attention.wq.weight", pre + "attention.wv.weight"), "qkv")
+            self._wgrad(dqkv, k["xn"], self._gview(pre + "attention.wq.weight", pre + "attention.wv.weight"), "qkv",
+                        (pre + "attention.wq.weight", pre + "attention.wk.weight", pre + "attention.wv.weight"))
         self._dgrad(dqkv, im[f"qkv.{i}.t"], dxn)
         if self.lora:
             self._lora_bwd(i, f"qkv.{i}", dqkv, k["xn"], lt["qkv"], dxn)
@@ -441,7 +457,7 @@ class TrainEngine:
         dlog = self._buf("dlogits", (B * T, V))
         ops.cross_entropy(s["logits"], s["lab"], self._buf("row_loss", (B * T,), torch.float32), dlog, s["n_valid"], grad_scale)
         if self._has("output.weight"):
-            self._wgrad(dlog, s["xt"], self._views["output.weight"], "out")
+            self._wgrad(dlog, s["xt"], self._views["output.weight"], "out", ("output.weight",))
         dxt = self._buf("dxn_text", (B * T, dim))
         self._dgrad(dlog, im["out.t"], dxt)
         dh = self._buf("dh", (rows, dim), torch.float32, zero=True)

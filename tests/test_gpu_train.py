@@ -253,6 +253,14 @@ def test_train_step_fp32_matches_autograd(with_visual, recompute):
     eng.backward(0.5)
     assert relerr(m.layers[0].feed_forward.w2.weight.grad, 1.5 * want["layers.0.feed_forward.w2.weight"]) < 1e-3
     assert relerr(m.tok_embeddings.weight.grad, 1.5 * want["tok_embeddings.weight"]) < 1e-3
+    # zero_grad(set_to_none=True) then a new step: the big matrices are WRITTEN by their first weight-gradient GEMM (their
+    # storage still holds the previous step's values), everything else is re-zeroed -> exactly one step's gradient again
+    for p in m.parameters():
+        p.grad = None
+    eng.forward_loss(ex.to(DEV), lab.to(DEV), img.to(DEV) if with_visual else None)
+    eng.backward(1.0)
+    for name, p in m.get_trainable_params().items():
+        assert relerr(p.grad, want[name]) < 1e-3, name
 
 
 def test_train_step_bf16_close_to_fp32_reference():
