@@ -9,7 +9,7 @@
 //      S^T  = K . Q^T ,  dP^T = V . dO^T            (A = K / V rows from LDS, B = Q / dO in registers)
 //      P^T  = exp(S^T*scale - lse[q]) ;  dS^T = P^T o (dP^T - D[q]) * scale     (lane-local)
 //      dQ^T += K^T . dS^T                            (A = K^T rows from LDS, B = dS^T from the accumulators)
-//  dK/dV kernel (grid over kv tiles; loops over queries and the n_rep query heads):   lane <-> key
+//  dK/dV kernels (grid over kv tiles; loop over queries and the n_rep query heads; one launch per output):   lane <-> key
 //      S    = Q . K^T ,  dP = dO . V^T               (A = Q / dO rows from LDS, B = K / V in registers)
 //      P, dS with lse[q], D[q] per REGISTER row (read from LDS)
 //      dV^T += dO^T . P ,  dK^T += Q^T . dS          (A = dO^T / Q^T rows from LDS, B = P / dS)
@@ -98,7 +98,7 @@ __device__ __forceinline__ bf16x8 frag_cols(const char* lds, int db, int tb, int
 
 // ------------------------------------------------------------------ dQ
 template <int HD>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BwdArgs p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs p) {
   constexpr int TILE = 64 * HD * 2;                 // bytes of one 64-row tile (== HD x 128 B)
   __shared__ __attribute__((aligned(16))) char lds[3 * TILE];
   char* Ks = lds; char* Vs = lds + TILE; char* Kts = lds + 2 * TILE;
@@ -136,27 +136,27 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BwdArgs p) {
     stage_rows<HD>(V, p.v_ss, kv0, p.S, Vs, tid);
     stage_cols<HD>(KT, p.Sp, kv0, p.S, Kts, tid);
     __syncthreads();
-    f32x16 s[2], dp[2];
-#pragma unroll
-    for (int tb = 0; tb < 2; ++tb) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { s[tb][r] = 0.f; dp[tb][r] = 0.f; }
-#pragma unroll
-      for (int ks = 0; ks < HD / 16; ++ks) {
-        s[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<HD>(Ks, tb, ks, ql, hh), qf[ks], s[tb], 0, 0, 0);
-        dp[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<HD>(Vs, tb, ks, ql, hh), dof[ks], dp[tb], 0, 0, 0);
-      }
-    }
+    // one 32-key block at a time: S^T and dP^T accumulators (32 VGPRs) are dead before the next block starts, which keeps
+    // the kernel under 256 VGPRs = two waves per SIMD
     bf16x8 dsf[2][2];
 #pragma unroll
-    for (int tb = 0; tb < 2; ++tb)
+    for (int tb = 0; tb < 2; ++tb) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < HD / 16; ++ks) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<HD>(Ks, tb, ks, ql, hh), qf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<HD>(Vs, tb, ks, ql, hh), dof[ks], dp, 0, 0, 0);
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int kv = kv0 + tb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
         const bool ok = (kv < p.S) && (!p.causal || kv <= qrow);
-        const float pr = ok ? __expf(s[tb][r] * p.scale - lse) : 0.f;
-        dsf[tb][r >> 3][r & 7] = f2bf(pr * (dp[tb][r] - Dq) * p.scale);
+        const float pr = ok ? __expf(s[r] * p.scale - lse) : 0.f;
+        dsf[tb][r >> 3][r & 7] = f2bf(pr * (dp[r] - Dq) * p.scale);
       }
+    }
 #pragma unroll
     for (int d = 0; d < HD / 32; ++d)
 #pragma unroll
@@ -180,12 +180,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BwdArgs p) {
 }
 
 // ------------------------------------------------------------------ dK, dV
-template <int HD>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(BwdArgs p) {
+// Two specialisations of one kernel, launched back to back: WHICH == 0 accumulates dV (needs S only), WHICH == 1
+// accumulates dK (needs S and dP).  Each keeps ONE [HD x 32-key] accumulator set (64 VGPRs) instead of two, which brings
+// the kernel under 256 VGPRs = two waves per SIMD and cuts the LDS tiles staged per query tile from four to two / three;
+// the price is one extra S^T recompute (5 instead of 4 tile products), paid back ~1.5x by the doubled occupancy.
+template <int HD, int WHICH>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs p) {
   constexpr int TILE = 64 * HD * 2;
-  __shared__ __attribute__((aligned(16))) char lds[4 * TILE + 512];
-  char* Qs = lds; char* DOs = lds + TILE; char* Qts = lds + 2 * TILE; char* DOts = lds + 3 * TILE;
-  float* lse_s = reinterpret_cast<float*>(lds + 4 * TILE);       // [64]
+  constexpr int NT = WHICH == 0 ? 2 : 3;
+  __shared__ __attribute__((aligned(16))) char lds[NT * TILE + 512];
+  char* Qs = lds;
+  char* T1 = lds + TILE;                    // dV: dO^T tile; dK: dO tile
+  char* T2 = lds + (NT - 1) * TILE;         // dK: Q^T tile
+  float* lse_s = reinterpret_cast<float*>(lds + NT * TILE);      // [64]
   float* D_s = lse_s + 64;                                       // [64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kt_ = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
@@ -195,17 +202,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(BwdArgs p) {
   const int kc = kvrow < p.S ? kvrow : p.S - 1;
   const bf16_t* Kr = p.k + b * p.k_sb + hk * p.k_sh + (int64_t)kc * HD;
   const bf16_t* Vr = p.v + b * p.v_sb + hk * p.v_sh + (int64_t)kc * p.v_ss;
-  bf16x8 kf[HD / 16], vf[HD / 16];
+  bf16x8 kf[HD / 16], vf[WHICH == 1 ? HD / 16 : 1];
 #pragma unroll
   for (int ks = 0; ks < HD / 16; ++ks) {
     kf[ks] = *reinterpret_cast<const bf16x8*>(Kr + ks * 16 + hh * 8);
-    vf[ks] = *reinterpret_cast<const bf16x8*>(Vr + ks * 16 + hh * 8);
+    if (WHICH == 1) vf[ks] = *reinterpret_cast<const bf16x8*>(Vr + ks * 16 + hh * 8);
   }
-  f32x16 dkacc[HD / 32], dvacc[HD / 32];
+  f32x16 acc[HD / 32];
 #pragma unroll
   for (int d = 0; d < HD / 32; ++d)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { dkacc[d][r] = 0.f; dvacc[d][r] = 0.f; }
+    for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
   const int q_begin = p.causal ? (kt_ * 128) / 64 : 0;      // first q tile that can see this block's keys
   const int n_qt = (p.S + 63) / 64;
   for (int rep = 0; rep < nrep; ++rep) {
@@ -218,61 +225,67 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(BwdArgs p) {
       const int q0 = t * 64;
       __syncthreads();
       stage_rows<HD>(Q, (int64_t)p.H * HD, q0, p.S, Qs, tid);
-      stage_rows<HD>(DO, (int64_t)p.H * HD, q0, p.S, DOs, tid);
-      stage_cols<HD>(QT, p.Sp, q0, p.S, Qts, tid);
-      stage_cols<HD>(DOT, p.Sp, q0, p.S, DOts, tid);
+      if (WHICH == 0) {
+        stage_cols<HD>(DOT, p.Sp, q0, p.S, T1, tid);
+      } else {
+        asm volatile("" ::: "memory");       // one tile's staging registers at a time (VGPR budget of two waves per SIMD)
+        stage_rows<HD>(DO, (int64_t)p.H * HD, q0, p.S, T1, tid);
+        asm volatile("" ::: "memory");
+        stage_cols<HD>(QT, p.Sp, q0, p.S, T2, tid);
+      }
       if (tid < 64) {
         const int qq = min(q0 + tid, p.S - 1);
         lse_s[tid] = p.lse[((int64_t)b * p.H + h) * p.S + qq];
-        D_s[tid] = p.D[((int64_t)b * p.S + qq) * p.H + h];
+        if (WHICH == 1) D_s[tid] = p.D[((int64_t)b * p.S + qq) * p.H + h];
       }
       __syncthreads();
-      f32x16 s[2], dp[2];
+      bf16x8 bf[2][2];                       // P (dV) or dS (dK) as the B operand of the accumulation products
 #pragma unroll
       for (int tb = 0; tb < 2; ++tb) {
+        f32x16 s, dp;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s[tb][r] = 0.f; dp[tb][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
         for (int ks = 0; ks < HD / 16; ++ks) {
-          s[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<HD>(Qs, tb, ks, kl, hh), kf[ks], s[tb], 0, 0, 0);
-          dp[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<HD>(DOs, tb, ks, kl, hh), vf[ks], dp[tb], 0, 0, 0);
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<HD>(Qs, tb, ks, kl, hh), kf[ks], s, 0, 0, 0);
+          if (WHICH == 1) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<HD>(T1, tb, ks, kl, hh), vf[ks], dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int qb = tb * 32 + 8 * g4 + 4 * hh;                       // 4 consecutive query rows of the tile
+          const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qb);
+          f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
+          if (WHICH == 1) d4 = *reinterpret_cast<const f32x4*>(D_s + qb);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = g4 * 4 + e;
+            const int qg = q0 + qb + e;
+            const bool ok = (qg < p.S) && (kvrow < p.S) && (!p.causal || kvrow <= qg);
+            const float pr = ok ? __expf(s[r] * p.scale - l4[e]) : 0.f;
+            bf[tb][r >> 3][r & 7] = WHICH == 0 ? f2bf(pr) : f2bf(pr * (dp[r] - d4[e]) * p.scale);
+          }
         }
       }
-      bf16x8 pf[2][2], dsf[2][2];
-#pragma unroll
-      for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int ql_ = tb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;      // query row inside the tile
-          const int qg = q0 + ql_;
-          const bool ok = (qg < p.S) && (kvrow < p.S) && (!p.causal || kvrow <= qg);
-          const float pr = ok ? __expf(s[tb][r] * p.scale - lse_s[ql_]) : 0.f;
-          pf[tb][r >> 3][r & 7] = f2bf(pr);
-          dsf[tb][r >> 3][r & 7] = f2bf(pr * (dp[tb][r] - D_s[ql_]) * p.scale);
-        }
+      const char* At = WHICH == 0 ? T1 : T2;
 #pragma unroll
       for (int d = 0; d < HD / 32; ++d)
 #pragma unroll
         for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
-          for (int c = 0; c < 2; ++c) {
-            dvacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(DOts, d, tb, c, kl, hh), pf[tb][c], dvacc[d], 0, 0, 0);
-            dkacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(Qts, d, tb, c, kl, hh), dsf[tb][c], dkacc[d], 0, 0, 0);
-          }
+          for (int c = 0; c < 2; ++c)
+            acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(At, d, tb, c, kl, hh), bf[tb][c], acc[d], 0, 0, 0);
     }
   }
   if (kvrow < p.S) {
-    bf16_t* DK = p.dk + (((int64_t)b * p.Hkv + hk) * p.S + kvrow) * HD;
-    bf16_t* DV = p.dv + (((int64_t)b * p.Hkv + hk) * p.S + kvrow) * HD;
+    bf16_t* O = (WHICH == 0 ? p.dv : p.dk) + (((int64_t)b * p.Hkv + hk) * p.S + kvrow) * HD;
 #pragma unroll
     for (int d = 0; d < HD / 32; ++d)
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
-        bf16x4 a, c;
+        bf16x4 a;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { a[e] = f2bf(dkacc[d][g4 * 4 + e]); c[e] = f2bf(dvacc[d][g4 * 4 + e]); }
-        *reinterpret_cast<bf16x4*>(DK + d * 32 + g4 * 8 + hh * 4) = a;
-        *reinterpret_cast<bf16x4*>(DV + d * 32 + g4 * 8 + hh * 4) = c;
+        for (int e = 0; e < 4; ++e) a[e] = f2bf(acc[d][g4 * 4 + e]);
+        *reinterpret_cast<bf16x4*>(O + d * 32 + g4 * 8 + hh * 4) = a;
       }
   }
 }
@@ -320,10 +333,12 @@ extern "C" int a3v_attention_bwd_mfma(const void* q, const void* k, int64_t k_sb
   dim3 gq((S + 127) / 128, H, B), gk((S + 127) / 128, Hkv, B);
   if (hd == 128) {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, gq, dim3(256), 0, st, p);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, gk, dim3(256), 0, st, p);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 0>), gk, dim3(256), 0, st, p);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 1>), gk, dim3(256), 0, st, p);
   } else {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, gq, dim3(256), 0, st, p);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, gk, dim3(256), 0, st, p);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, 0>), gk, dim3(256), 0, st, p);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, 1>), gk, dim3(256), 0, st, p);
   }
   A3V_LAUNCH_CHECK();
   return A3V_OK;
