@@ -39,9 +39,8 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_bf16_kernel(AttnArgs p) {
   constexpr int KCH = HD / 8;             // 16-B chunks per K row
   constexpr int K_LOADS = KVB * KCH / 256;   // 16-B chunks per thread (4 for HD=128, 2 for 64)
   constexpr int V_LOADS = HD * 8 / 256;      // V^T tile: HD rows x 8 chunks of 16 B
-  __shared__ __attribute__((aligned(16))) char lds[KVB * KROW + HD * 128];
-  char* Ks = lds;
-  char* Vs = lds + KVB * KROW;
+  constexpr int TILEB = KVB * KROW + HD * 128;   // K tile + V^T tile
+  __shared__ __attribute__((aligned(1024))) char lds[2 * TILEB];   // double buffered: tile t+1 lands by LDS-DMA while tile t is consumed
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int qt = gridDim.x - 1 - blockIdx.x;   // heavy (late) causal tiles first
@@ -107,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_bf16_kernel(AttnArgs p) {
       vreg[i] = v;
     }
   };
-  auto write_tile = [&]() {
+  auto write_tile = [&](char* Ks, char* Vs) {
 #pragma unroll
     for (int i = 0; i < K_LOADS; ++i) {
       const int id = tid + i * 256;
@@ -119,22 +118,51 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_bf16_kernel(AttnArgs p) {
     for (int i = 0; i < V_LOADS; ++i) {
       const int id = tid + i * 256;
       const int d = id >> 3, ch = id & 7;
-      const int g = (d >> 1) & 15;
-      u32x2 lo = {vreg[i][0], vreg[i][1]}, hi = {vreg[i][2], vreg[i][3]};
-      *reinterpret_cast<u32x2*>(Vs + d * 128 + (((2 * ch) ^ g) << 3)) = lo;
-      *reinterpret_cast<u32x2*>(Vs + d * 128 + (((2 * ch + 1) ^ g) << 3)) = hi;
+      *reinterpret_cast<u32x4*>(Vs + d * 128 + ((ch ^ ((d >> 1) & 7)) << 4)) = vreg[i];
     }
   };
+  // LDS-DMA form of load_tile + write_tile for tiles whose 64 keys all exist (kv0 + 64 <= Sk): the chunk permutation is
+  // applied on the per-lane SOURCE address (DMA destinations are lane-linear), no VGPRs are held while the tile is in flight.
+  auto dma_tile = [&](int kv0, char* Ks, char* Vs) {
+#pragma unroll
+    for (int i = 0; i < K_LOADS; ++i) {
+      const int id = tid + i * 256;
+      const int row = id / KCH, slot = id % KCH;
+      const int sw = (HD == 128) ? (row & 15) : ((row >> 1) & 7);
+      const bf16_t* src = K + (int64_t)(kv0 + row) * p.k_ss + (slot ^ sw) * 8;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(Ks + (wave * 64 + i * 256) * 16), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < V_LOADS; ++i) {
+      const int id = tid + i * 256;
+      const int d = id >> 3, slot = id & 7;
+      const bf16_t* src = VT + (int64_t)d * p.v_sd + kv0 + (slot ^ ((d >> 1) & 7)) * 8;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(Vs + (wave * 64 + i * 256) * 16), 16, 0, 0);
+    }
+  };
+  auto full_tile = [&](int t) { return t * KVB + KVB <= p.Sk; };
 
-  // Two waves per SIMD (launch bound below) hide the staging latency across blocks; a register prefetch of the
-  // next tile costs 32 VGPRs, pushes the kernel to one wave per SIMD and measured 37 % slower (356 vs 252 us at
-  // 8 x 32 heads x 1091 tokens, tools/attn_bench.py).
+  // Software pipeline: the DMA of tile t+1 is issued before tile t is consumed (two LDS buffers, no staging registers), so
+  // a block no longer stalls a full global-load latency per tile.  A ragged last tile (keys past Sk inside it) takes the
+  // register path, which zero-fills the missing V^T columns.
+  if (n_tiles > 0 && full_tile(0)) dma_tile(0, lds, lds + KVB * KROW);
   for (int t = 0; t < n_tiles; ++t) {
     const int kv0 = t * KVB;
-    load_tile(kv0);
-    __syncthreads();
-    write_tile();
-    __syncthreads();
+    char* Ks = lds + (t & 1) * TILEB;
+    char* Vs = Ks + KVB * KROW;
+    const bool next_dma = t + 1 < n_tiles && full_tile(t + 1);
+    if (next_dma) dma_tile(kv0 + KVB, lds + ((t + 1) & 1) * TILEB, lds + ((t + 1) & 1) * TILEB + KVB * KROW);
+    if (full_tile(t)) {
+      if (next_dma) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K_LOADS + V_LOADS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    } else {
+      load_tile(kv0);
+      write_tile(Ks, Vs);
+      __syncthreads();
+    }
 
     // ---- S^T = K . Q^T : two 32-row kv blocks ----
     f32x16 s[2];
@@ -153,29 +181,39 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_bf16_kernel(AttnArgs p) {
     }
     // ---- mask + online softmax (lane owns query column ql; kv = 32tb + (r&3)+8(r>>2)+4hh) ----
     const int qlim = CAUSAL ? (qrow + off) : 0x7fffffff;
+    // interior tiles (every key of the tile visible to every query row of this wave) skip the 32 compare/selects
+    const bool need_mask = (kv0 + KVB > p.Sk) || (CAUSAL && kv0 + KVB - 1 > q0 + off);
     float mx = -INFINITY;
+    if (need_mask) {
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kv = kv0 + tb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          const bool ok = (kv < p.Sk) && (kv <= qlim);
+          s[tb][r] = ok ? s[tb][r] : -INFINITY;
+        }
+    }
 #pragma unroll
     for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kv = kv0 + tb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        const bool ok = (kv < p.Sk) && (kv <= qlim);
-        s[tb][r] = ok ? s[tb][r] : -INFINITY;
-        mx = fmaxf(mx, s[tb][r]);
-      }
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[tb][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
     // rows past Sq (clamped duplicates) and fully-masked tiles keep m finite once any tile was seen
     const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = exp2f((m_run - m_use) * p.scale_log2);
+    // raw v_exp_f32 (the arguments are <= 0 and results below the denormal range flush to 0, which is what a probability
+    // that small should do; exp2f() wraps every call in a range fix-up: +4 VALU per element)
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * p.scale_log2);
     m_run = m_new;
     float lsum = 0.f;
+    const float mb = m_use * p.scale_log2;
     bf16x8 pf[2][2];
 #pragma unroll
     for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = exp2f((s[tb][r] - m_use) * p.scale_log2);
+        const float pv = __builtin_amdgcn_exp2f(fmaf(s[tb][r], p.scale_log2, -mb));
         lsum += pv;
         pf[tb][r >> 3][r & 7] = f2bf(pv);
       }
@@ -188,21 +226,22 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_bf16_kernel(AttnArgs p) {
 #pragma unroll
     for (int d = 0; d < HD / 32; ++d) {
       const int drow = d * 32 + ql;
-      const int g = (drow >> 1) & 15;
-      const char* vp = Vs + drow * 128;
+      const int g = (drow >> 1) & 7;
+      const char* vp = Vs + drow * 128 + hh * 8;
 #pragma unroll
       for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-          const int ca = 8 * tb + 4 * c + hh;
-          const u32x2 a0 = *reinterpret_cast<const u32x2*>(vp + ((ca ^ g) << 3));
-          const u32x2 a1 = *reinterpret_cast<const u32x2*>(vp + (((ca + 2) ^ g) << 3));
+          const int c16 = 4 * tb + 2 * c;      // 16-B chunk of kv columns {0..7}; lane half hh takes its 8-B half (k = 4hh..4hh+3)
+          const u32x2 a0 = *reinterpret_cast<const u32x2*>(vp + ((c16 ^ g) << 4));
+          const u32x2 a1 = *reinterpret_cast<const u32x2*>(vp + (((c16 + 1) ^ g) << 4));
           const u32x4 av = {a0[0], a0[1], a1[0], a1[1]};
           bf16x8 vf;
           __builtin_memcpy(&vf, &av, 16);
           o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[tb][c], o[d], 0, 0, 0);
         }
     }
+    __syncthreads();      // every wave is done with this buffer before the DMA of tile t+2 (issued next iteration) overwrites it
   }
 
   // ---- normalise and store O[q][d], d = 32*db + 8*g + 4*hh + {0..3} ----
