@@ -119,7 +119,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs p) {
     qf[ks] = *reinterpret_cast<const bf16x8*>(Q + ks * 16 + hh * 8);
     dof[ks] = *reinterpret_cast<const bf16x8*>(DO + ks * 16 + hh * 8);
   }
-  const float lse = p.lse[((int64_t)b * p.H + h) * p.S + qc];
+  const float lse2 = p.lse[((int64_t)b * p.H + h) * p.S + qc] * 1.4426950408889634f;
+  const float sl2 = p.scale * 1.4426950408889634f;
   const float Dq = p.D[((int64_t)b * p.S + qc) * p.H + h];
   f32x16 acc[HD / 32];
 #pragma unroll
@@ -149,12 +150,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs p) {
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<HD>(Ks, tb, ks, ql, hh), qf[ks], s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<HD>(Vs, tb, ks, ql, hh), dof[ks], dp, 0, 0, 0);
       }
+      // P = exp2(s * scale*log2e - lse*log2e) with the raw v_exp_f32; interior tiles (all 64 keys visible to all 32 query
+      // rows of the wave) skip the compare/select per element
+      const bool need_mask = (kv0 + 64 > p.S) || (p.causal && kv0 + 63 > qt * 128 + wave * 32);
+      if (need_mask) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kv = kv0 + tb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        const bool ok = (kv < p.S) && (!p.causal || kv <= qrow);
-        const float pr = ok ? __expf(s[r] * p.scale - lse) : 0.f;
-        dsf[tb][r >> 3][r & 7] = f2bf(pr * (dp[r] - Dq) * p.scale);
+        for (int r = 0; r < 16; ++r) {
+          const int kv = kv0 + tb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          const bool ok = (kv < p.S) && (!p.causal || kv <= qrow);
+          const float pr = ok ? __builtin_amdgcn_exp2f(fmaf(s[r], sl2, -lse2)) : 0.f;
+          dsf[tb][r >> 3][r & 7] = f2bf(pr * (dp[r] - Dq) * p.scale);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pr = __builtin_amdgcn_exp2f(fmaf(s[r], sl2, -lse2));
+          dsf[tb][r >> 3][r & 7] = f2bf(pr * (dp[r] - Dq) * p.scale);
+        }
       }
     }
 #pragma unroll
@@ -213,6 +225,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs p) {
   for (int d = 0; d < HD / 32; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+  const float sl2 = p.scale * 1.4426950408889634f;
   const int q_begin = p.causal ? (kt_ * 128) / 64 : 0;      // first q tile that can see this block's keys
   const int n_qt = (p.S + 63) / 64;
   for (int rep = 0; rep < nrep; ++rep) {
@@ -235,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs p) {
       }
       if (tid < 64) {
         const int qq = min(q0 + tid, p.S - 1);
-        lse_s[tid] = p.lse[((int64_t)b * p.H + h) * p.S + qq];
+        lse_s[tid] = p.lse[((int64_t)b * p.H + h) * p.S + qq] * 1.4426950408889634f;
         if (WHICH == 1) D_s[tid] = p.D[((int64_t)b * p.S + qq) * p.H + h];
       }
       __syncthreads();
@@ -253,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs p) {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
           const int qb = tb * 32 + 8 * g4 + 4 * hh;                       // 4 consecutive query rows of the tile
-          const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qb);
+          const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qb);   // lse * log2(e)
           f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
           if (WHICH == 1) d4 = *reinterpret_cast<const f32x4*>(D_s + qb);
 #pragma unroll
@@ -261,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs p) {
             const int r = g4 * 4 + e;
             const int qg = q0 + qb + e;
             const bool ok = (qg < p.S) && (kvrow < p.S) && (!p.causal || kvrow <= qg);
-            const float pr = ok ? __expf(s[r] * p.scale - l4[e]) : 0.f;
+            const float pr = ok ? __builtin_amdgcn_exp2f(fmaf(s[r], sl2, -l4[e])) : 0.f;
             bf[tb][r >> 3][r & 7] = WHICH == 0 ? f2bf(pr) : f2bf(pr * (dp[r] - d4[e]) * p.scale);
           }
         }
