@@ -118,6 +118,7 @@ int a3v_gemv_fused(const void* A, int64_t lda, const void* W, int64_t ldw, void*
                    const void* residual, int64_t ldr, int epilogue, const void* norm_w, const float* ssq_in, float eps,
                    float* ssq_out, int rope, const float* cos_sin, void* k_cache, void* vt_cache, int H, int Hkv, int hd,
                    int Smax, int pos, void* ws, void* stream);
+bool a3v_gemv_supported(int M, int N, int K, int epilogue);
 int a3v_attention_decode_fused(const void* q, const void* k, const void* vt, void* out, int B, int Sk, int H, int Hkv, int hd,
                                const int64_t* strides, float* scratch, int* counters, void* stream);
 

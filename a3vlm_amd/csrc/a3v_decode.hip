@@ -39,8 +39,10 @@ extern "C" int a3v_llama_decode_step(const a3v_llama_layer* layers, int n_layers
                                (int64_t)Hkv * hd * Smax, (int64_t)hd * Smax, Smax,
                                (int64_t)H * hd, (int64_t)H * hd, hd};
   int rc;
-  const bool fused = dim % 128 == 0 && ffn % 128 == 0 && (H * hd) % 128 == 0 && (hd == 64 || hd == 128) && ldq <= 65536 &&
-                     2 * ffn <= 65536 && dim / 16 * 16 * 4 <= A3V_WS_PARTIALS - A3V_WS_SSQ;
+  const bool fused = (hd == 64 || hd == 128) && dim % 16 == 0 && dim / 16 * 16 * 4 <= A3V_WS_PARTIALS - A3V_WS_SSQ &&
+                     a3v_gemv_supported(B, (int)ldq, dim, 0) && a3v_gemv_supported(B, dim, H * hd, A3V_EPI_RESIDUAL) &&
+                     a3v_gemv_supported(B, 2 * ffn, dim, A3V_EPI_SWIGLU) && a3v_gemv_supported(B, dim, ffn, A3V_EPI_RESIDUAL) &&
+                     ldq % 16 == 0 && (2 * ffn) % 32 == 0;
   if (fused) {
     float* ssq = (float*)((char*)skinny_ws + A3V_WS_SSQ);
     int* actr = (int*)((char*)skinny_ws + A3V_WS_ATTN_COUNTERS);

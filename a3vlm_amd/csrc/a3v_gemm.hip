@@ -1274,6 +1274,15 @@ static int gemv_split(int N, int K) {
   return S;
 }
 
+// can the LDS-DMA GEMV take this problem (else: the direct-to-VGPR kernel, which has no fused decode forms)
+static bool gemv_fits(int M, int N, int K, int epi) {
+  if (K % 128 || K < 128 || N > 65536 || M > 16) return false;
+  const int S = gemv_split(N, K), nkb = K / 128;
+  const size_t ldsb = (size_t)((nkb + S - 1) / S) * (M <= 8 ? 8 : 16) * 256 + 4 * 2 * 4096;
+  return ldsb <= 150 * 1024 && !((epi & A3V_EPI_SWIGLU) && S == 1);
+}
+bool a3v_gemv_supported(int M, int N, int K, int epilogue) { return gemv_fits(M, N, K, epilogue); }
+
 // fills the split-K plan + workspace pointers of `g` and launches; false when the shape needs the direct-to-VGPR kernel
 static bool gemv_launch(GemvArgs& g, void* ws, hipStream_t st) {
   g.counters = (int*)ws;
@@ -1282,7 +1291,7 @@ static bool gemv_launch(GemvArgs& g, void* ws, hipStream_t st) {
   g.maxkb = (g.nkb + g.S - 1) / g.S;
   const int arows = g.M <= 8 ? 8 : 16;
   const size_t ldsb = (size_t)g.maxkb * arows * 256 + 4 * 2 * 4096;
-  if (ldsb > 150 * 1024 || ((g.epi & A3V_EPI_SWIGLU) && g.S == 1)) return false;
+  if (!gemv_fits(g.M, g.N, g.K, g.epi)) return false;
   const int blocks = ((g.tgs + 7) / 8) * 8 * g.S;
   const bool pro = g.norm_w != nullptr;
   void (*kern)(GemvArgs) = arows == 8 ? (pro ? gemv_dma_bf16_kernel<8, true> : gemv_dma_bf16_kernel<8, false>)

@@ -76,6 +76,10 @@ def load() -> ctypes.CDLL:
             f"{LIB_PATH} not found: the HIP extension is not built. Run "
             "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C a3vlm_amd/csrc`). "
             "a3vlm_amd has no non-HIP fallback.")
+    # PyTorch-ROCm ships its own libamdhip64; it must be the HIP runtime this library binds to (device memory and
+    # streams come from torch).  dlopen-ing liba3vlm_hip.so BEFORE torch would pull in /opt/rocm's copy as a second
+    # runtime in the process, and every launch from here would then fail with hipErrorNoDevice.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the export is missing

@@ -269,10 +269,11 @@ def test_vit_single_crop_geometry_bf16():
     assert rel_err(outb, want.numpy()) < 5e-2
 
 
-@pytest.mark.parametrize("heads,kv,dim,B", [(4, 4, 256, 5), (4, 2, 512, 8), (2, 1, 256, 1), (8, 8, 512, 11)])
+@pytest.mark.parametrize("heads,kv,dim,B", [(4, 4, 256, 5), (4, 2, 512, 8), (2, 1, 256, 1), (8, 8, 512, 11), (2, 2, 128, 2)])
 def test_fused_decode_step_matches_per_kernel_path(heads, kv, dim, B):
     """a3v_llama_decode_step's fused form (RMSNorm folded into the consuming GEMV, RoPE + KV write in the QKV epilogue,
-    attention combine in-kernel) vs the same step run kernel by kernel: same rounding points, so logits agree to bf16
+    attention combine in-kernel; dim = 128 has a single 128-wide K block, so the step falls back to the per-kernel sequence
+    inside the same C call) vs the same step run kernel by kernel: same rounding points, so logits agree to bf16
     accumulation-order noise, the KV cache rows written at the decode positions included; and vs the bf16 oracle."""
     args = plugin.ModelArgs(dim=dim, n_layers=3, n_heads=heads, n_kv_heads=kv, vocab_size=640, multiple_of=128, max_seq_len=192)
     oargs = ref_cpu.OracleArgs(dim=dim, n_layers=3, n_heads=heads, n_kv_heads=kv, vocab_size=640, multiple_of=128, max_seq_len=192)
