@@ -267,32 +267,44 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TA* __restrict
 
 // ------------------------------------------------------------------ SwiGLU on the interleaved layout
 // gu[r, 32 j + t] = gate col 16 j + t (t<16), gu[r, 32 j + 16 + t] = up col 16 j + t
+// 8 consecutive columns per thread (16-B bf16 accesses); F % 16 == 0 so a vector never straddles a 16-column block.
 template <typename TA>
 __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const TA* __restrict__ gu, int64_t ldg, TA* __restrict__ act, int64_t lda, int rows, int F, int inter) {
-  const int64_t n = (int64_t)rows * F;
+  const int F8 = F >> 3;
+  const int64_t n = (int64_t)rows * F8;
   const int ustep = inter ? 16 : F;
   for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const int r = i / F, c = i % F;
+    const int r = (int)(i / F8), c = (int)(i - (int64_t)r * F8) * 8;
     const TA* p = gu + (int64_t)r * ldg + (inter ? (c >> 4) * 32 + (c & 15) : c);
-    const float g = Cvt<TA>::ld(p), u = Cvt<TA>::ld(p + ustep);
-    const float sg = Cvt<TA>::rnd(g / (1.f + __expf(-g)));
-    Cvt<TA>::st(act + (int64_t)r * lda + c, sg * u);
+    float g[8], u[8], o[8];
+    load8(p, g);
+    load8(p + ustep, u);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = Cvt<TA>::rnd(g[e] / (1.f + __expf(-g[e]))) * u[e];
+    store8(act + (int64_t)r * lda + c, o);
   }
 }
 template <typename TA>
 __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const TA* __restrict__ gu, int64_t ldg, const TA* __restrict__ dact, int64_t lda,
                                                          TA* __restrict__ dgu, int64_t lddg, int rows, int F, int inter) {
-  const int64_t n = (int64_t)rows * F;
+  const int F8 = F >> 3;
+  const int64_t n = (int64_t)rows * F8;
   const int ustep = inter ? 16 : F;
   for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const int r = i / F, c = i % F;
+    const int r = (int)(i / F8), c = (int)(i - (int64_t)r * F8) * 8;
     const int64_t o = inter ? (int64_t)(c >> 4) * 32 + (c & 15) : c;
-    const float g = Cvt<TA>::ld(gu + (int64_t)r * ldg + o), u = Cvt<TA>::ld(gu + (int64_t)r * ldg + o + ustep);
-    const float da = Cvt<TA>::ld(dact + (int64_t)r * lda + c);
-    const float sig = 1.f / (1.f + __expf(-g));
-    const float sg = g * sig;
-    Cvt<TA>::st(dgu + (int64_t)r * lddg + o, da * u * (sig * (1.f + g * (1.f - sig))));
-    Cvt<TA>::st(dgu + (int64_t)r * lddg + o + ustep, da * sg);
+    float g[8], u[8], da[8], dg[8], du[8];
+    load8(gu + (int64_t)r * ldg + o, g);
+    load8(gu + (int64_t)r * ldg + o + ustep, u);
+    load8(dact + (int64_t)r * lda + c, da);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float sig = 1.f / (1.f + __expf(-g[e]));
+      dg[e] = da[e] * u[e] * (sig * (1.f + g[e] * (1.f - sig)));
+      du[e] = da[e] * (g[e] * sig);
+    }
+    store8(dgu + (int64_t)r * lddg + o, dg);
+    store8(dgu + (int64_t)r * lddg + o + ustep, du);
   }
 }
 
@@ -570,7 +582,8 @@ extern "C" int a3v_layernorm_bwd(const void* x, int64_t ldx, const float* w, con
 extern "C" int a3v_swiglu_fwd(const void* gu, int64_t ldg, void* act, int64_t lda, int rows, int F, int interleaved, int dtype, void* stream) {
   const int inter = interleaved;
   if (!gu || !act || rows <= 0 || F <= 0 || (F % 16)) return A3V_ERR_ARG;
-  int64_t n = (int64_t)rows * F;
+  if ((ldg % 8) || (lda % 8)) return A3V_ERR_SHAPE;
+  int64_t n = (int64_t)rows * (F / 8);
   int blocks = (int)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256);
   if (dtype == A3V_BF16) hipLaunchKernelGGL(swiglu_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, ST, (const bf16_t*)gu, ldg, (bf16_t*)act, lda, rows, F, inter);
   else if (dtype == A3V_F32) hipLaunchKernelGGL(swiglu_fwd_kernel<float>, dim3(blocks), dim3(256), 0, ST, (const float*)gu, ldg, (float*)act, lda, rows, F, inter);
@@ -583,7 +596,8 @@ extern "C" int a3v_swiglu_bwd(const void* gu, int64_t ldg, const void* dact, int
                               int interleaved, int dtype, void* stream) {
   const int inter = interleaved;
   if (!gu || !dact || !dgu || rows <= 0 || F <= 0 || (F % 16)) return A3V_ERR_ARG;
-  int64_t n = (int64_t)rows * F;
+  if ((ldg % 8) || (lda % 8) || (lddg % 8)) return A3V_ERR_SHAPE;
+  int64_t n = (int64_t)rows * (F / 8);
   int blocks = (int)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256);
   if (dtype == A3V_BF16) hipLaunchKernelGGL(swiglu_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, ST, (const bf16_t*)gu, ldg, (const bf16_t*)dact, lda, (bf16_t*)dgu, lddg, rows, F, inter);
   else if (dtype == A3V_F32) hipLaunchKernelGGL(swiglu_bwd_kernel<float>, dim3(blocks), dim3(256), 0, ST, (const float*)gu, ldg, (const float*)dact, lda, (float*)dgu, lddg, rows, F, inter);
