@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
 
 // Vector form (dim % 4 == 0, 16-B aligned rows): a thread keeps its float4 slices of x and dy in registers across the two
 // passes of a row (one HBM read each), RPB rows per block for the weight-gradient partials.
-template <typename TA, int RPB, int MAXV>
+template <typename TA, int RPB, int MAXV, bool PART>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_vec_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ w,
                                                               const TA* __restrict__ dy, int64_t lddy, float* __restrict__ dh,
                                                               int64_t lddh, float* __restrict__ dw, int rows, int dim, float eps) {
@@ -195,15 +195,43 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_vec_kernel(const float* __res
     }
   }
   if (dw) {
+    if (PART) {         // dw = per-block partial rows [gridDim.x][dim]: summed by colsum_add_kernel (1091 blocks x 4096 atomics on
+                        // the same 16 KB cost 110 of this kernel's 195 us at 8728 x 4096)
+      f32x4* out = reinterpret_cast<f32x4*>(dw + (int64_t)blockIdx.x * dim);
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-      const int c = tid + i * 256;
-      if (c < nv) {
+      for (int i = 0; i < MAXV; ++i) {
+        const int c = tid + i * 256;
+        if (c < nv) out[c] = dwp[i];
+      }
+    } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) atomicAdd(dw + 4 * c + e, dwp[i][e]);
+      for (int i = 0; i < MAXV; ++i) {
+        const int c = tid + i * 256;
+        if (c < nv) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) atomicAdd(dw + 4 * c + e, dwp[i][e]);
+        }
       }
     }
   }
+}
+
+// out[c] += sum_r part[r][c]: grid (cols / 256, row chunks); one atomic per column per chunk
+__global__ __launch_bounds__(256) void colsum_add_kernel(const float* __restrict__ part, int nrows, int cols, float* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  const int per = (nrows + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * per, r1 = min(nrows, r0 + per);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int r = r0;
+  for (; r + 4 <= r1; r += 4) {
+    a0 += part[(int64_t)r * cols + c];
+    a1 += part[(int64_t)(r + 1) * cols + c];
+    a2 += part[(int64_t)(r + 2) * cols + c];
+    a3 += part[(int64_t)(r + 3) * cols + c];
+  }
+  for (; r < r1; ++r) a0 += part[(int64_t)r * cols + c];
+  if (r1 > r0) atomicAdd(out + c, (a0 + a1) + (a2 + a3));
 }
 
 // ------------------------------------------------------------------ LayerNorm backward (projector LN)
@@ -538,23 +566,34 @@ extern "C" int a3v_transpose(const void* src, int64_t ld_src, int64_t bs_src, vo
   return A3V_OK;
 }
 
+extern "C" int64_t a3v_rmsnorm_bwd_scratch_floats(int rows, int dim) { return (int64_t)((rows + 7) / 8) * dim; }
+
 extern "C" int a3v_rmsnorm_bwd(const float* x, int64_t ldx, const float* w, const void* dy, int64_t lddy, float* dh, int64_t lddh,
-                               float* dw, int rows, int dim, float eps, int act_dtype, void* stream) {
+                               float* dw, float* dw_scratch, int rows, int dim, float eps, int act_dtype, void* stream) {
   if (!x || !w || !dy || !dh || rows <= 0) return A3V_ERR_ARG;
   if (dim > 8192) return A3V_ERR_SHAPE;
   if (dim % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && lddh % 4 == 0 && (act_dtype == A3V_BF16 || act_dtype == A3V_F32) &&
       ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dh) | reinterpret_cast<uintptr_t>(w)) & 15) == 0 &&
       (reinterpret_cast<uintptr_t>(dy) & (act_dtype == A3V_BF16 ? 7 : 15)) == 0) {
     constexpr int RV = 8;
-    dim3 gv((rows + RV - 1) / RV);
+    const int nb = (rows + RV - 1) / RV;
+    dim3 gv(nb);
+    const bool part = dw && dw_scratch && (reinterpret_cast<uintptr_t>(dw_scratch) & 15) == 0;
+    float* dwo = part ? dw_scratch : dw;
+#define A3V_RB(TT, MV, PP) hipLaunchKernelGGL((rmsnorm_bwd_vec_kernel<TT, RV, MV, PP>), gv, dim3(256), 0, ST, x, ldx, w, (const TT*)dy, lddy, dh, lddh, dwo, rows, dim, eps)
     if (dim <= 4096) {
-      if (act_dtype == A3V_BF16) hipLaunchKernelGGL((rmsnorm_bwd_vec_kernel<bf16_t, RV, 4>), gv, dim3(256), 0, ST, x, ldx, w, (const bf16_t*)dy, lddy, dh, lddh, dw, rows, dim, eps);
-      else hipLaunchKernelGGL((rmsnorm_bwd_vec_kernel<float, RV, 4>), gv, dim3(256), 0, ST, x, ldx, w, (const float*)dy, lddy, dh, lddh, dw, rows, dim, eps);
+      if (act_dtype == A3V_BF16) { if (part) A3V_RB(bf16_t, 4, true); else A3V_RB(bf16_t, 4, false); }
+      else { if (part) A3V_RB(float, 4, true); else A3V_RB(float, 4, false); }
     } else {
-      if (act_dtype == A3V_BF16) hipLaunchKernelGGL((rmsnorm_bwd_vec_kernel<bf16_t, RV, 8>), gv, dim3(256), 0, ST, x, ldx, w, (const bf16_t*)dy, lddy, dh, lddh, dw, rows, dim, eps);
-      else hipLaunchKernelGGL((rmsnorm_bwd_vec_kernel<float, RV, 8>), gv, dim3(256), 0, ST, x, ldx, w, (const float*)dy, lddy, dh, lddh, dw, rows, dim, eps);
+      if (act_dtype == A3V_BF16) { if (part) A3V_RB(bf16_t, 8, true); else A3V_RB(bf16_t, 8, false); }
+      else { if (part) A3V_RB(float, 8, true); else A3V_RB(float, 8, false); }
     }
+#undef A3V_RB
     A3V_LAUNCH_CHECK();
+    if (part) {
+      hipLaunchKernelGGL(colsum_add_kernel, dim3((dim + 255) / 256, 16), dim3(256), 0, ST, dw_scratch, nb, dim, dw);
+      A3V_LAUNCH_CHECK();
+    }
     return A3V_OK;
   }
   constexpr int RPB = 16;

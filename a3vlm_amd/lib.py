@@ -42,7 +42,8 @@ SIGNATURES = {
     "a3v_cross_entropy": (I, [P, L, P, P, P, L, P, F, I, I, I, P]),
     "a3v_attention_lse": (I, [P, P, P, P, P, I, I, I, I, I, I, ctypes.POINTER(c_int64), I, I, P]),
     "a3v_transpose": (I, [P, L, L, P, L, L, I, I, I, I, I, P]),
-    "a3v_rmsnorm_bwd": (I, [P, L, P, P, L, P, L, P, I, I, F, I, P]),
+    "a3v_rmsnorm_bwd_scratch_floats": (L, [I, I]),
+    "a3v_rmsnorm_bwd": (I, [P, L, P, P, L, P, L, P, P, I, I, F, I, P]),
     "a3v_layernorm_bwd": (I, [P, L, P, P, L, P, P, L, P, P, I, I, F, I, P]),
     "a3v_swiglu_fwd": (I, [P, L, P, L, I, I, I, I, P]),
     "a3v_swiglu_bwd": (I, [P, L, P, L, P, L, I, I, I, I, P]),

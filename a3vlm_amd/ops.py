@@ -228,11 +228,21 @@ def add2d(dst, src):
     return dst
 
 
+_rb_scratch = {}
+
+
 def rmsnorm_bwd(x, w, dy, dh, dw, eps):
     _dev(x, w, dy, dh, dw)
     assert x.dtype == torch.float32 and w.dtype == torch.float32 and dh.dtype == torch.float32
     rows, dim = x.shape
-    rc = _l.load().a3v_rmsnorm_bwd(_p(x), x.stride(0), _p(w), _p(dy), dy.stride(0), _p(dh), dh.stride(0), _p(dw), rows, dim,
+    scratch = None
+    if dw is not None:                       # per-device scratch for the weight-gradient partial rows (grown on demand)
+        need = int(_l.load().a3v_rmsnorm_bwd_scratch_floats(rows, dim))
+        scratch = _rb_scratch.get(x.device)
+        if scratch is None or scratch.numel() < need:
+            scratch = torch.empty(need, dtype=torch.float32, device=x.device)
+            _rb_scratch[x.device] = scratch
+    rc = _l.load().a3v_rmsnorm_bwd(_p(x), x.stride(0), _p(w), _p(dy), dy.stride(0), _p(dh), dh.stride(0), _p(dw), _p(scratch), rows, dim,
                                    eps, dt(dy), _stream())
     _l.check(rc, "a3v_rmsnorm_bwd")
 

@@ -198,10 +198,13 @@ int a3v_attention_lse(const void* q, const void* k, const void* vt, void* out, f
 int a3v_transpose(const void* src, int64_t ld_src, int64_t bs_src, void* dst, int64_t ld_dst,
                   int64_t bs_dst, int R, int C, int Rpad, int batch, int dtype, void* stream);
 
-/* backward of a3v_rmsnorm with fp32 x, w: dh += d/dx ; dw += d/dw (may be NULL). dy in act_dtype. */
+/* backward of a3v_rmsnorm with fp32 x, w: dh += d/dx ; dw += d/dw (may be NULL). dy in act_dtype.
+ * dw_scratch (may be NULL): a3v_rmsnorm_bwd_scratch_floats(rows, dim) floats; with it the per-block weight-gradient
+ * partials are written as rows and column-summed by a second small kernel instead of ~rows/8 x dim atomics on dw. */
+int64_t a3v_rmsnorm_bwd_scratch_floats(int rows, int dim);
 int a3v_rmsnorm_bwd(const float* x, int64_t ldx, const float* w, const void* dy, int64_t lddy,
-                    float* dh, int64_t lddh, float* dw, int rows, int dim, float eps, int act_dtype,
-                    void* stream);
+                    float* dh, int64_t lddh, float* dw, float* dw_scratch, int rows, int dim, float eps,
+                    int act_dtype, void* stream);
 
 /* backward of a3v_layernorm (x in act_dtype, fp32 w; dy fp32 rows gathered through row_map):
  * dx (act_dtype), dw += , db += . */
