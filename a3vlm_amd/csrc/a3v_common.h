@@ -11,6 +11,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 #define A3V_WAVE 64
@@ -114,11 +115,11 @@ __device__ __forceinline__ float ld_agent(const float* p) {          // issue + 
 constexpr int A3V_WS_ATTN_COUNTERS = 16384;
 constexpr int A3V_WS_SSQ = 32768;
 constexpr int A3V_WS_PARTIALS = 49152;
-int a3v_gemv_fused(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int M, int N, int K,
-                   const void* residual, int64_t ldr, int epilogue, const void* norm_w, const float* ssq_in, float eps,
+int a3v_gemv_fused(const void* A, int64_t lda, const void* W, int64_t ldw, const float* wscale, void* C, int64_t ldc, int M, int N,
+                   int K, const void* residual, int64_t ldr, int epilogue, const void* norm_w, const float* ssq_in, float eps,
                    float* ssq_out, int rope, const float* cos_sin, void* k_cache, void* vt_cache, int H, int Hkv, int hd,
                    int Smax, int pos, void* ws, void* stream);
-bool a3v_gemv_supported(int M, int N, int K, int epilogue);
+bool a3v_gemv_supported(int M, int N, int K, int epilogue, int w8);
 int a3v_attention_decode_fused(const void* q, const void* k, const void* vt, void* out, int B, int Sk, int H, int Hkv, int hd,
                                const int64_t* strides, float* scratch, int* counters, void* stream);
 

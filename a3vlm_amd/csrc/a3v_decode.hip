@@ -39,10 +39,17 @@ extern "C" int a3v_llama_decode_step(const a3v_llama_layer* layers, int n_layers
                                (int64_t)Hkv * hd * Smax, (int64_t)hd * Smax, Smax,
                                (int64_t)H * hd, (int64_t)H * hd, hd};
   int rc;
+  const int w8 = layers[0].wqkv_q != nullptr;
+  for (int i = 0; i < n_layers; ++i) {
+    const a3v_llama_layer& L = layers[i];
+    const int q8 = (L.wqkv_q != nullptr) + (L.wo_q != nullptr) + (L.w13_q != nullptr) + (L.w2_q != nullptr);
+    if (q8 != (w8 ? 4 : 0) || (w8 && (!L.wqkv_s || !L.wo_s || !L.w13_s || !L.w2_s))) return A3V_ERR_ARG;   // all four or none
+  }
   const bool fused = (hd == 64 || hd == 128) && dim % 16 == 0 && dim / 16 * 16 * 4 <= A3V_WS_PARTIALS - A3V_WS_SSQ &&
-                     a3v_gemv_supported(B, (int)ldq, dim, 0) && a3v_gemv_supported(B, dim, H * hd, A3V_EPI_RESIDUAL) &&
-                     a3v_gemv_supported(B, 2 * ffn, dim, A3V_EPI_SWIGLU) && a3v_gemv_supported(B, dim, ffn, A3V_EPI_RESIDUAL) &&
+                     a3v_gemv_supported(B, (int)ldq, dim, 0, w8) && a3v_gemv_supported(B, dim, H * hd, A3V_EPI_RESIDUAL, w8) &&
+                     a3v_gemv_supported(B, 2 * ffn, dim, A3V_EPI_SWIGLU, w8) && a3v_gemv_supported(B, dim, ffn, A3V_EPI_RESIDUAL, w8) &&
                      ldq % 16 == 0 && (2 * ffn) % 32 == 0;
+  if (w8 && !fused) return A3V_ERR_SHAPE;          // the fp8 images exist only for the fused form
   if (fused) {
     float* ssq = (float*)((char*)skinny_ws + A3V_WS_SSQ);
     int* actr = (int*)((char*)skinny_ws + A3V_WS_ATTN_COUNTERS);
@@ -51,15 +58,15 @@ extern "C" int a3v_llama_decode_step(const a3v_llama_layer* layers, int n_layers
     A3V_LAUNCH_CHECK();
     for (int i = 0; i < n_layers; ++i) {
       const a3v_llama_layer& L = layers[i];
-      if ((rc = a3v_gemv_fused(h, dim, L.wqkv, dim, qkv, ldq, B, (int)ldq, dim, nullptr, 0, 0, L.attn_norm_w, ssq, eps, nullptr, 1, cos_sin,
-                               L.k_cache, L.vt_cache, H, Hkv, hd, Smax, pos, skinny_ws, stream))) return rc;
+      if ((rc = a3v_gemv_fused(h, dim, w8 ? L.wqkv_q : L.wqkv, dim, L.wqkv_s, qkv, ldq, B, (int)ldq, dim, nullptr, 0, 0, L.attn_norm_w, ssq, eps,
+                               nullptr, 1, cos_sin, L.k_cache, L.vt_cache, H, Hkv, hd, Smax, pos, skinny_ws, stream))) return rc;
       if ((rc = a3v_attention_decode_fused(qkv, L.k_cache, L.vt_cache, att, B, pos + 1, H, Hkv, hd, strides, attn_scratch, actr, stream))) return rc;
-      if ((rc = a3v_gemv_fused(att, (int64_t)H * hd, L.wo, (int64_t)H * hd, h, dim, B, dim, H * hd, h, dim, A3V_EPI_RESIDUAL, nullptr, nullptr, eps,
-                               ssq, 0, nullptr, nullptr, nullptr, H, Hkv, hd, Smax, pos, skinny_ws, stream))) return rc;
-      if ((rc = a3v_gemv_fused(h, dim, L.w13, dim, act, ffn, B, 2 * ffn, dim, nullptr, 0, A3V_EPI_SWIGLU, L.ffn_norm_w, ssq, eps, nullptr, 0, nullptr,
-                               nullptr, nullptr, H, Hkv, hd, Smax, pos, skinny_ws, stream))) return rc;
-      if ((rc = a3v_gemv_fused(act, ffn, L.w2, ffn, h, dim, B, dim, ffn, h, dim, A3V_EPI_RESIDUAL, nullptr, nullptr, eps, ssq, 0, nullptr, nullptr,
-                               nullptr, H, Hkv, hd, Smax, pos, skinny_ws, stream))) return rc;
+      if ((rc = a3v_gemv_fused(att, (int64_t)H * hd, w8 ? L.wo_q : L.wo, (int64_t)H * hd, L.wo_s, h, dim, B, dim, H * hd, h, dim, A3V_EPI_RESIDUAL,
+                               nullptr, nullptr, eps, ssq, 0, nullptr, nullptr, nullptr, H, Hkv, hd, Smax, pos, skinny_ws, stream))) return rc;
+      if ((rc = a3v_gemv_fused(h, dim, w8 ? L.w13_q : L.w13, dim, L.w13_s, act, ffn, B, 2 * ffn, dim, nullptr, 0, A3V_EPI_SWIGLU, L.ffn_norm_w, ssq,
+                               eps, nullptr, 0, nullptr, nullptr, nullptr, H, Hkv, hd, Smax, pos, skinny_ws, stream))) return rc;
+      if ((rc = a3v_gemv_fused(act, ffn, w8 ? L.w2_q : L.w2, ffn, L.w2_s, h, dim, B, dim, ffn, h, dim, A3V_EPI_RESIDUAL, nullptr, nullptr, eps, ssq,
+                               0, nullptr, nullptr, nullptr, H, Hkv, hd, Smax, pos, skinny_ws, stream))) return rc;
     }
     return A3V_OK;
   }

@@ -805,6 +805,7 @@ struct GemvArgs {
   const float* cos_sin;     // GEMV_EPI_ROPEKV: fp32 [pos][hd/2][2]
   bf16_t* k_cache;          //   [M, Hkv, Smax, hd]
   bf16_t* vt_cache;         //   [M, Hkv, hd, Smax]
+  const float* wscale;      // W8: per-row dequantisation scales (W rows are fp8 e4m3fn bytes, ldw in BYTES)
   float eps;
   int ssq_tiles, H, Hkv, hd, Smax, pos;
 };
@@ -812,7 +813,10 @@ struct GemvArgs {
 constexpr int GEMV_EPI_ROPEKV = 1 << 24;
 constexpr int GEMV_EPI_SSQ = 1 << 25;
 
-template <int AROWS, bool PRO>
+// W8: the weight rows are OCP fp8 e4m3fn (weight-only quantisation, one fp32 scale per row applied to the summed
+// accumulator).  A ring stage is still 16 rows x 256 B, i.e. 256 k instead of 128; fragments are read 8 B per lane and
+// widened fp8 -> f32 -> bf16 in registers (exact), so the arithmetic is the bf16 MFMA on dequantised weights.
+template <int AROWS, bool PRO, bool W8>
 __global__ __launch_bounds__(256) void gemv_dma_bf16_kernel(GemvArgs p) {
   extern __shared__ __attribute__((aligned(1024))) char gemv_lds[];
   __shared__ float rinv_s[16];
@@ -822,8 +826,11 @@ __global__ __launch_bounds__(256) void gemv_dma_bf16_kernel(GemvArgs p) {
   const int sl = xq % p.S;
   const int tg = (xq / p.S) * 8 + (blockIdx.x & 7);
   if (tg >= p.tgs) return;
-  const int kb0 = (int)(((int64_t)sl * p.nkb) / p.S), kb1 = (int)(((int64_t)(sl + 1) * p.nkb) / p.S);
-  const int nkb = kb1 - kb0;
+  constexpr int APB = W8 ? 2 : 1;                      // 128-k blocks of A per ring stage of W
+  const int nst_all = p.nkb / APB;
+  const int st0 = (int)(((int64_t)sl * nst_all) / p.S), st1 = (int)(((int64_t)(sl + 1) * nst_all) / p.S);
+  const int nst = st1 - st0;                           // ring stages of this slice
+  const int kb0 = st0 * APB, nkb = nst * APB;          // ... in 128-k blocks of A
   constexpr int ABLK = AROWS * 256;                    // bytes of A per 128-k block
   char* Alds = gemv_lds;
   char* Wring = gemv_lds + p.maxkb * ABLK + wave * 2 * 4096;
@@ -840,18 +847,18 @@ __global__ __launch_bounds__(256) void gemv_dma_bf16_kernel(GemvArgs p) {
                                        (__attribute__((address_space(3))) void*)(Alds + kb * ABLK + i * 1024), 16, 0, 0);
     }
   }
-  const bf16_t* wrow[4];
+  const char* wrow[4];                                 // a stage row is 256 B in both weight formats
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = 4 * i + dr;
     int wr = n0 + row;
     wr = wr < p.N ? wr : p.N - 1;
-    wrow[i] = p.W + (int64_t)wr * p.ldw + (int64_t)kb0 * 128 + ((dslot ^ row) & 15) * 8;
+    wrow[i] = reinterpret_cast<const char*>(p.W) + (int64_t)wr * p.ldw * (W8 ? 1 : 2) + (int64_t)st0 * 256 + ((dslot ^ row) & 15) * 16;
   }
-  auto dma_stage = [&](int kb, int slot) {
+  auto dma_stage = [&](int st, int slot) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wrow[i] + kb * 128),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wrow[i] + st * 256),
                                        (__attribute__((address_space(3))) void*)(Wring + slot * 4096 + i * 1024), 16, 0, 0);
   };
   if (PRO) {
@@ -902,7 +909,7 @@ __global__ __launch_bounds__(256) void gemv_dma_bf16_kernel(GemvArgs p) {
     };
     issue(0);
     dma_stage(0, 0);
-    if (nkb > 1) dma_stage(1, 1);
+    if (nst > 1) dma_stage(1, 1);
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
 #pragma unroll
@@ -921,7 +928,7 @@ __global__ __launch_bounds__(256) void gemv_dma_bf16_kernel(GemvArgs p) {
     }
   } else {
     dma_stage(0, 0);
-    if (nkb > 1) {
+    if (nst > 1) {
       dma_stage(1, 1);
       asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // in-order completion: the A pieces issued before the ring prologue
     } else {
@@ -938,24 +945,49 @@ __global__ __launch_bounds__(256) void gemv_dma_bf16_kernel(GemvArgs p) {
   int aoff[4];
 #pragma unroll
   for (int s4 = 0; s4 < 4; ++s4) aoff[s4] = (((4 * s4 + fg) ^ arow) & 15) * 16;
-  for (int kb = 0; kb < nkb; ++kb) {
-    const int slot = kb & 1;
-    if (kb + 2 <= nkb) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  for (int st = 0; st < nst; ++st) {
+    const int slot = st & 1;
+    if (st + 2 <= nst) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const char* Ws = Wring + slot * 4096 + fr * 256;
-    const char* As = Alds + kb * ABLK + arow * 256;
-    bf16x8 wf[4], af[4];
+    if (!W8) {
+      const char* As = Alds + st * ABLK + arow * 256;
+      bf16x8 wf[4], af[4];
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-      wf[s4] = *reinterpret_cast<const bf16x8*>(Ws + foff[s4]);
-      af[s4] = *reinterpret_cast<const bf16x8*>(As + aoff[s4]);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragments are in registers: the slot may be overwritten
-    if (kb + 2 < nkb) dma_stage(kb + 2, slot);
+      for (int s4 = 0; s4 < 4; ++s4) {
+        wf[s4] = *reinterpret_cast<const bf16x8*>(Ws + foff[s4]);
+        af[s4] = *reinterpret_cast<const bf16x8*>(As + aoff[s4]);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragments are in registers: the slot may be overwritten
+      if (st + 2 < nst) dma_stage(st + 2, slot);
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-      if (s4 & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s4], af[s4], acc1, 0, 0, 0);
-      else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s4], af[s4], acc0, 0, 0, 0);
+      for (int s4 = 0; s4 < 4; ++s4) {
+        if (s4 & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s4], af[s4], acc1, 0, 0, 0);
+        else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s4], af[s4], acc0, 0, 0, 0);
+      }
+    } else {
+      // 8 MFMA steps per stage: step s8 covers k = 32 s8 .. 32 s8 + 31; the lane's 8 bytes sit in 16-B chunk 2 s8 + (fg >> 1)
+      u32x2 wq[8];
+      bf16x8 af[8];
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) {
+        wq[s8] = *reinterpret_cast<const u32x2*>(Ws + (((2 * s8 + (fg >> 1)) ^ fr) & 15) * 16 + (fg & 1) * 8);
+        af[s8] = *reinterpret_cast<const bf16x8*>(Alds + (st * 2 + (s8 >> 2)) * ABLK + arow * 256 + aoff[s8 & 3]);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (st + 2 < nst) dma_stage(st + 2, slot);
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) {
+        bf16x8 wf;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)wq[s8][h2], false);
+          const f32x2 hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)wq[s8][h2], true);
+          wf[4 * h2 + 0] = f2bf(lo[0]); wf[4 * h2 + 1] = f2bf(lo[1]); wf[4 * h2 + 2] = f2bf(hi[0]); wf[4 * h2 + 3] = f2bf(hi[1]);
+        }
+        if (s8 & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[s8], acc1, 0, 0, 0);
+        else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[s8], acc0, 0, 0, 0);
+      }
     }
   }
   f32x4 v;
@@ -1008,6 +1040,17 @@ __global__ __launch_bounds__(256) void gemv_dma_bf16_kernel(GemvArgs p) {
           for (int r = 0; r < 4; ++r) u[r] += y[s8][r];
         }
       }
+  }
+  if (W8) {                 // per-row dequantisation scale on the summed accumulator (rows clamp: the stores are masked)
+    const int nr = nt0 + (lane >> 4) * 4;
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(p.wscale + (nr + 4 <= p.N ? nr : 0));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] *= sc[r];
+    if (swiglu) {
+      const f32x4 su = *reinterpret_cast<const f32x4*>(p.wscale + (nr + 20 <= p.N ? nr + 16 : 0));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) u[r] *= su[r];
+    }
   }
   // v[r] = D[n = nt0 + 4 (lane>>4) + r][m = lane & 15]   (u: the matching up-projection rows with SwiGLU)
   const int m = lane & 15;
@@ -1266,38 +1309,44 @@ extern "C" int a3v_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ld
   return A3V_OK;
 }
 
-// split-K factor of the DMA GEMV: enough blocks (row groups x S >= 1024) for 256 CUs, S <= 8, S <= K/128
-static int gemv_split(int N, int K) {
-  const int tgs = (N + 63) / 64, nkb = K / 128;
+// split-K factor of the DMA GEMV: enough blocks (row groups x S >= 1024) for 256 CUs, S <= 8, S <= number of ring stages
+static int gemv_split(int N, int K, bool w8) {
+  const int tgs = (N + 63) / 64, nst = K / (w8 ? 256 : 128);
   int S = 1;
-  while (S < 8 && tgs * S < 1024 && S * 2 <= nkb) S *= 2;
+  while (S < 8 && tgs * S < 1024 && S * 2 <= nst) S *= 2;
   return S;
 }
 
-// can the LDS-DMA GEMV take this problem (else: the direct-to-VGPR kernel, which has no fused decode forms)
-static bool gemv_fits(int M, int N, int K, int epi) {
-  if (K % 128 || K < 128 || N > 65536 || M > 16) return false;
-  const int S = gemv_split(N, K), nkb = K / 128;
-  const size_t ldsb = (size_t)((nkb + S - 1) / S) * (M <= 8 ? 8 : 16) * 256 + 4 * 2 * 4096;
+// can the LDS-DMA GEMV take this problem (else: the direct-to-VGPR kernel, which has no fused decode / fp8 forms)
+static bool gemv_fits(int M, int N, int K, int epi, bool w8) {
+  const int kst = w8 ? 256 : 128;
+  if (K % kst || K < kst || N > 65536 || M > 16) return false;
+  const int S = gemv_split(N, K, w8), nst = K / kst;
+  const size_t ldsb = (size_t)((nst + S - 1) / S) * (kst / 128) * (M <= 8 ? 8 : 16) * 256 + 4 * 2 * 4096;
   return ldsb <= 150 * 1024 && !((epi & A3V_EPI_SWIGLU) && S == 1);
 }
-bool a3v_gemv_supported(int M, int N, int K, int epilogue) { return gemv_fits(M, N, K, epilogue); }
+bool a3v_gemv_supported(int M, int N, int K, int epilogue, int w8) { return gemv_fits(M, N, K, epilogue, w8 != 0); }
 
 // fills the split-K plan + workspace pointers of `g` and launches; false when the shape needs the direct-to-VGPR kernel
 static bool gemv_launch(GemvArgs& g, void* ws, hipStream_t st) {
+  const bool w8 = g.wscale != nullptr;
+  if (!gemv_fits(g.M, g.N, g.K, g.epi, w8)) return false;
   g.counters = (int*)ws;
   g.part = (float*)((char*)ws + A3V_WS_PARTIALS);
-  g.S = gemv_split(g.N, g.K); g.nkb = g.K / 128; g.tgs = (g.N + 63) / 64;
-  g.maxkb = (g.nkb + g.S - 1) / g.S;
+  const int kst = w8 ? 256 : 128;
+  g.S = gemv_split(g.N, g.K, w8); g.nkb = g.K / 128; g.tgs = (g.N + 63) / 64;
+  g.maxkb = ((g.K / kst + g.S - 1) / g.S) * (kst / 128);
   const int arows = g.M <= 8 ? 8 : 16;
   const size_t ldsb = (size_t)g.maxkb * arows * 256 + 4 * 2 * 4096;
-  if (!gemv_fits(g.M, g.N, g.K, g.epi)) return false;
   const int blocks = ((g.tgs + 7) / 8) * 8 * g.S;
   const bool pro = g.norm_w != nullptr;
-  void (*kern)(GemvArgs) = arows == 8 ? (pro ? gemv_dma_bf16_kernel<8, true> : gemv_dma_bf16_kernel<8, false>)
-                                      : (pro ? gemv_dma_bf16_kernel<16, true> : gemv_dma_bf16_kernel<16, false>);
-  static bool attr_done[4] = {false, false, false, false};
-  const int ki = (arows == 16 ? 2 : 0) + (pro ? 1 : 0);
+  void (*kern)(GemvArgs);
+  if (w8) kern = arows == 8 ? (pro ? gemv_dma_bf16_kernel<8, true, true> : gemv_dma_bf16_kernel<8, false, true>)
+                            : (pro ? gemv_dma_bf16_kernel<16, true, true> : gemv_dma_bf16_kernel<16, false, true>);
+  else kern = arows == 8 ? (pro ? gemv_dma_bf16_kernel<8, true, false> : gemv_dma_bf16_kernel<8, false, false>)
+                         : (pro ? gemv_dma_bf16_kernel<16, true, false> : gemv_dma_bf16_kernel<16, false, false>);
+  static bool attr_done[8] = {false, false, false, false, false, false, false, false};
+  const int ki = (w8 ? 4 : 0) + (arows == 16 ? 2 : 0) + (pro ? 1 : 0);
   if (!attr_done[ki]) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_done[ki] = true; }
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), ldsb, st, g);
   return true;
@@ -1305,14 +1354,14 @@ static bool gemv_launch(GemvArgs& g, void* ws, hipStream_t st) {
 
 extern "C" int a3v_gemm_skinny_split(int M, int N, int K) {
   (void)M;
-  return (K % 128 == 0 && K >= 128) ? gemv_split(N, K) : 1;
+  return (K % 128 == 0 && K >= 128) ? gemv_split(N, K, false) : 1;
 }
 
 extern "C" int64_t a3v_gemm_skinny_ws_bytes(int M, int N, int K) {
   (void)M;
   if (K % 128 || K < 128) return A3V_WS_PARTIALS;
   const int64_t tgs = (N + 63) / 64;
-  return A3V_WS_PARTIALS + tgs * gemv_split(N, K) * 4 * 1024;
+  return A3V_WS_PARTIALS + tgs * 8 * 4 * 1024;     // sized for the largest split of either weight format
 }
 
 extern "C" int a3v_gemm_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
@@ -1347,8 +1396,8 @@ extern "C" int a3v_gemm_skinny(const void* A, int64_t lda, const void* W, int64_
 //   norm_w != NULL : A is the un-normalised residual rows h; RMSNorm(h) is applied while the A slice is staged (ssq_in)
 //   rope != 0      : [q|k|v] rows get RoPE and go to C (q) / the KV cache at `pos` (no separate rope kernel)
 //   ssq_out != NULL: with a residual epilogue, also emit the per-tile sums of squares of the new rows
-int a3v_gemv_fused(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int M, int N, int K,
-                   const void* residual, int64_t ldr, int epilogue, const void* norm_w, const float* ssq_in, float eps,
+int a3v_gemv_fused(const void* A, int64_t lda, const void* W, int64_t ldw, const float* wscale, void* C, int64_t ldc, int M, int N,
+                   int K, const void* residual, int64_t ldr, int epilogue, const void* norm_w, const float* ssq_in, float eps,
                    float* ssq_out, int rope, const float* cos_sin, void* k_cache, void* vt_cache, int H, int Hkv, int hd,
                    int Smax, int pos, void* ws, void* stream) {
   if (M <= 0 || M > 16 || K % 128 || N % 16 || N > 65536 || !ws) return A3V_ERR_SHAPE;
@@ -1357,6 +1406,7 @@ int a3v_gemv_fused(const void* A, int64_t lda, const void* W, int64_t ldw, void*
   g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.ldr = ldr;
   g.M = M; g.N = N; g.K = K;
   g.epi = epilogue | (rope ? GEMV_EPI_ROPEKV : 0) | (ssq_out ? GEMV_EPI_SSQ : 0);
+  g.wscale = wscale;
   g.norm_w = (const bf16_t*)norm_w; g.ssq_in = ssq_in; g.eps = eps; g.ssq_tiles = K / 16; g.ssq_out = ssq_out;
   g.cos_sin = cos_sin; g.k_cache = (bf16_t*)k_cache; g.vt_cache = (bf16_t*)vt_cache;
   g.H = H; g.Hkv = Hkv; g.hd = hd; g.Smax = Smax; g.pos = pos;
@@ -1365,3 +1415,24 @@ int a3v_gemv_fused(const void* A, int64_t lda, const void* W, int64_t ldw, void*
   A3V_LAUNCH_CHECK();
   return A3V_OK;
 }
+
+// Weight-only fp8 (OCP e4m3fn) form of a3v_gemm_skinny: Wq [N, K] bytes (row stride ldw BYTES), wscale [N] fp32;
+// C = epilogue((A . dequant(Wq)^T) * wscale).  K % 256 == 0.  BASELINE config 5 / SURVEY 8(a) row Q: no reference oracle
+// exists for this path (the reference's quantised path is bitsandbytes NF4, util/quant.py); parity is stated against
+// the bf16 GEMV on the dequantised weights.
+extern "C" int a3v_gemm_skinny_fp8(const void* A, int64_t lda, const void* Wq, int64_t ldw, const float* wscale, void* C, int64_t ldc,
+                                   int M, int N, int K, const void* residual, int64_t ldr, int epilogue, void* workspace, void* stream) {
+  if (M <= 0 || M > 16 || N <= 0 || K <= 0 || !A || !Wq || !wscale || !C || !workspace) return A3V_ERR_ARG;
+  if (K % 256 || lda % 8 || ldw % 16 || N % 4 || ldc % 4) return A3V_ERR_SHAPE;
+  if ((epilogue & A3V_EPI_SWIGLU) && (N % 32)) return A3V_ERR_SHAPE;
+  if (epilogue & ~(A3V_EPI_RESIDUAL | A3V_EPI_SWIGLU | A3V_EPI_OUT_F32)) return A3V_ERR_ARG;
+  if ((epilogue & A3V_EPI_RESIDUAL) && (!residual || (ldr % 4))) return A3V_ERR_ARG;
+  GemvArgs g{};
+  g.A = (const bf16_t*)A; g.W = (const bf16_t*)Wq; g.C = C; g.res = residual; g.wscale = wscale;
+  g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.ldr = ldr;
+  g.M = M; g.N = N; g.K = K; g.epi = epilogue;
+  if (!gemv_launch(g, workspace, (hipStream_t)stream)) return A3V_ERR_SHAPE;
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}
+

@@ -25,6 +25,7 @@ SIGNATURES = {
     "a3v_gemm_nt": (I, [P, L, P, L, P, L, I, I, I, P, P, L, I, I, P]),
     "a3v_gemm_skinny_split": (I, [I, I, I]),
     "a3v_gemm_skinny_ws_bytes": (L, [I, I, I]),
+    "a3v_gemm_skinny_fp8": (I, [P, L, P, L, P, P, L, I, I, I, P, L, I, P, P]),
     "a3v_gemm_skinny": (I, [P, L, P, L, P, L, I, I, I, P, L, I, P, P]),
     "a3v_rmsnorm": (I, [P, L, P, P, L, I, I, F, I, I, I, P]),
     "a3v_layernorm": (I, [P, L, P, P, P, L, P, I, I, F, I, I, I, P]),
@@ -59,7 +60,8 @@ SIGNATURES = {
 
 class LlamaLayer(ctypes.Structure):
     """a3v_llama_layer of include/a3vlm_hip.h"""
-    _fields_ = [(n, c_void_p) for n in ("attn_norm_w", "wqkv", "wo", "ffn_norm_w", "w13", "w2", "k_cache", "vt_cache")]
+    _fields_ = [(n, c_void_p) for n in ("attn_norm_w", "wqkv", "wo", "ffn_norm_w", "w13", "w2", "k_cache", "vt_cache",
+                                        "wqkv_q", "wqkv_s", "wo_q", "wo_s", "w13_q", "w13_s", "w2_q", "w2_s")]
 
 
 SIGNATURES["a3v_llama_decode_step"] = (I, [ctypes.POINTER(LlamaLayer), I, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, F, P])

@@ -395,16 +395,44 @@ class Transformer(nn.Module):
             self._linear(xn, pk[f"w13.{i}"], act, epilogue=ops.EPI_SWIGLU)
             self._linear(act, lyr.feed_forward.w2.weight, h, residual=h)
 
+    def quantize_decode_weights(self, mode: str = "fp8") -> None:
+        """Opt-in weight-only fp8 images of the four decode matrices of every layer (a3vlm_amd/quant.py; BASELINE config 5).
+        Prefill keeps the bf16 weights; only the single-call decode step streams the fp8 images (half the bytes).
+        ``mode=None`` drops them.  Re-run after the weights change."""
+        from ...quant import quantize_rows_fp8
+        self._q8 = None
+        self._layer_tab_key = None
+        if mode is None:
+            return
+        if mode != "fp8":
+            raise ValueError("only weight-only 'fp8' (OCP e4m3fn) is implemented")
+        a = self.args
+        if a.dim % 256 or self.ffn % 256 or (self.n_heads * self.head_dim) % 256 or self._dtype != torch.bfloat16:
+            raise ValueError("fp8 decode weights need bf16 parameters and dim, ffn, n_heads*head_dim multiples of 256")
+        pk = self._pack(check=True)
+        q8 = []
+        with torch.no_grad():
+            for i, lyr in enumerate(self.layers):
+                q8.append(tuple(quantize_rows_fp8(w) for w in (pk[f"wqkv.{i}"], lyr.attention.wo.weight, pk[f"w13.{i}"],
+                                                               lyr.feed_forward.w2.weight)))
+        self._q8 = (self._packed_version, q8)
+
     def _decode_step(self, h: torch.Tensor, B: int, pos: int) -> None:
         """seqlen == 1, bf16: the whole layer stack from one C call (a3v_llama_decode_step)."""
         import ctypes
         from ... import lib as _l
         a = self.args
         pk = self._pack()
-        key = (self._packed_version, self._cache_shape)
+        q8 = getattr(self, "_q8", None)
+        if q8 is not None and q8[0] != self._packed_version:
+            raise RuntimeError("parameters changed after quantize_decode_weights(): call it again (or with mode=None)")
+        key = (self._packed_version, self._cache_shape, q8 is not None)
         if getattr(self, "_layer_tab_key", None) != key:
             tab = (_l.LlamaLayer * self.n_layers)()
             for i, lyr in enumerate(self.layers):
+                if q8 is not None:
+                    (tab[i].wqkv_q, tab[i].wqkv_s), (tab[i].wo_q, tab[i].wo_s), (tab[i].w13_q, tab[i].w13_s), (tab[i].w2_q, tab[i].w2_s) = \
+                        [(q.data_ptr(), sc.data_ptr()) for q, sc in q8[1][i]]
                 tab[i].attn_norm_w = lyr.attention_norm.weight.data_ptr()
                 tab[i].wqkv = pk[f"wqkv.{i}"].data_ptr()
                 tab[i].wo = lyr.attention.wo.weight.data_ptr()

@@ -84,6 +84,21 @@ def gemm_skinny(a, w, out, partial, *, residual=None, epilogue: int = 0):
     return out
 
 
+def gemm_skinny_fp8(a, wq, wscale, out, workspace, *, residual=None, epilogue: int = 0):
+    """out = epilogue((a . float(wq)^T) * wscale): weight-only fp8 (torch.float8_e4m3fn / uint8 bytes) decode GEMV."""
+    _dev(a, wq, wscale, out, workspace, residual)
+    M, K = a.shape
+    N = wq.shape[0]
+    assert wq.element_size() == 1 and wscale.dtype == torch.float32 and wscale.numel() == N
+    if workspace.numel() * workspace.element_size() < gemm_skinny_ws_bytes(M, N, K):
+        raise ValueError("gemm_skinny workspace too small (a3v_gemm_skinny_ws_bytes)")
+    ep = epilogue | (EPI_RESIDUAL if residual is not None else 0)
+    rc = _l.load().a3v_gemm_skinny_fp8(_p(a), a.stride(0), _p(wq), wq.stride(0), _p(wscale), _p(out), out.stride(0), M, N, K,
+                                       _p(residual), residual.stride(0) if residual is not None else 0, ep, _p(workspace), _stream())
+    _l.check(rc, f"a3v_gemm_skinny_fp8(M={M},N={N},K={K},epi={ep})")
+    return out
+
+
 def rmsnorm(x, w, out, eps: float):
     _dev(x, w, out)
     rows, dim = x.shape

@@ -109,6 +109,16 @@ def bytes_decode_step(args, B, ctx):
     return 2 * (p_dec + d * args.vocab_size) + B * 2 * L * ctx * nkv * hd * 2
 
 
+def bytes_decoder_matrices(args):
+    """bytes SAVED per decode step by 1-byte decoder matrices (wqkv, wo, w1|w3, w2 of every layer) relative to bf16"""
+    from a3vlm_amd.model.LLM.llama_ens5 import _ffn_hidden
+    d, L = args.dim, args.n_layers
+    hd = d // args.n_heads
+    nkv = args.n_kv_heads or args.n_heads
+    ffn = _ffn_hidden(d, args.multiple_of, args.ffn_dim_multiplier)
+    return L * (d * (args.n_heads + 2 * nkv) * hd + d * d + 3 * d * ffn)
+
+
 def time_gemm_shapes(m, args, B, T, W, dev):
     """Event-time every distinct gemm_nt_bf16_kernel shape of one step (same stream the step uses);
     returns (flops per step in that kernel, seconds per step in that kernel, per-shape rows)."""
@@ -421,6 +431,40 @@ def main():
     ctx = S + 2 + a.decode_steps // 2
     dec_bytes = bytes_decode_step(args, B, ctx)
 
+    # ---- decode with weight-only fp8 images of the decoder matrices (BASELINE config 5 semantics; opt-in, separate from the
+    # bf16 headline: the reference has no fp8 path, so this leg is reported beside it, never instead of it)
+    fp8 = None
+    try:
+        m.quantize_decode_weights("fp8")
+        logits = step()
+        for _ in range(2):
+            ops.argmax(logits, nt)
+            cur[:, 0] = nt
+            logits = m.forward_inference(cur, T, None)
+        sync_all()
+        t0 = time.perf_counter()
+        for i in range(a.decode_steps):
+            ops.argmax(logits, nt)
+            cur[:, 0] = nt
+            logits = m.forward_inference(cur, T + 2 + i, None)
+        sync_all()
+        f_el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([f_el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            f_el = float(t.item())
+        f_ms = f_el / a.decode_steps * 1e3
+        f_bytes = bytes_decode_step(args, B, ctx) - bytes_decoder_matrices(args)          # the four matrices per layer at 1 B/weight
+        fp8 = {"tok_s": round(B * world * a.decode_steps / f_el, 1), "ms_per_step": round(f_ms, 3),
+               "hbm_frac": round(f_bytes / (f_ms * 1e-3) / HBM_PEAK, 4), "bytes_per_step": f_bytes,
+               "note": "weight-only OCP e4m3fn decoder matrices with per-row fp32 scales (embeddings, norms, LM head, KV cache bf16); "
+                       "no reference oracle exists for fp8 (SURVEY 8(a) row Q): parity is stated against the bf16 kernels on the "
+                       "dequantised weights (tests/test_gpu_fp8.py)"}
+    except Exception as e:
+        fp8 = {"tok_s": None, "error": repr(e)[:300]}
+    finally:
+        m.quantize_decode_weights(None)
+
     lora = None
     if not a.no_train and a.model != "13b":
         try:
@@ -476,6 +520,7 @@ def main():
                                 "frac": round(dec_bytes / (dec_ms * 1e-3) / HBM_PEAK, 4), "bytes_per_step": dec_bytes,
                                 "note": "bf16 weights once per step + KV of all sequences (SURVEY 8(d)); whole step incl. host launch gaps"},
         }
+        out["decode_fp8"] = fp8
         out["train"] = train
         out["train_lora"] = lora
         if not a.no_cpu_baseline:

@@ -75,6 +75,13 @@ int a3v_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ldw, void* C,
  * a3v_gemm_skinny_split reports the split-K factor used.  Epilogues: NONE, RESIDUAL, SWIGLU, OUT_F32. */
 int a3v_gemm_skinny_split(int M, int N, int K);
 int64_t a3v_gemm_skinny_ws_bytes(int M, int N, int K);
+/* Weight-only fp8 form (BASELINE config 5): Wq [N,K] OCP e4m3fn bytes (row stride ldw in BYTES,
+ * % 16 == 0), wscale [N] fp32 per-row dequantisation scales; C = epilogue((A . float(Wq)^T) * wscale), K % 256 == 0.
+ * The reference's quantised path is CUDA-only bitsandbytes NF4 (util/quant.py:95-163): there is NO reference oracle for
+ * fp8 -- parity is stated against the bf16 kernel on the dequantised weights. */
+int a3v_gemm_skinny_fp8(const void* A, int64_t lda, const void* Wq, int64_t ldw, const float* wscale, void* C,
+                        int64_t ldc, int M, int N, int K, const void* residual, int64_t ldr, int epilogue,
+                        void* workspace, void* stream);
 int a3v_gemm_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
                     int M, int N, int K, const void* residual, int64_t ldr, int epilogue,
                     void* partial, void* stream);
@@ -174,6 +181,12 @@ typedef struct a3v_llama_layer {
   const void* w2;
   void* k_cache;        /* [B,Hkv,Smax,hd] */
   void* vt_cache;       /* [B,Hkv,hd,Smax] */
+  /* optional weight-only fp8 (OCP e4m3fn) images of the four matrices, same row order as the bf16 images, with one fp32
+   * scale per row (a3v_gemm_skinny_fp8); all NULL = bf16.  Used only by the fused step form (dims % 256 == 0). */
+  const void* wqkv_q; const float* wqkv_s;
+  const void* wo_q;   const float* wo_s;
+  const void* w13_q;  const float* w13_s;
+  const void* w2_q;   const float* w2_s;
 } a3v_llama_layer;
 int a3v_llama_decode_step(const a3v_llama_layer* layers, int n_layers, void* h, void* xn, void* qkv,
                           void* att, void* act, float* attn_scratch, void* skinny_ws, const float* cos_sin, int B,
