@@ -123,6 +123,11 @@ def test_g6_generate_greedy_bit_exact_fp32(gold, key, max_gen, stops):
                              additional_stop_symbols=stops, return_ids=True)
     assert ids == gold["j"][key + "_ids"]
     assert texts == gold["j"][key + "_text"]
+    # the stop flag is polled every poll_every steps (default 4): identical outputs at the reference's cadence (1) and beyond
+    for pe in (1, 3, 64):
+        t2, i2 = mm.generate(gold["j"]["prompts"], None, max_gen_len=max_gen, temperature=0.0, additional_stop_symbols=stops,
+                             return_ids=True, poll_every=pe)
+        assert i2 == ids and t2 == texts, pe
 
 
 def vision_model(gold, dtype=torch.float32):
