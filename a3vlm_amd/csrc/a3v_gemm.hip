@@ -23,6 +23,7 @@ namespace {
 
 constexpr int BK = 64;
 constexpr int GROUP_M = 8;
+constexpr int GEMM_EPI_RAW = 1 << 20;     // internal: fp32 output without the bf16 rounding of the accumulator
 
 struct GemmArgs {
   const bf16_t* A;
@@ -34,6 +35,7 @@ struct GemmArgs {
   int M, N, K, epi;
   int tiles_m, tiles_n;
   int dbg;   // ablation switches for tuning runs (0 in production): 1 = no DMA in the k-loop, 2 = no ds_read in the k-loop
+  int64_t c_split;   // split-K (128x128 kernel, gridDim.y slices): byte stride between the slices' output planes
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
@@ -101,8 +103,10 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GemmAr
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += bf2f(b[r]);
       }
+      if (!(epi & GEMM_EPI_RAW)) {      // split-K planes keep the raw fp32 partial sums (rounded once by the reduce pass)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = rbf(v[r]);   // the bf16 value F.linear returns
+        for (int r = 0; r < 4; ++r) v[r] = rbf(v[r]);   // the bf16 value F.linear returns
+      }
       if (epi & A3V_EPI_GELU) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = rbf(gelu_erf(v[r]));
@@ -174,9 +178,21 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_bf16_kernel(Ge
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = p.K / BK;
-  stage_tile<TBM, NW>(p.A, p.lda, m0, p.M - 1, 0, lds, wave, lane);
-  stage_tile<TBN, NW>(p.W, p.ldw, n0, p.N - 1, 0, lds + TBM * BK * 2, wave, lane);
+  // split-K: slice z of gridDim.y takes the k-tiles [z nk/S, (z+1) nk/S) and writes its own output plane (summed by
+  // splitk_reduce_kernel); skinny problems (N or M = 64) otherwise run as a few blocks with a long serial K loop
+  int nk = p.K / BK;
+  if (gridDim.y > 1) {
+    const int z = blockIdx.y, S = gridDim.y;
+    const int t0 = (int)(((int64_t)z * nk) / S), t1 = (int)(((int64_t)(z + 1) * nk) / S);
+    p.A += (int64_t)t0 * BK;
+    p.W += (int64_t)t0 * BK;
+    p.C = reinterpret_cast<char*>(p.C) + (int64_t)z * p.c_split;
+    nk = t1 - t0;
+  }
+  if (nk > 0) {
+    stage_tile<TBM, NW>(p.A, p.lda, m0, p.M - 1, 0, lds, wave, lane);
+    stage_tile<TBN, NW>(p.W, p.ldw, n0, p.N - 1, 0, lds + TBM * BK * 2, wave, lane);
+  }
   __syncthreads();
 
   const int frow = lane & 15;            // row inside a 16-row MFMA tile
@@ -1432,6 +1448,61 @@ extern "C" int a3v_gemm_skinny_fp8(const void* A, int64_t lda, const void* Wq, i
   g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.ldr = ldr;
   g.M = M; g.N = N; g.K = K; g.epi = epilogue;
   if (!gemv_launch(g, workspace, (hipStream_t)stream)) return A3V_ERR_SHAPE;
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// Split-K skinny GEMM for the LoRA adapter products (N or M = 64 with K in the thousands): S slices of the K loop run
+// as gridDim.y planes of the 128x128 kernel writing fp32 partial outputs; a3v_splitk_reduce sums the planes in slice
+// order (deterministic), optionally accumulates into the destination, and rounds once -- the same fp32-accumulate,
+// round-once arithmetic as the un-split kernel.
+// ------------------------------------------------------------------------------------
+namespace {
+template <typename TO>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int S, int64_t plane, int M, int N, TO* __restrict__ out,
+                                                            int64_t ldo, int accumulate) {
+  const int64_t n4 = (int64_t)M * (N / 4);
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const int r = (int)(i / (N / 4)), c = (int)(i % (N / 4)) * 4;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < S; ++s) {
+      const f32x4 x = *reinterpret_cast<const f32x4*>(part + (int64_t)s * plane + (int64_t)r * N + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] += x[e];
+    }
+    TO* o = out + (int64_t)r * ldo + c;
+    // the product is rounded to bf16 exactly once, like the un-split kernel's epilogue (the value autocast's bf16 matmul
+    // returns), also when it is then accumulated into an fp32 gradient
+#pragma unroll
+    for (int e = 0; e < 4; ++e) Cvt<TO>::st(o + e, accumulate ? Cvt<TO>::ld(o + e) + rbf(a[e]) : rbf(a[e]));
+  }
+}
+}  // namespace
+
+extern "C" int a3v_gemm_nt_splitk(const void* A, int64_t lda, const void* W, int64_t ldw, float* partial, int M, int N, int K, int S,
+                                  void* stream) {
+  if (!A || !W || !partial || M <= 0 || N <= 0 || K <= 0 || S < 1 || S > 64) return A3V_ERR_ARG;
+  if (K % 64 || lda % 8 || ldw % 8 || N % 4 || S > K / 64) return A3V_ERR_SHAPE;
+  GemmArgs p{};
+  p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.C = partial; p.bias = nullptr; p.res = nullptr;
+  p.lda = lda; p.ldw = ldw; p.ldc = N; p.ldr = 0;
+  p.M = M; p.N = N; p.K = K; p.epi = A3V_EPI_OUT_F32 | GEMM_EPI_RAW; p.dbg = 0;
+  p.tiles_m = (M + 127) / 128; p.tiles_n = (N + 127) / 128;
+  p.c_split = (int64_t)M * N * 4;
+  hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 128, 2, 2>), dim3(p.tiles_m * p.tiles_n, S), dim3(256), 0, (hipStream_t)stream, p);
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}
+
+extern "C" int a3v_splitk_reduce(const float* partial, int S, int M, int N, void* out, int64_t ldo, int out_dtype, int accumulate, void* stream) {
+  if (!partial || !out || S < 1 || M <= 0 || N <= 0) return A3V_ERR_ARG;
+  if (N % 4) return A3V_ERR_SHAPE;
+  const int64_t n4 = (int64_t)M * (N / 4);
+  const int blocks = (int)((n4 + 255) / 256 > 4096 ? 4096 : (n4 + 255) / 256);
+  if (out_dtype == A3V_BF16) hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partial, S, (int64_t)M * N, M, N, (bf16_t*)out, ldo, accumulate);
+  else if (out_dtype == A3V_F32) hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partial, S, (int64_t)M * N, M, N, (float*)out, ldo, accumulate);
+  else return A3V_ERR_DTYPE;
   A3V_LAUNCH_CHECK();
   return A3V_OK;
 }

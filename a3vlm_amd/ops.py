@@ -56,6 +56,18 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, r
     return out
 
 
+def gemm_nt_splitk(a, w, out, scratch, S: int, accumulate: bool = False):
+    """out (+)= a @ w.T through S split-K planes (fp32 scratch of >= S*M*N floats); rounds once to out.dtype."""
+    _dev(a, w, out, scratch)
+    M, K = a.shape
+    N = w.shape[0]
+    assert scratch.dtype == torch.float32 and scratch.numel() >= S * M * N
+    lib = _l.load()
+    _l.check(lib.a3v_gemm_nt_splitk(_p(a), a.stride(0), _p(w), w.stride(0), _p(scratch), M, N, K, S, _stream()), f"a3v_gemm_nt_splitk(M={M},N={N},K={K},S={S})")
+    _l.check(lib.a3v_splitk_reduce(_p(scratch), S, M, N, _p(out), out.stride(0), dt(out), 1 if accumulate else 0, _stream()), "a3v_splitk_reduce")
+    return out
+
+
 def gemm_skinny_split(M: int, N: int, K: int) -> int:
     return _l.load().a3v_gemm_skinny_split(M, N, K)
 

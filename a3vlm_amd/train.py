@@ -205,7 +205,27 @@ class TrainEngine:
             ops.gemm_nt(dyt, xt, grad, epilogue=ops.EPI_OUT_F32 if self.act == torch.bfloat16 else 0)
         else:
             assert not any(n in self._fresh for n in names), "partially fresh fused gradient view"
-            ops.gemm_nt(dyt, xt, grad, residual=grad, epilogue=ops.EPI_RES_F32 if self.act == torch.bfloat16 else 0)
+            if min(N, K) <= 64:
+                self._skinny(dyt, xt, grad, accumulate=True)
+            else:
+                ops.gemm_nt(dyt, xt, grad, residual=grad, epilogue=ops.EPI_RES_F32 if self.act == torch.bfloat16 else 0)
+
+    def _skinny(self, a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, accumulate: bool = False):
+        """out (+)= a @ w.T for adapter-sized problems (M or N <= 64, long K): split-K planes of the 128x128 kernel + one
+        reduce pass; a plain launch would be a handful of blocks with a serial K loop (122 us instead of ~25 at 8728 x 64 x 4096)."""
+        M, K = a.shape
+        N = w.shape[0]
+        blocks = ((M + 127) // 128) * ((N + 127) // 128)
+        nk = K // 64
+        S = 1
+        while blocks * S < 512 and S * 2 <= nk and S < 32:
+            S *= 2
+        if S == 1 or self.act != torch.bfloat16 or K % 64:
+            f32 = out.dtype == torch.float32 and self.act == torch.bfloat16
+            ops.gemm_nt(a, w, out, residual=out if accumulate else None,
+                        epilogue=(ops.EPI_RES_F32 if accumulate else ops.EPI_OUT_F32) if f32 else 0)
+            return
+        ops.gemm_nt_splitk(a, w, out, self._buf("splitk", (S * M * N,), torch.float32), S, accumulate)
 
     def _dgrad(self, dy: torch.Tensor, wt: torch.Tensor, out: torch.Tensor):
         """out[M,K] = dy[M,N] @ W[N,K] with wt = W^T [K, Np]; dy may have N < Np columns -> padded copy."""
@@ -215,7 +235,10 @@ class TrainEngine:
             dyp = self._buf("dg_pad", (M, Np), zero=True)
             dyp[:, :N].copy_(dy)
             dy = dyp
-        ops.gemm_nt(dy, wt, out)
+        if wt.shape[0] <= 64:
+            self._skinny(dy, wt, out)
+        else:
+            ops.gemm_nt(dy, wt, out)
 
     # ------------------------------------------------------------------ LoRA adapters (model/peft.py semantics)
     def _lora_step_images(self):
@@ -245,7 +268,7 @@ class TrainEngine:
         li = self._lora_step_images()
         A, Bm = li[key + ".A"], li[key + ".B"]
         t = self._buf("lora_t." + key.split(".")[0] + tag, (x.shape[0], A.shape[0]))
-        ops.gemm_nt(x, A, t)
+        self._skinny(x, A, t)
         f32 = y.dtype == torch.float32 and self.act == torch.bfloat16
         ops.gemm_nt(t, Bm, y, residual=y, epilogue=ops.EPI_RES_F32 if f32 else 0)
         return t
@@ -324,7 +347,7 @@ class TrainEngine:
         if self.lora:                                     # t = lora_a(act) of w2 is needed by the backward even without the output
             li = self._lora_step_images()
             lt["w2"] = self._buf("lora_t.w2" + tag, (rows, li[f"w2.{i}.A"].shape[0]))
-            ops.gemm_nt(actb, li[f"w2.{i}.A"], lt["w2"])
+            self._skinny(actb, li[f"w2.{i}.A"], lt["w2"])
         kept = dict(xn=xn, qkv=qkv, qrot=qrot, kc=kc, att=att, lse=lse, h_mid=h_mid, xn2=xn2, gu=gu, act=actb, spad=spad, lt=lt)
         if keep and h_out is None:
             return kept                                   # recompute inside backward: the block output is not needed

@@ -68,6 +68,14 @@ int a3v_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ldw, void* C,
                 int M, int N, int K, const void* bias, const void* residual, int64_t ldr,
                 int epilogue, int dtype, void* stream);
 
+/* Split-K form for skinny products with a long K (the LoRA adapter GEMMs of model/peft.py:84-99 and their gradients:
+ * N or M = 64, K = 4096 ... 22016): slice s of S writes the fp32 plane partial[s][M][N]; a3v_splitk_reduce sums the
+ * planes in order, optionally accumulates into `out` (fp32 gradients) and rounds once to out_dtype. */
+int a3v_gemm_nt_splitk(const void* A, int64_t lda, const void* W, int64_t ldw, float* partial, int M, int N,
+                       int K, int S, void* stream);
+int a3v_splitk_reduce(const float* partial, int S, int M, int N, void* out, int64_t ldo, int out_dtype,
+                      int accumulate, void* stream);
+
 /* Skinny-M (decode) form of the same contract, M <= 16: streams W once from HBM (one launch).
  * `partial` is a workspace of a3v_gemm_skinny_ws_bytes(M, N, K) bytes: the first 16384 bytes are
  * split-K arrival counters that the caller zero-fills ONCE; every call leaves them zero.  The

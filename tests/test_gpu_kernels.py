@@ -456,3 +456,23 @@ def test_cross_entropy(dtype):
     F.cross_entropy(lgf, lab, ignore_index=0).backward()
     tol = dict(rtol=1e-4, atol=1e-8) if dtype == torch.float32 else dict(rtol=2 ** -7, atol=1e-7)
     assert_close(dl, lgf.grad, what="ce grad", **tol)
+
+
+@pytest.mark.parametrize("M,N,K,S", [(300, 64, 4096, 8), (64, 520, 8768, 16), (1000, 64, 22016, 4), (130, 96, 128, 2), (64, 64, 8768, 7)])
+def test_gemm_nt_splitk(M, N, K, S):
+    """split-K planes + ordered reduce == the fp32-accumulate / round-once result of the un-split GEMM; accumulate form adds
+    into an fp32 destination; uneven slices (137 k-tiles over 16 / 7 slices)."""
+    a, w = rt(gen(M, K, seed=31)), rt(gen(N, K, seed=32, scale=0.05))
+    ad, wd = a.to(BF).to(DEV), w.to(BF).to(DEV)
+    want = a @ w.t()
+    scratch = torch.empty(S * M * N, dtype=torch.float32, device=DEV)
+    ob = torch.empty(M, N, dtype=BF, device=DEV)
+    ops.gemm_nt_splitk(ad, wd, ob, scratch, S)
+    assert_close(ob, want, rtol=2 ** -7, atol=2e-3 * math.sqrt(K) * 0.05 + 1e-3, what="splitk bf16")
+    acc0 = gen(M, N, seed=33)
+    of = acc0.to(DEV).clone()
+    ops.gemm_nt_splitk(ad, wd, of, scratch, S, accumulate=True)
+    assert_close(of, acc0 + rt(want), rtol=2 ** -7, atol=2e-3 * math.sqrt(K) * 0.05 + 1e-3, what="splitk f32 accumulate")
+    ob2 = torch.empty_like(ob)
+    ops.gemm_nt_splitk(ad, wd, ob2, scratch, S)
+    assert torch.equal(ob, ob2)
