@@ -1223,6 +1223,55 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(GemmF32Args p) {
 
 extern "C" int a3v_version(void) { return 100; }
 
+// Optional scratch for the split-K form of the hybrid dispatch's tail rows (a3v_gemm_set_workspace): the library never
+// allocates, so without it the tail runs as a plain 128x128 launch.
+static float* g_gemm_ws = nullptr;
+static int64_t g_gemm_ws_bytes = 0;
+extern "C" int a3v_gemm_set_workspace(void* ptr, int64_t bytes) {
+  g_gemm_ws = (float*)ptr;
+  g_gemm_ws_bytes = ptr ? bytes : 0;
+  return A3V_OK;
+}
+
+namespace {
+// sum of S raw fp32 planes [M][N] -> rounded once to bf16 ("the value F.linear returns") -> residual / output forms of gemm_epilogue
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __restrict__ part, int S, int64_t plane, int M, int N, void* __restrict__ C,
+                                                              int64_t ldc, const void* __restrict__ res, int64_t ldr, int epi) {
+  const int64_t n4 = (int64_t)M * (N / 4);
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const int r = (int)(i / (N / 4)), c = (int)(i % (N / 4)) * 4;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < S; ++s) {
+      const f32x4 x = *reinterpret_cast<const f32x4*>(part + (int64_t)s * plane + (int64_t)r * N + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] += x[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[e] = rbf(a[e]);
+    if (epi & A3V_EPI_RES_F32) {
+      const f32x4 rr = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(res) + (int64_t)r * ldr + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] += rr[e];
+      *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(C) + (int64_t)r * ldc + c) = a;
+      continue;
+    }
+    if (epi & A3V_EPI_RESIDUAL) {
+      const bf16x4 rr = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(res) + (int64_t)r * ldr + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] += bf2f(rr[e]);
+    }
+    if (epi & A3V_EPI_OUT_F32) {
+      *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(C) + (int64_t)r * ldc + c) = a;
+    } else {
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = f2bf(a[e]);
+      *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(C) + (int64_t)r * ldc + c) = o;
+    }
+  }
+}
+}  // namespace
+
 extern "C" int a3v_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
                            int M, int N, int K, const void* bias, const void* residual, int64_t ldr,
                            int epilogue, int dtype, void* stream) {
@@ -1316,7 +1365,26 @@ extern "C" int a3v_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ld
       const int esz = (p.epi & (A3V_EPI_OUT_F32 | A3V_EPI_RES_F32)) ? 4 : 2;
       r.C = (char*)p.C + (int64_t)m_big * ldc * esz;
       if (p.res) r.res = (const char*)p.res + (int64_t)m_big * ldr * ((p.epi & A3V_EPI_RES_F32) ? 4 : 2);
-      launch(128, r);
+      // tail rows: a few hundred rows x N on 128x128 tiles = ~160 blocks with a serial K loop (50 us at K = 4096, 135 us at
+      // K = 11008).  With a registered workspace the K loop is split into S planes (more blocks, 1/S the latency) and a
+      // reduce pass applies the epilogue; only the plain / residual / fp32 forms are handled there.
+      const int simple = A3V_EPI_RESIDUAL | A3V_EPI_RES_F32 | A3V_EPI_OUT_F32;
+      int S = 1;
+      const int tblocks = ((r.M + 127) / 128) * ((N + 127) / 128);
+      while (tblocks * S < 512 && S < 8 && K / 64 >= 16 * S) S *= 2;
+      if (S > 1 && !(p.epi & ~simple) && g_gemm_ws && (int64_t)S * r.M * N * 4 <= g_gemm_ws_bytes && N % 4 == 0) {
+        GemmArgs t = r;
+        t.C = g_gemm_ws; t.ldc = N; t.res = nullptr; t.bias = nullptr;
+        t.epi = A3V_EPI_OUT_F32 | GEMM_EPI_RAW;
+        t.tiles_m = (t.M + 127) / 128; t.tiles_n = (N + 127) / 128;
+        t.c_split = (int64_t)t.M * N * 4;
+        hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 128, 2, 2>), dim3(t.tiles_m * t.tiles_n, S), dim3(256), 0, st, t);
+        const int64_t n4 = (int64_t)r.M * (N / 4);
+        const int rb = (int)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256);
+        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(rb), dim3(256), 0, st, g_gemm_ws, S, (int64_t)r.M * N, r.M, N, r.C, r.ldc, r.res, r.ldr, p.epi);
+      } else {
+        launch(128, r);
+      }
     } else {
       launch(128, p);
     }

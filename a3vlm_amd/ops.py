@@ -37,10 +37,23 @@ def _dev(*ts):
             raise RuntimeError("a3vlm_amd ops need device tensors (no CPU fallback exists)")
 
 
+_gemm_ws = {}
+
+
+def _ensure_gemm_workspace(device) -> None:
+    """Register (once per process) the scratch a3v_gemm_nt may use for the split-K tail of its hybrid dispatch."""
+    if _gemm_ws:
+        return
+    ws = torch.empty(96 << 20, dtype=torch.uint8, device=device)
+    _gemm_ws[device] = ws
+    _l.check(_l.load().a3v_gemm_set_workspace(ws.data_ptr(), ws.numel()), "a3v_gemm_set_workspace")
+
+
 def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, residual=None,
             epilogue: int = 0) -> torch.Tensor:
     """out[M, N or N/2] = epilogue(a[M,K] @ w[N,K]^T); a/w/out 2-D with unit inner stride."""
     _dev(a, w, out, bias, residual)
+    _ensure_gemm_workspace(a.device)
     M, K = a.shape
     N = w.shape[0]
     assert w.shape[1] == K and a.stride(1) == 1 and w.stride(1) == 1 and out.stride(1) == 1

@@ -68,6 +68,11 @@ int a3v_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ldw, void* C,
                 int M, int N, int K, const void* bias, const void* residual, int64_t ldr,
                 int epilogue, int dtype, void* stream);
 
+/* Optional: register a scratch buffer (device memory, >= 32 MiB recommended; NULL unregisters) that a3v_gemm_nt may use
+ * to split the K loop of the few-hundred-row tail of its hybrid tile dispatch.  The library itself never allocates.  One
+ * buffer per process (one process per GPU); it must outlive every later a3v_gemm_nt call and is used on the call's stream. */
+int a3v_gemm_set_workspace(void* ptr, int64_t bytes);
+
 /* Split-K form for skinny products with a long K (the LoRA adapter GEMMs of model/peft.py:84-99 and their gradients:
  * N or M = 64, K = 4096 ... 22016): slice s of S writes the fp32 plane partial[s][M][N]; a3v_splitk_reduce sums the
  * planes in order, optionally accumulates into `out` (fp32 gradients) and rounds once to out_dtype. */
