@@ -1,0 +1,54 @@
+"""CPU: the pieces of bench.py that do not need a GPU -- argument defaults, the FLOP / byte accounting the reported fractions
+are built on (SURVEY 8(d) conventions), and the committed bench lines under profiles/ carry every field of the contract."""
+import glob
+import json
+import os
+import sys
+import types
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_defaults_finish_quickly_and_name_the_workload():
+    sys_argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        a = bench.parse()
+    finally:
+        sys.argv = sys_argv
+    assert a.gpus == 1 and a.steps <= 10 and a.warmup <= 5 and a.batch == 8 and a.prompt == 512 and a.model == "7b"
+
+
+def test_flop_and_byte_accounting_7b():
+    from a3vlm_amd.model.LLM.llama_ens5 import ModelArgs
+    args = ModelArgs(vocab_size=32000, max_seq_len=2048, vit_patch=14, vit_crop=336, n_views=1, vit_width=1024, vit_layers=24, vit_heads=16,
+                     **bench.GEOM["7b"])
+    B, T, W = 8, 512, 579
+    fl = bench.flops_forward(args, B, T, W)
+    S = T + W
+    lin = 2 * B * S * 32 * (4096 * 3 * 4096 + 4096 * 4096 + 3 * 4096 * 11008)
+    assert abs(fl["gemm"] - lin) / lin < 0.05                          # decoder linears dominate the GEMM count
+    assert 14.0e12 < fl["total"] / B < 15.5e12                          # 14.83 TFLOP per sample
+    by = bench.bytes_decode_step(args, B, 1100)
+    weights = 2 * (32 * (4096 * 3 * 4096 + 4096 * 4096 + 3 * 4096 * 11008) + 4096 * 32000)
+    kv = B * 2 * 32 * 1100 * 32 * 128 * 2
+    assert by == weights + kv
+    assert bench.bytes_decoder_matrices(args) == 32 * (4096 * 3 * 4096 + 4096 * 4096 + 3 * 4096 * 11008)
+
+
+def test_committed_bench_lines_follow_the_contract():
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01*_bench_7b.json")))
+    assert files, "no committed bench line under profiles/"
+    d = json.loads(open(files[-1]).read().strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "samples/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "bf16" and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["peak"] == 2500.0
+    assert r["traffic"] is None or r["traffic"]["bytes_per_launch"] > r["traffic"]["algorithmic_bytes_per_launch"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["unit"] == "samples/s" and c["sample"]
+    assert abs(d["value"] - 8 * 1000.0 / d["ms_per_step"]) / d["value"] < 0.01
