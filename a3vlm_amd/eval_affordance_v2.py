@@ -131,10 +131,12 @@ def main(args):
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
     if args.model_parallel_size != 1:
         raise SystemExit("tensor parallelism is not part of this build (DP replicas only): use --model_parallel_size 1")
+    if os.environ.get("A3V_ONE_DEVICE") == "1":      # tests: several ranks on a single-GPU box (with A3V_DIST_BACKEND=gloo)
+        local = 0
     torch.cuda.set_device(local)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(os.environ.get("A3V_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
     dev = torch.device("cuda", local)
     cfg = args.llama_config or []
     old = torch.get_default_dtype()

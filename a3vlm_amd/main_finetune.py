@@ -108,10 +108,12 @@ def main(args):
         raise SystemExit("tensor parallelism is not part of this build (DP replicas only, SURVEY 8(e)): use --model_parallel_size 1")
     if args.quant:
         raise SystemExit("--quant (bitsandbytes NF4) is CUDA-only and out of scope (SURVEY 8(a) row Q)")
+    if os.environ.get("A3V_ONE_DEVICE") == "1":      # tests: several ranks on a single-GPU box (with A3V_DIST_BACKEND=gloo)
+        local = 0
     torch.cuda.set_device(local)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)     # "nccl" on ROCm is RCCL (util/misc.py:141-145)
+        dist.init_process_group(os.environ.get("A3V_DIST_BACKEND", "nccl"), rank=rank, world_size=world)     # "nccl" on ROCm is RCCL (util/misc.py:141-145)
     seed = args.seed + rank                                              # main_finetune.py:152-154
     torch.manual_seed(seed)
     np.random.seed(seed)

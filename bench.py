@@ -361,8 +361,11 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # A3V_BENCH_ONE_DEVICE=1 + A3V_DIST_BACKEND=gloo: exercise the multi-rank code path on a single-GPU box (tests only)
+        if os.environ.get("A3V_BENCH_ONE_DEVICE") == "1":
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(os.environ.get("A3V_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
     else:
         dist = None
         torch.cuda.set_device(0)

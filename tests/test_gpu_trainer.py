@@ -82,3 +82,82 @@ def test_main_finetune_lora_only_save_trainable(tmp_path):
     assert any("lora_a" in k for k in keys) and any("attention_norm" in k for k in keys) and "llma.visual_proj.0.weight" in keys
     assert not any(k.endswith("attention.wq.weight") for k in keys) and "llma.tok_embeddings.weight" not in keys
     assert json.load(open(out / "epoch0" / "meta.json"))["llama_type"] == "llama_ens5_peft"
+
+
+def test_bench_two_ranks_code_path_on_one_gpu(tmp_path):
+    """bench.py --gpus 2 through torch.distributed.run: both ranks share cuda:0 and talk over gloo (this box has one GPU; the
+    driver's N>1 runs use RCCL).  Checks the barrier / max-over-ranks timing, the weak-scaling value, the DP reducer of the
+    training legs with real gradients, and that exactly one JSON line comes out."""
+    e = dict(os.environ)
+    e["PYTHONPATH"] = ROOT + os.pathsep + e.get("PYTHONPATH", "")
+    e.update(A3V_BENCH_ONE_DEVICE="1", A3V_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        e.pop(k, None)
+    port = 29500 + os.getpid() % 2000
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--model", "tiny", "--steps", "2",
+                        "--warmup", "1", "--batch", "2", "--prompt", "32", "--decode-steps", "4", "--train-steps", "1", "--no-cpu-baseline"],
+                       cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 4
+    assert abs(d["value"] - 4 * 1000.0 / d["ms_per_step"]) / d["value"] < 0.02
+    assert d["train"] and d["train"].get("samples_s"), d["train"]
+    assert d["train_lora"] and d["train_lora"].get("samples_s"), d["train_lora"]
+    assert d["decode_tok_s"] > 0
+
+
+def _torchrun(module_args, tmp_env=None, nproc=2):
+    e = dict(os.environ)
+    e["PYTHONPATH"] = ROOT + os.pathsep + e.get("PYTHONPATH", "")
+    e.update(A3V_ONE_DEVICE="1", A3V_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        e.pop(k, None)
+    port = 31500 + os.getpid() % 2000
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), "-m"] + module_args, cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return r.stdout
+
+
+def test_main_finetune_two_ranks_dp(tmp_path):
+    """Data-parallel trainer entry point with world_size 2 (both ranks on cuda:0, gloo): weight broadcast, sampler sharding,
+    per-layer gradient buckets reduced on the side stream during backward, rank-0 checkpoint + per-rank files."""
+    gd = os.path.join(ROOT, "tests", "golden")
+    extra = tmp_path / "vit.json"
+    extra.write_text(json.dumps(dict(vit_width=64, vit_layers=2, vit_heads=4, vit_crop=112, n_views=1)))
+    out = tmp_path / "out"
+    log = _torchrun(["a3vlm_amd.main_finetune", "--llama_type", "llama_ens5", "--llama_config", os.path.join(gd, "tiny_params.json"), str(extra),
+                     "--tokenizer_path", os.path.join(gd, "tokenizer.model"), "--batch_size", "2", "--accum_iter", "2", "--epochs", "1",
+                     "--warmup_epochs", "0.5", "--lr", "1e-3", "--min_lr", "0", "--clip_grad", "8", "--weight_decay", "0", "--max_words", "120",
+                     "--precision", "bf16", "--output_dir", str(out), "--synthetic", "32", "--num_workers", "0", "--dialog",
+                     "--model_parallel_size", "1"])
+    assert "closs" in log
+    files = set(os.listdir(out / "epoch0"))
+    assert {"consolidated.00-of-01.model.pth", "rank-specific-00000-of-00002.pth", "rank-specific-00001-of-00002.pth"} <= files
+
+
+def test_eval_entry_two_ranks(tmp_path):
+    """Batch-inference entry point with world_size 2: the dataset is sharded by rank and the answers are gathered on rank 0."""
+    import types
+    from a3vlm_amd import checkpoint as ck
+    from a3vlm_amd.model.meta import MetaModel
+    from oracle import ref_cpu
+    from oracle.gen_golden import TINY
+    gd = os.path.join(ROOT, "tests", "golden")
+    vit = dict(vit_width=64, vit_layers=2, vit_heads=4, vit_crop=112, n_views=5)
+    cfgp = tmp_path / "cfg.json"
+    cfgp.write_text(json.dumps({**{k: v for k, v in TINY.items() if k != "max_seq_len"}, **vit}))
+    mm = MetaModel("llama_ens5", str(cfgp), os.path.join(gd, "tokenizer.model"), with_visual=True, max_seq_len=512)
+    sd = ref_cpu.make_decoder_weights(ref_cpu.OracleArgs(vocab_size=mm.tokenizer.n_words, **TINY), seed=0, std=0.08)
+    vsd = ref_cpu.make_vision_weights(64, width=64, layers=2, patch=14, grid=8, seed=1, std=0.05)
+    mm.llma.load_state_dict({**sd, **vsd})
+    ckdir = ck.save_checkpoint(str(tmp_path / "ck"), types.SimpleNamespace(precision="tf32", only_save_trainable=False), mm, None, None, None, epoch=0)
+    _torchrun(["a3vlm_amd.eval_affordance_v2", "--llama_type", "llama_ens5", "--llama_config", str(cfgp), "--tokenizer_path",
+               os.path.join(gd, "tokenizer.model"), "--pretrained_path", ckdir, "--batch_size", "1", "--num_workers", "0", "--dataset",
+               os.path.join(gd, "demo", "demo.json"), "--input_size", "224", "--addition_flag", "t2", "--max_gen_len", "6", "--max_seq_len", "512",
+               "--temperature", "0", "--image_root", os.path.join(gd, "demo"), "--output_root", str(tmp_path / "logs"), "--precision", "tf32"])
+    recs = json.load(open(tmp_path / "logs" / "t2" / "demo.json"))
+    assert len(recs) == 3 and recs[0]["answer"] == recs[1]["answer"] == recs[2]["answer"]
