@@ -33,8 +33,7 @@ class TrainEngine:
         self.lora = int(getattr(model, "lora_rank", 0) or 0) > 0
         self.act = compute_dtype
         self.recompute = recompute
-        self._img: Dict[str, torch.Tensor] = {}
-        self._img_version = None
+        self._img = None
         self._ws: Dict[tuple, torch.Tensor] = {}
         self._flat: Optional[torch.Tensor] = None
         self._views: Dict[str, torch.Tensor] = {}
@@ -154,41 +153,12 @@ class TrainEngine:
 
     # ------------------------------------------------------------------ weight images in the compute dtype
     def _images(self):
-        m = self.m
-        base = [q for n, q in m.named_parameters() if "lora_" not in n and not n.startswith("clip.")]
-        ver = tuple(q._version for q in base) + (self.act, str(m._device))
-        if self._img_version == ver:
-            return self._img
-        act = self.act
-        im: Dict[str, torch.Tensor] = {}
-
-        def both(key, w):     # W [N,K] and W^T [K, N] (N padded to 64 for the dgrad GEMM's K dim)
-            wa = w.to(act).contiguous()
-            N, K = wa.shape
-            Np = _pad64(N)
-            if Np != N:
-                wp = torch.zeros(Np, K, dtype=act, device=wa.device)
-                wp[:N] = wa
-            else:
-                wp = wa
-            im[key] = wa
-            wt = torch.empty(K, Np, dtype=act, device=wa.device)
-            ops.transpose(wp, wt, Np, K, Np)
-            im[key + ".t"] = wt
-        with torch.no_grad():
-            for i, l in enumerate(m.layers):
-                a, f = l.attention, l.feed_forward
-                both(f"qkv.{i}", torch.cat([a.wq.weight, a.wk.weight, a.wv.weight], dim=0))
-                both(f"wo.{i}", a.wo.weight)
-                both(f"w13.{i}", torch.cat([f.w1.weight, f.w3.weight], dim=0))
-                both(f"w2.{i}", f.w2.weight)
-            both("out", m.output.weight)
-            if m.with_visual:
-                vp0 = getattr(m.visual_proj, "0")
-                both("vp", vp0.weight)
-                im["vp.b"] = vp0.bias.to(act)
-        self._img, self._img_version = im, ver
-        return im
+        """Lazy bf16 weight images: group ``L{i}`` (qkv / wo / w13 / w2 and their transposes of layer i), ``out``, ``vp``; a group
+        is (re)built on first use after its parameters changed.  (Issuing the AdamW update per layer on a side stream under the
+        next forward was tried on top of this and measured no gain: the 256x256 GEMM leaves no VGPRs for a co-resident kernel.)"""
+        if self._img is None or not isinstance(self._img, _Images):
+            self._img = _Images(self)
+        return self._img
 
     # ------------------------------------------------------------------ GEMM helpers
     def _wgrad(self, dy: torch.Tensor, x: torch.Tensor, grad: torch.Tensor, tag: str, names=()):
@@ -548,6 +518,66 @@ class TrainEngine:
         for j, sl in enumerate(vis["slots"]):
             ops.rows_sum(dh, vis["start_rows"][j], vis["start_rows"][j].numel(), self._views[names[sl][0]].view(-1))
             ops.rows_sum(dh, vis["end_rows"][j], vis["end_rows"][j].numel(), self._views[names[sl][1]].view(-1))
+
+
+class _Images:
+    """dict-like view of the engine's compute-dtype weight images, built per group on demand."""
+
+    def __init__(self, eng: "TrainEngine"):
+        self.eng = eng
+        self.store: Dict[str, torch.Tensor] = {}
+        self.ver: Dict[str, tuple] = {}
+
+    def _group(self, key: str):
+        if key.startswith(("qkv.", "wo.", "w13.", "w2.")):
+            return "L" + key.split(".")[1]
+        return "vp" if key.startswith("vp") else "out"
+
+    def _both(self, key, w):      # W [N,K] and W^T [K, N] (N padded to 64 for the dgrad GEMM's K dim)
+        act = self.eng.act
+        wa = w.to(act).contiguous()
+        N, K = wa.shape
+        Np = _pad64(N)
+        if Np != N:
+            wp = torch.zeros(Np, K, dtype=act, device=wa.device)
+            wp[:N] = wa
+        else:
+            wp = wa
+        self.store[key] = wa
+        wt = self.store.get(key + ".t")
+        if wt is None or wt.shape != (K, Np) or wt.dtype != act:
+            wt = torch.empty(K, Np, dtype=act, device=wa.device)
+        ops.transpose(wp, wt, Np, K, Np)
+        self.store[key + ".t"] = wt
+
+    def __getitem__(self, key: str) -> torch.Tensor:
+        eng, m = self.eng, self.eng.m
+        g = self._group(key)
+        if g.startswith("L"):
+            i = int(g[1:])
+            l = m.layers[i]
+            a, f = l.attention, l.feed_forward
+            ps = (a.wq.weight, a.wk.weight, a.wv.weight, a.wo.weight, f.w1.weight, f.w3.weight, f.w2.weight)
+        elif g == "out":
+            ps = (m.output.weight,)
+        else:
+            vp0 = getattr(m.visual_proj, "0")
+            ps = (vp0.weight, vp0.bias)
+        ver = tuple(q._version for q in ps) + (eng.act, str(m._device))
+        if self.ver.get(g) != ver:
+            with torch.no_grad():
+                if g.startswith("L"):
+                    self._both(f"qkv.{i}", torch.cat([ps[0], ps[1], ps[2]], dim=0))
+                    self._both(f"wo.{i}", ps[3])
+                    self._both(f"w13.{i}", torch.cat([ps[4], ps[5]], dim=0))
+                    self._both(f"w2.{i}", ps[6])
+                elif g == "out":
+                    self._both("out", ps[0])
+                else:
+                    self._both("vp", ps[0])
+                    self.store["vp.b"] = ps[1].to(eng.act)
+            self.ver[g] = ver
+        return self.store[key]
 
 
 class _StepLoss(torch.autograd.Function):
