@@ -65,12 +65,13 @@ class GradReducer:
     def finish(self) -> None:
         """Join every outstanding bucket (call before clipping / optimizer.step)."""
         for work, seg, low in self._pending:
-            work.wait()
-            if seg is not None:
-                if seg.is_cuda:
-                    with torch.cuda.stream(self._stream):
-                        seg.copy_(low)
-                else:
+            if seg is not None and seg.is_cuda:
+                with torch.cuda.stream(self._stream):     # the copy-back runs on the side stream: THAT stream must wait for the collective
+                    work.wait()
+                    seg.copy_(low)
+            else:
+                work.wait()
+                if seg is not None:
                     seg.copy_(low)
         self._pending.clear()
         if self._stream is not None:

@@ -136,7 +136,8 @@ def main(args):
         model.train_compute_dtype = torch.float32
 
     optimizer = torch.optim.AdamW(add_weight_decay(model, args.weight_decay), lr=args.lr, betas=(0.9, 0.95), fused=True)
-    reducer = GradReducer(model.train_engine(), dist) if distributed else None
+    # gradient wire dtype = FSDP's MixedPrecision(reduce_dtype) of the reference (:251-255): bf16 under --precision bf16
+    reducer = GradReducer(model.train_engine(), dist, reduce_dtype=torch.bfloat16 if args.precision == "bf16" else None) if distributed else None
 
     image_words = model.get_image_words()
     if args.synthetic:

@@ -178,7 +178,8 @@ def train_leg(m, args, B, T, image, tokens, steps, dist, dev):
     eng = TrainEngine(m, torch.bfloat16)
     params = [p for p in m.parameters() if p.requires_grad]
     opt = torch.optim.AdamW(params, lr=2e-5, betas=(0.9, 0.95), weight_decay=0.0, fused=True)
-    red = GradReducer(eng, dist) if dist is not None else None
+    # bf16 on the wire = the reference's FSDP MixedPrecision(reduce_dtype=bf16) (main_finetune.py:251-255); fp32 accumulation buffers
+    red = GradReducer(eng, dist, reduce_dtype=torch.bfloat16) if dist is not None else None
     labels = tokens.clone()
     labels[:, :T // 2] = 0
 
@@ -242,7 +243,8 @@ def lora_leg(m, args, B, T, image, tokens, steps, dist, dev, rank=16):
     n_train = sum(p.numel() for p in pm.parameters() if p.requires_grad)
     eng = TrainEngine(pm, torch.bfloat16)
     opt = torch.optim.AdamW([p for p in pm.parameters() if p.requires_grad], lr=2e-5, betas=(0.9, 0.95), weight_decay=0.0, fused=True)
-    red = GradReducer(eng, dist) if dist is not None else None
+    # bf16 on the wire = the reference's FSDP MixedPrecision(reduce_dtype=bf16) (main_finetune.py:251-255); fp32 accumulation buffers
+    red = GradReducer(eng, dist, reduce_dtype=torch.bfloat16) if dist is not None else None
     labels = tokens.clone()
     labels[:, :T // 2] = 0
 
