@@ -550,6 +550,152 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_pp_kernel(GemmArgs p) {
   gemm_epilogue<TM, TN>(acc, p, m0 + wr * WTM, n0 + wc * WTN, lane);
 }
 
+// ------------------------------------------------------------------------------------
+// "TN" form of the 256x256 ping-pong kernel: C[M,N] = At^T . Wt with BOTH operands K-major, At [K][lda] (m contiguous)
+// and Wt [K][ldw] (n contiguous) -- the weight-gradient product dW = dY^T . X on the activations as they sit in memory
+// (token-major), without materialising dY^T and X^T.  A stage tile is [64 k][256 m] (512-B rows, LDS-DMA of two k-rows
+// per instruction); MFMA fragments come from ds_read_b64_tr_b16 (gfx950 transpose read: the 16 lanes of a group pass the
+// addresses of a 4 x 16 block -- lane i: row i>>2, columns 4 (i&3).. -- and lane c receives column c), two reads per
+// 8-k operand.  The 32-B column chunks of a row are XOR-swizzled on the DMA source side with key(k) = (k>>3 & 3)*4 + (k & 3):
+// the 16 k-rows one read instruction touches (k = 8g + 4jj + r over lane groups g and r = 0..3) get 16 different keys, and
+// the 8 rows of either wave half 8 different keys mod 8 -- 512 B over all 64 banks twice, conflict-free.  K need not be
+// a tile multiple: rows past K are out of the buffer descriptor's range and read as zero.
+// ------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+__global__ __launch_bounds__(512) void gemm_tn_bf16_pp_kernel(GemmArgs p) {
+  constexpr int TBM = 256, TBN = 256, WTM = 128, WTN = 64, TM = 8, TN = 4;
+  constexpr int STAGE = (TBM + TBN) * BK * 2;   // 64 KiB
+  __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int per_group = GROUP_M * p.tiles_n;
+  const int group = bid / per_group;
+  const int first_m = group * GROUP_M;
+  const int gsz = min(p.tiles_m - first_m, GROUP_M);
+  const int in_g = bid - group * per_group;
+  const int tm = first_m + in_g % gsz;
+  const int tn = in_g / gsz;
+  const int m0 = tm * TBM, n0 = tn * TBN;
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (p.K + BK - 1) / BK;
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)(((int64_t)(p.K - 1) * p.lda + p.M) * 2), 0x00020000);
+  const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)(((int64_t)(p.K - 1) * p.ldw + p.N) * 2), 0x00020000);
+  // piece c of this wave: DMA instruction q = wave*4 + c of the tile (k-rows 2q, 2q+1); lane -> row 2q + (lane>>5),
+  // 16-B position lane&31 of the 512-B row, which holds source chunk ((pos>>1) ^ key(k)) * 32 B + (pos&1) * 16 B
+  unsigned voA[4], voW[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const unsigned kin = 2 * (wave * 4 + c) + (lane >> 5);
+    const unsigned col = (((((unsigned)lane & 31) >> 1) ^ (((kin >> 3) & 3) * 4 + (kin & 3))) << 5) + (lane & 1) * 16;
+    voA[c] = (unsigned)(kin * p.lda * 2) + col;
+    voW[c] = (unsigned)(kin * p.ldw * 2) + col;
+  }
+  auto stage_piece = [&](int t, int c) {
+    char* dst = lds + (t & 1) * STAGE + (c >= 4 ? TBM * BK * 2 : 0) + (wave * 4 + (c & 3)) * 1024;
+    if (c < 4) {
+      const unsigned so = (unsigned)(((int64_t)t * BK * p.lda + m0) * 2);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)dst, 16, voA[c & 3] + so, 0, 0, 0);
+    } else {
+      const unsigned so = (unsigned)(((int64_t)t * BK * p.ldw + n0) * 2);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)dst, 16, voW[c & 3] + so, 0, 0, 0);
+    }
+  };
+  auto stage = [&](int t) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) stage_piece(t, c);
+  };
+  stage(0);
+  if (nk > 1) stage(1);
+  A3V_WAIT_VM0();
+  A3V_BARRIER();
+
+  // fragment addressing: lane (g = lane>>4, il = lane&15); k sub-block (ks, jj): rows ks*32 + 8g + 4jj + (il>>2)
+  const int fg = lane >> 4, il = lane & 15;
+  int kro[2][2], kxo[2][2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int k = ks * 32 + 8 * fg + 4 * jj + (il >> 2);
+      kro[ks][jj] = k * 512 + (il & 3) * 8;
+      kxo[ks][jj] = ((k >> 3) & 3) * 4 + (k & 3);
+    }
+  bf16x8 af0[TM], af1[TM], wf0[TN], wf1[TN];
+  auto tr8 = [&](const char* tile, int blk16, int ks) -> bf16x8 {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(tile + kro[ks][0] + ((blk16 ^ kxo[ks][0]) << 5)));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(tile + kro[ks][1] + ((blk16 ^ kxo[ks][1]) << 5)));
+    bf16x8 r;
+    const short v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    __builtin_memcpy(&r, v, 16);
+    return r;
+  };
+#define TN_READ_FRAGS(cur)                                                                           \
+  do {                                                                                               \
+    const char* At_ = (cur);                                                                         \
+    const char* Wt_ = (cur) + TBM * BK * 2;                                                          \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                 \
+      wf0[j] = tr8(Wt_, wc * 4 + j, 0);                                                              \
+      wf1[j] = tr8(Wt_, wc * 4 + j, 1);                                                              \
+    }                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                 \
+      af0[i] = tr8(At_, wr * 8 + i, 0);                                                              \
+      af1[i] = tr8(At_, wr * 8 + i, 1);                                                              \
+    }                                                                                                \
+  } while (0)
+#define TN_MFMA_ALL()                                                                                \
+  do {                                                                                               \
+    __builtin_amdgcn_s_setprio(1);                                                                   \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                   \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                 \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[j], af0[i], acc[i][j], 0, 0, 0);     \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                   \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                 \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[j], af1[i], acc[i][j], 0, 0, 0);     \
+    __builtin_amdgcn_s_setprio(0);                                                                   \
+  } while (0)
+  if (wr == 0) {
+    for (int t = 0; t < nk; ++t) {
+      TN_READ_FRAGS(lds + (t & 1) * STAGE);
+      if (t >= 1 && t + 1 < nk) stage(t + 1);
+      A3V_WAIT_LGKM0();
+      A3V_BARRIER();
+      TN_MFMA_ALL();
+      A3V_WAIT_VM0();
+      A3V_BARRIER();
+    }
+    A3V_BARRIER();
+  } else {
+    A3V_BARRIER();
+    for (int t = 0; t < nk; ++t) {
+      TN_READ_FRAGS(lds + (t & 1) * STAGE);
+      A3V_WAIT_LGKM0();
+      A3V_WAIT_VM0();
+      A3V_BARRIER();
+      if (t + 2 < nk) stage(t + 2);
+      TN_MFMA_ALL();
+      A3V_BARRIER();
+    }
+  }
+#undef TN_READ_FRAGS
+#undef TN_MFMA_ALL
+  gemm_epilogue<TM, TN>(acc, p, m0 + wr * WTM, n0 + wc * WTN, lane);
+}
+
 // Same schedule with v_mfma_f32_32x32x16_bf16 (8-pass, higher sustained rate than 16x16x32):
 // wave tile 128x64 = 4x2 tiles of 32x32, 4 k-steps of 16 per K-tile, 32 MFMAs per interval.
 template <int DBG>
@@ -1571,6 +1717,26 @@ extern "C" int a3v_splitk_reduce(const float* partial, int S, int M, int N, void
   if (out_dtype == A3V_BF16) hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partial, S, (int64_t)M * N, M, N, (bf16_t*)out, ldo, accumulate);
   else if (out_dtype == A3V_F32) hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partial, S, (int64_t)M * N, M, N, (float*)out, ldo, accumulate);
   else return A3V_ERR_DTYPE;
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}
+
+// C[M,N] = epilogue(At^T . Wt): At [K, M] (row stride lda), Wt [K, N] (row stride ldw), both bf16 with the CONTRACTED index
+// as the row index -- dW = dY^T . X straight from the token-major activations (no a3v_transpose of either operand).
+// 256x256 tiles only (M, N >= 256 recommended); plain / residual / fp32 epilogues as a3v_gemm_nt; any K >= 1.
+extern "C" int a3v_gemm_tn(const void* At, int64_t lda, const void* Wt, int64_t ldw, void* C, int64_t ldc, int M, int N, int K,
+                           const void* residual, int64_t ldr, int epilogue, void* stream) {
+  if (!At || !Wt || !C || M <= 0 || N <= 0 || K <= 0) return A3V_ERR_ARG;
+  if (lda % 8 || ldw % 8 || N % 4 || ldc % 4 || M % 8) return A3V_ERR_SHAPE;
+  if (epilogue & ~(A3V_EPI_RESIDUAL | A3V_EPI_RES_F32 | A3V_EPI_OUT_F32)) return A3V_ERR_ARG;
+  if ((epilogue & (A3V_EPI_RESIDUAL | A3V_EPI_RES_F32)) && !residual) return A3V_ERR_ARG;
+  if (((int64_t)(K - 1) * lda + M) * 2 >= (1LL << 31) || ((int64_t)(K - 1) * ldw + N) * 2 >= (1LL << 31)) return A3V_ERR_SHAPE;
+  GemmArgs p{};
+  p.A = (const bf16_t*)At; p.W = (const bf16_t*)Wt; p.C = C; p.bias = nullptr; p.res = residual;
+  p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr;
+  p.M = M; p.N = N; p.K = K; p.epi = epilogue; p.dbg = 0;
+  p.tiles_m = (M + 255) / 256; p.tiles_n = (N + 255) / 256;
+  hipLaunchKernelGGL(gemm_tn_bf16_pp_kernel, dim3(p.tiles_m * p.tiles_n), dim3(512), 0, (hipStream_t)stream, p);
   A3V_LAUNCH_CHECK();
   return A3V_OK;
 }

@@ -69,6 +69,21 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, r
     return out
 
 
+def gemm_tn(at, wt, out, *, residual=None, epilogue: int = 0):
+    """out[M, N] = epilogue(at[K, M]^T @ wt[K, N]) -- both operands with the contracted index as rows (no transposes)."""
+    _dev(at, wt, out, residual)
+    K, M = at.shape
+    N = wt.shape[1]
+    assert wt.shape[0] == K and at.stride(1) == 1 and wt.stride(1) == 1 and out.stride(1) == 1
+    ep = epilogue
+    if residual is not None and not (ep & EPI_RES_F32):
+        ep |= EPI_RESIDUAL
+    rc = _l.load().a3v_gemm_tn(_p(at), at.stride(0), _p(wt), wt.stride(0), _p(out), out.stride(0), M, N, K,
+                               _p(residual), residual.stride(0) if residual is not None else 0, ep, _stream())
+    _l.check(rc, f"a3v_gemm_tn(M={M},N={N},K={K},epi={ep})")
+    return out
+
+
 def gemm_nt_splitk(a, w, out, scratch, S: int, accumulate: bool = False):
     """out (+)= a @ w.T through S split-K planes (fp32 scratch of >= S*M*N floats); rounds once to out.dtype."""
     _dev(a, w, out, scratch)

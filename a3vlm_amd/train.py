@@ -38,6 +38,7 @@ class TrainEngine:
         self._flat: Optional[torch.Tensor] = None
         self._views: Dict[str, torch.Tensor] = {}
         self._ranges: List[Tuple[str, int, int]] = []       # (bucket name, start, end) in the flat grad buffer
+        self.tn_wgrad = True                                # weight gradients by a3v_gemm_tn (False: transposes + NT kernel)
         self._fresh: set = set()                            # grads attached this step whose storage is still undefined
         self._gemm_written: set = set()                     # names whose gradient comes from exactly one wgrad GEMM per micro-step
         self.on_layer_grads_ready: Optional[Callable[[str, int, int], None]] = None
@@ -165,16 +166,23 @@ class TrainEngine:
         """grad[N,K] (fp32) += dy[M,N]^T @ x[M,K]; plain store when every parameter in ``names`` is fresh this step."""
         M, N = dy.shape
         K = x.shape[1]
+        fresh = bool(names) and all(n in self._fresh for n in names)
+        assert fresh or not any(n in self._fresh for n in names), "partially fresh fused gradient view"
+        if (self.tn_wgrad and self.act == torch.bfloat16 and min(N, K) >= 256 and N % 8 == 0 and K % 4 == 0
+                and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0 and 2 * M * max(dy.stride(0), x.stride(0)) < 2 ** 31):
+            # both operands as they are (token-major): the TN kernel transposes fragments on the LDS read
+            self._fresh.difference_update(names if fresh else ())
+            ops.gemm_tn(dy, x, grad, residual=None if fresh else grad, epilogue=ops.EPI_OUT_F32 if fresh else ops.EPI_RES_F32)
+            return
         Mp = _pad64(M)
         dyt = self._buf("wg_dyt" + tag, (N, Mp))
         xt = self._buf("wg_xt" + tag, (K, Mp))
         ops.transpose(dy, dyt, M, N, Mp)
         ops.transpose(x, xt, M, K, Mp)
-        if names and all(n in self._fresh for n in names):
+        if fresh:
             self._fresh.difference_update(names)
             ops.gemm_nt(dyt, xt, grad, epilogue=ops.EPI_OUT_F32 if self.act == torch.bfloat16 else 0)
         else:
-            assert not any(n in self._fresh for n in names), "partially fresh fused gradient view"
             if min(N, K) <= 64:
                 self._skinny(dyt, xt, grad, accumulate=True)
             else:

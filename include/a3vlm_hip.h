@@ -68,6 +68,12 @@ int a3v_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ldw, void* C,
                 int M, int N, int K, const void* bias, const void* residual, int64_t ldr,
                 int epilogue, int dtype, void* stream);
 
+/* "TN" GEMM: C[M,N] = epilogue(At^T . Wt) with At [K, M] and Wt [K, N] (the contracted index is the ROW index of both
+ * operands): the weight gradient dW = dY^T . X on the token-major activations autograd holds (engine_finetune.py:55-57
+ * loss.backward()), without transposing either.  lda, ldw % 8 == 0, M % 8 == 0; epilogues NONE / RESIDUAL / RES_F32 / OUT_F32. */
+int a3v_gemm_tn(const void* At, int64_t lda, const void* Wt, int64_t ldw, void* C, int64_t ldc, int M, int N,
+                int K, const void* residual, int64_t ldr, int epilogue, void* stream);
+
 /* Optional: register a scratch buffer (device memory, >= 32 MiB recommended; NULL unregisters) that a3v_gemm_nt may use
  * to split the K loop of the few-hundred-row tail of its hybrid tile dispatch.  The library itself never allocates.  One
  * buffer per process (one process per GPU); it must outlive every later a3v_gemm_nt call and is used on the call's stream. */

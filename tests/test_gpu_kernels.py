@@ -476,3 +476,30 @@ def test_gemm_nt_splitk(M, N, K, S):
     ob2 = torch.empty_like(ob)
     ops.gemm_nt_splitk(ad, wd, ob2, scratch, S)
     assert torch.equal(ob, ob2)
+
+
+@pytest.mark.parametrize("M,N,K,lda,ldw", [(512, 512, 256, 512, 512), (4096, 1024, 1000, 4096, 1024), (264, 260, 70, 272, 264),
+                                           (1024, 4096, 8728, 3 * 1024, 4096), (256, 256, 1, 256, 256)])
+def test_gemm_tn(M, N, K, lda, ldw):
+    """C = At^T @ Wt with both operands row-indexed by the contracted index (ds_read_tr fragments, swizzled [k][m] LDS tiles):
+    equal to the NT kernel on the transposed operands to fp32-accumulation order; ragged K (buffer OOB zero fill), strided
+    operands (a q-slice of a fused qkv gradient), partial tiles, and the three epilogues the weight-gradient step uses."""
+    at_full, wt_full = rt(gen(K, lda, seed=41)), rt(gen(K, ldw, seed=42, scale=0.05))
+    atd, wtd = at_full.to(BF).to(DEV)[:, :M], wt_full.to(BF).to(DEV)[:, :N]
+    want = at_full[:, :M].t() @ wt_full[:, :N]
+    tol = dict(rtol=2 ** -7, atol=2e-3 * math.sqrt(K) * 0.05 + 1e-3)
+    ob = torch.empty(M, N, dtype=BF, device=DEV)
+    ops.gemm_tn(atd, wtd, ob)
+    assert_close(ob, want, what="tn bf16", **tol)
+    of = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+    ops.gemm_tn(atd, wtd, of, epilogue=ops.EPI_OUT_F32)
+    assert_close(of, want, what="tn f32 store", **tol)
+    # bit-identical to the NT kernel on materialised transposes when K is a whole number of 64-tiles (same k order per lane)
+    if K % 64 == 0:
+        ref = torch.empty_like(of)
+        ops.gemm_nt(atd.t().contiguous(), wtd.t().contiguous(), ref, epilogue=ops.EPI_OUT_F32)
+        assert_close(of, ref, rtol=1e-5, atol=1e-5, what="tn vs nt")
+    acc0 = gen(M, N, seed=43)
+    og = acc0.to(DEV).clone()
+    ops.gemm_tn(atd, wtd, og, residual=og, epilogue=ops.EPI_RES_F32)
+    assert_close(og.cpu() - acc0, want, what="tn f32 accumulate", **tol)   # product rounded once to bf16, then added in fp32

@@ -285,6 +285,42 @@ def test_train_step_bf16_close_to_fp32_reference():
         assert cos > 0.99, (name, cos)
 
 
+def test_train_step_bf16_tn_weight_gradients():
+    """dim 256: every decoder matrix takes the a3v_gemm_tn weight-gradient path (ragged token count, fused qkv / w13 views,
+    fresh store then accumulate).  Same gradients as the transpose + NT path to fp32 summation order, and bf16-level
+    agreement with the oracle's autograd."""
+    big = dict(dim=256, n_layers=2, n_heads=4, n_kv_heads=2, vocab_size=512, multiple_of=256, max_seq_len=256)
+    oargs = ref_cpu.OracleArgs(**big)
+    sd = ref_cpu.make_decoder_weights(oargs, seed=2, std=0.05)
+    g = torch.Generator().manual_seed(8)
+    B, T = 3, 37
+    ex = torch.randint(3, 512, (B, T), generator=g)
+    ex[:, 0] = 1
+    lab = ex.clone()
+    lab[:, :6] = 0
+    got = {}
+    for tn in (True, False):
+        m = plugin.Transformer(plugin.ModelArgs(**big), with_visual=False)
+        m.load_state_dict(sd)
+        m.to(BF).to(DEV)
+        promote_trainable_params_to_fp32(m)
+        eng = TrainEngine(m, BF)
+        eng.tn_wgrad = tn
+        for scale in (1.0, 0.5):
+            eng.forward_loss(ex.to(DEV), lab.to(DEV), None)
+            eng.backward(scale)
+        got[tn] = {n: p.grad.float().cpu() for n, p in m.get_trainable_params().items()}
+    for n in got[True]:
+        assert relerr(got[True][n], got[False][n]) < 1e-5, n
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    loss = ref_cpu.meta_forward_loss(ref_cpu.OracleDecoder(oargs, sdg), ex, lab, None)
+    loss.backward()
+    for n, gr in got[True].items():
+        a, b = gr.flatten(), 1.5 * sdg[n].grad.flatten()
+        assert float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-20)) > 0.99, n
+        assert abs(float(a.norm() / b.norm()) - 1) < 0.05, n
+
+
 def test_metamodel_loss_backward_drop_in(golden_dir=None):
     """loss, _ = model(examples, labels); loss.backward() -- the trainer's call sequence (engine_finetune.py:50-68)."""
     import os
