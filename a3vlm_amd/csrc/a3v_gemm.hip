@@ -24,6 +24,17 @@ namespace {
 constexpr int BK = 64;
 constexpr int GROUP_M = 8;
 constexpr int GEMM_EPI_RAW = 1 << 20;     // internal: fp32 output without the bf16 rounding of the accumulator
+constexpr int GEMM_EPI_ROPEKV = 1 << 21;  // internal: fused-qkv epilogue (a3v_gemm_qkv_rope): RoPE on q / k, k -> K cache, v -> V^T cache
+
+// destination of the fused-qkv epilogue: C row m = b*S + s; columns [q heads | k heads | v heads], hd = 1 << hd_shift each
+struct RopeKvArgs {
+  bf16_t* q_out;         // [rows][ldq], head-major columns (may alias nothing else the GEMM reads)
+  bf16_t* k_cache;       // [B][Hkv][Smax][hd]
+  bf16_t* vt_cache;      // [B][Hkv][hd][Smax]
+  const float* cos_sin;  // [pos][hd/2][2]
+  int64_t ldq;
+  int S, H, Hkv, hd_shift, Smax, start_pos, rope_pos0, m_off;
+};
 
 struct GemmArgs {
   const bf16_t* A;
@@ -36,6 +47,7 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   int dbg;   // ablation switches for tuning runs (0 in production): 1 = no DMA in the k-loop, 2 = no ds_read in the k-loop
   int64_t c_split;   // split-K (128x128 kernel, gridDim.y slices): byte stride between the slices' output planes
+  RopeKvArgs rk;     // GEMM_EPI_ROPEKV only
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
@@ -106,6 +118,31 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GemmAr
       if (!(epi & GEMM_EPI_RAW)) {      // split-K planes keep the raw fp32 partial sums (rounded once by the reduce pass)
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = rbf(v[r]);   // the bf16 value F.linear returns
+      }
+      if (epi & GEMM_EPI_ROPEKV) {
+        // v[] = the bf16 qkv values of token (b, s), columns n..n+3 of head slot n >> hd_shift: rotate the two (even, odd)
+        // pairs of q / k by the token's position (LLM/llama_ens5.py:123-135 apply_rotary_emb) and store where attention
+        // reads them (q in place of the qkv row, k into the K cache, v transposed into the V^T cache)
+        const RopeKvArgs& k = p.rk;
+        const int mg = m + k.m_off;
+        const int b = mg / k.S, sq = mg - b * k.S;
+        const int slot = n >> k.hd_shift, d = n & ((1 << k.hd_shift) - 1);
+        if (slot < k.H + k.Hkv) {
+          const f32x4 cs = *reinterpret_cast<const f32x4*>(k.cos_sin + (((int64_t)(k.rope_pos0 + sq) << (k.hd_shift - 1)) + (d >> 1)) * 2);
+          bf16x4 o;
+          o[0] = f2bf(v[0] * cs[0] - v[1] * cs[1]);
+          o[1] = f2bf(v[0] * cs[1] + v[1] * cs[0]);
+          o[2] = f2bf(v[2] * cs[2] - v[3] * cs[3]);
+          o[3] = f2bf(v[2] * cs[3] + v[3] * cs[2]);
+          bf16_t* dst = slot < k.H ? k.q_out + (int64_t)mg * k.ldq + n
+                                   : k.k_cache + ((((int64_t)b * k.Hkv + (slot - k.H)) * k.Smax + k.start_pos + sq) << k.hd_shift) + d;
+          *reinterpret_cast<bf16x4*>(dst) = o;
+        } else {
+          bf16_t* dst = k.vt_cache + ((((int64_t)b * k.Hkv + (slot - k.H - k.Hkv)) << k.hd_shift) + d) * k.Smax + k.start_pos + sq;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dst[(int64_t)r * k.Smax] = f2bf(v[r]);
+        }
+        continue;
       }
       if (epi & A3V_EPI_GELU) {
 #pragma unroll
@@ -1418,9 +1455,9 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
 }
 }  // namespace
 
-extern "C" int a3v_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
-                           int M, int N, int K, const void* bias, const void* residual, int64_t ldr,
-                           int epilogue, int dtype, void* stream) {
+static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
+                        int M, int N, int K, const void* bias, const void* residual, int64_t ldr,
+                        int epilogue, int dtype, void* stream, const RopeKvArgs* rk) {
   if (M <= 0 || N <= 0 || K <= 0 || !A || !W || !C) return A3V_ERR_ARG;
   if ((epilogue & A3V_EPI_BIAS) && !bias) return A3V_ERR_ARG;
   if ((epilogue & (A3V_EPI_RESIDUAL | A3V_EPI_RES_F32)) && !residual) return A3V_ERR_ARG;
@@ -1446,6 +1483,9 @@ extern "C" int a3v_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ld
   p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr;
   p.M = M; p.N = N; p.K = K; p.epi = epilogue & 0xffff;
   p.dbg = (epilogue >> 24) & 0xf;
+  p.c_split = 0;
+  p.rk = RopeKvArgs{};
+  if (rk) { p.rk = *rk; p.epi |= GEMM_EPI_ROPEKV; }
   // Tile choice.  256x256 ping-pong (8 waves, 1 block/CU) for the rows that fill whole 256-row
   // tiles when its grid keeps the 256 CUs busy (>= 75 % of its last round); the remaining (< 256)
   // rows, and every problem the big tile would quantise badly, go to the 128x128 kernel (4 waves,
@@ -1508,6 +1548,7 @@ extern "C" int a3v_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ld
       GemmArgs r = p;
       r.M = M - m_big;
       r.A = p.A + (int64_t)m_big * lda;
+      r.rk.m_off = m_big;
       const int esz = (p.epi & (A3V_EPI_OUT_F32 | A3V_EPI_RES_F32)) ? 4 : 2;
       r.C = (char*)p.C + (int64_t)m_big * ldc * esz;
       if (p.res) r.res = (const char*)p.res + (int64_t)m_big * ldr * ((p.epi & A3V_EPI_RES_F32) ? 4 : 2);
@@ -1537,6 +1578,27 @@ extern "C" int a3v_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ld
   }
   A3V_LAUNCH_CHECK();
   return A3V_OK;
+}
+
+extern "C" int a3v_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
+                           int M, int N, int K, const void* bias, const void* residual, int64_t ldr,
+                           int epilogue, int dtype, void* stream) {
+  return gemm_nt_impl(A, lda, W, ldw, C, ldc, M, N, K, bias, residual, ldr, epilogue, dtype, stream, nullptr);
+}
+
+// qkv = A . Wqkv^T with the rotary embedding and the KV-cache write in the GEMM epilogue (prefill: LLM/llama_ens5.py:155-176
+// xq, xk, xv = wq(x), wk(x), wv(x); apply_rotary_emb; cache_k / cache_v[:bsz, start_pos:start_pos+seqlen] = xk / xv).
+// Same values as a3v_gemm_nt followed by a3v_rope_kvcache (the accumulator is rounded to the bf16 qkv value first).
+extern "C" int a3v_gemm_qkv_rope(const void* A, int64_t lda, const void* W, int64_t ldw, int K, void* q_out, int64_t ldq,
+                                 void* k_cache, void* vt_cache, const float* cos_sin, int B, int S, int H, int Hkv, int hd,
+                                 int Smax, int start_pos, int rope_pos0, void* stream) {
+  if (!q_out || !k_cache || !vt_cache || !cos_sin || B <= 0 || S <= 0 || H <= 0 || Hkv <= 0) return A3V_ERR_ARG;
+  if ((hd != 64 && hd != 128) || ldq % 4 || start_pos < 0 || start_pos + S > Smax) return A3V_ERR_SHAPE;
+  RopeKvArgs rk;
+  rk.q_out = (bf16_t*)q_out; rk.k_cache = (bf16_t*)k_cache; rk.vt_cache = (bf16_t*)vt_cache; rk.cos_sin = cos_sin;
+  rk.ldq = ldq; rk.S = S; rk.H = H; rk.Hkv = Hkv; rk.hd_shift = hd == 128 ? 7 : 6; rk.Smax = Smax;
+  rk.start_pos = start_pos; rk.rope_pos0 = rope_pos0; rk.m_off = 0;
+  return gemm_nt_impl(A, lda, W, ldw, q_out, ldq, B * S, (H + 2 * Hkv) * hd, K, nullptr, nullptr, 0, 0, A3V_BF16, stream, &rk);
 }
 
 // split-K factor of the DMA GEMV: enough blocks (row groups x S >= 1024) for 256 CUs, S <= 8, S <= number of ring stages

@@ -188,6 +188,7 @@ class Transformer(nn.Module):
     def __init__(self, args: ModelArgs, with_visual: bool = False):
         super().__init__()
         self.args = args
+        self._fuse_qkv_rope = True      # prefill: RoPE + KV-cache write in the qkv GEMM epilogue (False: separate kernel; test hook)
         self.vocab_size = args.vocab_size
         self.n_layers = args.n_layers
         self.n_heads = args.n_heads
@@ -383,8 +384,12 @@ class Transformer(nn.Module):
             kc, vc = k_caches[i], vt_caches[i]
             smax = kc.shape[2]
             ops.rmsnorm(h, lyr.attention_norm.weight, xn, a.norm_eps)
-            self._linear(xn, pk[f"wqkv.{i}"], qkv)
-            ops.rope_kvcache(qkv, qkv, kc, vc, cs, B, S, H, Hkv, hd, start_pos, rope_pos0)
+            if rows > 16 and h.dtype == torch.bfloat16 and hd in (64, 128) and self._fuse_qkv_rope:
+                # rotary embedding + cache write in the GEMM epilogue: qkv never makes a second trip through HBM
+                ops.gemm_qkv_rope(xn, pk[f"wqkv.{i}"], qkv, kc, vc, cs, B, S, H, Hkv, hd, start_pos, rope_pos0)
+            else:
+                self._linear(xn, pk[f"wqkv.{i}"], qkv)
+                ops.rope_kvcache(qkv, qkv, kc, vc, cs, B, S, H, Hkv, hd, start_pos, rope_pos0)
             strides = (S * ldq, ldq, hd,                       # q: view into the qkv buffer
                        Hkv * smax * hd, smax * hd, hd,         # k cache
                        Hkv * hd * smax, hd * smax, smax,       # v^T cache

@@ -503,3 +503,31 @@ def test_gemm_tn(M, N, K, lda, ldw):
     og = acc0.to(DEV).clone()
     ops.gemm_tn(atd, wtd, og, residual=og, epilogue=ops.EPI_RES_F32)
     assert_close(og.cpu() - acc0, want, what="tn f32 accumulate", **tol)   # product rounded once to bf16, then added in fp32
+
+
+@pytest.mark.parametrize("B,S,H,Hkv,hd,K,start_pos", [(2, 150, 4, 4, 128, 256, 0), (3, 77, 4, 2, 64, 128, 5), (8, 1091, 8, 8, 128, 512, 0),
+                                                      (1, 40, 2, 1, 128, 192, 3)])
+def test_gemm_qkv_rope_equals_gemm_then_rope(B, S, H, Hkv, hd, K, start_pos):
+    """qkv GEMM with RoPE + KV-cache write in the epilogue == a3v_gemm_nt then a3v_rope_kvcache, bit for bit (same rounding
+    points: accumulator -> bf16 qkv -> fp32 rotation -> bf16); GQA, both head sizes, a cache offset, and the 8 x 1091-row
+    case that takes the hybrid 256x256 + 128x128-tail dispatch (rows of the tail carry their global token index)."""
+    from a3vlm_amd.model.LLM.llama_ens5 import precompute_cos_sin
+    rows, N = B * S, (H + 2 * Hkv) * hd
+    Smax = (start_pos + S + 63) // 64 * 64 + 64
+    x = gen(rows, K, seed=51).to(BF).to(DEV)
+    w = gen(N, K, seed=52, scale=0.05).to(BF).to(DEV)
+    cs = precompute_cos_sin(hd, 2 * Smax, 10000.0, None).to(DEV)
+    outs = []
+    for fused in (False, True):
+        qkv = torch.zeros(rows, N, dtype=BF, device=DEV)
+        kc = torch.zeros(B, Hkv, Smax, hd, dtype=BF, device=DEV)
+        vc = torch.zeros(B, Hkv, hd, Smax, dtype=BF, device=DEV)
+        if fused:
+            ops.gemm_qkv_rope(x, w, qkv, kc, vc, cs, B, S, H, Hkv, hd, start_pos, start_pos + 2)
+        else:
+            ops.gemm_nt(x, w, qkv)
+            ops.rope_kvcache(qkv, qkv, kc, vc, cs, B, S, H, Hkv, hd, start_pos, start_pos + 2)
+        outs.append((qkv[:, :H * hd].clone(), kc, vc))
+    for a, b, what in zip(outs[0], outs[1], ("q", "k cache", "v^T cache")):
+        assert torch.equal(a, b), what
+    assert float(outs[1][0].float().abs().max()) > 0.1

@@ -314,3 +314,34 @@ def test_fused_decode_step_matches_per_kernel_path(heads, kv, dim, B):
     # the arrival counters are left at zero
     ws = m._ws["skinny_ws"]
     assert int(ws[:8192].view(torch.int32).abs().sum()) == 0
+
+
+def test_prefill_fused_qkv_rope_matches_separate_kernels():
+    """forward_inference prefill + two decode steps with the qkv/RoPE/KV-write fusion on and off: identical logits and caches
+    (the fused epilogue reproduces the separate kernels' values exactly)."""
+    args = plugin.ModelArgs(dim=256, n_layers=3, n_heads=4, n_kv_heads=2, vocab_size=640, multiple_of=128, max_seq_len=192)
+    oargs = ref_cpu.OracleArgs(dim=256, n_layers=3, n_heads=4, n_kv_heads=2, vocab_size=640, multiple_of=128, max_seq_len=192)
+    sd = ref_cpu.make_decoder_weights(oargs, seed=12, std=0.06)
+    m = plugin.Transformer(args)
+    m.load_state_dict(sd)
+    m.to(BF).to(DEV)
+    g = torch.Generator().manual_seed(3)
+    B, T0 = 4, 61
+    ex = torch.randint(3, 640, (B, T0 + 2), generator=g)
+    ex[:, 0] = 1
+    exd = ex.to(DEV)
+    got = {}
+    for fuse in (True, False):
+        m._fuse_qkv_rope = fuse
+        lg = [m.forward_inference(exd[:, :T0], 0).float().clone()]
+        for t in range(T0, T0 + 2):
+            lg.append(m.forward_inference(exd[:, t:t + 1], t).float().clone())
+        got[fuse] = (lg, [k.clone() for k in m._k_cache], [v.clone() for v in m._vt_cache])
+    for a, b in zip(got[True][0], got[False][0]):
+        assert torch.equal(a, b)
+    for l in range(3):
+        assert torch.equal(got[True][1][l][:, :, :T0 + 2], got[False][1][l][:, :, :T0 + 2])
+        assert torch.equal(got[True][2][l][:, :, :, :T0 + 2], got[False][2][l][:, :, :, :T0 + 2])
+    dec = ref_cpu.OracleDecoder(oargs, {k: v.to(BF) for k, v in sd.items()})
+    want = dec.forward_inference(ex[:, :T0], 0).float()
+    assert float((got[True][0][0].cpu() - want).abs().max()) / float(want.abs().max()) < 4e-2
