@@ -32,7 +32,8 @@ struct RopeKvArgs {
   bf16_t* k_cache;       // [B][Hkv][Smax][hd]
   bf16_t* vt_cache;      // [B][Hkv][hd][Smax]
   const float* cos_sin;  // [pos][hd/2][2]
-  int64_t ldq;
+  bf16_t* v_rows;        // optional [rows][ldv]: v also token-major (the attention backward reads it that way)
+  int64_t ldq, ldv;
   int S, H, Hkv, hd_shift, Smax, start_pos, rope_pos0, m_off;
 };
 
@@ -141,6 +142,12 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GemmAr
           bf16_t* dst = k.vt_cache + ((((int64_t)b * k.Hkv + (slot - k.H - k.Hkv)) << k.hd_shift) + d) * k.Smax + k.start_pos + sq;
 #pragma unroll
           for (int r = 0; r < 4; ++r) dst[(int64_t)r * k.Smax] = f2bf(v[r]);
+          if (k.v_rows) {
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = f2bf(v[r]);
+            *reinterpret_cast<bf16x4*>(k.v_rows + (int64_t)mg * k.ldv + (n - ((k.H + k.Hkv) << k.hd_shift))) = o;
+          }
         }
         continue;
       }
@@ -1590,12 +1597,13 @@ extern "C" int a3v_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ld
 // xq, xk, xv = wq(x), wk(x), wv(x); apply_rotary_emb; cache_k / cache_v[:bsz, start_pos:start_pos+seqlen] = xk / xv).
 // Same values as a3v_gemm_nt followed by a3v_rope_kvcache (the accumulator is rounded to the bf16 qkv value first).
 extern "C" int a3v_gemm_qkv_rope(const void* A, int64_t lda, const void* W, int64_t ldw, int K, void* q_out, int64_t ldq,
-                                 void* k_cache, void* vt_cache, const float* cos_sin, int B, int S, int H, int Hkv, int hd,
-                                 int Smax, int start_pos, int rope_pos0, void* stream) {
+                                 void* k_cache, void* vt_cache, void* v_rows, int64_t ldv, const float* cos_sin, int B, int S,
+                                 int H, int Hkv, int hd, int Smax, int start_pos, int rope_pos0, void* stream) {
   if (!q_out || !k_cache || !vt_cache || !cos_sin || B <= 0 || S <= 0 || H <= 0 || Hkv <= 0) return A3V_ERR_ARG;
-  if ((hd != 64 && hd != 128) || ldq % 4 || start_pos < 0 || start_pos + S > Smax) return A3V_ERR_SHAPE;
+  if ((hd != 64 && hd != 128) || ldq % 4 || (v_rows && ldv % 4) || start_pos < 0 || start_pos + S > Smax) return A3V_ERR_SHAPE;
   RopeKvArgs rk;
   rk.q_out = (bf16_t*)q_out; rk.k_cache = (bf16_t*)k_cache; rk.vt_cache = (bf16_t*)vt_cache; rk.cos_sin = cos_sin;
+  rk.v_rows = (bf16_t*)v_rows; rk.ldv = ldv;
   rk.ldq = ldq; rk.S = S; rk.H = H; rk.Hkv = Hkv; rk.hd_shift = hd == 128 ? 7 : 6; rk.Smax = Smax;
   rk.start_pos = start_pos; rk.rope_pos0 = rope_pos0; rk.m_off = 0;
   return gemm_nt_impl(A, lda, W, ldw, q_out, ldq, B * S, (H + 2 * Hkv) * hd, K, nullptr, nullptr, 0, 0, A3V_BF16, stream, &rk);

@@ -24,6 +24,9 @@ def _pad64(n: int) -> int:
 
 
 class TrainEngine:
+    fuse_qkv_rope = True      # qkv GEMM with the RoPE / cache-write epilogue (False: separate kernels; A/B and test hook)
+    tn_wgrad = True           # weight gradients by a3v_gemm_tn (False: transposes + NT kernel; A/B and test hook)
+
     def __init__(self, model, compute_dtype: torch.dtype = torch.bfloat16, recompute: Optional[bool] = None):
         """``recompute``: True = keep only each block's input and re-run the block in backward (the reference's
         activation checkpointing, main_finetune.py:268-276); False = keep every block's intermediates (about
@@ -38,7 +41,6 @@ class TrainEngine:
         self._flat: Optional[torch.Tensor] = None
         self._views: Dict[str, torch.Tensor] = {}
         self._ranges: List[Tuple[str, int, int]] = []       # (bucket name, start, end) in the flat grad buffer
-        self.tn_wgrad = True                                # weight gradients by a3v_gemm_tn (False: transposes + NT kernel)
         self._fresh: set = set()                            # grads attached this step whose storage is still undefined
         self._gemm_written: set = set()                     # names whose gradient comes from exactly one wgrad GEMM per micro-step
         self.on_layer_grads_ready: Optional[Callable[[str, int, int], None]] = None
@@ -298,11 +300,16 @@ class TrainEngine:
         att = self._buf("att" + tag, (rows, H * hd))
         lse = self._buf("lse" + tag, (B, H, S), torch.float32)
         ops.rmsnorm(h, l.attention_norm.weight, xn, a.norm_eps)
-        ops.gemm_nt(xn, im[f"qkv.{i}"], qkv)
         lt = {}
-        if self.lora:
-            lt["qkv"] = self._lora_fwd(f"qkv.{i}", xn, qkv, tag)
-        ops.rope_kvcache(qkv, qrot, kc, vc, m._cos_sin_dev(), B, S, H, Hkv, hd, 0, 0)
+        if not self.lora and self.act == torch.bfloat16 and hd in (64, 128) and rows > 16 and self.fuse_qkv_rope:
+            # RoPE + K / V^T writes in the GEMM epilogue; v also token-major in its qkv columns for the attention backward
+            ops.gemm_qkv_rope(xn, im[f"qkv.{i}"], qrot, kc, vc, m._cos_sin_dev(), B, S, H, Hkv, hd, 0, 0,
+                              v_rows=qkv[:, (H + Hkv) * hd:])
+        else:
+            ops.gemm_nt(xn, im[f"qkv.{i}"], qkv)
+            if self.lora:
+                lt["qkv"] = self._lora_fwd(f"qkv.{i}", xn, qkv, tag)
+            ops.rope_kvcache(qkv, qrot, kc, vc, m._cos_sin_dev(), B, S, H, Hkv, hd, 0, 0)
         strides = (S * H * hd, H * hd, hd, Hkv * spad * hd, spad * hd, hd, Hkv * hd * spad, hd * spad, spad, S * H * hd, H * hd, hd)
         ops.attention_lse(qrot, kc, vc, att, lse, B, S, S, H, Hkv, hd, strides, True)
         res_flag = ops.EPI_RES_F32 if self.act == torch.bfloat16 else 0

@@ -72,10 +72,11 @@ int a3v_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ldw, void* C,
  * xq, xk, xv = wq(x), wk(x), wv(x); apply_rotary_emb; cache_k/cache_v[:bsz, start_pos:start_pos+seqlen] = xk/xv) --
  * a3v_gemm_nt on the fused [(H+2Hkv)*hd, K] weight followed by a3v_rope_kvcache, value for value (the accumulator is rounded
  * to the bf16 activation before the rotation), minus one HBM round trip of the [B*S, (H+2Hkv)*hd] activation.
- * A [B*S, K] bf16; q_out [B*S, ldq] receives the rotated q in columns 0..H*hd; caches as a3v_rope_kvcache; hd 64 or 128. */
+ * A [B*S, K] bf16; q_out [B*S, ldq] receives the rotated q in columns 0..H*hd; caches as a3v_rope_kvcache; hd 64 or 128.
+ * v_rows (optional, [B*S, ldv]): v also stored token-major, the layout the attention backward reads (training forward). */
 int a3v_gemm_qkv_rope(const void* A, int64_t lda, const void* W, int64_t ldw, int K, void* q_out, int64_t ldq,
-                      void* k_cache, void* vt_cache, const float* cos_sin, int B, int S, int H, int Hkv, int hd,
-                      int Smax, int start_pos, int rope_pos0, void* stream);
+                      void* k_cache, void* vt_cache, void* v_rows, int64_t ldv, const float* cos_sin, int B, int S,
+                      int H, int Hkv, int hd, int Smax, int start_pos, int rope_pos0, void* stream);
 
 /* "TN" GEMM: C[M,N] = epilogue(At^T . Wt) with At [K, M] and Wt [K, N] (the contracted index is the ROW index of both
  * operands): the weight gradient dW = dY^T . X on the token-major activations autograd holds (engine_finetune.py:55-57

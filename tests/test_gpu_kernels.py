@@ -523,11 +523,13 @@ def test_gemm_qkv_rope_equals_gemm_then_rope(B, S, H, Hkv, hd, K, start_pos):
         kc = torch.zeros(B, Hkv, Smax, hd, dtype=BF, device=DEV)
         vc = torch.zeros(B, Hkv, hd, Smax, dtype=BF, device=DEV)
         if fused:
-            ops.gemm_qkv_rope(x, w, qkv, kc, vc, cs, B, S, H, Hkv, hd, start_pos, start_pos + 2)
+            vr = torch.zeros(rows, Hkv * hd + 8, dtype=BF, device=DEV)
+            ops.gemm_qkv_rope(x, w, qkv, kc, vc, cs, B, S, H, Hkv, hd, start_pos, start_pos + 2, v_rows=vr[:, :Hkv * hd])
+            assert torch.equal(vr[:, :Hkv * hd], outs[0][3]) and float(vr[:, Hkv * hd:].float().abs().sum()) == 0
         else:
             ops.gemm_nt(x, w, qkv)
             ops.rope_kvcache(qkv, qkv, kc, vc, cs, B, S, H, Hkv, hd, start_pos, start_pos + 2)
-        outs.append((qkv[:, :H * hd].clone(), kc, vc))
-    for a, b, what in zip(outs[0], outs[1], ("q", "k cache", "v^T cache")):
+        outs.append((qkv[:, :H * hd].clone(), kc, vc, qkv[:, (H + Hkv) * hd:].clone()))
+    for a, b, what in zip(outs[0][:3], outs[1][:3], ("q", "k cache", "v^T cache")):
         assert torch.equal(a, b), what
     assert float(outs[1][0].float().abs().max()) > 0.1

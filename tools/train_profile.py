@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run a few fine-tuning steps of the bench workload in ONE mode (full | lora) -- for clean rocprofv3 kernel tables.
-usage: train_profile.py full|lora [steps]"""
+usage: train_profile.py full|lora [steps] [engine_attr=0|1 ...]   (e.g. tn_wgrad=0 for an A/B on one box)"""
 import os
 import sys
 
@@ -11,6 +11,11 @@ import bench  # noqa: E402
 
 mode = sys.argv[1]
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+for kv in sys.argv[3:]:
+    from a3vlm_amd.train import TrainEngine
+    name, val = kv.split("=")
+    assert hasattr(TrainEngine, name), name
+    setattr(TrainEngine, name, bool(int(val)))
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 B, T = 8, 512
