@@ -636,7 +636,12 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_pp_kernel(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (p.K + BK - 1) / BK;
+  // split-K: gridDim.y slices of the k-tile range, slice z -> output plane z (raw fp32 partial sums, a3v_splitk_reduce adds them)
+  const int nk_all = (p.K + BK - 1) / BK;
+  const int kt0 = (int)((int64_t)nk_all * blockIdx.y / gridDim.y), nk = (int)((int64_t)nk_all * (blockIdx.y + 1) / gridDim.y);
+  if (gridDim.y > 1) p.C = reinterpret_cast<char*>(p.C) + (int64_t)blockIdx.y * p.c_split;
+  // waves whose 128 x 64 part of the tile lies outside C (adapter-sized M or N) keep the barriers but skip reads and MFMAs
+  const bool active = (m0 + wr * WTM < p.M) && (n0 + wc * WTN < p.N);
   const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)(((int64_t)(p.K - 1) * p.lda + p.M) * 2), 0x00020000);
   const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)(((int64_t)(p.K - 1) * p.ldw + p.N) * 2), 0x00020000);
   // piece c of this wave: DMA instruction q = wave*4 + c of the tile (k-rows 2q, 2q+1); lane -> row 2q + (lane>>5),
@@ -663,8 +668,8 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_pp_kernel(GemmArgs p) {
 #pragma unroll
     for (int c = 0; c < 8; ++c) stage_piece(t, c);
   };
-  stage(0);
-  if (nk > 1) stage(1);
+  stage(kt0);
+  if (nk > kt0 + 1) stage(kt0 + 1);
   A3V_WAIT_VM0();
   A3V_BARRIER();
 
@@ -713,31 +718,31 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_pp_kernel(GemmArgs p) {
     __builtin_amdgcn_s_setprio(0);                                                                   \
   } while (0)
   if (wr == 0) {
-    for (int t = 0; t < nk; ++t) {
-      TN_READ_FRAGS(lds + (t & 1) * STAGE);
-      if (t >= 1 && t + 1 < nk) stage(t + 1);
+    for (int t = kt0; t < nk; ++t) {
+      if (active) TN_READ_FRAGS(lds + (t & 1) * STAGE);
+      if (t >= kt0 + 1 && t + 1 < nk) stage(t + 1);
       A3V_WAIT_LGKM0();
       A3V_BARRIER();
-      TN_MFMA_ALL();
+      if (active) TN_MFMA_ALL();
       A3V_WAIT_VM0();
       A3V_BARRIER();
     }
     A3V_BARRIER();
   } else {
     A3V_BARRIER();
-    for (int t = 0; t < nk; ++t) {
-      TN_READ_FRAGS(lds + (t & 1) * STAGE);
+    for (int t = kt0; t < nk; ++t) {
+      if (active) TN_READ_FRAGS(lds + (t & 1) * STAGE);
       A3V_WAIT_LGKM0();
       A3V_WAIT_VM0();
       A3V_BARRIER();
       if (t + 2 < nk) stage(t + 2);
-      TN_MFMA_ALL();
+      if (active) TN_MFMA_ALL();
       A3V_BARRIER();
     }
   }
 #undef TN_READ_FRAGS
 #undef TN_MFMA_ALL
-  gemm_epilogue<TM, TN>(acc, p, m0 + wr * WTM, n0 + wc * WTN, lane);
+  if (active) gemm_epilogue<TM, TN>(acc, p, m0 + wr * WTM, n0 + wc * WTN, lane);
 }
 
 // Same schedule with v_mfma_f32_32x32x16_bf16 (8-pass, higher sustained rate than 16x16x32):
@@ -1811,3 +1816,21 @@ extern "C" int a3v_gemm_tn(const void* At, int64_t lda, const void* Wt, int64_t 
   return A3V_OK;
 }
 
+// split-K form of a3v_gemm_tn for adapter-sized outputs (M or N of a few dozen, long K: the LoRA weight gradients
+// dB = dY^T . t and dA = dt^T . X): S slices of the contracted index write raw fp32 planes partial[s][M][N]; a3v_splitk_reduce
+// sums them in slice order.  Waves of the 256 x 256 tile that fall outside C idle.
+extern "C" int a3v_gemm_tn_splitk(const void* At, int64_t lda, const void* Wt, int64_t ldw, float* partial, int M, int N, int K, int S,
+                                  void* stream) {
+  if (!At || !Wt || !partial || M <= 0 || N <= 0 || K <= 0 || S < 1 || S > 64) return A3V_ERR_ARG;
+  if (lda % 8 || ldw % 8 || N % 4 || M % 8 || S > (K + 63) / 64) return A3V_ERR_SHAPE;
+  if (((int64_t)(K - 1) * lda + M) * 2 >= (1LL << 31) || ((int64_t)(K - 1) * ldw + N) * 2 >= (1LL << 31)) return A3V_ERR_SHAPE;
+  GemmArgs p{};
+  p.A = (const bf16_t*)At; p.W = (const bf16_t*)Wt; p.C = partial; p.bias = nullptr; p.res = nullptr;
+  p.lda = lda; p.ldw = ldw; p.ldc = N; p.ldr = 0;
+  p.M = M; p.N = N; p.K = K; p.epi = A3V_EPI_OUT_F32 | GEMM_EPI_RAW; p.dbg = 0;
+  p.tiles_m = (M + 255) / 256; p.tiles_n = (N + 255) / 256;
+  p.c_split = (int64_t)M * N * 4;
+  hipLaunchKernelGGL(gemm_tn_bf16_pp_kernel, dim3(p.tiles_m * p.tiles_n, S), dim3(512), 0, (hipStream_t)stream, p);
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}

@@ -24,6 +24,7 @@ SIGNATURES = {
     "a3v_version": (I, []),
     "a3v_gemm_nt": (I, [P, L, P, L, P, L, I, I, I, P, P, L, I, I, P]),
     "a3v_gemm_qkv_rope": (I, [P, L, P, L, I, P, L, P, P, P, L, P, I, I, I, I, I, I, I, I, P]),
+    "a3v_gemm_tn_splitk": (I, [P, L, P, L, P, I, I, I, I, P]),
     "a3v_gemm_tn": (I, [P, L, P, L, P, L, I, I, I, P, L, I, P]),
     "a3v_gemm_set_workspace": (I, [P, L]),
     "a3v_gemm_nt_splitk": (I, [P, L, P, L, P, I, I, I, I, P]),

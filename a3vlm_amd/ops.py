@@ -96,6 +96,19 @@ def gemm_nt_splitk(a, w, out, scratch, S: int, accumulate: bool = False):
     return out
 
 
+def gemm_tn_splitk(at, wt, out, scratch, S: int, accumulate: bool = False):
+    """out[M, N] (+)= at[K, M]^T @ wt[K, N] through S split-K planes of the TN kernel (adapter-sized M or N, long K)."""
+    _dev(at, wt, out, scratch)
+    K, M = at.shape
+    N = wt.shape[1]
+    assert wt.shape[0] == K and at.stride(1) == 1 and wt.stride(1) == 1
+    assert scratch.dtype == torch.float32 and scratch.numel() >= S * M * N
+    lib = _l.load()
+    _l.check(lib.a3v_gemm_tn_splitk(_p(at), at.stride(0), _p(wt), wt.stride(0), _p(scratch), M, N, K, S, _stream()), f"a3v_gemm_tn_splitk(M={M},N={N},K={K},S={S})")
+    _l.check(lib.a3v_splitk_reduce(_p(scratch), S, M, N, _p(out), out.stride(0), dt(out), 1 if accumulate else 0, _stream()), "a3v_splitk_reduce")
+    return out
+
+
 def gemm_skinny_split(M: int, N: int, K: int) -> int:
     return _l.load().a3v_gemm_skinny_split(M, N, K)
 

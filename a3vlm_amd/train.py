@@ -164,17 +164,27 @@ class TrainEngine:
         return self._img
 
     # ------------------------------------------------------------------ GEMM helpers
-    def _wgrad(self, dy: torch.Tensor, x: torch.Tensor, grad: torch.Tensor, tag: str, names=()):
-        """grad[N,K] (fp32) += dy[M,N]^T @ x[M,K]; plain store when every parameter in ``names`` is fresh this step."""
+    def _wgrad(self, dy: torch.Tensor, x: torch.Tensor, grad: torch.Tensor, tag: str, names=(), store: bool = False):
+        """grad[N,K] (fp32) += dy[M,N]^T @ x[M,K]; plain store when every parameter in ``names`` is fresh this step (or ``store``)."""
         M, N = dy.shape
         K = x.shape[1]
-        fresh = bool(names) and all(n in self._fresh for n in names)
+        fresh = store or (bool(names) and all(n in self._fresh for n in names))
         assert fresh or not any(n in self._fresh for n in names), "partially fresh fused gradient view"
-        if (self.tn_wgrad and self.act == torch.bfloat16 and min(N, K) >= 256 and N % 8 == 0 and K % 4 == 0
-                and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0 and 2 * M * max(dy.stride(0), x.stride(0)) < 2 ** 31):
+        tn_ok = (self.tn_wgrad and self.act == torch.bfloat16 and N % 8 == 0 and K % 4 == 0 and dy.stride(0) % 8 == 0
+                 and x.stride(0) % 8 == 0 and 2 * M * max(dy.stride(0), x.stride(0)) < 2 ** 31)
+        if tn_ok and min(N, K) >= 256:
             # both operands as they are (token-major): the TN kernel transposes fragments on the LDS read
             self._fresh.difference_update(names if fresh else ())
             ops.gemm_tn(dy, x, grad, residual=None if fresh else grad, epilogue=ops.EPI_OUT_F32 if fresh else ops.EPI_RES_F32)
+            return
+        if tn_ok and min(N, K) <= 64 and max(N, K) >= 256:
+            # adapter gradients: a strip of 256 x 256 tiles, split over the tokens so the whole chip streams dy / x once
+            blocks = ((N + 255) // 256) * ((K + 255) // 256)
+            S = 1
+            while blocks * S < 256 and S < 16 and 2 * S <= (M + 63) // 64:
+                S *= 2
+            self._fresh.difference_update(names if fresh else ())
+            ops.gemm_tn_splitk(dy, x, grad, self._buf("splitk", (S * N * K,), torch.float32), S, accumulate=not fresh)
             return
         Mp = _pad64(M)
         dyt = self._buf("wg_dyt" + tag, (N, Mp))
@@ -183,7 +193,10 @@ class TrainEngine:
         ops.transpose(x, xt, M, K, Mp)
         if fresh:
             self._fresh.difference_update(names)
-            ops.gemm_nt(dyt, xt, grad, epilogue=ops.EPI_OUT_F32 if self.act == torch.bfloat16 else 0)
+            if min(N, K) <= 64:
+                self._skinny(dyt, xt, grad)
+            else:
+                ops.gemm_nt(dyt, xt, grad, epilogue=ops.EPI_OUT_F32 if self.act == torch.bfloat16 else 0)
         else:
             if min(N, K) <= 64:
                 self._skinny(dyt, xt, grad, accumulate=True)
@@ -264,10 +277,10 @@ class TrainEngine:
         dt = self._buf("lora_dt", (M, Rp))
         self._dgrad(dy, Bt, dt)                              # dt = dy @ B
         g = key.split(".")[0]
-        gB = self._buf("lora_gB." + g, (N, Rp), torch.float32, zero=True)
-        gA = self._buf("lora_gA." + g, (Rp, x.shape[1]), torch.float32, zero=True)
-        self._wgrad(dy, t, gB, "lb")
-        self._wgrad(dt, x, gA, "la")
+        gB = self._buf("lora_gB." + g, (N, Rp), torch.float32)
+        gA = self._buf("lora_gA." + g, (Rp, x.shape[1]), torch.float32)
+        self._wgrad(dy, t, gB, "lb", store=True)
+        self._wgrad(dt, x, gA, "la", store=True)
         names = {"qkv": ["attention.wq", "attention.wk", "attention.wv"], "wo": ["attention.wo"],
                  "w13": ["feed_forward.w1", "feed_forward.w3"], "w2": ["feed_forward.w2"]}[g]
         row = 0

@@ -84,6 +84,11 @@ int a3v_gemm_qkv_rope(const void* A, int64_t lda, const void* W, int64_t ldw, in
 int a3v_gemm_tn(const void* At, int64_t lda, const void* Wt, int64_t ldw, void* C, int64_t ldc, int M, int N,
                 int K, const void* residual, int64_t ldr, int epilogue, void* stream);
 
+/* Split-K form of a3v_gemm_tn for adapter-sized outputs (the LoRA weight gradients, model/peft.py:40-64 under autograd):
+ * partial [S][M][N] raw fp32 planes, to be summed by a3v_splitk_reduce. */
+int a3v_gemm_tn_splitk(const void* At, int64_t lda, const void* Wt, int64_t ldw, float* partial, int M, int N, int K,
+                       int S, void* stream);
+
 /* Optional: register a scratch buffer (device memory, >= 32 MiB recommended; NULL unregisters) that a3v_gemm_nt may use
  * to split the K loop of the few-hundred-row tail of its hybrid tile dispatch.  The library itself never allocates.  One
  * buffer per process (one process per GPU); it must outlive every later a3v_gemm_nt call and is used on the call's stream. */

@@ -533,3 +533,24 @@ def test_gemm_qkv_rope_equals_gemm_then_rope(B, S, H, Hkv, hd, K, start_pos):
     for a, b, what in zip(outs[0][:3], outs[1][:3], ("q", "k cache", "v^T cache")):
         assert torch.equal(a, b), what
     assert float(outs[1][0].float().abs().max()) > 0.1
+
+
+@pytest.mark.parametrize("M,N,K,S", [(4096, 64, 8728, 8), (64, 1024, 1000, 4), (520, 64, 130, 3), (64, 64, 4096, 16), (2048, 32, 640, 1)])
+def test_gemm_tn_splitk(M, N, K, S):
+    """adapter-sized TN products through split-K planes: slices of uneven k-tile counts, idle waves on either side of the
+    tile, a ragged last k-tile; store and accumulate forms of the reduce; deterministic."""
+    at, wt = rt(gen(K, M, seed=61)), rt(gen(K, N, seed=62, scale=0.05))
+    atd, wtd = at.to(BF).to(DEV), wt.to(BF).to(DEV)
+    want = at.t() @ wt
+    tol = dict(rtol=2 ** -7, atol=2e-3 * math.sqrt(K) * 0.05 + 1e-3)
+    scratch = torch.full((S * M * N,), float("nan"), dtype=torch.float32, device=DEV)
+    of = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+    ops.gemm_tn_splitk(atd, wtd, of, scratch, S)
+    assert_close(of, want, what="tn splitk store", **tol)
+    acc0 = gen(M, N, seed=63)
+    og = acc0.to(DEV).clone()
+    ops.gemm_tn_splitk(atd, wtd, og, scratch, S, accumulate=True)
+    assert_close(og.cpu() - acc0, want, what="tn splitk accumulate", **tol)
+    of2 = torch.empty_like(of)
+    ops.gemm_tn_splitk(atd, wtd, of2, scratch, S)
+    assert torch.equal(of, of2)

@@ -154,3 +154,37 @@ def test_lora_bf16_step_and_optimizer(golden_dir):
     for n, p in m.named_parameters():
         changed = not torch.equal(before[n], p.detach())
         assert changed == (n in tr), n
+
+
+def test_lora_bf16_tn_adapter_gradients_match_transposed_path():
+    """dim 256, 150 tokens: every adapter weight gradient goes through a3v_gemm_tn_splitk on the token-major operands; same
+    values as the transpose + NT split-K path up to fp32 summation order before the single bf16 rounding of the product."""
+    big = dict(dim=256, n_layers=2, n_heads=4, n_kv_heads=2, vocab_size=320, multiple_of=256, max_seq_len=256)
+    oargs = ref_cpu.OracleArgs(**big)
+    sd = ref_cpu.make_decoder_weights(oargs, seed=3, std=0.05)
+    lsd = ref_cpu.make_lora_weights(oargs, RANK, seed=6, std_a=0.05, std_b=0.05)
+    g = torch.Generator().manual_seed(9)
+    B, T = 3, 50
+    ex = torch.randint(3, 320, (B, T), generator=g)
+    ex[:, 0] = 1
+    lab = ex.clone()
+    lab[:, :7] = 0
+    got = {}
+    for tn in (True, False):
+        m = peft.Transformer(peft.ModelArgs(**big, lora_rank=RANK), with_visual=False)
+        m.load_state_dict({**sd, **lsd}, strict=True)
+        train = m.get_trainable_params()
+        for n, p in m.named_parameters():
+            p.requires_grad = n in train
+        m.to(BF).to(DEV)
+        promote_trainable_params_to_fp32(m)
+        eng = TrainEngine(m, BF)
+        eng.tn_wgrad = tn
+        for scale in (1.0, 0.5):
+            eng.forward_loss(ex.to(DEV), lab.to(DEV), None)
+            eng.backward(scale)
+        got[tn] = {n: p.grad.float().cpu() for n, p in train.items()}
+    assert any("lora_a" in n for n in got[True]) and any("lora_b" in n for n in got[True])
+    for n in got[True]:
+        assert relerr(got[True][n], got[False][n]) < 1e-2, n
+        assert float(got[True][n].abs().max()) > 0
