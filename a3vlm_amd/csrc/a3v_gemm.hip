@@ -24,6 +24,7 @@ namespace {
 constexpr int BK = 64;
 constexpr int GROUP_M = 8;
 constexpr int GEMM_EPI_RAW = 1 << 20;     // internal: fp32 output without the bf16 rounding of the accumulator
+constexpr int GEMM_EPI_SCALE = 1 << 22;   // internal: fp8 operands -- accumulator *= sa[m] * sw[n] (per-row scales of A and W) first
 constexpr int GEMM_EPI_ROPEKV = 1 << 21;  // internal: fused-qkv epilogue (a3v_gemm_qkv_rope): RoPE on q / k, k -> K cache, v -> V^T cache
 
 // destination of the fused-qkv epilogue: C row m = b*S + s; columns [q heads | k heads | v heads], hd = 1 << hd_shift each
@@ -49,6 +50,8 @@ struct GemmArgs {
   int dbg;   // ablation switches for tuning runs (0 in production): 1 = no DMA in the k-loop, 2 = no ds_read in the k-loop
   int64_t c_split;   // split-K (128x128 kernel, gridDim.y slices): byte stride between the slices' output planes
   RopeKvArgs rk;     // GEMM_EPI_ROPEKV only
+  const float* sa;   // GEMM_EPI_SCALE: per-row dequantisation scales of A [M] and W [N]
+  const float* sw;
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
@@ -76,17 +79,39 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, int64_t
 
 // Epilogue shared by the tile kernels.  The lane holds, for each (i, j) MFMA tile,
 // C[m = mbase + 16 i + (lane&15)][n = nbase + 16 j + 4 (lane>>4) + 0..3].
-template <int TM, int TN>
+template <int TM, int TN, bool F8 = false>
 __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GemmArgs& p, int mbase, int nbase, int lane) {
   // ---- epilogue: lane holds C[m][n..n+3], m = .. + (lane&15), n = .. + (lane>>4)*4 ----
   const int epi = p.epi;
   const int mrow = lane & 15;
   const int ncol = (lane >> 4) * 4;
+  if constexpr (F8) {
+    // fp8 operands: the accumulator holds sum_k qa[m][k] qw[n][k]; the value of the product is that times sa[m] sw[n].
+    // All scale loads are issued before the first store of the tile: a load behind a store would wait for the store to drain.
+    f32x4 swv[TN];
+    float sam[TM];
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int m = mbase + i * 16 + mrow;
-    if (m >= p.M) continue;
-    if (epi & A3V_EPI_SWIGLU) {
+    for (int j = 0; j < TN; ++j) {
+      const int n = nbase + j * 16 + ncol;
+      swv[j] = n < p.N ? *reinterpret_cast<const f32x4*>(p.sw + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = mbase + i * 16 + mrow;
+      sam[i] = m < p.M ? p.sa[m] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] *= sam[i] * swv[j][r];
+  }
+  if (epi & A3V_EPI_SWIGLU) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = mbase + i * 16 + mrow;
+      if (m >= p.M) continue;
       // W rows interleaved in blocks of 16: even 16-block = w1 (gate), odd = w3 (up)
 #pragma unroll
       for (int j = 0; j < TN; j += 2) {
@@ -102,84 +127,107 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GemmAr
         }
         *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + oc) = o;
       }
-      continue;
     }
+    return;
+  }
+  // Phase 1 -- values: bias, the bf16 rounding F.linear applies, activation, rotary embedding, residual; everything that LOADS
+  // (bias, cos/sin rows, residual) happens here, before the tile's first store: on this ISA a load issued behind stores can
+  // only be waited for together with them, and at the end of a tile round the whole chip's store burst takes microseconds to
+  // drain.  The loads of half the tile (TM/2 x TN vectors) are in flight at a time; the results overwrite the accumulators.
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int i = half * (TM / 2); i < (half + 1) * (TM / 2); ++i) {
+      const int m = mbase + i * 16 + mrow;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = nbase + j * 16 + ncol;
+        if (n >= p.N) continue;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
+        if (epi & A3V_EPI_BIAS) {
+          const bf16x4 b = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(p.bias) + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += bf2f(b[r]);
+        }
+        if (!(epi & GEMM_EPI_RAW)) {      // split-K planes keep the raw fp32 partial sums (rounded once by the reduce pass)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = rbf(v[r]);   // the bf16 value F.linear returns
+        }
+        if (epi & GEMM_EPI_ROPEKV) {
+          // v[] = the bf16 qkv values of token (b, s), columns n..n+3 of head slot n >> hd_shift: rotate the two (even, odd)
+          // pairs of q / k by the token's position (LLM/llama_ens5.py:123-135 apply_rotary_emb); v passes through
+          const RopeKvArgs& k = p.rk;
+          const int mg = m + k.m_off;
+          const int sq = mg - (mg / k.S) * k.S;
+          const int slot = n >> k.hd_shift, d = n & ((1 << k.hd_shift) - 1);
+          if (slot < k.H + k.Hkv) {
+            const f32x4 cs = *reinterpret_cast<const f32x4*>(k.cos_sin + (((int64_t)(k.rope_pos0 + sq) << (k.hd_shift - 1)) + (d >> 1)) * 2);
+            const float o0 = v[0] * cs[0] - v[1] * cs[1], o1 = v[0] * cs[1] + v[1] * cs[0];
+            const float o2 = v[2] * cs[2] - v[3] * cs[3], o3 = v[2] * cs[3] + v[3] * cs[2];
+            v[0] = o0; v[1] = o1; v[2] = o2; v[3] = o3;
+          }
+        } else {
+          if (epi & A3V_EPI_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = rbf(gelu_erf(v[r]));
+          } else if (epi & A3V_EPI_QUICKGELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = rbf(quick_gelu(v[r]));
+          }
+          if (epi & A3V_EPI_RES_F32) {
+            const f32x4 rr = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.res) + (int64_t)m * p.ldr + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = rr[r] + v[r];
+          } else if (epi & A3V_EPI_RESIDUAL) {
+            const bf16x4 rr = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(p.res) + (int64_t)m * p.ldr + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = bf2f(rr[r]) + v[r];
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = v[r];
+      }
+    }
+  }
+  // Phase 2 -- stores only
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = mbase + i * 16 + mrow;
+    if (m >= p.M) continue;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = nbase + j * 16 + ncol;
       if (n >= p.N) continue;
-      float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
-      if (epi & A3V_EPI_BIAS) {
-        const bf16x4 b = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(p.bias) + n);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += bf2f(b[r]);
-      }
-      if (!(epi & GEMM_EPI_RAW)) {      // split-K planes keep the raw fp32 partial sums (rounded once by the reduce pass)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = rbf(v[r]);   // the bf16 value F.linear returns
-      }
       if (epi & GEMM_EPI_ROPEKV) {
-        // v[] = the bf16 qkv values of token (b, s), columns n..n+3 of head slot n >> hd_shift: rotate the two (even, odd)
-        // pairs of q / k by the token's position (LLM/llama_ens5.py:123-135 apply_rotary_emb) and store where attention
-        // reads them (q in place of the qkv row, k into the K cache, v transposed into the V^T cache)
+        // q in place of the qkv row, k into the K cache, v transposed into the V^T cache (and token-major into v_rows)
         const RopeKvArgs& k = p.rk;
         const int mg = m + k.m_off;
         const int b = mg / k.S, sq = mg - b * k.S;
         const int slot = n >> k.hd_shift, d = n & ((1 << k.hd_shift) - 1);
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = f2bf(acc[i][j][r]);
         if (slot < k.H + k.Hkv) {
-          const f32x4 cs = *reinterpret_cast<const f32x4*>(k.cos_sin + (((int64_t)(k.rope_pos0 + sq) << (k.hd_shift - 1)) + (d >> 1)) * 2);
-          bf16x4 o;
-          o[0] = f2bf(v[0] * cs[0] - v[1] * cs[1]);
-          o[1] = f2bf(v[0] * cs[1] + v[1] * cs[0]);
-          o[2] = f2bf(v[2] * cs[2] - v[3] * cs[3]);
-          o[3] = f2bf(v[2] * cs[3] + v[3] * cs[2]);
           bf16_t* dst = slot < k.H ? k.q_out + (int64_t)mg * k.ldq + n
                                    : k.k_cache + ((((int64_t)b * k.Hkv + (slot - k.H)) * k.Smax + k.start_pos + sq) << k.hd_shift) + d;
           *reinterpret_cast<bf16x4*>(dst) = o;
         } else {
           bf16_t* dst = k.vt_cache + ((((int64_t)b * k.Hkv + (slot - k.H - k.Hkv)) << k.hd_shift) + d) * k.Smax + k.start_pos + sq;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) dst[(int64_t)r * k.Smax] = f2bf(v[r]);
-          if (k.v_rows) {
-            bf16x4 o;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = f2bf(v[r]);
-            *reinterpret_cast<bf16x4*>(k.v_rows + (int64_t)mg * k.ldv + (n - ((k.H + k.Hkv) << k.hd_shift))) = o;
-          }
+          for (int r = 0; r < 4; ++r) dst[(int64_t)r * k.Smax] = o[r];
+          if (k.v_rows) *reinterpret_cast<bf16x4*>(k.v_rows + (int64_t)mg * k.ldv + (n - ((k.H + k.Hkv) << k.hd_shift))) = o;
         }
         continue;
       }
-      if (epi & A3V_EPI_GELU) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = rbf(gelu_erf(v[r]));
-      } else if (epi & A3V_EPI_QUICKGELU) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = rbf(quick_gelu(v[r]));
-      }
-      if (epi & A3V_EPI_RES_F32) {
-        const f32x4 rr = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.res) + (int64_t)m * p.ldr + n);
-        f32x4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = rr[r] + v[r];
-        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n) = o;
-        continue;
-      }
-      if (epi & A3V_EPI_RESIDUAL) {
-        const bf16x4 rr = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(p.res) + (int64_t)m * p.ldr + n);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = bf2f(rr[r]) + v[r];
-      }
-      if (epi & A3V_EPI_OUT_F32) {
-        f32x4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = v[r];
-        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n) = o;
+      if (epi & (A3V_EPI_RES_F32 | A3V_EPI_OUT_F32)) {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n) = acc[i][j];
       } else {
         bf16x4 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = f2bf(v[r]);
+        for (int r = 0; r < 4; ++r) o[r] = f2bf(acc[i][j][r]);
         *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + n) = o;
       }
     }
@@ -592,6 +640,130 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_pp_kernel(GemmArgs p) {
 #undef PP_READ_FRAGS
 #undef PP_MFMA_ALL
   gemm_epilogue<TM, TN>(acc, p, m0 + wr * WTM, n0 + wc * WTN, lane);
+}
+
+// ------------------------------------------------------------------------------------
+// fp8 (OCP e4m3fn) form of the 256x256 ping-pong kernel: A [M][K] and W [N][K] are fp8 bytes, one k-tile is 128 elements =
+// the same 128-byte LDS rows, DMA pieces and swizzle as the bf16 kernel's 64-element tile, and the two 16-byte fragment reads
+// of a lane (16-B chunks g and 4 + g of its row) feed ONE v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales) instead of
+// two 16x16x32 bf16 MFMAs: the same cycles per k-tile for twice the k.  Which 32 of the 128 k a lane group holds does not
+// matter as long as A and W agree (tools/ubench/mxfp8.hip).  Per-row dequantisation scales are applied in the epilogue.
+// ------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+__global__ __launch_bounds__(512) void gemm_nt_fp8_pp_kernel(GemmArgs p) {
+  constexpr int TBM = 256, TBN = 256, WTM = 128, WTN = 64, TM = 8, TN = 4, KT = 128;
+  constexpr int STAGE = (TBM + TBN) * KT;   // 64 KiB
+  __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int per_group = GROUP_M * p.tiles_n;
+  const int group = bid / per_group;
+  const int first_m = group * GROUP_M;
+  const int gsz = min(p.tiles_m - first_m, GROUP_M);
+  const int in_g = bid - group * per_group;
+  const int tm = first_m + in_g % gsz;
+  const int tn = in_g / gsz;
+  const int m0 = tm * TBM, n0 = tn * TBN;
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / KT;
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)((int64_t)(p.M - 1) * p.lda + p.K), 0x00020000);
+  const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)((int64_t)(p.N - 1) * p.ldw + p.K), 0x00020000);
+  const unsigned lr = lane >> 3;
+  unsigned voA[2], voW[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par) {
+    const unsigned sl = (lane & 7) ^ ((par * 4 + (lane >> 4)) & 7);
+    voA[par] = (unsigned)(lr * p.lda + sl * 16);
+    voW[par] = (unsigned)(lr * p.ldw + sl * 16);
+  }
+  auto stage = [&](int t) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int ch = wave * 4 + (c & 3);
+      char* dst = lds + (t & 1) * STAGE + (c >= 4 ? TBM * KT : 0) + ch * 1024;
+      if (c < 4) {
+        const unsigned so = (unsigned)((int64_t)(m0 + ch * 8) * p.lda + t * KT);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)dst, 16, voA[c & 1] + so, 0, 0, 0);
+      } else {
+        const unsigned so = (unsigned)((int64_t)(n0 + ch * 8) * p.ldw + t * KT);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)dst, 16, voW[c & 1] + so, 0, 0, 0);
+      }
+    }
+  };
+  stage(0);
+  if (nk > 1) stage(1);
+  A3V_WAIT_VM0();
+  A3V_BARRIER();
+
+  const int frow = lane & 15, fsw = (lane >> 1) & 7, fks = lane >> 4;
+  const int off0 = ((0 * 4 + fks) ^ fsw) << 4, off1 = ((1 * 4 + fks) ^ fsw) << 4;
+  const int a_base = (wr * WTM + frow) * 128;
+  const int w_base = TBM * KT + (wc * WTN + frow) * 128;
+  i32x4 alo[TM], ahi[TM], wlo[TN], whi[TN];
+#define F8_READ_FRAGS(cur)                                                                           \
+  do {                                                                                               \
+    const char* At_ = (cur) + a_base;                                                                \
+    const char* Wt_ = (cur) + w_base;                                                                \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                 \
+      wlo[j] = *reinterpret_cast<const i32x4*>(Wt_ + j * 2048 + off0);                               \
+      whi[j] = *reinterpret_cast<const i32x4*>(Wt_ + j * 2048 + off1);                               \
+    }                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                 \
+      alo[i] = *reinterpret_cast<const i32x4*>(At_ + i * 2048 + off0);                               \
+      ahi[i] = *reinterpret_cast<const i32x4*>(At_ + i * 2048 + off1);                               \
+    }                                                                                                \
+  } while (0)
+#define F8_MFMA_ALL()                                                                                \
+  do {                                                                                               \
+    __builtin_amdgcn_s_setprio(1);                                                                   \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                   \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                 \
+        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(__builtin_shufflevector(wlo[j], whi[j], 0, 1, 2, 3, 4, 5, 6, 7), \
+            __builtin_shufflevector(alo[i], ahi[i], 0, 1, 2, 3, 4, 5, 6, 7), acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);    \
+    __builtin_amdgcn_s_setprio(0);                                                                   \
+  } while (0)
+  if (wr == 0) {
+    for (int t = 0; t < nk; ++t) {
+      F8_READ_FRAGS(lds + (t & 1) * STAGE);
+      if (t >= 1 && t + 1 < nk) stage(t + 1);
+      A3V_WAIT_LGKM0();
+      A3V_BARRIER();
+      F8_MFMA_ALL();
+      A3V_WAIT_VM0();
+      A3V_BARRIER();
+    }
+    A3V_BARRIER();
+  } else {
+    A3V_BARRIER();
+    for (int t = 0; t < nk; ++t) {
+      F8_READ_FRAGS(lds + (t & 1) * STAGE);
+      A3V_WAIT_LGKM0();
+      A3V_WAIT_VM0();
+      A3V_BARRIER();
+      if (t + 2 < nk) stage(t + 2);
+      F8_MFMA_ALL();
+      A3V_BARRIER();
+    }
+  }
+#undef F8_READ_FRAGS
+#undef F8_MFMA_ALL
+  gemm_epilogue<TM, TN, true>(acc, p, m0 + wr * WTM, n0 + wc * WTN, lane);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1834,3 +2006,46 @@ extern "C" int a3v_gemm_tn_splitk(const void* At, int64_t lda, const void* Wt, i
   A3V_LAUNCH_CHECK();
   return A3V_OK;
 }
+
+// C = epilogue((Aq . Wq^T) * sa[m] * sw[n]): fp8 (OCP e4m3fn) activations and weights with per-row fp32 scales, MX-scaled
+// MFMA at twice the bf16 rate.  K % 128 == 0; 256 x 256 tiles for the whole problem; epilogues as a3v_gemm_nt (bf16 C).
+static int gemm_nt_fp8_impl(const void* Aq, int64_t lda, const float* sa, const void* Wq, int64_t ldw, const float* sw, void* C,
+                            int64_t ldc, int M, int N, int K, const void* bias, const void* residual, int64_t ldr, int epilogue,
+                            void* stream, const RopeKvArgs* rk) {
+  if (!Aq || !sa || !Wq || !sw || !C || M <= 0 || N <= 0 || K <= 0) return A3V_ERR_ARG;
+  if (K % 128 || lda % 16 || ldw % 16 || N % 4 || ldc % 4) return A3V_ERR_SHAPE;
+  if (epilogue & ~(A3V_EPI_BIAS | A3V_EPI_GELU | A3V_EPI_QUICKGELU | A3V_EPI_RESIDUAL | A3V_EPI_SWIGLU | A3V_EPI_OUT_F32 | A3V_EPI_RES_F32)) return A3V_ERR_ARG;
+  if ((epilogue & A3V_EPI_BIAS) && !bias) return A3V_ERR_ARG;
+  if ((epilogue & (A3V_EPI_RESIDUAL | A3V_EPI_RES_F32)) && (!residual || ldr % 4)) return A3V_ERR_ARG;
+  if ((epilogue & A3V_EPI_SWIGLU) && (N % 32)) return A3V_ERR_SHAPE;
+  if ((int64_t)(M - 1) * lda + K >= (1LL << 31) || (int64_t)(N - 1) * ldw + K >= (1LL << 31)) return A3V_ERR_SHAPE;
+  GemmArgs p{};
+  p.A = (const bf16_t*)Aq; p.W = (const bf16_t*)Wq; p.C = C; p.bias = bias; p.res = residual;
+  p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr;
+  p.M = M; p.N = N; p.K = K; p.epi = epilogue | GEMM_EPI_SCALE; p.dbg = 0;
+  p.sa = sa; p.sw = sw;
+  if (rk) { p.rk = *rk; p.epi |= GEMM_EPI_ROPEKV; }
+  p.tiles_m = (M + 255) / 256; p.tiles_n = (N + 255) / 256;
+  hipLaunchKernelGGL(gemm_nt_fp8_pp_kernel, dim3(p.tiles_m * p.tiles_n), dim3(512), 0, (hipStream_t)stream, p);
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}
+
+extern "C" int a3v_gemm_nt_fp8(const void* Aq, int64_t lda, const float* sa, const void* Wq, int64_t ldw, const float* sw, void* C,
+                               int64_t ldc, int M, int N, int K, const void* bias, const void* residual, int64_t ldr, int epilogue,
+                               void* stream) {
+  return gemm_nt_fp8_impl(Aq, lda, sa, Wq, ldw, sw, C, ldc, M, N, K, bias, residual, ldr, epilogue, stream, nullptr);
+}
+
+extern "C" int a3v_gemm_qkv_rope_fp8(const void* Aq, int64_t lda, const float* sa, const void* Wq, int64_t ldw, const float* sw, int K,
+                                     void* q_out, int64_t ldq, void* k_cache, void* vt_cache, const float* cos_sin, int B, int S,
+                                     int H, int Hkv, int hd, int Smax, int start_pos, int rope_pos0, void* stream) {
+  if (!q_out || !k_cache || !vt_cache || !cos_sin || B <= 0 || S <= 0 || H <= 0 || Hkv <= 0) return A3V_ERR_ARG;
+  if ((hd != 64 && hd != 128) || ldq % 4 || start_pos < 0 || start_pos + S > Smax) return A3V_ERR_SHAPE;
+  RopeKvArgs rk{};
+  rk.q_out = (bf16_t*)q_out; rk.k_cache = (bf16_t*)k_cache; rk.vt_cache = (bf16_t*)vt_cache; rk.cos_sin = cos_sin;
+  rk.ldq = ldq; rk.S = S; rk.H = H; rk.Hkv = Hkv; rk.hd_shift = hd == 128 ? 7 : 6; rk.Smax = Smax;
+  rk.start_pos = start_pos; rk.rope_pos0 = rope_pos0; rk.m_off = 0;
+  return gemm_nt_fp8_impl(Aq, lda, sa, Wq, ldw, sw, q_out, ldq, B * S, (H + 2 * Hkv) * hd, K, nullptr, nullptr, 0, 0, stream, &rk);
+}
+

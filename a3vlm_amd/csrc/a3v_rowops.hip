@@ -42,6 +42,81 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const TX* __restrict__ x, 
   }
 }
 
+// ---------------------------------------------------------------- per-row fp8 (OCP e4m3fn) quantisation of activations
+// q[row][k] = fp8(y[row][k] / scale[row]), scale[row] = max_k |y[row][k]| / 448, with y = the bf16 rows x themselves (NORM = false)
+// or the bf16 RMSNorm output of x (NORM = true: the values rmsnorm_kernel<.., bf16_t> stores, never written to memory).
+// Feeds a3v_gemm_nt_fp8 (a3v_gemm.hip), which multiplies the accumulator of row m by scale[m].
+template <typename TX, typename TW, bool NORM>
+__global__ __launch_bounds__(256) void rows_quant_fp8_kernel(const TX* __restrict__ x, int64_t ldx, const TW* __restrict__ w,
+                                                             uint8_t* __restrict__ q, int64_t ldq, float* __restrict__ scales, int dim,
+                                                             float eps) {
+  __shared__ float red[4];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const TX* xr = x + (int64_t)row * ldx;
+  constexpr int MAXV = 6;  // dim <= 256*8*6 = 12288
+  float v[MAXV][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = (tid + i * 256) * 8;
+    if (c < dim) {
+      load8(xr + c, v[i]);
+      if (NORM) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ss = fmaf(v[i][e], v[i][e], ss);
+      }
+    }
+  }
+  float amax = 0.f;
+  if (NORM) {
+    ss = block_sum<256>(ss, red);
+    const float inv = rsqrtf(ss / (float)dim + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = (tid + i * 256) * 8;
+      if (c < dim) {
+        float wv[8];
+        load8(w + c, wv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[i][e] = rbf(Cvt<TX>::rnd(v[i][e] * inv) * wv[e]);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = (tid + i * 256) * 8;
+    if (c < dim) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[i][e]));
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = amax;
+  __syncthreads();
+  amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float scale = fmaxf(amax, 1e-12f) * (1.f / 448.f);
+  const float rs = 1.f / scale;
+  if (tid == 0) scales[row] = scale;
+  uint8_t* qr = q + (int64_t)row * ldq;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = (tid + i * 256) * 8;
+    if (c < dim) {
+      float t[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t[e] = fminf(fmaxf(v[i][e] * rs, -448.f), 448.f);
+      int lo = 0, hi = 0;
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(t[0], t[1], lo, false);
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(t[2], t[3], lo, true);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(t[4], t[5], hi, false);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(t[6], t[7], hi, true);
+      *reinterpret_cast<int2*>(qr + c) = make_int2(lo, hi);
+    }
+  }
+}
+
 // ---------------------------------------------------------------- LayerNorm (torch.nn.LayerNorm)
 template <typename T, typename TP, typename TY>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, int64_t ldx, const TP* __restrict__ w,
@@ -594,3 +669,19 @@ extern "C" int a3v_cross_entropy(const void* logits, int64_t ld, const int64_t* 
   A3V_LAUNCH_CHECK();
   return A3V_OK;
 }
+
+extern "C" int a3v_quantize_rows_fp8(const void* x, int64_t ldx, const void* norm_w, float eps, void* q, int64_t ldq, float* scales,
+                                     int rows, int dim, int x_dtype, void* stream) {
+  if (!x || !q || !scales || rows <= 0 || dim <= 0) return A3V_ERR_ARG;
+  if (dim % 8 || dim > 12288 || ldx % 8 || ldq % 8) return A3V_ERR_SHAPE;
+  dim3 g(rows), b(256);
+  if (x_dtype == A3V_BF16) {
+    if (norm_w) hipLaunchKernelGGL((rows_quant_fp8_kernel<bf16_t, bf16_t, true>), g, b, 0, ST, (const bf16_t*)x, ldx, (const bf16_t*)norm_w, (uint8_t*)q, ldq, scales, dim, eps);
+    else hipLaunchKernelGGL((rows_quant_fp8_kernel<bf16_t, bf16_t, false>), g, b, 0, ST, (const bf16_t*)x, ldx, (const bf16_t*)nullptr, (uint8_t*)q, ldq, scales, dim, eps);
+  } else {
+    return A3V_ERR_DTYPE;
+  }
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}
+

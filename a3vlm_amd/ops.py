@@ -137,6 +137,42 @@ def gemm_skinny(a, w, out, partial, *, residual=None, epilogue: int = 0):
     return out
 
 
+def quantize_rows_fp8(x, q, scales, norm_w=None, eps: float = 0.0):
+    """q[r] = fp8(y[r] / scales[r]), scales[r] = max|y[r]| / 448; y = x, or the bf16 RMSNorm of x when norm_w is given."""
+    _dev(x, q, scales, norm_w)
+    rows, dim = x.shape
+    assert q.dtype == torch.uint8 and scales.dtype == torch.float32 and scales.numel() >= rows
+    rc = _l.load().a3v_quantize_rows_fp8(_p(x), x.stride(0), _p(norm_w), eps, _p(q), q.stride(0), _p(scales), rows, dim, dt(x), _stream())
+    _l.check(rc, "a3v_quantize_rows_fp8")
+    return q, scales
+
+
+def gemm_nt_fp8(aq, sa, wq, sw, out, *, bias=None, residual=None, epilogue: int = 0):
+    """out = epilogue((aq @ wq.T) * sa[:, None] * sw[None, :]) with fp8 operands (uint8 views of e4m3fn) on the MX-scaled MFMA."""
+    _dev(aq, sa, wq, sw, out, bias, residual)
+    M, K = aq.shape
+    N = wq.shape[0]
+    assert aq.dtype == torch.uint8 and wq.dtype == torch.uint8 and wq.shape[1] == K
+    ep = epilogue
+    if bias is not None:
+        ep |= EPI_BIAS
+    if residual is not None and not (ep & EPI_RES_F32):
+        ep |= EPI_RESIDUAL
+    rc = _l.load().a3v_gemm_nt_fp8(_p(aq), aq.stride(0), _p(sa), _p(wq), wq.stride(0), _p(sw), _p(out), out.stride(0), M, N, K,
+                                   _p(bias), _p(residual), residual.stride(0) if residual is not None else 0, ep, _stream())
+    _l.check(rc, f"a3v_gemm_nt_fp8(M={M},N={N},K={K},epi={ep})")
+    return out
+
+
+def gemm_qkv_rope_fp8(xq, sx, wq, sw, qkv, k_cache, vt_cache, cos_sin, B, S, H, Hkv, hd, start_pos, rope_pos0):
+    _dev(xq, sx, wq, sw, qkv, k_cache, vt_cache, cos_sin)
+    assert xq.shape[0] == B * S and wq.shape[0] == (H + 2 * Hkv) * hd
+    rc = _l.load().a3v_gemm_qkv_rope_fp8(_p(xq), xq.stride(0), _p(sx), _p(wq), wq.stride(0), _p(sw), xq.shape[1], _p(qkv),
+                                         qkv.stride(0), _p(k_cache), _p(vt_cache), _p(cos_sin), B, S, H, Hkv, hd,
+                                         k_cache.shape[2], start_pos, rope_pos0, _stream())
+    _l.check(rc, "a3v_gemm_qkv_rope_fp8")
+
+
 def gemm_skinny_fp8(a, wq, wscale, out, workspace, *, residual=None, epilogue: int = 0):
     """out = epilogue((a . float(wq)^T) * wscale): weight-only fp8 (torch.float8_e4m3fn / uint8 bytes) decode GEMV."""
     _dev(a, wq, wscale, out, workspace, residual)

@@ -78,6 +78,24 @@ int a3v_gemm_qkv_rope(const void* A, int64_t lda, const void* W, int64_t ldw, in
                       void* k_cache, void* vt_cache, void* v_rows, int64_t ldv, const float* cos_sin, int B, int S,
                       int H, int Hkv, int hd, int Smax, int start_pos, int rope_pos0, void* stream);
 
+/* fp8 (OCP e4m3fn) W8A8 prefill GEMM (BASELINE config 5 "quantised inference"; the reference's quantised path is bitsandbytes
+ * NF4/INT8, util/quant.py:95-163, so there is no reference oracle: parity is stated against the exact product of the
+ * dequantised operands): C = epilogue((Aq . Wq^T) * sa[m] * sw[n]) on v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales.
+ * Aq [M, K] / Wq [N, K] fp8 bytes (lda, ldw % 16 == 0, K % 128 == 0), sa [M] / sw [N] fp32 per-row scales; C bf16 (or fp32 with
+ * OUT_F32 / RES_F32); epilogues BIAS / GELU / QUICKGELU / RESIDUAL / SWIGLU / OUT_F32 / RES_F32 as a3v_gemm_nt. */
+int a3v_gemm_nt_fp8(const void* Aq, int64_t lda, const float* sa, const void* Wq, int64_t ldw, const float* sw, void* C,
+                    int64_t ldc, int M, int N, int K, const void* bias, const void* residual, int64_t ldr, int epilogue,
+                    void* stream);
+/* a3v_gemm_qkv_rope with fp8 operands. */
+int a3v_gemm_qkv_rope_fp8(const void* Aq, int64_t lda, const float* sa, const void* Wq, int64_t ldw, const float* sw, int K,
+                          void* q_out, int64_t ldq, void* k_cache, void* vt_cache, const float* cos_sin, int B, int S,
+                          int H, int Hkv, int hd, int Smax, int start_pos, int rope_pos0, void* stream);
+/* Dynamic per-row activation quantisation for a3v_gemm_nt_fp8: scales[r] = max|y[r,:]| / 448, q[r,k] = fp8(y[r,k] / scales[r]),
+ * y = x (bf16 rows) or, with norm_w != NULL, the bf16 RMSNorm of x (model/components.py:39,52-53) without writing it out.
+ * dim % 8 == 0, dim <= 12288. */
+int a3v_quantize_rows_fp8(const void* x, int64_t ldx, const void* norm_w, float eps, void* q, int64_t ldq, float* scales,
+                          int rows, int dim, int x_dtype, void* stream);
+
 /* "TN" GEMM: C[M,N] = epilogue(At^T . Wt) with At [K, M] and Wt [K, N] (the contracted index is the ROW index of both
  * operands): the weight gradient dW = dY^T . X on the token-major activations autograd holds (engine_finetune.py:55-57
  * loss.backward()), without transposing either.  lda, ldw % 8 == 0, M % 8 == 0; epilogues NONE / RESIDUAL / RES_F32 / OUT_F32. */

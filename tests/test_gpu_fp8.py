@@ -26,6 +26,17 @@ def gen(*shape, seed, scale=1.0):
     return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
 
 
+def assert_close(got, want, rtol, atol, what=""):
+    got, want = got.detach().float().cpu(), want.detach().float().cpu()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    err = (got - want).abs()
+    bad = err > atol + rtol * want.abs()
+    if bad.any():
+        i = torch.nonzero(bad)[0].tolist()
+        raise AssertionError(f"{what}: {int(bad.sum())}/{bad.numel()} out of tol; first at {i}: got {got[tuple(i)]:.6g} "
+                             f"want {want[tuple(i)]:.6g}; max err {err.max():.4g}")
+
+
 def test_quantizer_roundtrip():
     w = gen(300, 512, seed=1, scale=0.03)
     q, s = quantize_rows_fp8(w)
@@ -114,3 +125,76 @@ def test_fp8_decode_step_vs_bf16(heads, kv, dim, B):
     m.quantize_decode_weights(None)
     again = run()
     assert torch.equal(again[1], base[1])
+
+
+# ------------------------------------------------------------------ W8A8 prefill: activation quantiser + MX-scaled fp8 GEMM
+def _deq(q, s):
+    return q.cpu().view(torch.float8_e4m3fn).float() * s.cpu()[:, None]
+
+
+@pytest.mark.parametrize("rows,dim,norm", [(37, 4096, False), (5, 11008, False), (64, 512, True), (19, 4096, True), (3, 264, False)])
+def test_quantize_rows_fp8(rows, dim, norm):
+    """scale = max|y| / 448 per row, q = fp8(y / scale) with y the bf16 rows or their bf16 RMSNorm (never stored): the
+    dequantised value is within half an e4m3 step of y, the row maximum maps to +-448, a zero row stays finite."""
+    g = torch.Generator().manual_seed(rows * 7 + dim)
+    x = (torch.randn(rows, dim, generator=g) * torch.rand(rows, 1, generator=g) * 3).to(BF)
+    x[rows // 2] = 0
+    w = (1 + 0.1 * torch.randn(dim, generator=g)).to(BF)
+    xd = x.to(DEV)
+    y = x.float()
+    if norm:
+        yd = torch.empty_like(xd)
+        ops.rmsnorm(xd, w.to(DEV), yd, 1e-5)
+        y = yd.float().cpu()
+    q = torch.zeros(rows, dim + 8, dtype=torch.uint8, device=DEV)
+    s = torch.empty(rows, dtype=torch.float32, device=DEV)
+    ops.quantize_rows_fp8(xd, q[:, :dim], s, w.to(DEV) if norm else None, 1e-5)
+    assert int(q[:, dim:].sum()) == 0
+    amax = y.abs().amax(dim=1)
+    want_s = amax.clamp_min(1e-12) / 448
+    assert torch.allclose(s.cpu(), want_s, rtol=1e-6, atol=0)
+    d = _deq(q[:, :dim], s)
+    assert torch.isfinite(d).all()
+    step = torch.maximum(y.abs() * 2 ** -4, want_s[:, None] * 2 ** -10)     # half ulp of 3 mantissa bits / half a subnormal step
+    assert bool(((d - y).abs() <= step * 1.001).all())
+    nz = amax > 0
+    assert torch.allclose(d.abs().amax(dim=1)[nz], amax[nz], rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(300, 520, 256, "plain"), (1091, 768, 1024, "residual"), (512, 1024, 128, "swiglu"),
+                                       (260, 256, 384, "f32"), (8728, 512, 512, "plain")])
+def test_gemm_nt_fp8(M, N, K, epi):
+    """MX-scaled fp8 MFMA GEMM == the fp32 product of the dequantised operands (fp8 x fp8 products are exact in fp32), then
+    the same rounding points as the bf16 kernel's epilogues; partial tiles in M and N, one to eight k-tiles."""
+    from a3vlm_amd.quant import quantize_rows_fp8 as qhost
+    a, w = gen(M, K, seed=71), gen(N, K, seed=72, scale=0.05)
+    aq, sa = qhost(a)
+    wq, sw = qhost(w)
+    want = (aq.view(torch.float8_e4m3fn).float() * sa[:, None]) @ (wq.view(torch.float8_e4m3fn).float() * sw[:, None]).t()
+    aqd, sad, wqd, swd = aq.to(DEV), sa.to(DEV), wq.to(DEV), sw.to(DEV)
+    tol = dict(rtol=2 ** -7, atol=1e-3 * math.sqrt(K) * 0.05 + 1e-3)
+    if epi == "plain":
+        out = torch.empty(M, N, dtype=BF, device=DEV)
+        ops.gemm_nt_fp8(aqd, sad, wqd, swd, out)
+        assert_close(out, want, what="fp8 plain", **tol)
+        out2 = torch.empty_like(out)
+        ops.gemm_nt_fp8(aqd, sad, wqd, swd, out2)
+        assert torch.equal(out, out2)
+    elif epi == "residual":
+        res = rt(gen(M, N, seed=73))
+        out = res.to(BF).to(DEV)
+        ops.gemm_nt_fp8(aqd, sad, wqd, swd, out, residual=out)
+        # the product is rounded to bf16 before the add: a rounding flip is one bf16 step of the PRODUCT, whatever the sum is
+        assert_close(out, res + rt(want), what="fp8 residual", rtol=2 ** -7, atol=tol["atol"] + 2 ** -8 * float(want.abs().max()))
+    elif epi == "f32":
+        res = gen(M, N, seed=74)
+        out = res.to(DEV).clone()
+        ops.gemm_nt_fp8(aqd, sad, wqd, swd, out, residual=out, epilogue=ops.EPI_RES_F32)
+        assert_close(out.cpu() - res, want, what="fp8 f32 residual", **tol)
+    else:
+        # rows interleaved in blocks of 16: even block = gate, odd = up (A3V_EPI_SWIGLU)
+        out = torch.empty(M, N // 2, dtype=BF, device=DEV)
+        ops.gemm_nt_fp8(aqd, sad, wqd, swd, out, epilogue=ops.EPI_SWIGLU)
+        wb = rt(want).view(M, N // 32, 2, 16)
+        gate, up = wb[:, :, 0].reshape(M, N // 2), wb[:, :, 1].reshape(M, N // 2)
+        assert_close(out, rt(torch.nn.functional.silu(gate)) * up, what="fp8 swiglu", rtol=2 ** -6, atol=tol["atol"])
