@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void rows_quant_fp8_kernel(const TX* __restric
   __shared__ float red[4];
   const int row = blockIdx.x, tid = threadIdx.x;
   const TX* xr = x + (int64_t)row * ldx;
-  constexpr int MAXV = 6;  // dim <= 256*8*6 = 12288
+  constexpr int MAXV = 8;  // dim <= 256*8*8 = 16384
   float v[MAXV][8];
   float ss = 0.f;
 #pragma unroll
@@ -673,7 +673,7 @@ extern "C" int a3v_cross_entropy(const void* logits, int64_t ld, const int64_t* 
 extern "C" int a3v_quantize_rows_fp8(const void* x, int64_t ldx, const void* norm_w, float eps, void* q, int64_t ldq, float* scales,
                                      int rows, int dim, int x_dtype, void* stream) {
   if (!x || !q || !scales || rows <= 0 || dim <= 0) return A3V_ERR_ARG;
-  if (dim % 8 || dim > 12288 || ldx % 8 || ldq % 8) return A3V_ERR_SHAPE;
+  if (dim % 8 || dim > 16384 || ldx % 8 || ldq % 8) return A3V_ERR_SHAPE;
   dim3 g(rows), b(256);
   if (x_dtype == A3V_BF16) {
     if (norm_w) hipLaunchKernelGGL((rows_quant_fp8_kernel<bf16_t, bf16_t, true>), g, b, 0, ST, (const bf16_t*)x, ldx, (const bf16_t*)norm_w, (uint8_t*)q, ldq, scales, dim, eps);

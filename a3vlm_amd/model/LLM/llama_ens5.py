@@ -380,9 +380,36 @@ class Transformer(nn.Module):
         if S == 1 and h.dtype == torch.bfloat16:
             scratch = self._buf("attn_scratch", (2 * ops.attention_scratch_floats(B, H, hd, a.max_seq_len + 64),), torch.float32)
         ldq = qkv.stride(0)
+        q8 = getattr(self, "_q8", None)
+        w8a8 = (q8 is not None and getattr(self, "_fp8_prefill", False) and rows > 16 and h.dtype == torch.bfloat16
+                and hd in (64, 128))
+        if w8a8:
+            if q8[0] != self._packed_version:
+                raise RuntimeError("parameters changed after quantize_decode_weights(): call it again (or with mode=None)")
+            xq = self._buf("fp8_x", (rows, max(dim, H * hd)), torch.uint8)
+            aq = self._buf("fp8_act", (rows, self.ffn), torch.uint8)
+            sx = self._buf("fp8_sx", (rows,), torch.float32)
         for i, lyr in enumerate(self.layers):
             kc, vc = k_caches[i], vt_caches[i]
             smax = kc.shape[2]
+            strides = (S * ldq, ldq, hd,                       # q: view into the qkv buffer
+                       Hkv * smax * hd, smax * hd, hd,         # k cache
+                       Hkv * hd * smax, hd * smax, smax,       # v^T cache
+                       S * H * hd, H * hd, hd)                 # out
+            if w8a8:
+                # W8A8 prefill (opt-in, BASELINE config 5): every decoder GEMM on fp8 operands -- activations quantised per
+                # token on the fly (the RMSNorm output never exists in bf16), weights per output row, MX-scaled MFMA
+                (wqkv_q, wqkv_s), (wo_q, wo_s), (w13_q, w13_s), (w2_q, w2_s) = q8[1][i]
+                ops.quantize_rows_fp8(h, xq[:, :dim], sx, lyr.attention_norm.weight, a.norm_eps)
+                ops.gemm_qkv_rope_fp8(xq[:, :dim], sx, wqkv_q, wqkv_s, qkv, kc, vc, cs, B, S, H, Hkv, hd, start_pos, rope_pos0)
+                ops.attention(qkv, kc, vc, att, B, S, Sk, H, Hkv, hd, strides, causal and S > 1, scratch)
+                ops.quantize_rows_fp8(att, xq[:, :H * hd], sx)
+                ops.gemm_nt_fp8(xq[:, :H * hd], sx, wo_q, wo_s, h, residual=h)
+                ops.quantize_rows_fp8(h, xq[:, :dim], sx, lyr.ffn_norm.weight, a.norm_eps)
+                ops.gemm_nt_fp8(xq[:, :dim], sx, w13_q, w13_s, act, epilogue=ops.EPI_SWIGLU)
+                ops.quantize_rows_fp8(act, aq, sx)
+                ops.gemm_nt_fp8(aq, sx, w2_q, w2_s, h, residual=h)
+                continue
             ops.rmsnorm(h, lyr.attention_norm.weight, xn, a.norm_eps)
             if rows > 16 and h.dtype == torch.bfloat16 and hd in (64, 128) and self._fuse_qkv_rope:
                 # rotary embedding + cache write in the GEMM epilogue: qkv never makes a second trip through HBM
@@ -390,22 +417,20 @@ class Transformer(nn.Module):
             else:
                 self._linear(xn, pk[f"wqkv.{i}"], qkv)
                 ops.rope_kvcache(qkv, qkv, kc, vc, cs, B, S, H, Hkv, hd, start_pos, rope_pos0)
-            strides = (S * ldq, ldq, hd,                       # q: view into the qkv buffer
-                       Hkv * smax * hd, smax * hd, hd,         # k cache
-                       Hkv * hd * smax, hd * smax, smax,       # v^T cache
-                       S * H * hd, H * hd, hd)                 # out
             ops.attention(qkv, kc, vc, att, B, S, Sk, H, Hkv, hd, strides, causal and S > 1, scratch)
             self._linear(att, lyr.attention.wo.weight, h, residual=h)
             ops.rmsnorm(h, lyr.ffn_norm.weight, xn, a.norm_eps)
             self._linear(xn, pk[f"w13.{i}"], act, epilogue=ops.EPI_SWIGLU)
             self._linear(act, lyr.feed_forward.w2.weight, h, residual=h)
 
-    def quantize_decode_weights(self, mode: str = "fp8") -> None:
-        """Opt-in weight-only fp8 images of the four decode matrices of every layer (a3vlm_amd/quant.py; BASELINE config 5).
-        Prefill keeps the bf16 weights; only the single-call decode step streams the fp8 images (half the bytes).
-        ``mode=None`` drops them.  Re-run after the weights change."""
+    def quantize_decode_weights(self, mode: str = "fp8", prefill: bool = False) -> None:
+        """Opt-in fp8 images of the four decoder matrices of every layer (a3vlm_amd/quant.py; BASELINE config 5).
+        The single-call decode step streams them weight-only (half the bytes, bf16 activations).  ``prefill=True`` also runs
+        the multi-token forward W8A8 (a3v_gemm_nt_fp8: activations quantised per token on the fly); otherwise prefill keeps
+        the bf16 weights.  ``mode=None`` drops the images.  Re-run after the weights change."""
         from ...quant import quantize_rows_fp8
         self._q8 = None
+        self._fp8_prefill = bool(prefill) and mode is not None
         self._layer_tab_key = None
         if mode is None:
             return

@@ -465,8 +465,26 @@ def main():
                "note": "weight-only OCP e4m3fn decoder matrices with per-row fp32 scales (embeddings, norms, LM head, KV cache bf16); "
                        "no reference oracle exists for fp8 (SURVEY 8(a) row Q): parity is stated against the bf16 kernels on the "
                        "dequantised weights (tests/test_gpu_fp8.py)"}
+        # W8A8 prefill: the same forward step with every decoder GEMM on fp8 operands (MX-scaled MFMA); ViT and LM head bf16
+        m.quantize_decode_weights("fp8", prefill=True)
+        for _ in range(2):
+            step()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        sync_all()
+        p_el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([p_el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            p_el = float(t.item())
+        fp8["forward_w8a8"] = {"samples_s": round(B * world * a.steps / p_el, 2), "ms_per_step": round(p_el / a.steps * 1e3, 2),
+                               "tflops": round(flops_forward(args, B, T, W)["total"] * world * a.steps / p_el / 1e12, 1),
+                               "note": "opt-in quantize_decode_weights('fp8', prefill=True): per-token dynamic e4m3 activations x "
+                                       "per-row e4m3 weights, fp32 accumulate; never the headline value"}
     except Exception as e:
-        fp8 = {"tok_s": None, "error": repr(e)[:300]}
+        fp8 = dict(fp8 or {}, error=repr(e)[:300])
     finally:
         m.quantize_decode_weights(None)
 

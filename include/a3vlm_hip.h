@@ -92,7 +92,7 @@ int a3v_gemm_qkv_rope_fp8(const void* Aq, int64_t lda, const float* sa, const vo
                           int H, int Hkv, int hd, int Smax, int start_pos, int rope_pos0, void* stream);
 /* Dynamic per-row activation quantisation for a3v_gemm_nt_fp8: scales[r] = max|y[r,:]| / 448, q[r,k] = fp8(y[r,k] / scales[r]),
  * y = x (bf16 rows) or, with norm_w != NULL, the bf16 RMSNorm of x (model/components.py:39,52-53) without writing it out.
- * dim % 8 == 0, dim <= 12288. */
+ * dim % 8 == 0, dim <= 16384. */
 int a3v_quantize_rows_fp8(const void* x, int64_t ldx, const void* norm_w, float eps, void* q, int64_t ldq, float* scales,
                           int rows, int dim, int x_dtype, void* stream);
 

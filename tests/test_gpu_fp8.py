@@ -127,6 +127,60 @@ def test_fp8_decode_step_vs_bf16(heads, kv, dim, B):
     assert torch.equal(again[1], base[1])
 
 
+class _W8A8Oracle(ref_cpu.OracleDecoder):
+    """The CPU restatement with the W8A8 arithmetic of the prefill path spelled out: per-row fp8 weights (dequantised), the
+    input of every decoder linear fake-quantised per token (scale = max|x| / 448), fp32 product, one bf16 rounding."""
+
+    def lin(self, x, name):
+        if not name.startswith("layers."):
+            return super().lin(x, name)
+        w = dequantize_rows_fp8(*quantize_rows_fp8(self.sd[name + ".weight"]))
+        xf = x.float()
+        sc = xf.abs().amax(dim=-1, keepdim=True).clamp_min(1e-12) / 448.0
+        xq = (xf / sc).clamp(-448, 448).to(torch.float8_e4m3fn).float() * sc
+        return F.linear(xq, w).to(x.dtype)
+
+
+@pytest.mark.parametrize("heads,kv,dim,B,T0,L", [(4, 4, 512, 4, 33, 1), (8, 2, 1024, 3, 150, 1), (4, 4, 512, 4, 33, 3)])
+def test_fp8_w8a8_prefill(heads, kv, dim, B, T0, L):
+    """quantize_decode_weights("fp8", prefill=True): the multi-token forward runs every decoder GEMM on fp8 operands.
+    (i) really quantised; (ii) explained by the W8A8 restatement of the oracle -- tightly for one block, and for three blocks
+    (where random N(0, 0.05) weights, a worst case for e4m3, make the logits sums of amplified rounding noise) better than by
+    the bf16 forward; (iii) the KV cache it leaves serves the following (weight-only fp8) decode steps; (iv) mode=None
+    restores bf16.  The exact statements are at kernel level: test_gemm_nt_fp8 / test_quantize_rows_fp8."""
+    args = plugin.ModelArgs(dim=dim, n_layers=L, n_heads=heads, n_kv_heads=kv, vocab_size=640, multiple_of=256, max_seq_len=256)
+    oargs = ref_cpu.OracleArgs(dim=dim, n_layers=L, n_heads=heads, n_kv_heads=kv, vocab_size=640, multiple_of=256, max_seq_len=256)
+    sd = ref_cpu.make_decoder_weights(oargs, seed=21, std=0.05)
+    m = plugin.Transformer(args)
+    m.load_state_dict(sd)
+    m.to(BF).to(DEV)
+    g = torch.Generator().manual_seed(4)
+    ex = torch.randint(3, 640, (B, T0 + 2), generator=g)
+    ex[:, 0] = 1
+    exd = ex.to(DEV)
+    base = m.forward_inference(exd[:, :T0], 0).float().clone()
+    m.quantize_decode_weights("fp8", prefill=True)
+    got = m.forward_inference(exd[:, :T0], 0).float().clone()
+    nxt = [m.forward_inference(exd[:, t:t + 1], t).float().clone() for t in range(T0, T0 + 2)]
+    def rms(a, b):
+        a, b = a.float().cpu(), b.float().cpu()
+        return float((a - b).norm() / b.norm())
+    # random N(0, 0.05) weights are a worst case for e4m3 (logits are sums of noise): stated as relative RMS error
+    e_bf = rms(got, base)
+    dec = _W8A8Oracle(oargs, {k: v.to(BF) for k, v in sd.items()})
+    want = dec.forward_inference(ex[:, :T0], 0).float()
+    e_or, e_or_bf = rms(got, want), rms(want, base)
+    print(f"w8a8 prefill: rms vs bf16 {e_bf:.4f}, vs W8A8 oracle {e_or:.4f} (oracle vs bf16 {e_or_bf:.4f})")
+    assert 0 < e_bf < 0.4, e_bf
+    assert e_or < 0.7 * e_bf and (L > 1 or e_or < 0.08), (e_or, e_bf)   # a bf16-level upstream difference flips ~6 % of the fp8 roundings
+    for i, t in enumerate(range(T0, T0 + 2)):          # decode continues on the cache the fp8 prefill wrote
+        w2 = dec.forward_inference(ex[:, t:t + 1], t).float()
+        e_d = rms(nxt[i], w2)
+        assert e_d < (0.12 if L == 1 else 0.25), (i, e_d)
+    m.quantize_decode_weights(None)
+    assert torch.equal(m.forward_inference(exd[:, :T0], 0).float(), base)
+
+
 # ------------------------------------------------------------------ W8A8 prefill: activation quantiser + MX-scaled fp8 GEMM
 def _deq(q, s):
     return q.cpu().view(torch.float8_e4m3fn).float() * s.cpu()[:, None]
