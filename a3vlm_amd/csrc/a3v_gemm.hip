@@ -444,26 +444,26 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_pp_kernel(GemmArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
 
-  const int nwg = gridDim.x;
-  int bid = blockIdx.x;
-  {
-    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  const int per_group = GROUP_M * p.tiles_n;
-  const int group = bid / per_group;
-  const int first_m = group * GROUP_M;
-  const int gsz = min(p.tiles_m - first_m, GROUP_M);
-  const int in_g = bid - group * per_group;
-  const int tm = first_m + in_g % gsz;
-  const int tn = in_g / gsz;
-  const int m0 = tm * TBM, n0 = tn * TBN;
-
+  // Persistent over tiles: block b takes tiles b, b + gridDim.x, ... of the XCD-aware order below (gridDim.x is a multiple of 8,
+  // so a block's tiles all map to its own XCD).  The next tile's first two k-stages are issued BEFORE this tile's epilogue:
+  // the store burst of a tile round (every CU writes its 128 KiB at once) drains while the next operands are already in flight,
+  // and there is no workgroup launch between tiles.
+  const int ntiles = p.tiles_m * p.tiles_n;
+  auto tile_of = [&](int vb, int& tm0, int& tn0) {
+    const int xcd = vb & 7, q = ntiles >> 3, r = ntiles & 7;
+    const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
+    const int per_group = GROUP_M * p.tiles_n;
+    const int group = bid / per_group;
+    const int first_m = group * GROUP_M;
+    const int gsz = min(p.tiles_m - first_m, GROUP_M);
+    const int in_g = bid - group * per_group;
+    tm0 = (first_m + in_g % gsz) * TBM;
+    tn0 = (in_g / gsz) * TBN;
+  };
+  int m0, n0, sm0, sn0;     // tile being computed / tile being staged
+  tile_of(blockIdx.x, m0, n0);
+  sm0 = m0; sn0 = n0;
   f32x4 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = p.K / BK;
   // LDS-DMA through buffer descriptors: rows past M / N are out of range and read as zero (no
@@ -486,10 +486,10 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_pp_kernel(GemmArgs p) {
     if (c < 4) {
       // (row-chunk + k) offset is wave-uniform and changes with t: an SGPR sum added per piece, so
       // nothing per-piece stays live in VGPRs across the loop
-      const unsigned so = (unsigned)(((int64_t)(m0 + ch * 8) * p.lda + t * BK) * 2);
+      const unsigned so = (unsigned)(((int64_t)(sm0 + ch * 8) * p.lda + t * BK) * 2);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)dst, 16, voA[c & 1] + so, 0, 0, 0);
     } else {
-      const unsigned so = (unsigned)(((int64_t)(n0 + ch * 8) * p.ldw + t * BK) * 2);
+      const unsigned so = (unsigned)(((int64_t)(sn0 + ch * 8) * p.ldw + t * BK) * 2);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)dst, 16, voW[c & 1] + so, 0, 0, 0);
     }
   };
@@ -499,8 +499,6 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_pp_kernel(GemmArgs p) {
   };
   stage(0);
   if (nk > 1) stage(1);
-  A3V_WAIT_VM0();
-  A3V_BARRIER();
 
   const int frow = lane & 15, fsw = (lane >> 1) & 7, fks = lane >> 4;
   const int off0 = ((0 * 4 + fks) ^ fsw) << 4, off1 = ((1 * 4 + fks) ^ fsw) << 4;
@@ -539,6 +537,13 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_pp_kernel(GemmArgs p) {
   unsigned long long* stamps = (DBG == 4 && blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0)
                                    ? (unsigned long long*)p.bias + (wave ? 1 : 0) * 64 * 8 : nullptr;
 #define PP_STAMP(t, k) do { if (DBG == 4 && stamps && (t) < 64) stamps[(t) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+  for (int vb = blockIdx.x;;) {
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  A3V_WAIT_VM0();
+  A3V_BARRIER();
   if constexpr (SCHED == 1) {
     // Schedule 1: both groups issue the DMA of tile t+1 in their own LOAD interval (the MFMA intervals
     // carry no VMEM issue) and wait for it at the end of that interval.  That only works if the DMA
@@ -636,10 +641,24 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_pp_kernel(GemmArgs p) {
       PP_STAMP(t, 5);
     }
   }
+  // every read of both stage buffers is behind the last barrier: stage the next tile now, store this one after
+  const int nb = vb + (int)gridDim.x;
+  if (nb < ntiles) {
+    tile_of(nb, sm0, sn0);
+    stage(0);
+    if (nk > 1) stage(1);
+  }
+  {
+    int lane_e = lane;                       // opaque copy: keeps the epilogue's per-lane address arithmetic from being hoisted
+    asm volatile("" : "+v"(lane_e));         // out of the tile loop (and held in VGPRs across the k-loop)
+    gemm_epilogue<TM, TN>(acc, p, m0 + wr * WTM, n0 + wc * WTN, lane_e);
+  }
+  if (nb >= ntiles) break;
+  vb = nb; m0 = sm0; n0 = sn0;
+  }
 #undef PP_STAMP
 #undef PP_READ_FRAGS
 #undef PP_MFMA_ALL
-  gemm_epilogue<TM, TN>(acc, p, m0 + wr * WTM, n0 + wc * WTN, lane);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1639,6 +1658,21 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
 }
 }  // namespace
 
+static int cu_count() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v & ~7;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+static bool pp_persistent() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("A3V_GEMM_PERSISTENT"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v != 0;
+}
+
 static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
                         int M, int N, int K, const void* bias, const void* residual, int64_t ldr,
                         int epilogue, int dtype, void* stream, const RopeKvArgs* rk) {
@@ -1681,7 +1715,9 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
       return;
     }
     q.tiles_m = (q.M + 255) / 256; q.tiles_n = (q.N + 255) / 256;
-    const dim3 g(q.tiles_m * q.tiles_n), b(512);
+    const int nt = q.tiles_m * q.tiles_n;
+    // the ping-pong kernel is persistent: one block per CU walks its tiles (A3V_GEMM_PERSISTENT=0: one block per tile, for A/B runs)
+    const dim3 g(cfg == 257 && pp_persistent() ? std::min(nt, cu_count()) : nt), b(512);
     if (cfg == 256) hipLaunchKernelGGL((gemm_nt_bf16_kernel<256, 256, 2, 4>), g, b, 0, st, q);
     else if (cfg == 258) hipLaunchKernelGGL(gemm_nt_bf16_pp32_kernel<0>, g, b, 0, st, q);
     else {
