@@ -12,6 +12,8 @@ an all-reduce of a layer's gradient range while earlier layers are still back-pr
 """
 from __future__ import annotations
 
+import os
+
 from typing import Callable, Dict, List, Optional, Tuple
 
 import torch
@@ -24,8 +26,9 @@ def _pad64(n: int) -> int:
 
 
 class TrainEngine:
-    fuse_qkv_rope = True      # qkv GEMM with the RoPE / cache-write epilogue (False: separate kernels; A/B and test hook)
-    tn_wgrad = True           # weight gradients by a3v_gemm_tn (False: transposes + NT kernel; A/B and test hook)
+    # A/B and test hooks (environment A3V_FUSE_QKV_ROPE=0 / A3V_TN_WGRAD=0 flips the default for a whole process)
+    fuse_qkv_rope = os.environ.get("A3V_FUSE_QKV_ROPE", "1") != "0"   # qkv GEMM with the RoPE / cache-write epilogue
+    tn_wgrad = os.environ.get("A3V_TN_WGRAD", "1") != "0"              # weight gradients by a3v_gemm_tn (else transposes + NT)
 
     def __init__(self, model, compute_dtype: torch.dtype = torch.bfloat16, recompute: Optional[bool] = None):
         """``recompute``: True = keep only each block's input and re-run the block in backward (the reference's

@@ -173,7 +173,10 @@ def train_leg(m, args, B, T, image, tokens, steps, dist, dev):
     for n, p in m.named_parameters():
         p.requires_grad = not n.startswith("clip.")
     m._ws.clear(); m._packed.clear(); m._packed_version = None; m._destroy_kv_cache()
+    import gc
+    gc.collect()
     torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
     promote_trainable_params_to_fp32(m)
     eng = TrainEngine(m, torch.bfloat16)
     params = [p for p in m.parameters() if p.requires_grad]
@@ -219,6 +222,7 @@ def lora_leg(m, args, B, T, image, tokens, steps, dist, dev, rank=16):
     from a3vlm_amd.train import TrainEngine
     from a3vlm_amd.util import promote_trainable_params_to_fp32
     from a3vlm_amd.dp import GradReducer
+    torch.cuda.reset_peak_memory_stats()
     pargs = peft.ModelArgs(**dataclasses.asdict(args), lora_rank=rank)
     with torch.device("meta"):
         pm = peft.Transformer(pargs, with_visual=True)
@@ -276,7 +280,9 @@ def lora_leg(m, args, B, T, image, tokens, steps, dist, dev, rank=16):
     # restore the shared parameters' state for the legs that follow
     for n, p in m.named_parameters():
         p.grad = None
-    del eng, opt, red, pm
+    del eng, opt, red, pm, one
+    import gc
+    gc.collect()                        # the engine holds lazy weight-image objects that point back at it: a cycle, not a leak
     torch.cuda.empty_cache()
     return el / steps, float(loss), mem, n_train
 
