@@ -700,7 +700,10 @@ __global__ __launch_bounds__(512) void gemm_nt_fp8_pp_kernel(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = p.K / KT;
+  // split-K (gridDim.y slices -> raw fp32 planes, the tail rows of the hybrid dispatch): this block's k-tile range [kt0, nk)
+  const int nk_all = p.K / KT;
+  const int kt0 = (int)((int64_t)nk_all * blockIdx.y / gridDim.y), nk = (int)((int64_t)nk_all * (blockIdx.y + 1) / gridDim.y);
+  if (gridDim.y > 1) p.C = reinterpret_cast<char*>(p.C) + (int64_t)blockIdx.y * p.c_split;
   const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)((int64_t)(p.M - 1) * p.lda + p.K), 0x00020000);
   const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)((int64_t)(p.N - 1) * p.ldw + p.K), 0x00020000);
   const unsigned lr = lane >> 3;
@@ -725,8 +728,8 @@ __global__ __launch_bounds__(512) void gemm_nt_fp8_pp_kernel(GemmArgs p) {
       }
     }
   };
-  stage(0);
-  if (nk > 1) stage(1);
+  stage(kt0);
+  if (nk > kt0 + 1) stage(kt0 + 1);
   A3V_WAIT_VM0();
   A3V_BARRIER();
 
@@ -758,9 +761,9 @@ __global__ __launch_bounds__(512) void gemm_nt_fp8_pp_kernel(GemmArgs p) {
     __builtin_amdgcn_s_setprio(0);                                                                   \
   } while (0)
   if (wr == 0) {
-    for (int t = 0; t < nk; ++t) {
+    for (int t = kt0; t < nk; ++t) {
       F8_READ_FRAGS(lds + (t & 1) * STAGE);
-      if (t >= 1 && t + 1 < nk) stage(t + 1);
+      if (t >= kt0 + 1 && t + 1 < nk) stage(t + 1);
       A3V_WAIT_LGKM0();
       A3V_BARRIER();
       F8_MFMA_ALL();
@@ -770,7 +773,7 @@ __global__ __launch_bounds__(512) void gemm_nt_fp8_pp_kernel(GemmArgs p) {
     A3V_BARRIER();
   } else {
     A3V_BARRIER();
-    for (int t = 0; t < nk; ++t) {
+    for (int t = kt0; t < nk; ++t) {
       F8_READ_FRAGS(lds + (t & 1) * STAGE);
       A3V_WAIT_LGKM0();
       A3V_WAIT_VM0();
@@ -2061,8 +2064,46 @@ static int gemm_nt_fp8_impl(const void* Aq, int64_t lda, const float* sa, const 
   p.M = M; p.N = N; p.K = K; p.epi = epilogue | GEMM_EPI_SCALE; p.dbg = 0;
   p.sa = sa; p.sw = sw;
   if (rk) { p.rk = *rk; p.epi |= GEMM_EPI_ROPEKV; }
-  p.tiles_m = (M + 255) / 256; p.tiles_n = (N + 255) / 256;
-  hipLaunchKernelGGL(gemm_nt_fp8_pp_kernel, dim3(p.tiles_m * p.tiles_n), dim3(512), 0, (hipStream_t)stream, p);
+  p.tiles_n = (N + 255) / 256;
+  hipStream_t st = (hipStream_t)stream;
+  // Tile rounds: tiles_m x tiles_n blocks over the CUs.  When the last round would be mostly empty (e.g. 35 x 16 = 560 tiles on 256
+  // CUs: a third round at 19 %), the tile rows that fill whole rounds run as usual and the remaining rows (< one round of tiles)
+  // are split over K into raw fp32 planes -- S times the blocks at 1/S the length -- which a reduce pass rounds and stores with
+  // the residual forms of the epilogue (needs the registered workspace of a3v_gemm_set_workspace; otherwise one plain launch).
+  const int ncu = cu_count();
+  const int tm_all = (M + 255) / 256;
+  const long total = (long)tm_all * p.tiles_n;
+  const int simple = A3V_EPI_RESIDUAL | A3V_EPI_RES_F32 | A3V_EPI_OUT_F32;
+  const long mt_h = (total / ncu) * ncu / p.tiles_n;                 // tile rows that make whole rounds
+  const long rem_tiles = total - mt_h * p.tiles_n;
+  int S = 1;
+  while (rem_tiles * S * 2 <= ncu && S < 8 && (K / 128) >= 8 * S) S *= 2;   // measured on wo / w2 of 7B: S = 2 (96 blocks) beats 4 and 8
+  const int m_big = (int)(mt_h * 256);
+  if (!rk && !(epilogue & ~simple) && mt_h >= 1 && m_big < M && S > 1 && rem_tiles * 4 < 3 * ncu && g_gemm_ws &&
+      (int64_t)S * (M - m_big) * N * 4 <= g_gemm_ws_bytes) {
+    GemmArgs q = p;
+    q.M = m_big; q.tiles_m = (int)mt_h;
+    hipLaunchKernelGGL(gemm_nt_fp8_pp_kernel, dim3(q.tiles_m * q.tiles_n), dim3(512), 0, st, q);
+    GemmArgs t = p;
+    t.M = M - m_big;
+    t.A = (const bf16_t*)((const char*)Aq + (int64_t)m_big * lda);
+    t.sa = sa + m_big;
+    t.C = g_gemm_ws; t.ldc = N; t.res = nullptr; t.bias = nullptr;
+    t.epi = A3V_EPI_OUT_F32 | GEMM_EPI_RAW | GEMM_EPI_SCALE;
+    t.tiles_m = (t.M + 255) / 256;
+    t.c_split = (int64_t)t.M * N * 4;
+    hipLaunchKernelGGL(gemm_nt_fp8_pp_kernel, dim3(t.tiles_m * t.tiles_n, S), dim3(512), 0, st, t);
+    const int esz = (epilogue & (A3V_EPI_OUT_F32 | A3V_EPI_RES_F32)) ? 4 : 2;
+    void* Ct = (char*)C + (int64_t)m_big * ldc * esz;
+    const void* Rt = residual ? (const char*)residual + (int64_t)m_big * ldr * ((epilogue & A3V_EPI_RES_F32) ? 4 : 2) : nullptr;
+    const int64_t n4 = (int64_t)t.M * (N / 4);
+    const int rb = (int)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256);
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(rb), dim3(256), 0, st, g_gemm_ws, S, (int64_t)t.M * N, t.M, N, Ct, ldc, Rt, ldr, epilogue);
+    A3V_LAUNCH_CHECK();
+    return A3V_OK;
+  }
+  p.tiles_m = tm_all;
+  hipLaunchKernelGGL(gemm_nt_fp8_pp_kernel, dim3(p.tiles_m * p.tiles_n), dim3(512), 0, st, p);
   A3V_LAUNCH_CHECK();
   return A3V_OK;
 }

@@ -153,6 +153,7 @@ def gemm_nt_fp8(aq, sa, wq, sw, out, *, bias=None, residual=None, epilogue: int 
     M, K = aq.shape
     N = wq.shape[0]
     assert aq.dtype == torch.uint8 and wq.dtype == torch.uint8 and wq.shape[1] == K
+    _ensure_gemm_workspace(aq.device)
     ep = epilogue
     if bias is not None:
         ep |= EPI_BIAS

@@ -252,3 +252,31 @@ def test_gemm_nt_fp8(M, N, K, epi):
         wb = rt(want).view(M, N // 32, 2, 16)
         gate, up = wb[:, :, 0].reshape(M, N // 2), wb[:, :, 1].reshape(M, N // 2)
         assert_close(out, rt(torch.nn.functional.silu(gate)) * up, what="fp8 swiglu", rtol=2 ** -6, atol=tol["atol"])
+
+
+@pytest.mark.parametrize("M,N,K,mode", [(4452, 4096, 2048, "residual"), (4452, 4096, 4096, "f32"), (8728, 4096, 1024, "plain")])
+def test_gemm_nt_fp8_split_tail(M, N, K, mode):
+    """18 x 16 (35 x 16) tiles on 256 CUs: the tile rows that fill whole rounds run as one launch, the remaining rows as split-K
+    planes + the reduce epilogue -- same values as the un-split kernel up to fp32 summation order before the bf16 rounding.
+    Reference: fp32 torch matmul of the dequantised operands on the device (exact products)."""
+    from a3vlm_amd.quant import quantize_rows_fp8 as qhost
+    a, w = gen(M, K, seed=81), gen(N, K, seed=82, scale=0.05)
+    aq, sa = qhost(a)
+    wq, sw = qhost(w)
+    aqd, sad, wqd, swd = aq.to(DEV), sa.to(DEV), wq.to(DEV), sw.to(DEV)
+    want = ((aqd.view(torch.float8_e4m3fn).float() * sad[:, None]) @ (wqd.view(torch.float8_e4m3fn).float() * swd[:, None]).t()).cpu()
+    atol = 1e-3 * math.sqrt(K) * 0.05 + 1e-3 + 2 ** -8 * float(want.abs().max())
+    if mode == "plain":
+        out = torch.empty(M, N, dtype=BF, device=DEV)
+        ops.gemm_nt_fp8(aqd, sad, wqd, swd, out)
+        assert_close(out, want, rtol=2 ** -7, atol=atol, what="fp8 plain (rows in rounds + tail)")
+    elif mode == "residual":
+        res = rt(gen(M, N, seed=83))
+        out = res.to(BF).to(DEV)
+        ops.gemm_nt_fp8(aqd, sad, wqd, swd, out, residual=out)
+        assert_close(out, res + rt(want), rtol=2 ** -7, atol=atol, what="fp8 residual split tail")
+    else:
+        res = gen(M, N, seed=84)
+        out = res.to(DEV).clone()
+        ops.gemm_nt_fp8(aqd, sad, wqd, swd, out, residual=out, epilogue=ops.EPI_RES_F32)
+        assert_close(out.cpu() - res, want, rtol=2 ** -7, atol=atol, what="fp8 f32 residual split tail")
