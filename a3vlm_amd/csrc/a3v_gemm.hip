@@ -2077,7 +2077,7 @@ static int gemm_nt_fp8_impl(const void* Aq, int64_t lda, const float* sa, const 
   const long mt_h = (total / ncu) * ncu / p.tiles_n;                 // tile rows that make whole rounds
   const long rem_tiles = total - mt_h * p.tiles_n;
   int S = 1;
-  while (rem_tiles * S * 2 <= ncu && S < 8 && (K / 128) >= 8 * S) S *= 2;   // measured on wo / w2 of 7B: S = 2 (96 blocks) beats 4 and 8
+  while (rem_tiles * S * 2 <= ncu && S < 8 && (K / 128) >= 8 * S) S *= 2;   // measured on wo / w2 of 7B: S = 2 (96 blocks) beat S = 8 (384 blocks)
   const int m_big = (int)(mt_h * 256);
   if (!rk && !(epilogue & ~simple) && mt_h >= 1 && m_big < M && S > 1 && rem_tiles * 4 < 3 * ncu && g_gemm_ws &&
       (int64_t)S * (M - m_big) * N * 4 <= g_gemm_ws_bytes) {
