@@ -32,11 +32,6 @@ struct AttnArgs {
   float* lse;                   // optional [B,H,Sq] log-sum-exp of the scaled scores (training backward)
 };
 
-// one 16-B-per-lane LDS-DMA through a buffer descriptor: per-lane byte offset + wave-uniform byte offset (an SGPR)
-__device__ __forceinline__ void buf_dma16(__amdgpu_buffer_rsrc_t rs, char* lds_dst, unsigned voff, unsigned soff) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
-}
-
 template <int HD, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_prefill_bf16_kernel(AttnArgs p) {
   constexpr int KVB = 64;
@@ -161,11 +156,13 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_bf16_kernel(AttnArgs p) {
   auto dma_tile = [&](int kv0, char* Ks, char* Vs) {
     const unsigned ks_off = (unsigned)(kv0 * p.k_ss * 2), vs_off = (unsigned)(kv0 * 2);
 #pragma unroll
-    for (int i = 0; i < K_LOADS; ++i)
-      buf_dma16(rsK, Ks + (wave_u * 64 + i * 256) * 16, koff[i], ks_off);
+    for (int i = 0; i < K_LOADS; ++i) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (__attribute__((address_space(3))) void*)(Ks + (wave_u * 64 + i * 256) * 16), 16, koff[i], ks_off, 0, 0);
+    }
 #pragma unroll
-    for (int i = 0; i < V_LOADS; ++i)
-      buf_dma16(rsV, Vs + (wave_u * 64 + i * 256) * 16, voff[i], vs_off);
+    for (int i = 0; i < V_LOADS; ++i) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (__attribute__((address_space(3))) void*)(Vs + (wave_u * 64 + i * 256) * 16), 16, voff[i], vs_off, 0, 0);
+    }
   };
   auto full_tile = [&](int t) { return t * KVB + KVB <= p.Sk; };
 

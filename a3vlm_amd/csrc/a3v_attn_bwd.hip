@@ -97,13 +97,26 @@ __device__ __forceinline__ bf16x8 frag_cols(const char* lds, int db, int tb, int
 }
 
 // ------------------------------------------------------------------ dQ
+// 1-D grid -> (tile, head slot) with the XCD-aware order of attn_prefill_bf16_kernel: workgroup id & 7 is the XCD, and each XCD
+// takes a contiguous range of (head, tile) pairs so the K / V / Q / dO tiles a head's blocks share stay in one L2.
+__device__ __forceinline__ void xcd_head_tile(int nt, int& head_slot, int& t) {
+  const int total = gridDim.x, id = blockIdx.x;
+  const int xcd = id & 7, q = total >> 3, r = total & 7;
+  const int vb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  head_slot = vb / nt;
+  t = vb - head_slot * nt;
+}
+
 template <int HD>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs p) {
   constexpr int TILE = 64 * HD * 2;                 // bytes of one 64-row tile (== HD x 128 B)
   __shared__ __attribute__((aligned(16))) char lds[3 * TILE];
   char* Ks = lds; char* Vs = lds + TILE; char* Kts = lds + 2 * TILE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int qt = gridDim.x - 1 - blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int nqt = (p.S + 127) / 128;
+  int head_slot, ti;
+  xcd_head_tile(nqt, head_slot, ti);
+  const int qt = nqt - 1 - ti, b = head_slot / p.H, h = head_slot - b * p.H;     // heavy causal tiles first within a head
   const int hk = h / (p.H / p.Hkv);
   const int ql = lane & 31, hh = lane >> 5;
   const int qrow = qt * 128 + wave * 32 + ql;
@@ -207,7 +220,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs p) {
   float* lse_s = reinterpret_cast<float*>(lds + NT * TILE);      // [64]
   float* D_s = lse_s + 64;                                       // [64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int kt_ = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
+  int head_slot, kt_;
+  xcd_head_tile((p.S + 127) / 128, head_slot, kt_);
+  const int b = head_slot / p.Hkv, hk = head_slot - b * p.Hkv;
   const int nrep = p.H / p.Hkv;
   const int kl = lane & 31, hh = lane >> 5;
   const int kvrow = kt_ * 128 + wave * 32 + kl;
@@ -343,7 +358,7 @@ extern "C" int a3v_attention_bwd_mfma(const void* q, const void* k, int64_t k_sb
   p.k_sb = k_sb; p.k_sh = k_sh; p.v_sb = v_sb; p.v_ss = v_ss; p.v_sh = v_sh;
   p.B = B; p.S = S; p.Sp = Sp; p.H = H; p.Hkv = Hkv; p.causal = causal;
   p.scale = 1.0f / sqrtf((float)hd);
-  dim3 gq((S + 127) / 128, H, B), gk((S + 127) / 128, Hkv, B);
+  dim3 gq(((S + 127) / 128) * H * B), gk(((S + 127) / 128) * Hkv * B);
   if (hd == 128) {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, gq, dim3(256), 0, st, p);
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 0>), gk, dim3(256), 0, st, p);
