@@ -353,7 +353,7 @@ def pmc_traffic():
     """HBM-side bytes per launch of the dominant GEMM from the committed rocprofv3 PMC passes (counters cannot be read
     from inside the process); None when the summary is absent."""
     try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01e_pmc_traffic.json")) as f:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01i_pmc_traffic.json")) as f:
             d = json.load(f)
         return {"bytes_per_launch": d["traffic_bytes_per_launch"], "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
                 "shape": d["shape"], "source": d["source"]}
