@@ -800,6 +800,7 @@ __global__ __launch_bounds__(512) void gemm_nt_fp8_pp_kernel(GemmArgs p) {
 // a tile multiple: rows past K are out of the buffer descriptor's range and read as zero.
 // ------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(4))) short s16x4;
+template <bool A_ROWS>
 __global__ __launch_bounds__(512) void gemm_tn_bf16_pp_kernel(GemmArgs p) {
   constexpr int TBM = 256, TBN = 256, WTM = 128, WTN = 64, TM = 8, TN = 4;
   constexpr int STAGE = (TBM + TBN) * BK * 2;   // 64 KiB
@@ -836,7 +837,10 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_pp_kernel(GemmArgs p) {
   if (gridDim.y > 1) p.C = reinterpret_cast<char*>(p.C) + (int64_t)blockIdx.y * p.c_split;
   // waves whose 128 x 64 part of the tile lies outside C (adapter-sized M or N) keep the barriers but skip reads and MFMAs
   const bool active = (m0 + wr * WTM < p.M) && (n0 + wc * WTN < p.N);
-  const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)(((int64_t)(p.K - 1) * p.lda + p.M) * 2), 0x00020000);
+  // A_ROWS ("NN" form, C = A . Wt): A is [M][K] row-major and takes the NT kernel's staging (8-row chunks of 128-B rows, 16-B slot
+  // swizzle) and ds_read_b128 fragments; only Wt [K][N] goes through the transpose reads.  K % 64 == 0 there (host-checked).
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, A_ROWS ? (int)(((int64_t)(p.M - 1) * p.lda + p.K) * 2)
+                                                                           : (int)(((int64_t)(p.K - 1) * p.lda + p.M) * 2), 0x00020000);
   const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)(((int64_t)(p.K - 1) * p.ldw + p.N) * 2), 0x00020000);
   // piece c of this wave: DMA instruction q = wave*4 + c of the tile (k-rows 2q, 2q+1); lane -> row 2q + (lane>>5),
   // 16-B position lane&31 of the 512-B row, which holds source chunk ((pos>>1) ^ key(k)) * 32 B + (pos&1) * 16 B
@@ -847,11 +851,16 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_pp_kernel(GemmArgs p) {
     const unsigned col = (((((unsigned)lane & 31) >> 1) ^ (((kin >> 3) & 3) * 4 + (kin & 3))) << 5) + (lane & 1) * 16;
     voA[c] = (unsigned)(kin * p.lda * 2) + col;
     voW[c] = (unsigned)(kin * p.ldw * 2) + col;
+    if constexpr (A_ROWS) {   // row = lane/8 of the 8-row chunk, 16-B slot = (lane%8) ^ ((chunk*4 + lane/16) & 7); chunk parity = c & 1
+      const unsigned sl = (lane & 7) ^ (((c & 1) * 4 + (lane >> 4)) & 7);
+      voA[c] = (unsigned)(((lane >> 3) * p.lda + sl * 8) * 2);
+    }
   }
   auto stage_piece = [&](int t, int c) {
     char* dst = lds + (t & 1) * STAGE + (c >= 4 ? TBM * BK * 2 : 0) + (wave * 4 + (c & 3)) * 1024;
     if (c < 4) {
-      const unsigned so = (unsigned)(((int64_t)t * BK * p.lda + m0) * 2);
+      const unsigned so = A_ROWS ? (unsigned)(((int64_t)(m0 + (wave * 4 + c) * 8) * p.lda + t * BK) * 2)
+                                 : (unsigned)(((int64_t)t * BK * p.lda + m0) * 2);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)dst, 16, voA[c & 3] + so, 0, 0, 0);
     } else {
       const unsigned so = (unsigned)(((int64_t)t * BK * p.ldw + n0) * 2);
@@ -878,6 +887,8 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_pp_kernel(GemmArgs p) {
       kro[ks][jj] = k * 512 + (il & 3) * 8;
       kxo[ks][jj] = ((k >> 3) & 3) * 4 + (k & 3);
     }
+  const int off0 = ((0 * 4 + fg) ^ ((lane >> 1) & 7)) << 4, off1 = ((1 * 4 + fg) ^ ((lane >> 1) & 7)) << 4;   // A_ROWS fragment slots
+  const int a_base = (wr * WTM + il) * 128;
   bf16x8 af0[TM], af1[TM], wf0[TN], wf1[TN];
   auto tr8 = [&](const char* tile, int blk16, int ks) -> bf16x8 {
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(tile + kro[ks][0] + ((blk16 ^ kxo[ks][0]) << 5)));
@@ -896,8 +907,13 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_pp_kernel(GemmArgs p) {
       wf1[j] = tr8(Wt_, wc * 4 + j, 1);                                                              \
     }                                                                                                \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                 \
-      af0[i] = tr8(At_, wr * 8 + i, 0);                                                              \
-      af1[i] = tr8(At_, wr * 8 + i, 1);                                                              \
+      if constexpr (A_ROWS) {                                                                        \
+        af0[i] = *reinterpret_cast<const bf16x8*>(At_ + a_base + i * 2048 + off0);                   \
+        af1[i] = *reinterpret_cast<const bf16x8*>(At_ + a_base + i * 2048 + off1);                   \
+      } else {                                                                                       \
+        af0[i] = tr8(At_, wr * 8 + i, 0);                                                            \
+        af1[i] = tr8(At_, wr * 8 + i, 1);                                                            \
+      }                                                                                              \
     }                                                                                                \
   } while (0)
 #define TN_MFMA_ALL()                                                                                \
@@ -2022,7 +2038,7 @@ extern "C" int a3v_gemm_tn(const void* At, int64_t lda, const void* Wt, int64_t 
   p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr;
   p.M = M; p.N = N; p.K = K; p.epi = epilogue; p.dbg = 0;
   p.tiles_m = (M + 255) / 256; p.tiles_n = (N + 255) / 256;
-  hipLaunchKernelGGL(gemm_tn_bf16_pp_kernel, dim3(p.tiles_m * p.tiles_n), dim3(512), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(gemm_tn_bf16_pp_kernel<false>, dim3(p.tiles_m * p.tiles_n), dim3(512), 0, (hipStream_t)stream, p);
   A3V_LAUNCH_CHECK();
   return A3V_OK;
 }
@@ -2041,7 +2057,7 @@ extern "C" int a3v_gemm_tn_splitk(const void* At, int64_t lda, const void* Wt, i
   p.M = M; p.N = N; p.K = K; p.epi = A3V_EPI_OUT_F32 | GEMM_EPI_RAW; p.dbg = 0;
   p.tiles_m = (M + 255) / 256; p.tiles_n = (N + 255) / 256;
   p.c_split = (int64_t)M * N * 4;
-  hipLaunchKernelGGL(gemm_tn_bf16_pp_kernel, dim3(p.tiles_m * p.tiles_n, S), dim3(512), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(gemm_tn_bf16_pp_kernel<false>, dim3(p.tiles_m * p.tiles_n, S), dim3(512), 0, (hipStream_t)stream, p);
   A3V_LAUNCH_CHECK();
   return A3V_OK;
 }
@@ -2124,5 +2140,58 @@ extern "C" int a3v_gemm_qkv_rope_fp8(const void* Aq, int64_t lda, const float* s
   rk.ldq = ldq; rk.S = S; rk.H = H; rk.Hkv = Hkv; rk.hd_shift = hd == 128 ? 7 : 6; rk.Smax = Smax;
   rk.start_pos = start_pos; rk.rope_pos0 = rope_pos0; rk.m_off = 0;
   return gemm_nt_fp8_impl(Aq, lda, sa, Wq, ldw, sw, q_out, ldq, B * S, (H + 2 * Hkv) * hd, K, nullptr, nullptr, 0, 0, stream, &rk);
+}
+
+// "NN" GEMM: C[M,N] = epilogue(A . Wt) with A [M, K] row-major and Wt [K, N] row-major (the contracted index is Wt's ROW index) --
+// the input gradient dX = dY . W on the weight image the forward pass uses, without a transposed copy of W.  K % 64 == 0.
+// Tile rows that fill whole rounds of the CUs run as one launch; the remaining rows are split over K into fp32 planes + the
+// reduce epilogue when a workspace is registered (a3v_gemm_set_workspace), exactly as in a3v_gemm_nt / a3v_gemm_nt_fp8.
+extern "C" int a3v_gemm_nn(const void* A, int64_t lda, const void* Wt, int64_t ldw, void* C, int64_t ldc, int M, int N, int K,
+                           const void* residual, int64_t ldr, int epilogue, void* stream) {
+  if (!A || !Wt || !C || M <= 0 || N <= 0 || K <= 0) return A3V_ERR_ARG;
+  if (K % 64 || lda % 8 || ldw % 8 || N % 8 || ldc % 4) return A3V_ERR_SHAPE;
+  const int simple = A3V_EPI_RESIDUAL | A3V_EPI_RES_F32 | A3V_EPI_OUT_F32;
+  if (epilogue & ~simple) return A3V_ERR_ARG;
+  if ((epilogue & (A3V_EPI_RESIDUAL | A3V_EPI_RES_F32)) && (!residual || ldr % 4)) return A3V_ERR_ARG;
+  if (((int64_t)(M - 1) * lda + K) * 2 >= (1LL << 31) || ((int64_t)(K - 1) * ldw + N) * 2 >= (1LL << 31)) return A3V_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  GemmArgs p{};
+  p.A = (const bf16_t*)A; p.W = (const bf16_t*)Wt; p.C = C; p.bias = nullptr; p.res = residual;
+  p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr;
+  p.M = M; p.N = N; p.K = K; p.epi = epilogue; p.dbg = 0;
+  p.tiles_n = (N + 255) / 256;
+  const int ncu = cu_count();
+  const int tm_all = (M + 255) / 256;
+  const long total = (long)tm_all * p.tiles_n;
+  const long mt_h = (total / ncu) * ncu / p.tiles_n;
+  const long rem_tiles = total - mt_h * p.tiles_n;
+  int S = 1;
+  while (rem_tiles * S * 2 <= ncu && S < 8 && (K / 64) >= 16 * S) S *= 2;
+  const int m_big = (int)(mt_h * 256);
+  if (mt_h >= 1 && m_big < M && S > 1 && rem_tiles * 4 < 3 * ncu && g_gemm_ws && (int64_t)S * (M - m_big) * N * 4 <= g_gemm_ws_bytes) {
+    GemmArgs q = p;
+    q.M = m_big; q.tiles_m = (int)mt_h;
+    hipLaunchKernelGGL(gemm_tn_bf16_pp_kernel<true>, dim3(q.tiles_m * q.tiles_n), dim3(512), 0, st, q);
+    GemmArgs t = p;
+    t.M = M - m_big;
+    t.A = p.A + (int64_t)m_big * lda;
+    t.C = g_gemm_ws; t.ldc = N; t.res = nullptr;
+    t.epi = A3V_EPI_OUT_F32 | GEMM_EPI_RAW;
+    t.tiles_m = (t.M + 255) / 256;
+    t.c_split = (int64_t)t.M * N * 4;
+    hipLaunchKernelGGL(gemm_tn_bf16_pp_kernel<true>, dim3(t.tiles_m * t.tiles_n, S), dim3(512), 0, st, t);
+    const int esz = (epilogue & (A3V_EPI_OUT_F32 | A3V_EPI_RES_F32)) ? 4 : 2;
+    void* Ct = (char*)C + (int64_t)m_big * ldc * esz;
+    const void* Rt = residual ? (const char*)residual + (int64_t)m_big * ldr * ((epilogue & A3V_EPI_RES_F32) ? 4 : 2) : nullptr;
+    const int64_t n4 = (int64_t)t.M * (N / 4);
+    const int rb = (int)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256);
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(rb), dim3(256), 0, st, g_gemm_ws, S, (int64_t)t.M * N, t.M, N, Ct, ldc, Rt, ldr, epilogue);
+    A3V_LAUNCH_CHECK();
+    return A3V_OK;
+  }
+  p.tiles_m = tm_all;
+  hipLaunchKernelGGL(gemm_tn_bf16_pp_kernel<true>, dim3(p.tiles_m * p.tiles_n), dim3(512), 0, st, p);
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
 }
 

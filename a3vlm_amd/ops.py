@@ -96,6 +96,22 @@ def gemm_nt_splitk(a, w, out, scratch, S: int, accumulate: bool = False):
     return out
 
 
+def gemm_nn(a, wt, out, *, residual=None, epilogue: int = 0):
+    """out[M, N] = epilogue(a[M, K] @ wt[K, N]) -- wt row-indexed by the contracted index (dX = dY @ W on the forward image)."""
+    _dev(a, wt, out, residual)
+    M, K = a.shape
+    N = wt.shape[1]
+    assert wt.shape[0] == K and a.stride(1) == 1 and wt.stride(1) == 1 and out.stride(1) == 1
+    _ensure_gemm_workspace(a.device)
+    ep = epilogue
+    if residual is not None and not (ep & EPI_RES_F32):
+        ep |= EPI_RESIDUAL
+    rc = _l.load().a3v_gemm_nn(_p(a), a.stride(0), _p(wt), wt.stride(0), _p(out), out.stride(0), M, N, K,
+                               _p(residual), residual.stride(0) if residual is not None else 0, ep, _stream())
+    _l.check(rc, f"a3v_gemm_nn(M={M},N={N},K={K},epi={ep})")
+    return out
+
+
 def gemm_tn_splitk(at, wt, out, scratch, S: int, accumulate: bool = False):
     """out[M, N] (+)= at[K, M]^T @ wt[K, N] through S split-K planes of the TN kernel (adapter-sized M or N, long K)."""
     _dev(at, wt, out, scratch)

@@ -26,9 +26,10 @@ def _pad64(n: int) -> int:
 
 
 class TrainEngine:
-    # A/B and test hooks (environment A3V_FUSE_QKV_ROPE=0 / A3V_TN_WGRAD=0 flips the default for a whole process)
+    # A/B and test hooks (environment A3V_FUSE_QKV_ROPE=0 / A3V_TN_WGRAD=0 / A3V_NN_DGRAD=0 flips the default for a whole process)
     fuse_qkv_rope = os.environ.get("A3V_FUSE_QKV_ROPE", "1") != "0"   # qkv GEMM with the RoPE / cache-write epilogue
     tn_wgrad = os.environ.get("A3V_TN_WGRAD", "1") != "0"              # weight gradients by a3v_gemm_tn (else transposes + NT)
+    nn_dgrad = os.environ.get("A3V_NN_DGRAD", "1") != "0"              # input gradients by a3v_gemm_nn (else NT on W^T images)
 
     def __init__(self, model, compute_dtype: torch.dtype = torch.bfloat16, recompute: Optional[bool] = None):
         """``recompute``: True = keep only each block's input and re-run the block in backward (the reference's
@@ -223,6 +224,19 @@ class TrainEngine:
             return
         ops.gemm_nt_splitk(a, w, out, self._buf("splitk", (S * M * N,), torch.float32), S, accumulate)
 
+    def _dgrad_w(self, dy: torch.Tensor, key: str, out: torch.Tensor):
+        """out[M,K] = dy[M,N] @ W[N,K] for the weight image ``key``: the NN kernel on the forward image itself (the transposed
+        image ``key.t`` is then never built: no per-step transpose of the updated weights, no second copy in HBM); falls back
+        to the NT kernel on the transposed image for shapes / dtypes the NN kernel does not take."""
+        im = self._images()
+        M, N = dy.shape
+        if self.nn_dgrad and self.act == torch.bfloat16 and N % 64 == 0 and dy.stride(0) % 8 == 0:
+            w = im[key]
+            if w.shape[0] == N and w.shape[1] % 8 == 0 and w.shape[1] >= 256 and 2 * M * dy.stride(0) < 2 ** 31 and 2 * w.numel() < 2 ** 31:
+                ops.gemm_nn(dy, w, out)
+                return
+        self._dgrad(dy, im[key + ".t"], out)
+
     def _dgrad(self, dy: torch.Tensor, wt: torch.Tensor, out: torch.Tensor):
         """out[M,K] = dy[M,N] @ W[N,K] with wt = W^T [K, Np]; dy may have N < Np columns -> padded copy."""
         M, N = dy.shape
@@ -373,7 +387,7 @@ class TrainEngine:
         if self._has(pre + "feed_forward.w2.weight"):
             self._wgrad(dha, k["act"], self._views[pre + "feed_forward.w2.weight"], "w2", (pre + "feed_forward.w2.weight",))
         dact = self._buf("dact", (rows, F))
-        self._dgrad(dha, im[f"w2.{i}.t"], dact)
+        self._dgrad_w(dha, f"w2.{i}", dact)
         if self.lora:
             self._lora_bwd(i, f"w2.{i}", dha, k["act"], lt["w2"], dact)
         dgu = self._buf("dgu", (rows, 2 * F))
@@ -382,7 +396,7 @@ class TrainEngine:
             self._wgrad(dgu, k["xn2"], self._gview(pre + "feed_forward.w1.weight", pre + "feed_forward.w3.weight"), "w13",
                         (pre + "feed_forward.w1.weight", pre + "feed_forward.w3.weight"))
         dxn = self._buf("dxn", (rows, dim))
-        self._dgrad(dgu, im[f"w13.{i}.t"], dxn)
+        self._dgrad_w(dgu, f"w13.{i}", dxn)
         if self.lora:
             self._lora_bwd(i, f"w13.{i}", dgu, k["xn2"], lt["w13"], dxn)
         ops.rmsnorm_bwd(k["h_mid"], l.ffn_norm.weight, dxn, dh, self._views.get(pre + "ffn_norm.weight"), a.norm_eps)
@@ -391,7 +405,7 @@ class TrainEngine:
         if self._has(pre + "attention.wo.weight"):
             self._wgrad(dha, k["att"], self._views[pre + "attention.wo.weight"], "wo", (pre + "attention.wo.weight",))
         datt = self._buf("datt", (rows, H * hd))
-        self._dgrad(dha, im[f"wo.{i}.t"], datt)
+        self._dgrad_w(dha, f"wo.{i}", datt)
         if self.lora:
             self._lora_bwd(i, f"wo.{i}", dha, k["att"], lt["wo"], datt)
         dq = self._buf("dq", (rows, H * hd))
@@ -412,7 +426,7 @@ class TrainEngine:
         if self._has(pre + "attention.wq.weight", pre + "attention.wk.weight", pre + "attention.wv.weight"):
             self._wgrad(dqkv, k["xn"], self._gview(pre + "attention.wq.weight", pre + "attention.wv.weight"), "qkv",
                         (pre + "attention.wq.weight", pre + "attention.wk.weight", pre + "attention.wv.weight"))
-        self._dgrad(dqkv, im[f"qkv.{i}.t"], dxn)
+        self._dgrad_w(dqkv, f"qkv.{i}", dxn)
         if self.lora:
             self._lora_bwd(i, f"qkv.{i}", dqkv, k["xn"], lt["qkv"], dxn)
         ops.rmsnorm_bwd(h_in, l.attention_norm.weight, dxn, dh, self._views.get(pre + "attention_norm.weight"), a.norm_eps)
@@ -483,7 +497,7 @@ class TrainEngine:
         if self._has("output.weight"):
             self._wgrad(dlog, s["xt"], self._views["output.weight"], "out", ("output.weight",))
         dxt = self._buf("dxn_text", (B * T, dim))
-        self._dgrad(dlog, im["out.t"], dxt)
+        self._dgrad_w(dlog, "out", dxt)
         dh = self._buf("dh", (rows, dim), torch.float32, zero=True)
         hv, dhv = s["h"].view(B, S, dim), dh.view(B, S, dim)
         for b in range(B):
@@ -558,28 +572,34 @@ class _Images:
         self.eng = eng
         self.store: Dict[str, torch.Tensor] = {}
         self.ver: Dict[str, tuple] = {}
+        self.tver: Dict[str, tuple] = {}      # version of each transposed image (built lazily, per key)
 
     def _group(self, key: str):
         if key.startswith(("qkv.", "wo.", "w13.", "w2.")):
             return "L" + key.split(".")[1]
         return "vp" if key.startswith("vp") else "out"
 
-    def _both(self, key, w):      # W [N,K] and W^T [K, N] (N padded to 64 for the dgrad GEMM's K dim)
-        act = self.eng.act
-        wa = w.to(act).contiguous()
-        N, K = wa.shape
-        Np = _pad64(N)
-        if Np != N:
-            wp = torch.zeros(Np, K, dtype=act, device=wa.device)
-            wp[:N] = wa
-        else:
-            wp = wa
-        self.store[key] = wa
-        wt = self.store.get(key + ".t")
-        if wt is None or wt.shape != (K, Np) or wt.dtype != act:
-            wt = torch.empty(K, Np, dtype=act, device=wa.device)
-        ops.transpose(wp, wt, Np, K, Np)
-        self.store[key + ".t"] = wt
+    def _both(self, key, w):      # forward image W [N,K] now; W^T [K, N padded to 64] only when somebody asks for key + ".t"
+        self.store[key] = w.to(self.eng.act).contiguous()
+
+    def _transposed(self, key: str, ver) -> torch.Tensor:
+        if self.tver.get(key) != ver:
+            act = self.eng.act
+            wa = self.store[key[:-2]]
+            N, K = wa.shape
+            Np = _pad64(N)
+            if Np != N:
+                wp = torch.zeros(Np, K, dtype=act, device=wa.device)
+                wp[:N] = wa
+            else:
+                wp = wa
+            wt = self.store.get(key)
+            if wt is None or wt.shape != (K, Np) or wt.dtype != act:
+                wt = torch.empty(K, Np, dtype=act, device=wa.device)
+            ops.transpose(wp, wt, Np, K, Np)
+            self.store[key] = wt
+            self.tver[key] = ver
+        return self.store[key]
 
     def __getitem__(self, key: str) -> torch.Tensor:
         eng, m = self.eng, self.eng.m
@@ -608,6 +628,8 @@ class _Images:
                     self._both("vp", ps[0])
                     self.store["vp.b"] = ps[1].to(eng.act)
             self.ver[g] = ver
+        if key.endswith(".t"):
+            return self._transposed(key, ver)
         return self.store[key]
 
 

@@ -102,6 +102,12 @@ int a3v_quantize_rows_fp8(const void* x, int64_t ldx, const void* norm_w, float 
 int a3v_gemm_tn(const void* At, int64_t lda, const void* Wt, int64_t ldw, void* C, int64_t ldc, int M, int N,
                 int K, const void* residual, int64_t ldr, int epilogue, void* stream);
 
+/* "NN" GEMM: C[M,N] = epilogue(A . Wt), A [M, K] and Wt [K, N] both row-major (the contracted index is Wt's ROW index): the
+ * input gradient dX = dY . W of F.linear (autograd of LLM/llama_ens5.py:112,169,214-217) on the weight image the forward pass
+ * uses -- no transposed copy of W.  K % 64 == 0, N % 8 == 0; epilogues NONE / RESIDUAL / RES_F32 / OUT_F32. */
+int a3v_gemm_nn(const void* A, int64_t lda, const void* Wt, int64_t ldw, void* C, int64_t ldc, int M, int N, int K,
+                const void* residual, int64_t ldr, int epilogue, void* stream);
+
 /* Split-K form of a3v_gemm_tn for adapter-sized outputs (the LoRA weight gradients, model/peft.py:40-64 under autograd):
  * partial [S][M][N] raw fp32 planes, to be summed by a3v_splitk_reduce. */
 int a3v_gemm_tn_splitk(const void* At, int64_t lda, const void* Wt, int64_t ldw, float* partial, int M, int N, int K,

@@ -554,3 +554,39 @@ def test_gemm_tn_splitk(M, N, K, S):
     of2 = torch.empty_like(of)
     ops.gemm_tn_splitk(atd, wtd, of2, scratch, S)
     assert torch.equal(of, of2)
+
+
+@pytest.mark.parametrize("M,N,K,mode", [(300, 520, 256, "plain"), (512, 256, 64, "plain"), (1091, 1024, 1280, "residual"),
+                                        (8728, 4096, 2048, "plain"), (4452, 4096, 4096, "f32res"), (264, 264, 192, "f32")])
+def test_gemm_nn(M, N, K, mode):
+    """C = A @ Wt with Wt row-indexed by the contracted index (input gradients on the forward weight image): row-major A through
+    the NT staging, Wt through the transpose reads; equal to the NT kernel on the materialised W^T; the 35 x 16- and 18 x 16-tile
+    cases take the rows-in-rounds + split-K-tail dispatch."""
+    a = rt(gen(M, K, seed=91)).to(BF).to(DEV)
+    wt = rt(gen(K, N + 8, seed=92, scale=0.05)).to(BF).to(DEV)[:, :N]
+    want = (a.float() @ wt.float()).cpu()
+    atol = 2e-3 * math.sqrt(K) * 0.05 + 1e-3 + 2 ** -8 * float(want.abs().max())
+    if mode == "plain":
+        out = torch.empty(M, N, dtype=BF, device=DEV)
+        ops.gemm_nn(a, wt, out)
+        assert_close(out, want, rtol=2 ** -7, atol=atol, what="nn plain")
+        ref = torch.empty_like(out)
+        ops.gemm_nt(a, wt.t().contiguous(), ref)
+        assert float((out.float() - ref.float()).abs().max()) <= 2 ** -7 * float(want.abs().max())
+        out2 = torch.empty_like(out)
+        ops.gemm_nn(a, wt, out2)
+        assert torch.equal(out, out2)
+    elif mode == "residual":
+        res = rt(gen(M, N, seed=93))
+        out = res.to(BF).to(DEV)
+        ops.gemm_nn(a, wt, out, residual=out)
+        assert_close(out, res + rt(want), rtol=2 ** -7, atol=atol, what="nn residual")
+    elif mode == "f32":
+        out = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+        ops.gemm_nn(a, wt, out, epilogue=ops.EPI_OUT_F32)
+        assert_close(out, want, rtol=2 ** -7, atol=atol, what="nn f32")
+    else:
+        res = gen(M, N, seed=94)
+        out = res.to(DEV).clone()
+        ops.gemm_nn(a, wt, out, residual=out, epilogue=ops.EPI_RES_F32)
+        assert_close(out.cpu() - res, want, rtol=2 ** -7, atol=atol, what="nn f32 residual")

@@ -305,7 +305,7 @@ def test_train_step_bf16_tn_weight_gradients():
         m.to(BF).to(DEV)
         promote_trainable_params_to_fp32(m)
         eng = TrainEngine(m, BF)
-        eng.tn_wgrad = eng.fuse_qkv_rope = tn      # also: fused qkv / RoPE / cache epilogue vs the separate kernels
+        eng.tn_wgrad = eng.fuse_qkv_rope = eng.nn_dgrad = tn      # also: fused qkv / RoPE / cache epilogue, NN input gradients
         for scale in (1.0, 0.5):
             eng.forward_loss(ex.to(DEV), lab.to(DEV), None)
             eng.backward(scale)
