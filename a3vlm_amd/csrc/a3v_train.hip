@@ -710,3 +710,68 @@ extern "C" int a3v_rows_sum(const void* src, int64_t ld, const int32_t* row_idx,
   A3V_LAUNCH_CHECK();
   return A3V_OK;
 }
+
+// ------------------------------------------------------------------ AdamW (decoupled weight decay), one parameter tensor per launch
+// torch.optim.AdamW's update (main_finetune.py:138 builds the reference optimizer with betas (0.9, 0.95)):
+//   p *= 1 - lr*wd;  m += (1-b1)(g - m);  v = b2 v + (1-b2) g^2;  p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+// fp32 state, 28 B of HBM traffic per parameter: four 16-B loads and three 16-B stores per lane per iteration, every line touched
+// once.  Optionally also writes the bf16 image of the updated parameter (the GEMM operand of the next step).
+namespace {
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, int64_t n4, int64_t n, float decay, float b1, float b2,
+                                                    float step_size, float inv_bc2_sqrt, float eps, bf16_t* __restrict__ img) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    f32x4 pp = reinterpret_cast<const f32x4*>(p)[i];
+    const f32x4 gg = reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 mm = reinterpret_cast<const f32x4*>(m)[i];
+    f32x4 vv = reinterpret_cast<const f32x4*>(v)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      pp[e] *= decay;
+      mm[e] += (1.f - b1) * (gg[e] - mm[e]);
+      vv[e] = b2 * vv[e] + (1.f - b2) * gg[e] * gg[e];
+      pp[e] -= step_size * mm[e] / (sqrtf(vv[e]) * inv_bc2_sqrt + eps);
+    }
+    reinterpret_cast<f32x4*>(p)[i] = pp;
+    reinterpret_cast<f32x4*>(m)[i] = mm;
+    reinterpret_cast<f32x4*>(v)[i] = vv;
+    if (img) {
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = f2bf(pp[e]);
+      reinterpret_cast<bf16x4*>(img)[i] = o;
+    }
+  }
+  // tail (n % 4 elements), first block only
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n - n4 * 4)) {
+    const int64_t i = n4 * 4 + threadIdx.x;
+    float pp = p[i] * decay;
+    const float gg = g[i];
+    const float mm = m[i] + (1.f - b1) * (gg - m[i]);
+    const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
+    pp -= step_size * mm / (sqrtf(vv) * inv_bc2_sqrt + eps);
+    p[i] = pp; m[i] = mm; v[i] = vv;
+    if (img) img[i] = f2bf(pp);
+  }
+}
+}  // namespace
+
+extern "C" int a3v_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                         float beta2, float eps, float weight_decay, int64_t step, void* bf16_image, void* stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || step < 1) return A3V_ERR_ARG;
+  if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return A3V_ERR_SHAPE;
+  if (bf16_image && ((uintptr_t)bf16_image & 7)) return A3V_ERR_SHAPE;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr / bc1), inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+  const float decay = (float)(1.0 - (double)lr * (double)weight_decay);
+  const int64_t n4 = n / 4;
+  int64_t blocks = (n4 + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n4, n, decay,
+                     beta1, beta2, step_size, inv_bc2_sqrt, eps, (bf16_t*)bf16_image);
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}
+

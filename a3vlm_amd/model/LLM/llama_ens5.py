@@ -264,7 +264,8 @@ class Transformer(nn.Module):
         self._packed_version = None
 
     def _weights_version(self):
-        return tuple(p._version for p in self.parameters()) + (self._dtype, str(self._device))
+        from ...util import param_state_key
+        return tuple(param_state_key(p) for p in self.parameters()) + (self._dtype, str(self._device))
 
     def _pack(self, check: bool = False) -> Dict[str, torch.Tensor]:
         """Kernel-side weight images (built once per weight version):

@@ -1,0 +1,58 @@
+"""AdamW on the HIP kernel ``a3v_adamw`` with the state layout of ``torch.optim.AdamW`` (``step`` / ``exp_avg`` /
+``exp_avg_sq`` per parameter), so optimizer checkpoints written by either (util/misc.py:324-569 layout, ``checkpoint.py``)
+load into the other.  Reference: the trainer builds ``torch.optim.AdamW(param_groups, lr, betas=(0.9, 0.95))``
+(main_finetune.py:138 of this package mirrors accessory/main_finetune.py) and calls ``optimizer.step()`` once per
+accumulation cycle (engine_finetune.py:63).
+
+One launch per parameter tensor streams p, g, m, v once (28 B per parameter).  ``image_of`` (optional) maps a parameter to a
+bf16 tensor of the same shape that receives the rounded updated values in the same pass (the compute-dtype operand of the next
+step's GEMMs)."""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import torch
+
+from . import lib as _l
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
+                 image_of: Optional[Callable[[torch.Tensor], Optional[torch.Tensor]]] = None):
+        if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
+            raise ValueError("invalid AdamW hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+        self.image_of = image_of
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = _l.load()
+        stream = torch.cuda.current_stream().cuda_stream
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not p.is_cuda or p.dtype != torch.float32 or p.grad.dtype != torch.float32 or not p.is_contiguous() \
+                        or not p.grad.is_contiguous():
+                    raise RuntimeError("FusedAdamW takes contiguous fp32 device parameters and gradients (no CPU fallback)")
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0, dtype=torch.float32)          # torch.optim.AdamW's (non-capturable) layout
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                img = self.image_of(p) if self.image_of is not None else None
+                if img is not None and (img.dtype != torch.bfloat16 or img.shape != p.shape or not img.is_contiguous()):
+                    raise RuntimeError("image_of must return a contiguous bf16 tensor of the parameter's shape")
+                rc = lib.a3v_adamw(p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(),
+                                   float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
+                                   int(st["step"].item()), img.data_ptr() if img is not None else None, stream)
+                _l.check(rc, "a3v_adamw")
+                # the kernel wrote through raw pointers: tell autograd / version-keyed caches (the engine's bf16 weight images)
+                torch.autograd.graph.increment_version(p)
+        return loss

@@ -19,6 +19,7 @@ from typing import Callable, Dict, List, Optional, Tuple
 import torch
 
 from . import ops
+from .util import install_param_epoch_hook, param_state_key
 
 
 def _pad64(n: int) -> int:
@@ -36,6 +37,7 @@ class TrainEngine:
         activation checkpointing, main_finetune.py:268-276); False = keep every block's intermediates (about
         1.15 GB per 7B layer at 8 x 1091 tokens -- affordable in 288 GB of HBM and ~1/4 fewer GEMM FLOPs per step).
         None = decide from free HBM at the first step."""
+        install_param_epoch_hook()     # weight-image caches must notice optimizers that do not bump Tensor._version
         self.m = model
         self.lora = int(getattr(model, "lora_rank", 0) or 0) > 0
         self.act = compute_dtype
@@ -254,7 +256,7 @@ class TrainEngine:
     def _lora_step_images(self):
         """A [Rp,in], B [N,Rp] (+ transposes for the backward GEMMs) of every adapter group in the compute dtype."""
         m = self.m
-        ver = tuple(q._version for n, q in m.named_parameters() if "lora_" in n)
+        ver = tuple(param_state_key(q) for n, q in m.named_parameters() if "lora_" in n)
         if getattr(self, "_li_ver", None) == ver:
             return self._li
         src = m.lora_images(dtype=self.act, interleave_w13=False)
@@ -614,7 +616,7 @@ class _Images:
         else:
             vp0 = getattr(m.visual_proj, "0")
             ps = (vp0.weight, vp0.bias)
-        ver = tuple(q._version for q in ps) + (eng.act, str(m._device))
+        ver = tuple(param_state_key(q) for q in ps) + (eng.act, str(m._device))
         if self.ver.get(g) != ver:
             with torch.no_grad():
                 if g.startswith("L"):

@@ -36,3 +36,35 @@ def add_weight_decay(model: nn.Module, weight_decay: float = 1e-5, skip_list=())
         else:
             decay.append(p)
     return [{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": weight_decay}]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Parameter-update epochs.  The compute-dtype weight images (TrainEngine._Images, the LoRA step images, the plugin's packed
+# weights) are caches keyed on the parameters' state.  ``Tensor._version`` alone is NOT a safe key: torch.optim.AdamW(fused=True)
+# -- what the reference trainer's optimizer amounts to on recent torch -- updates parameters through a fused kernel that leaves
+# ``_version`` untouched (checked on torch 2.10 / ROCm), so a version-keyed cache would keep serving the pre-update weights.
+# A global optimizer post-step hook therefore counts, per parameter object, the optimizer steps that saw a gradient for it.
+_PARAM_EPOCH: "dict[int, int]" = {}
+_HOOKED = False
+
+
+def _after_optimizer_step(optimizer, args, kwargs) -> None:
+    for group in optimizer.param_groups:
+        for p in group["params"]:
+            if p.grad is not None:
+                _PARAM_EPOCH[id(p)] = _PARAM_EPOCH.get(id(p), 0) + 1
+
+
+def install_param_epoch_hook() -> None:
+    """Idempotent: registers the global torch.optim post-step hook (any optimizer class, fused or not)."""
+    global _HOOKED
+    if not _HOOKED:
+        from torch.optim.optimizer import register_optimizer_step_post_hook
+        register_optimizer_step_post_hook(_after_optimizer_step)
+        _HOOKED = True
+
+
+def param_state_key(p) -> tuple:
+    """Cache key of a parameter's current value: (autograd version, optimizer-step epoch)."""
+    return (p._version, _PARAM_EPOCH.get(id(p), 0))
+

@@ -180,7 +180,8 @@ def train_leg(m, args, B, T, image, tokens, steps, dist, dev):
     promote_trainable_params_to_fp32(m)
     eng = TrainEngine(m, torch.bfloat16)
     params = [p for p in m.parameters() if p.requires_grad]
-    opt = torch.optim.AdamW(params, lr=2e-5, betas=(0.9, 0.95), weight_decay=0.0, fused=True)
+    from a3vlm_amd.optim import FusedAdamW
+    opt = FusedAdamW(params, lr=2e-5, betas=(0.9, 0.95), weight_decay=0.0)
     # bf16 on the wire = the reference's FSDP MixedPrecision(reduce_dtype=bf16) (main_finetune.py:251-255); fp32 accumulation buffers
     red = GradReducer(eng, dist, reduce_dtype=torch.bfloat16) if dist is not None else None
     labels = tokens.clone()
@@ -246,7 +247,8 @@ def lora_leg(m, args, B, T, image, tokens, steps, dist, dev, rank=16):
     promote_trainable_params_to_fp32(pm)
     n_train = sum(p.numel() for p in pm.parameters() if p.requires_grad)
     eng = TrainEngine(pm, torch.bfloat16)
-    opt = torch.optim.AdamW([p for p in pm.parameters() if p.requires_grad], lr=2e-5, betas=(0.9, 0.95), weight_decay=0.0, fused=True)
+    from a3vlm_amd.optim import FusedAdamW
+    opt = FusedAdamW([p for p in pm.parameters() if p.requires_grad], lr=2e-5, betas=(0.9, 0.95), weight_decay=0.0)
     # bf16 on the wire = the reference's FSDP MixedPrecision(reduce_dtype=bf16) (main_finetune.py:251-255); fp32 accumulation buffers
     red = GradReducer(eng, dist, reduce_dtype=torch.bfloat16) if dist is not None else None
     labels = tokens.clone()
@@ -517,7 +519,7 @@ def main():
                      "hbm_gib": round(mem, 1), "tflops": round((3 * fl_t["total"]) * world / sec / 1e12, 1),
                      "mfma_frac": round(3 * fl_t["total"] / sec / MFMA_PEAK_BF16, 4),
                      "config": f"full fine-tune of decoder+projector (6.7 G trainable), bs={B}/GPU, {T}-token prompts + 579 image words, fp32 masters + "
-                               f"bf16 GEMMs, block activations kept in HBM (no recompute), fused AdamW, dp{world}"
+                               f"bf16 GEMMs, block activations kept in HBM (no recompute), AdamW (a3v_adamw), dp{world}"
                                + (" with RCCL all-reduce of per-layer fp32 grad buckets overlapped with backward" if world > 1 else ""),
                      "flop_convention": "3 x forward FLOPs of the step (SURVEY 8(d)); LM head on all text positions and the frozen ViT counted once are ignored"}
         except Exception as e:

@@ -329,6 +329,12 @@ int a3v_embed_bwd(const int64_t* tokens, int64_t ld_tok, const float* dh, float*
 int a3v_rows_sum(const void* src, int64_t ld, const int32_t* row_idx, int n_rows, int dim, float* out,
                  int dtype, void* stream);
 
+/* One AdamW step on one fp32 parameter tensor (torch.optim.AdamW semantics, decoupled weight decay; the reference optimizer of
+ * main_finetune.py:138 with engine_finetune.py:63 optimizer.step()): step = 1-based update count of this parameter.  All four
+ * arrays 16-B aligned.  bf16_image (optional): also store the updated parameter rounded to bf16 (the next step's GEMM operand). */
+int a3v_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+              float eps, float weight_decay, int64_t step, void* bf16_image, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -161,3 +161,94 @@ def test_eval_entry_two_ranks(tmp_path):
                "--temperature", "0", "--image_root", os.path.join(gd, "demo"), "--output_root", str(tmp_path / "logs"), "--precision", "tf32"])
     recs = json.load(open(tmp_path / "logs" / "t2" / "demo.json"))
     assert len(recs) == 3 and recs[0]["answer"] == recs[1]["answer"] == recs[2]["answer"]
+
+
+def test_fused_adamw_matches_torch_adamw():
+    """a3vlm_amd.optim.FusedAdamW == torch.optim.AdamW over several steps (weight decay groups, odd sizes incl. a 4-element
+    tail, bf16 image side output), and the two optimizers load each other's state_dict."""
+    import torch
+    from a3vlm_amd.optim import FusedAdamW
+    DEV = "cuda"
+    g = torch.Generator().manual_seed(1)
+    shapes = [(300, 257), (4096,), (7,), (64, 64)]
+    ref = [torch.randn(*s, generator=g).to(DEV).requires_grad_(True) for s in shapes]
+    got = [r.detach().clone().requires_grad_(True) for r in ref]
+    imgs = {id(p): torch.zeros(p.shape, dtype=torch.bfloat16, device=DEV) for p in got[:2]}
+    groups = lambda ps: [dict(params=ps[:2], weight_decay=0.1), dict(params=ps[2:], weight_decay=0.0)]
+    o_ref = torch.optim.AdamW(groups(ref), lr=3e-3, betas=(0.9, 0.95), eps=1e-8)
+    o_got = FusedAdamW(groups(got), lr=3e-3, betas=(0.9, 0.95), eps=1e-8, image_of=lambda p: imgs.get(id(p)))
+    for it in range(5):
+        for a, b in zip(ref, got):
+            gr = torch.randn(a.shape, generator=g).to(DEV) * (0.1 + it)
+            a.grad, b.grad = gr.clone(), gr.clone()
+        v0 = [b._version for b in got]
+        o_ref.step()
+        o_got.step()
+        assert all(b._version > v for b, v in zip(got, v0))      # version-keyed caches (bf16 weight images) see the update
+        for a, b in zip(ref, got):
+            assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max()) + 1e-7, it
+    for p in got[:2]:
+        assert torch.equal(imgs[id(p)], p.detach().to(torch.bfloat16))
+    sd = o_got.state_dict()
+    assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == 5
+    o_ref2 = torch.optim.AdamW(groups([r.detach().clone().requires_grad_(True) for r in ref]), lr=3e-3, betas=(0.9, 0.95))
+    import copy
+    o_ref2.load_state_dict(copy.deepcopy(sd))                       # torch's optimizer accepts the state the HIP optimizer wrote ...
+    o_got.load_state_dict(copy.deepcopy(o_ref.state_dict()))        # ... and vice versa (deep copies: load_state_dict aliases tensors)
+    for a, b in zip(ref, got):
+        gr = torch.randn(a.shape, generator=g).to(DEV)
+        a.grad, b.grad = gr.clone(), gr.clone()
+    o_ref.step()
+    o_got.step()
+    for a, b in zip(ref, got):
+        assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max()) + 1e-7
+    with pytest.raises(RuntimeError):
+        bad = torch.zeros(4, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+        bad.grad = torch.zeros_like(bad)
+        FusedAdamW([bad]).step()
+
+
+@pytest.mark.parametrize("opt_kind", ["torch_fused", "torch_plain", "hip"])
+def test_engine_sees_updates_of_any_optimizer(opt_kind):
+    """The engine's bf16 weight images are caches; torch.optim.AdamW(fused=True) updates parameters WITHOUT bumping
+    Tensor._version, so the cache key also counts optimizer steps (global post-step hook).  All three optimizers must give the
+    same loss trajectory on one repeated batch (they apply the same update)."""
+    import torch
+    import bench
+    from a3vlm_amd.optim import FusedAdamW
+    from a3vlm_amd.train import TrainEngine
+    from a3vlm_amd.util import promote_trainable_params_to_fp32
+    dev = torch.device("cuda", 0)
+
+    def run(kind):
+        torch.manual_seed(0)
+        m, args = bench.build_model("tiny", dev, 256)
+        for n, p in m.named_parameters():
+            p.requires_grad = not n.startswith("clip.")
+        promote_trainable_params_to_fp32(m)
+        eng = TrainEngine(m, torch.bfloat16)
+        params = [p for p in m.parameters() if p.requires_grad]
+        if kind == "torch_fused":
+            opt = torch.optim.AdamW(params, lr=2e-3, betas=(0.9, 0.95), weight_decay=0.0, fused=True)
+        elif kind == "torch_plain":
+            opt = torch.optim.AdamW(params, lr=2e-3, betas=(0.9, 0.95), weight_decay=0.0, fused=False, foreach=False)
+        else:
+            opt = FusedAdamW(params, lr=2e-3, betas=(0.9, 0.95), weight_decay=0.0)
+        g = torch.Generator(device=dev).manual_seed(1)
+        tokens = torch.randint(3, args.vocab_size, (4, 64), device=dev, generator=g)
+        tokens[:, 0] = 1
+        labels = tokens.clone()
+        labels[:, :32] = 0
+        out = []
+        for _ in range(4):
+            loss = eng.forward_loss(tokens, labels, None)
+            eng.backward(1.0)
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            out.append(float(loss))
+        return out
+    want = run("torch_plain")
+    got = want if opt_kind == "torch_plain" else run(opt_kind)
+    assert want[3] < want[0] - 1.0                      # the repeated batch is being fitted
+    for a, b in zip(got, want):
+        assert abs(a - b) < 2e-2 * abs(b), (opt_kind, got, want)
