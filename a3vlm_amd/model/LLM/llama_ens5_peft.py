@@ -81,7 +81,8 @@ class Transformer(base.Transformer):
         """Per group: ``A`` [Rp, in] (stacked lora_a, zero rows up to Rp = pad64(n*r)) and ``B`` [N, Rp] (block-diagonal
         lora_b in the row order of the fused base weight; w1/w3 rows interleaved in 16-row blocks when the base image is)."""
         dtype = dtype or self._dtype
-        ver = (tuple(p._version for n, p in self.named_parameters() if "lora_" in n), dtype, interleave_w13, str(self._device))
+        from ...util import param_state_key
+        ver = (tuple(param_state_key(p) for n, p in self.named_parameters() if "lora_" in n), dtype, interleave_w13, str(self._device))
         if self._lora_ver == ver:
             return self._lora_img
         r = self.lora_rank

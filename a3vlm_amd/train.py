@@ -254,15 +254,35 @@ class TrainEngine:
 
     # ------------------------------------------------------------------ LoRA adapters (model/peft.py semantics)
     def _lora_step_images(self):
-        """A [Rp,in], B [N,Rp] (+ transposes for the backward GEMMs) of every adapter group in the compute dtype."""
+        """A [Rp,in], B [N,Rp] (+ transposes for the backward GEMMs) of every adapter group in the compute dtype.  Built once;
+        after an optimizer step only the r rows / columns each adapter owns are re-written in place (four cast-copies per
+        adapter) -- rebuilding the padded / block-diagonal images from scratch was ~2500 small launches per step."""
         m = self.m
         ver = tuple(param_state_key(q) for n, q in m.named_parameters() if "lora_" in n)
         if getattr(self, "_li_ver", None) == ver:
             return self._li
+        li = getattr(self, "_li", None)
+        if li is not None and getattr(self, "_li_act", None) == self.act:
+            r = m.lora_rank
+            with torch.no_grad():
+                for i in range(m.n_layers):
+                    for key, mods, _ in m.lora_groups(i):
+                        A, Bm, At, Bt = li[key + ".A"], li[key + ".B"], li[key + ".At"], li[key + ".Bt"]
+                        row = 0
+                        for j, mod in enumerate(mods):
+                            wa, wb = mod.lora_a.weight, mod.lora_b.weight          # [r, in], [N_j, r]
+                            nj = wb.shape[0]
+                            A[j * r:(j + 1) * r].copy_(wa)
+                            At[:wa.shape[1], j * r:(j + 1) * r].copy_(wa.t())
+                            Bm[row:row + nj, j * r:(j + 1) * r].copy_(wb)
+                            Bt[j * r:(j + 1) * r, row:row + nj].copy_(wb.t())
+                            row += nj
+            self._li_ver = ver
+            return li
         src = m.lora_images(dtype=self.act, interleave_w13=False)
         li = {}
         for k, v in src.items():
-            li[k] = v
+            li[k] = v.clone()              # the engine's own copies (updated in place from now on)
             R, C = v.shape
             vt = torch.empty(C, _pad64(R), dtype=v.dtype, device=v.device)
             if _pad64(R) != R:
@@ -272,7 +292,7 @@ class TrainEngine:
                 vp = v
             ops.transpose(vp, vt, _pad64(R), C, _pad64(R))
             li[k + "t"] = vt
-        self._li, self._li_ver = li, ver
+        self._li, self._li_ver, self._li_act = li, ver, self.act
         return li
 
     def _lora_fwd(self, key: str, x: torch.Tensor, y: torch.Tensor, tag: str) -> torch.Tensor:

@@ -188,3 +188,30 @@ def test_lora_bf16_tn_adapter_gradients_match_transposed_path():
     for n in got[True]:
         assert relerr(got[True][n], got[False][n]) < 1e-2, n
         assert float(got[True][n].abs().max()) > 0
+
+
+def test_lora_step_images_refresh_in_place_after_optimizer_step():
+    """After an optimizer step the engine re-writes only the adapter rows / columns of its padded, block-diagonal images:
+    the result must equal images built from scratch, for an optimizer that bumps Tensor._version and for one that does not."""
+    from a3vlm_amd.optim import FusedAdamW
+    m, oargs, sd, lsd, vsd = build(False, BF)
+    promote_trainable_params_to_fp32(m)
+    g = torch.Generator().manual_seed(11)
+    ex = torch.randint(3, 192, (2, 20), generator=g)
+    ex[:, 0] = 1
+    lab = ex.clone()
+    lab[:, :4] = 0
+    eng = TrainEngine(m, BF)
+    params = [p for p in m.parameters() if p.requires_grad]
+    for opt in (FusedAdamW(params, lr=1e-2, betas=(0.9, 0.95), weight_decay=0.0),
+                torch.optim.AdamW(params, lr=1e-2, betas=(0.9, 0.95), weight_decay=0.0, fused=True)):
+        for _ in range(2):
+            eng.forward_loss(ex.to(DEV), lab.to(DEV), None)
+            eng.backward(1.0)
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            li = eng._lora_step_images()                  # refreshed in place
+            fresh = TrainEngine(m, BF)._lora_step_images()  # built from scratch from the updated parameters
+            assert set(li) == set(fresh)
+            for k in li:
+                assert torch.equal(li[k], fresh[k]), k
