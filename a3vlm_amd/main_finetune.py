@@ -141,7 +141,7 @@ def main(args):
         optimizer = torch.optim.AdamW(add_weight_decay(model, args.weight_decay), lr=args.lr, betas=(0.9, 0.95), fused=True)
     else:
         from .optim import FusedAdamW
-        optimizer = FusedAdamW(add_weight_decay(model, args.weight_decay), lr=args.lr, betas=(0.9, 0.95))
+        optimizer = FusedAdamW(add_weight_decay(model, args.weight_decay), lr=args.lr, betas=(0.9, 0.95), engine=model.train_engine())
     # gradient wire dtype = FSDP's MixedPrecision(reduce_dtype) of the reference (:251-255): bf16 under --precision bf16
     reducer = GradReducer(model.train_engine(), dist, reduce_dtype=torch.bfloat16 if args.precision == "bf16" else None) if distributed else None
 

@@ -17,12 +17,17 @@ from . import lib as _l
 
 
 class FusedAdamW(torch.optim.Optimizer):
+    bumps_version = True        # parameters' Tensor._version is incremented by step(): version-keyed caches need no extra hook
+
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
-                 image_of: Optional[Callable[[torch.Tensor], Optional[torch.Tensor]]] = None):
+                 image_of: Optional[Callable[[torch.Tensor], Optional[torch.Tensor]]] = None, engine=None):
         if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
             raise ValueError("invalid AdamW hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
-        self.image_of = image_of
+        # ``engine`` (a TrainEngine): the bf16 values go straight into the engine's fused weight images, which are then marked
+        # current -- the next step does not re-cast 6.7 G fp32 parameters (cat + cast = 14 B per parameter) to rebuild them
+        self.engine = engine
+        self.image_of = image_of if engine is None else engine.image_sink
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -32,6 +37,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 loss = closure()
         lib = _l.load()
         stream = torch.cuda.current_stream().cuda_stream
+        written = set()
         for group in self.param_groups:
             b1, b2 = group["betas"]
             for p in group["params"]:
@@ -55,4 +61,8 @@ class FusedAdamW(torch.optim.Optimizer):
                 _l.check(rc, "a3v_adamw")
                 # the kernel wrote through raw pointers: tell autograd / version-keyed caches (the engine's bf16 weight images)
                 torch.autograd.graph.increment_version(p)
+                if img is not None:
+                    written.add(id(p))
+        if self.engine is not None:
+            self.engine.images_adopted(written)
         return loss

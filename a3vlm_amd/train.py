@@ -64,6 +64,14 @@ class TrainEngine:
             t.zero_()
         return t
 
+    # ------------------------------------------------------------------ optimizer hand-off (a3vlm_amd.optim.FusedAdamW(engine=...))
+    def image_sink(self, p: torch.Tensor) -> Optional[torch.Tensor]:
+        """Where the optimizer may store the bf16 value of the updated parameter p (its rows of the fused forward image)."""
+        return self._images().sink(p)
+
+    def images_adopted(self, written_ids) -> None:
+        self._images().adopted(written_ids)
+
     def _check_dtypes(self):
         for n, p in self.m.get_trainable_params().items():
             if p.requires_grad and p.dtype != torch.float32:
@@ -595,6 +603,7 @@ class _Images:
         self.store: Dict[str, torch.Tensor] = {}
         self.ver: Dict[str, tuple] = {}
         self.tver: Dict[str, tuple] = {}      # version of each transposed image (built lazily, per key)
+        self._sinks = None                    # id(param) -> (image key, first row), built on first use
 
     def _group(self, key: str):
         if key.startswith(("qkv.", "wo.", "w13.", "w2.")):
@@ -623,20 +632,60 @@ class _Images:
             self.tver[key] = ver
         return self.store[key]
 
+    def _params(self, g: str):
+        """(parameters, [(image key, first row)] in the same order) of image group g."""
+        m = self.eng.m
+        if g.startswith("L"):
+            i = int(g[1:])
+            a, f = m.layers[i].attention, m.layers[i].feed_forward
+            H, Hkv, hd, F = m.n_heads, m.n_kv_heads, m.head_dim, m.ffn
+            return ((a.wq.weight, a.wk.weight, a.wv.weight, a.wo.weight, f.w1.weight, f.w3.weight, f.w2.weight),
+                    ((f"qkv.{i}", 0), (f"qkv.{i}", H * hd), (f"qkv.{i}", (H + Hkv) * hd), (f"wo.{i}", 0), (f"w13.{i}", 0), (f"w13.{i}", F),
+                     (f"w2.{i}", 0)))
+        if g == "out":
+            return (m.output.weight,), (("out", 0),)
+        vp0 = getattr(m.visual_proj, "0")
+        return (vp0.weight, vp0.bias), (("vp", 0), ("vp.b", 0))
+
+    def _key(self, ps) -> tuple:
+        return tuple(param_state_key(q) for q in ps) + (self.eng.act, str(self.eng.m._device))
+
+    def groups(self):
+        m = self.eng.m
+        return [f"L{i}" for i in range(m.n_layers)] + ["out"] + (["vp"] if getattr(m, "visual_proj", None) is not None else [])
+
+    def sink(self, p) -> Optional[torch.Tensor]:
+        """bf16 destination of parameter p inside its (already built) forward image, or None."""
+        if self.eng.act != torch.bfloat16:
+            return None
+        if self._sinks is None:
+            self._sinks = {}
+            for g in self.groups():
+                ps, where = self._params(g)
+                for q, (key, row) in zip(ps, where):
+                    self._sinks[id(q)] = (key, row)
+        ent = self._sinks.get(id(p))
+        if ent is None:
+            return None
+        img = self.store.get(ent[0])
+        if img is None or img.dtype != torch.bfloat16:
+            return None
+        return img[ent[1]:ent[1] + p.shape[0]] if img.dim() == 2 else img
+
+    def adopted(self, written_ids) -> None:
+        """The optimizer wrote the bf16 values of these parameters into their images: groups written completely are current."""
+        for g in self.groups():
+            ps, _ = self._params(g)
+            if g in self.ver and all(id(q) in written_ids for q in ps):
+                self.ver[g] = self._key(ps)
+
     def __getitem__(self, key: str) -> torch.Tensor:
         eng, m = self.eng, self.eng.m
         g = self._group(key)
+        ps, _ = self._params(g)
         if g.startswith("L"):
             i = int(g[1:])
-            l = m.layers[i]
-            a, f = l.attention, l.feed_forward
-            ps = (a.wq.weight, a.wk.weight, a.wv.weight, a.wo.weight, f.w1.weight, f.w3.weight, f.w2.weight)
-        elif g == "out":
-            ps = (m.output.weight,)
-        else:
-            vp0 = getattr(m.visual_proj, "0")
-            ps = (vp0.weight, vp0.bias)
-        ver = tuple(param_state_key(q) for q in ps) + (eng.act, str(m._device))
+        ver = self._key(ps)
         if self.ver.get(g) != ver:
             with torch.no_grad():
                 if g.startswith("L"):

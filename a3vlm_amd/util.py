@@ -49,6 +49,8 @@ _HOOKED = False
 
 
 def _after_optimizer_step(optimizer, args, kwargs) -> None:
+    if getattr(optimizer, "bumps_version", False):      # e.g. a3vlm_amd.optim.FusedAdamW: Tensor._version already moved
+        return
     for group in optimizer.param_groups:
         for p in group["params"]:
             if p.grad is not None:

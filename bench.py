@@ -181,7 +181,7 @@ def train_leg(m, args, B, T, image, tokens, steps, dist, dev):
     eng = TrainEngine(m, torch.bfloat16)
     params = [p for p in m.parameters() if p.requires_grad]
     from a3vlm_amd.optim import FusedAdamW
-    opt = FusedAdamW(params, lr=2e-5, betas=(0.9, 0.95), weight_decay=0.0)
+    opt = FusedAdamW(params, lr=2e-5, betas=(0.9, 0.95), weight_decay=0.0, engine=eng)
     # bf16 on the wire = the reference's FSDP MixedPrecision(reduce_dtype=bf16) (main_finetune.py:251-255); fp32 accumulation buffers
     red = GradReducer(eng, dist, reduce_dtype=torch.bfloat16) if dist is not None else None
     labels = tokens.clone()
@@ -248,7 +248,7 @@ def lora_leg(m, args, B, T, image, tokens, steps, dist, dev, rank=16):
     n_train = sum(p.numel() for p in pm.parameters() if p.requires_grad)
     eng = TrainEngine(pm, torch.bfloat16)
     from a3vlm_amd.optim import FusedAdamW
-    opt = FusedAdamW([p for p in pm.parameters() if p.requires_grad], lr=2e-5, betas=(0.9, 0.95), weight_decay=0.0)
+    opt = FusedAdamW([p for p in pm.parameters() if p.requires_grad], lr=2e-5, betas=(0.9, 0.95), weight_decay=0.0, engine=eng)
     # bf16 on the wire = the reference's FSDP MixedPrecision(reduce_dtype=bf16) (main_finetune.py:251-255); fp32 accumulation buffers
     red = GradReducer(eng, dist, reduce_dtype=torch.bfloat16) if dist is not None else None
     labels = tokens.clone()

@@ -208,7 +208,7 @@ def test_fused_adamw_matches_torch_adamw():
         FusedAdamW([bad]).step()
 
 
-@pytest.mark.parametrize("opt_kind", ["torch_fused", "torch_plain", "hip"])
+@pytest.mark.parametrize("opt_kind", ["torch_fused", "torch_plain", "hip", "hip_engine"])
 def test_engine_sees_updates_of_any_optimizer(opt_kind):
     """The engine's bf16 weight images are caches; torch.optim.AdamW(fused=True) updates parameters WITHOUT bumping
     Tensor._version, so the cache key also counts optimizer steps (global post-step hook).  All three optimizers must give the
@@ -232,8 +232,8 @@ def test_engine_sees_updates_of_any_optimizer(opt_kind):
             opt = torch.optim.AdamW(params, lr=2e-3, betas=(0.9, 0.95), weight_decay=0.0, fused=True)
         elif kind == "torch_plain":
             opt = torch.optim.AdamW(params, lr=2e-3, betas=(0.9, 0.95), weight_decay=0.0, fused=False, foreach=False)
-        else:
-            opt = FusedAdamW(params, lr=2e-3, betas=(0.9, 0.95), weight_decay=0.0)
+        else:      # "hip_engine": the optimizer also writes the bf16 images the engine's next step reads
+            opt = FusedAdamW(params, lr=2e-3, betas=(0.9, 0.95), weight_decay=0.0, engine=eng if kind == "hip_engine" else None)
         g = torch.Generator(device=dev).manual_seed(1)
         tokens = torch.randint(3, args.vocab_size, (4, 64), device=dev, generator=g)
         tokens[:, 0] = 1
@@ -246,6 +246,12 @@ def test_engine_sees_updates_of_any_optimizer(opt_kind):
             opt.step()
             opt.zero_grad(set_to_none=True)
             out.append(float(loss))
+        if kind == "hip_engine":      # the images the optimizer wrote ARE the bf16 roundings of the updated parameters, and current
+            im = eng._images()
+            l0 = m.layers[0]
+            want_qkv = torch.cat([l0.attention.wq.weight, l0.attention.wk.weight, l0.attention.wv.weight]).to(torch.bfloat16)
+            ver0 = dict(im.ver)
+            assert torch.equal(im["qkv.0"], want_qkv) and im.ver == ver0          # served from the adopted image, not rebuilt
         return out
     want = run("torch_plain")
     got = want if opt_kind == "torch_plain" else run(opt_kind)
