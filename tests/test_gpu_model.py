@@ -345,3 +345,59 @@ def test_prefill_fused_qkv_rope_matches_separate_kernels():
     dec = ref_cpu.OracleDecoder(oargs, {k: v.to(BF) for k, v in sd.items()})
     want = dec.forward_inference(ex[:, :T0], 0).float()
     assert float((got[True][0][0].cpu() - want).abs().max()) / float(want.abs().max()) < 4e-2
+
+
+def test_attach_hf_qformer_provider(gold):
+    """N4: the BLIP-2 Q-Former stream through stock transformers.Blip2Model behind the plugin's hook (the package the reference
+    itself instantiates, llama_ens5.py:285-293): module registered as ``qformer`` (checkpoint keys load by name), frozen, features
+    computed on the plugin's own five views; logits equal the oracle fed with the same module's features on the CPU views."""
+    transformers = pytest.importorskip("transformers")
+    from transformers import Blip2Config, Blip2QFormerConfig, Blip2VisionConfig, OPTConfig
+    from a3vlm_amd.model.encoders import attach_qformer, convnext_tokens as cnx_tokens, dinov2_input
+    V = gold["j"]["vocab_size"]
+    args = plugin.ModelArgs(vocab_size=V, **{**TINY, "max_seq_len": 1600}, vit_width=VIT["width"], vit_layers=VIT["layers"],
+                            vit_heads=VIT["heads"], vit_patch=VIT["patch"], vit_crop=224, n_views=5, qformer_tokens=32)
+    m = plugin.Transformer(args, with_visual=True)
+    sd = ref_cpu.make_decoder_weights(ref_cpu.OracleArgs(vocab_size=V, **TINY), seed=0, std=0.08)
+    vsd = ref_cpu.make_vision_weights(64, width=VIT["width"], layers=VIT["layers"], patch=VIT["patch"], grid=VIT["grid"],
+                                      with_qformer=True, seed=1, std=0.05)
+    m.load_state_dict({**sd, **vsd}, strict=True)
+    m.to(torch.float32).to(DEV)
+    torch.manual_seed(3)
+    cfg = Blip2Config(vision_config=Blip2VisionConfig(hidden_size=32, intermediate_size=64, num_hidden_layers=2, num_attention_heads=2,
+                                                      image_size=224, patch_size=14).to_dict(),
+                      qformer_config=Blip2QFormerConfig(hidden_size=768, num_hidden_layers=2, num_attention_heads=12, intermediate_size=128,
+                                                        encoder_hidden_size=32, vocab_size=100, max_position_embeddings=32).to_dict(),
+                      text_config=OPTConfig(vocab_size=64, hidden_size=16, num_hidden_layers=1, ffn_dim=16, num_attention_heads=2,
+                                            max_position_embeddings=32, word_embed_proj_dim=16).to_dict(), num_query_tokens=32)
+    attach_qformer(m, config=cfg)
+    assert any(k.startswith("qformer.qformer.") for k in m.state_dict()) and not any(p.requires_grad for p in m.qformer.parameters())
+    assert not any(n.startswith("qformer.") for n in m.get_trainable_params())
+    B = 2
+    img = synth_image(B)
+    g = torch.Generator().manual_seed(5)
+    ex = torch.randint(3, V, (B, 9), generator=g)
+    ex[:, 0] = 1
+    out = m(ex.to(DEV), img.to(DEV)).float().cpu()
+    assert m.image_words == (32 + 257 + 2) * 5
+    # oracle: same HF module (CPU copy) on the oracle's own views
+    import copy
+    q_cpu = copy.deepcopy(m.qformer).to("cpu")
+    with torch.no_grad():
+        qf = q_cpu.get_qformer_features(pixel_values=ref_cpu.split_views(img, 224))
+        qf = getattr(qf, "last_hidden_state", qf)
+    views = ref_cpu.encode_image(img, vsd, vit_layers=VIT["layers"], vit_heads=VIT["heads"], n_views=5, patch=VIT["patch"], qformer_feats=qf)
+    itok = ref_cpu.assemble_image_tokens(views, vsd["start_img"], vsd["end_img"])
+    dec = ref_cpu.OracleDecoder(ref_cpu.OracleArgs(vocab_size=V, **{**TINY, "max_seq_len": 1600}), sd)
+    want = dec.forward(ex, itok).float()
+    assert rel_err(out, want.numpy()) < 5e-3
+    # the two pure post-processing helpers of the other providers (no third-party net needed to check them)
+    fm = torch.arange(2 * 3072 * 64, dtype=torch.float32).view(2, 3072, 8, 8)
+    t = cnx_tokens(fm)
+    assert t.shape == (2, 257, 3072) and torch.allclose(t[:, 0], t[:, 1:].mean(1))
+    assert float(t[0, 1, 5]) == float(fm[0, 5, 0, 0]) == float(t[0, 2, 5]) and float(t[0, 3, 5]) == float(fm[0, 5, 0, 1])
+    x = torch.rand(1, 3, 4, 4)
+    from a3vlm_amd.data.transform import CLIP_MEAN, CLIP_STD
+    xn = (x - torch.tensor(CLIP_MEAN).view(3, 1, 1)) / torch.tensor(CLIP_STD).view(3, 1, 1)
+    want_d = (x - torch.tensor([0.485, 0.456, 0.406]).view(3, 1, 1)) / torch.tensor([0.229, 0.224, 0.225]).view(3, 1, 1)
+    assert torch.allclose(dinov2_input(xn), want_d, atol=1e-5)
