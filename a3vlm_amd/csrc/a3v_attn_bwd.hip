@@ -146,9 +146,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs p) {
   for (int t = 0; t < n_tiles; ++t) {
     const int kv0 = t * 64;
     __syncthreads();
-    stage_rows<HD>(K, HD, kv0, p.S, Ks, tid);
-    stage_rows<HD>(V, p.v_ss, kv0, p.S, Vs, tid);
-    stage_cols<HD>(KT, p.Sp, kv0, p.S, Kts, tid);
+#ifdef AB_NO_STAGE      // timing experiment: tiles staged once (results wrong by construction)
+    if (t == 0)
+#endif
+    {
+      stage_rows<HD>(K, HD, kv0, p.S, Ks, tid);
+      stage_rows<HD>(V, p.v_ss, kv0, p.S, Vs, tid);
+      stage_cols<HD>(KT, p.Sp, kv0, p.S, Kts, tid);
+    }
     __syncthreads();
     // one 32-key block at a time: S^T and dP^T accumulators (32 VGPRs) are dead before the next block starts, which keeps
     // the kernel under 256 VGPRs = two waves per SIMD
@@ -252,6 +257,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs p) {
     for (int t = q_begin; t < n_qt; ++t) {
       const int q0 = t * 64;
       __syncthreads();
+#ifdef AB_NO_STAGE
+      if (t == q_begin)
+#endif
+      {
       stage_rows<HD>(Q, (int64_t)p.H * HD, q0, p.S, Qs, tid);
       if (WHICH == 0) {
         stage_cols<HD>(DOT, p.Sp, q0, p.S, T1, tid);
@@ -260,6 +269,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs p) {
         stage_rows<HD>(DO, (int64_t)p.H * HD, q0, p.S, T1, tid);
         asm volatile("" ::: "memory");
         stage_cols<HD>(QT, p.Sp, q0, p.S, T2, tid);
+      }
       }
       if (tid < 64) {
         const int qq = min(q0 + tid, p.S - 1);
