@@ -352,15 +352,13 @@ extern "C" int a3v_attention_bwd_mfma(const void* q, const void* k, int64_t k_sb
   bf16_t* qt = kt + (int64_t)B * Hkv * hd * Sp;
   bf16_t* dot = qt + (int64_t)B * H * hd * Sp;
   int rc;
-  // K^T: per batch b, Hkv matrices [S, hd] (row stride hd, head stride k_sh) -> [hd, Sp]
-  for (int b = 0; b < B; ++b) {
-    rc = a3v_transpose((const bf16_t*)k + b * k_sb, hd, k_sh, kt + (int64_t)b * Hkv * hd * Sp, Sp, (int64_t)hd * Sp, S, hd, Sp, Hkv, A3V_BF16, stream);
-    if (rc) return rc;
-    rc = a3v_transpose((const bf16_t*)q + (int64_t)b * S * H * hd, (int64_t)H * hd, hd, qt + (int64_t)b * H * hd * Sp, Sp, (int64_t)hd * Sp, S, hd, Sp, H, A3V_BF16, stream);
-    if (rc) return rc;
-    rc = a3v_transpose((const bf16_t*)dout + (int64_t)b * S * H * hd, (int64_t)H * hd, hd, dot + (int64_t)b * H * hd * Sp, Sp, (int64_t)hd * Sp, S, hd, Sp, H, A3V_BF16, stream);
-    if (rc) return rc;
-  }
+  // K^T / Q^T / dO^T: all (batch, head) matrices [S, hd] -> [hd, Sp] of a tensor in ONE launch (24 small launches before)
+  rc = a3v_transpose_2level((const bf16_t*)k, hd, k_sh, k_sb, kt, Sp, (int64_t)hd * Sp, (int64_t)Hkv * hd * Sp, S, hd, Sp, Hkv, B, stream);
+  if (rc) return rc;
+  rc = a3v_transpose_2level((const bf16_t*)q, (int64_t)H * hd, hd, (int64_t)S * H * hd, qt, Sp, (int64_t)hd * Sp, (int64_t)H * hd * Sp, S, hd, Sp, H, B, stream);
+  if (rc) return rc;
+  rc = a3v_transpose_2level((const bf16_t*)dout, (int64_t)H * hd, hd, (int64_t)S * H * hd, dot, Sp, (int64_t)hd * Sp, (int64_t)H * hd * Sp, S, hd, Sp, H, B, stream);
+  if (rc) return rc;
   BwdArgs p;
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.dout = (const bf16_t*)dout;
   p.kt = kt; p.qt = qt; p.dot = dot; p.lse = lse; p.D = D;

@@ -33,10 +33,13 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ sr
 // bf16 fast path: 16-B global loads and stores, the 64 x 64 tile is transposed through LDS (row pitch 66 elements: the
 // eight 2-B column reads of a lane and the lanes of a wave fall on distinct banks).  C % 8 == 0, Rpad % 8 == 0, 16-B aligned.
 __global__ __launch_bounds__(256) void transpose_bf16_vec_kernel(const bf16_t* __restrict__ src, int64_t lds_, int64_t bs_s,
-                                                                 bf16_t* __restrict__ dst, int64_t ldd, int64_t bs_d, int R, int C, int Rpad) {
+                                                                 bf16_t* __restrict__ dst, int64_t ldd, int64_t bs_d, int R, int C, int Rpad,
+                                                                 int n_in = 0x7fffffff, int64_t bs_s2 = 0, int64_t bs_d2 = 0) {
   __shared__ uint32_t tile[64][33];                  // [row][column pair]: 66 bf16 per row
-  const bf16_t* s = src + blockIdx.z * bs_s;
-  bf16_t* d = dst + blockIdx.z * bs_d;
+  // two-level batch: z = outer * n_in + inner (one launch for all (batch, head) matrices of a [B, S, H, hd] activation)
+  const int zo = blockIdx.z / n_in, zi = blockIdx.z - zo * n_in;
+  const bf16_t* s = src + zi * bs_s + zo * bs_s2;
+  bf16_t* d = dst + zi * bs_d + zo * bs_d2;
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -562,6 +565,25 @@ extern "C" int a3v_transpose(const void* src, int64_t ld_src, int64_t bs_src, vo
   if (dtype == A3V_BF16) hipLaunchKernelGGL(transpose_kernel<bf16_t>, g, dim3(256), 0, ST, (const bf16_t*)src, ld_src, bs_src, (bf16_t*)dst, ld_dst, bs_dst, R, C, Rpad);
   else if (dtype == A3V_F32) hipLaunchKernelGGL(transpose_kernel<float>, g, dim3(256), 0, ST, (const float*)src, ld_src, bs_src, (float*)dst, ld_dst, bs_dst, R, C, Rpad);
   else return A3V_ERR_DTYPE;
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}
+
+// two-level batched bf16 transpose (internal: the attention backward's K^T / Q^T / dO^T images in one launch each)
+int a3v_transpose_2level(const bf16_t* src, int64_t ld_src, int64_t bs_in, int64_t bs_out, bf16_t* dst, int64_t ld_dst, int64_t bsd_in,
+                         int64_t bsd_out, int R, int C, int Rpad, int n_in, int n_out, void* stream) {
+  const bool vec = C % 8 == 0 && Rpad % 8 == 0 && ld_src % 8 == 0 && ld_dst % 8 == 0 && bs_in % 8 == 0 && bs_out % 8 == 0 && bsd_in % 8 == 0 &&
+                   bsd_out % 8 == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0 &&
+                   (int64_t)n_in * n_out <= 65535;
+  if (!vec) {
+    for (int o = 0; o < n_out; ++o) {
+      const int rc = a3v_transpose(src + o * bs_out, ld_src, bs_in, dst + o * bsd_out, ld_dst, bsd_in, R, C, Rpad, n_in, A3V_BF16, stream);
+      if (rc) return rc;
+    }
+    return A3V_OK;
+  }
+  dim3 g((C + 63) / 64, (Rpad + 63) / 64, n_in * n_out);
+  hipLaunchKernelGGL(transpose_bf16_vec_kernel, g, dim3(256), 0, ST, src, ld_src, bs_in, dst, ld_dst, bsd_in, R, C, Rpad, n_in, bs_out, bsd_out);
   A3V_LAUNCH_CHECK();
   return A3V_OK;
 }
