@@ -824,3 +824,40 @@ extern "C" int a3v_adamw(float* param, const float* grad, float* exp_avg, float*
   return A3V_OK;
 }
 
+// ------------------------------------------------------------------ LoRA step images: one adapter's share of a fused group
+// After an optimizer step the bf16 images of a fused adapter group (A [Rp, in] stacked lora_a, B [N, Rp] block-diagonal lora_b,
+// and their transposes At [in, Rp], Bt [Rp, Npad] for the backward GEMMs; model/peft.py:40-64 parameters) only change in the r
+// rows / columns this adapter owns.  One launch re-writes all four from the fp32 masters (was four strided torch copies).
+namespace {
+__global__ __launch_bounds__(256) void lora_refresh_kernel(const float* __restrict__ wa, const float* __restrict__ wb, int r, int in_f, int nj,
+                                                           bf16_t* __restrict__ A, int64_t lda, bf16_t* __restrict__ At, int64_t ldat,
+                                                           bf16_t* __restrict__ B, int64_t ldb, bf16_t* __restrict__ Bt, int64_t ldbt,
+                                                           int col0, int row0) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t < in_f) {                    // column t of lora_a [r, in]: A[col0 + i][t] and At[t][col0 + i]
+    for (int i = 0; i < r; ++i) {
+      const bf16_t v = f2bf(wa[(int64_t)i * in_f + t]);
+      A[(int64_t)(col0 + i) * lda + t] = v;
+      At[(int64_t)t * ldat + col0 + i] = v;
+    }
+  }
+  if (t < nj) {                      // row t of lora_b [nj, r]: B[row0 + t][col0 + i] and Bt[col0 + i][row0 + t]
+    for (int i = 0; i < r; ++i) {
+      const bf16_t v = f2bf(wb[(int64_t)t * r + i]);
+      B[(int64_t)(row0 + t) * ldb + col0 + i] = v;
+      Bt[(int64_t)(col0 + i) * ldbt + row0 + t] = v;
+    }
+  }
+}
+}  // namespace
+
+extern "C" int a3v_lora_refresh(const float* lora_a, const float* lora_b, int r, int in_f, int nj, void* A, int64_t lda, void* At,
+                                int64_t ldat, void* B, int64_t ldb, void* Bt, int64_t ldbt, int col0, int row0, void* stream) {
+  if (!lora_a || !lora_b || !A || !At || !B || !Bt || r <= 0 || in_f <= 0 || nj <= 0 || col0 < 0 || row0 < 0) return A3V_ERR_ARG;
+  const int n = in_f > nj ? in_f : nj;
+  hipLaunchKernelGGL(lora_refresh_kernel, dim3((n + 255) / 256), dim3(256), 0, ST, lora_a, lora_b, r, in_f, nj, (bf16_t*)A, lda, (bf16_t*)At, ldat,
+                     (bf16_t*)B, ldb, (bf16_t*)Bt, ldbt, col0, row0);
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}
+

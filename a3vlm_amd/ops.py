@@ -431,3 +431,17 @@ def rows_sum(src, row_idx, n_rows, out):
     _dev(src, row_idx, out)
     rc = _l.load().a3v_rows_sum(_p(src), src.stride(0), _p(row_idx), n_rows, src.shape[1], _p(out), dt(src), _stream())
     _l.check(rc, "a3v_rows_sum")
+
+
+def lora_refresh(wa, wb, A, At, B, Bt, col0: int, row0: int):
+    """One adapter's rows / columns of the fused group images (A, At, B, Bt; bf16) from its fp32 lora_a [r, in], lora_b [nj, r]."""
+    _dev(wa, wb, A, At, B, Bt)
+    assert wa.dtype == torch.float32 and wb.dtype == torch.float32 and wa.is_contiguous() and wb.is_contiguous()
+    assert all(t.dtype == torch.bfloat16 and t.stride(1) == 1 for t in (A, At, B, Bt))
+    r, in_f = wa.shape
+    nj = wb.shape[0]
+    assert wb.shape[1] == r and col0 + r <= A.shape[0] and in_f <= A.shape[1] and row0 + nj <= B.shape[0]
+    rc = _l.load().a3v_lora_refresh(_p(wa), _p(wb), r, in_f, nj, _p(A), A.stride(0), _p(At), At.stride(0), _p(B), B.stride(0), _p(Bt),
+                                    Bt.stride(0), col0, row0, _stream())
+    _l.check(rc, "a3v_lora_refresh")
+

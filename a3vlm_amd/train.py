@@ -263,8 +263,8 @@ class TrainEngine:
     # ------------------------------------------------------------------ LoRA adapters (model/peft.py semantics)
     def _lora_step_images(self):
         """A [Rp,in], B [N,Rp] (+ transposes for the backward GEMMs) of every adapter group in the compute dtype.  Built once;
-        after an optimizer step only the r rows / columns each adapter owns are re-written in place (four cast-copies per
-        adapter) -- rebuilding the padded / block-diagonal images from scratch was ~2500 small launches per step."""
+        after an optimizer step only the r rows / columns each adapter owns are re-written in place (one a3v_lora_refresh
+        launch per adapter) -- rebuilding the padded / block-diagonal images from scratch was ~2500 small launches per step."""
         m = self.m
         ver = tuple(param_state_key(q) for n, q in m.named_parameters() if "lora_" in n)
         if getattr(self, "_li_ver", None) == ver:
@@ -280,10 +280,13 @@ class TrainEngine:
                         for j, mod in enumerate(mods):
                             wa, wb = mod.lora_a.weight, mod.lora_b.weight          # [r, in], [N_j, r]
                             nj = wb.shape[0]
-                            A[j * r:(j + 1) * r].copy_(wa)
-                            At[:wa.shape[1], j * r:(j + 1) * r].copy_(wa.t())
-                            Bm[row:row + nj, j * r:(j + 1) * r].copy_(wb)
-                            Bt[j * r:(j + 1) * r, row:row + nj].copy_(wb.t())
+                            if self.act == torch.bfloat16 and wa.dtype == torch.float32 and wa.is_contiguous() and wb.is_contiguous():
+                                ops.lora_refresh(wa, wb, A, At, Bm, Bt, j * r, row)
+                            else:
+                                A[j * r:(j + 1) * r].copy_(wa)
+                                At[:wa.shape[1], j * r:(j + 1) * r].copy_(wa.t())
+                                Bm[row:row + nj, j * r:(j + 1) * r].copy_(wb)
+                                Bt[j * r:(j + 1) * r, row:row + nj].copy_(wb.t())
                             row += nj
             self._li_ver = ver
             return li
