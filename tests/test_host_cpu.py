@@ -106,3 +106,32 @@ def test_tokenizer_matches_reference_semantics(golden_dir):
     assert tk.need_space_before_segment == j["need_space_before_segment"]
     assert [tk.encode(p, bos=True, eos=False) for p in j["prompts"]] == j["prompt_ids"]
     assert tk.decode(j["gen12_ids"][2]) == j["gen12_text"][2]
+
+
+def test_param_state_key_counts_optimizer_steps():
+    """Weight-image caches are keyed on (Tensor._version, optimizer-step epoch): the epoch moves for every torch.optim optimizer
+    step that saw a gradient (fused optimizers do not bump _version), and only for those parameters."""
+    import torch
+    from a3vlm_amd.util import install_param_epoch_hook, param_state_key
+    install_param_epoch_hook()
+    install_param_epoch_hook()          # idempotent
+    a = torch.nn.Parameter(torch.ones(4))
+    b = torch.nn.Parameter(torch.ones(4))
+    opt = torch.optim.SGD([a, b], lr=0.1)
+    k0a, k0b = param_state_key(a), param_state_key(b)
+    a.grad = torch.ones(4)
+    opt.step()
+    assert param_state_key(a)[1] == k0a[1] + 1 and param_state_key(b) == k0b     # b had no gradient: untouched, key unchanged
+    opt.step()
+    assert param_state_key(a)[1] == k0a[1] + 2
+
+
+def test_fused_adamw_refuses_cpu_parameters():
+    """No CPU fallback in the optimizer either."""
+    import pytest
+    import torch
+    from a3vlm_amd.optim import FusedAdamW
+    p = torch.nn.Parameter(torch.ones(8))
+    p.grad = torch.ones(8)
+    with pytest.raises(Exception):
+        FusedAdamW([p], lr=1e-3).step()
