@@ -280,3 +280,22 @@ def test_gemm_nt_fp8_split_tail(M, N, K, mode):
         out = res.to(DEV).clone()
         ops.gemm_nt_fp8(aqd, sad, wqd, swd, out, residual=out, epilogue=ops.EPI_RES_F32)
         assert_close(out.cpu() - res, want, rtol=2 ** -7, atol=atol, what="fp8 f32 residual split tail")
+
+
+def test_gemm_nt_fp8_7b_size_scale_homogeneity():
+    """BASELINE-size property (wo of Llama-2-7B at 8728 tokens: rows in rounds + split-K tail): doubling the activation scales
+    doubles every output exactly (the scales enter once, in the epilogue, before the single bf16 rounding)."""
+    T, N, K = 8728, 4096, 4096
+    g = torch.Generator(device=DEV).manual_seed(6)
+    aq = torch.randint(0, 256, (T, K), device=DEV, generator=g, dtype=torch.uint8)
+    wq = torch.randint(0, 256, (N, K), device=DEV, generator=g, dtype=torch.uint8)
+    aq[(aq & 0x7f) == 0x7f] = 0x38       # no NaN encodings (e4m3fn: S.1111.111)
+    wq[(wq & 0x7f) == 0x7f] = 0x38
+    sa = torch.rand(T, device=DEV, generator=g) * 1e-3 + 1e-4
+    sw = torch.rand(N, device=DEV, generator=g) * 1e-3 + 1e-4
+    o1 = torch.empty(T, N, dtype=BF, device=DEV)
+    o2 = torch.empty_like(o1)
+    ops.gemm_nt_fp8(aq, sa, wq, sw, o1)
+    ops.gemm_nt_fp8(aq, sa * 2, wq, sw, o2)
+    assert torch.isfinite(o1.float()).all() and float(o1.float().abs().max()) > 0
+    assert torch.equal(o2.float(), o1.float() * 2)

@@ -590,3 +590,40 @@ def test_gemm_nn(M, N, K, mode):
         out = res.to(DEV).clone()
         ops.gemm_nn(a, wt, out, residual=out, epilogue=ops.EPI_RES_F32)
         assert_close(out.cpu() - res, want, rtol=2 ** -7, atol=atol, what="nn f32 residual")
+
+
+def test_weight_and_input_gradient_gemms_at_7b_size():
+    """BASELINE-size check of the TN / NN forms on the w2 shapes of Llama-2-7B at the bench's token count (8728, not a multiple
+    of 64): the transposed-operand kernels must agree with the NT kernel on materialised transposes (same products, same
+    per-lane k order; only the rows that go through a split-K tail may differ in fp32 summation order)."""
+    T, N, K = 8728, 4096, 11008
+    g = torch.Generator(device=DEV).manual_seed(5)
+    dy = (torch.randn(T, N, device=DEV, generator=g) * 0.05).to(BF)
+    x = (torch.randn(T, K, device=DEV, generator=g) * 0.5).to(BF)
+    w = (torch.randn(N, K, device=DEV, generator=g) * 0.02).to(BF)
+    # weight gradient dW[N, K] = dy^T x
+    Tp = (T + 63) // 64 * 64
+    dyt = torch.zeros(N, Tp, dtype=BF, device=DEV)
+    xt = torch.zeros(K, Tp, dtype=BF, device=DEV)
+    ops.transpose(dy, dyt, T, N, Tp)
+    ops.transpose(x, xt, T, K, Tp)
+    ref = torch.empty(N, K, dtype=torch.float32, device=DEV)
+    ops.gemm_nt(dyt, xt, ref, epilogue=ops.EPI_OUT_F32)
+    got = torch.empty_like(ref)
+    ops.gemm_tn(dy, x, got, epilogue=ops.EPI_OUT_F32)
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 2 ** -7 * scale and float((got - ref).abs().mean()) <= 1e-4 * scale
+    # input gradient dX[T, K] = dy W
+    wt = torch.empty(K, N, dtype=BF, device=DEV)
+    ops.transpose(w, wt, N, K, N)
+    ref2 = torch.empty(T, K, dtype=BF, device=DEV)
+    ops.gemm_nt(dy, wt, ref2)
+    got2 = torch.empty_like(ref2)
+    ops.gemm_nn(dy, w, got2)
+    s2 = float(ref2.float().abs().max())
+    d2 = (got2.float() - ref2.float()).abs()
+    assert float(d2.max()) <= 2 ** -6 * s2 and float((d2 > 0).float().mean()) < 0.02      # bf16 rounding flips only
+    # homogeneity of the TN product (a size-independent property that is exact in floating point): (2 a)^T x == 2 (a^T x)
+    o3 = torch.empty(N, K, dtype=torch.float32, device=DEV)
+    ops.gemm_tn((dy.float() * 2).to(BF), x, o3, epilogue=ops.EPI_OUT_F32)
+    assert torch.equal(o3, got * 2)
