@@ -31,6 +31,37 @@ if which == "13b":
     print(json.dumps({"model": "13b", "fwd_ms": round(dt * 1e3, 1), "samples_s": round(B / dt, 2), "mfma_frac": round(fl / dt / 2.5e15, 4),
                       "decode_ms": round(dd * 1e3, 3), "tok_s": round(B / dd, 1), "finite": bool(torch.isfinite(lg).all()),
                       "hbm_gib": round(torch.cuda.max_memory_allocated() / 2**30, 1)}))
+elif which == "13b_train":
+    # BASELINE configs[3]: 13B full fine-tune replica in 288 GB (fp32 masters + flat grads + AdamW state + bf16 images = 234 GB,
+    # block activations recomputed): one DP replica's step at micro-batch sys.argv[2] (default 1).
+    from a3vlm_amd.optim import FusedAdamW
+    from a3vlm_amd.train import TrainEngine
+    from a3vlm_amd.util import promote_trainable_params_to_fp32
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    T = 512
+    m, args = bench.build_model("13b", dev, 2048)
+    for n, p in m.named_parameters():
+        p.requires_grad = not n.startswith("clip.")
+    promote_trainable_params_to_fp32(m)
+    eng = TrainEngine(m, torch.bfloat16, recompute=True)
+    params = [p for p in m.parameters() if p.requires_grad]
+    opt = FusedAdamW(params, lr=2e-5, betas=(0.9, 0.95), weight_decay=0.0, engine=eng)
+    gen = torch.Generator(device=dev).manual_seed(1)
+    img = torch.randn(B, 3, 336, 336, device=dev, generator=gen)
+    tok = torch.randint(3, args.vocab_size, (B, T), device=dev, generator=gen); tok[:, 0] = 1
+    lab = tok.clone(); lab[:, :T // 2] = 0
+    times, losses = [], []
+    for it in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        loss = eng.forward_loss(tok, lab, img)
+        eng.backward(1.0)
+        opt.step(); opt.zero_grad(set_to_none=True)
+        torch.cuda.synchronize(); times.append(time.perf_counter() - t0); losses.append(round(float(loss), 4))
+        print(json.dumps({"step": it, "ms": round(times[-1] * 1e3, 1), "loss": losses[-1], "alloc_gib": round(torch.cuda.max_memory_allocated() / 2**30, 1),
+                          "reserved_gib": round(torch.cuda.max_memory_reserved() / 2**30, 1)}), flush=True)
+    ntr = sum(p.numel() for p in params)
+    print(json.dumps({"model": "13b full fine-tune replica", "micro_batch": B, "trainable_params": ntr, "ms_per_step": round(min(times[1:]) * 1e3, 1),
+                      "samples_s": round(B / min(times[1:]), 3), "losses": losses, "hbm_gib": round(torch.cuda.max_memory_allocated() / 2**30, 1)}))
 else:
     import dataclasses
     from a3vlm_amd.model.LLM import llama_ens5_2images as p2
