@@ -93,3 +93,17 @@ else:
     torch.cuda.synchronize(); dd = (time.perf_counter() - t0) / 16
     print(json.dumps({"model": "7b two-image", "S": S, "image_words": m.image_words, "fwd_ms": round(dt * 1e3, 1), "samples_s": round(B / dt, 2),
                       "decode_ms": round(dd * 1e3, 3), "tok_s": round(B / dd, 1), "finite": bool(torch.isfinite(lg).all())}))
+    # BASELINE configs[4]: the same two-image, 1024-token workload on the fp8 weight path (W8A8 prefill, weight-only fp8 decode)
+    m.quantize_decode_weights("fp8", prefill=True)
+    for _ in range(2): lg = m.forward_inference(tok, 0, img, dep)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(3): lg = m.forward_inference(tok, 0, img, dep)
+    torch.cuda.synchronize(); dt8 = (time.perf_counter() - t0) / 3
+    for i in range(2):
+        ops.argmax(lg, nt); cur[:, 0] = nt; lg = m.forward_inference(cur, T + i)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for i in range(16):
+        ops.argmax(lg, nt); cur[:, 0] = nt; lg = m.forward_inference(cur, T + 2 + i)
+    torch.cuda.synchronize(); dd8 = (time.perf_counter() - t0) / 16
+    print(json.dumps({"model": "7b two-image fp8 (configs[4])", "S": S, "fwd_ms": round(dt8 * 1e3, 1), "samples_s": round(B / dt8, 2),
+                      "decode_ms": round(dd8 * 1e3, 3), "tok_s": round(B / dd8, 1), "finite": bool(torch.isfinite(lg).all())}))
