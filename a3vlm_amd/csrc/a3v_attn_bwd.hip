@@ -96,6 +96,28 @@ __device__ __forceinline__ bf16x8 frag_cols(const char* lds, int db, int tb, int
   return f;
 }
 
+// The same A operand as frag_cols, taken from the ROW tile instead of a transposed copy: element e of lane (ql, hh) is
+// T[kv = 32 tb + 16 c + 4 hh + (e & 3) + 8 (e >> 2)][d = 32 db + ql], i.e. four consecutive rows of one column -- what gfx950's
+// ds_read_b64_tr_b16 delivers: the 16 lanes of a group pass the addresses of a 4 x 16 block (lane i: row i >> 2, columns
+// 4 (i & 3)..+3) and lane i receives column i (tools/ubench/trread.hip).  Rows r..r+3 carry different chunk swizzles, so the four
+// 32-B row segments of one read fall on different banks.
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+template <int HD>
+__device__ __forceinline__ bf16x8 frag_rows_tr(const char* lds, int db, int tb, int c, int lane) {
+  const int hh = lane >> 5, ql = lane & 31, i = lane & 15;
+  const int chunk16 = ((db * 32 + 16 * (ql >> 4)) >> 3) + ((i & 3) >> 1);
+  const int row0 = 32 * tb + 16 * c + 4 * hh + (i >> 2);
+  const int row1 = row0 + 8;
+  const int sw0 = (HD == 128) ? (row0 & 15) : ((row0 >> 1) & 7);
+  const int sw1 = (HD == 128) ? (row1 & 15) : ((row1 >> 1) & 7);
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(lds + row0 * (HD * 2) + ((chunk16 ^ sw0) << 4) + (i & 1) * 8));
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(lds + row1 * (HD * 2) + ((chunk16 ^ sw1) << 4) + (i & 1) * 8));
+  bf16x8 f;
+  const short v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  __builtin_memcpy(&f, v, 16);
+  return f;
+}
+
 // ------------------------------------------------------------------ dQ
 // 1-D grid -> (tile, head slot) with the XCD-aware order of attn_prefill_bf16_kernel: workgroup id & 7 is the XCD, and each XCD
 // takes a contiguous range of (head, tile) pairs so the K / V / Q / dO tiles a head's blocks share stay in one L2.
@@ -110,8 +132,8 @@ __device__ __forceinline__ void xcd_head_tile(int nt, int& head_slot, int& t) {
 template <int HD>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs p) {
   constexpr int TILE = 64 * HD * 2;                 // bytes of one 64-row tile (== HD x 128 B)
-  __shared__ __attribute__((aligned(16))) char lds[3 * TILE];
-  char* Ks = lds; char* Vs = lds + TILE; char* Kts = lds + 2 * TILE;
+  __shared__ __attribute__((aligned(16))) char lds[2 * TILE];
+  char* Ks = lds; char* Vs = lds + TILE;        // dQ^T += K^T . dS^T reads K^T fragments out of the K row tile (transpose reads)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nqt = (p.S + 127) / 128;
   int head_slot, ti;
@@ -125,7 +147,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs p) {
   const bf16_t* DO = p.dout + (((int64_t)b * p.S + qc) * p.H + h) * HD;
   const bf16_t* K = p.k + b * p.k_sb + hk * p.k_sh;
   const bf16_t* V = p.v + b * p.v_sb + hk * p.v_sh;
-  const bf16_t* KT = p.kt + ((int64_t)b * p.Hkv + hk) * HD * p.Sp;
   bf16x8 qf[HD / 16], dof[HD / 16];
 #pragma unroll
   for (int ks = 0; ks < HD / 16; ++ks) {
@@ -152,7 +173,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs p) {
     {
       stage_rows<HD>(K, HD, kv0, p.S, Ks, tid);
       stage_rows<HD>(V, p.v_ss, kv0, p.S, Vs, tid);
-      stage_cols<HD>(KT, p.Sp, kv0, p.S, Kts, tid);
     }
     __syncthreads();
     // one 32-key block at a time: S^T and dP^T accumulators (32 VGPRs) are dead before the next block starts, which keeps
@@ -193,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs p) {
       for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
         for (int c = 0; c < 2; ++c)
-          acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(Kts, d, tb, c, ql, hh), dsf[tb][c], acc[d], 0, 0, 0);
+          acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_tr<HD>(Ks, d, tb, c, lane), dsf[tb][c], acc[d], 0, 0, 0);
   }
   if (qrow < p.S) {
     bf16_t* O = p.dq + (((int64_t)b * p.S + qrow) * p.H + h) * HD;
