@@ -12,15 +12,14 @@
 //  dK/dV kernels (grid over kv tiles; loop over queries and the n_rep query heads; one launch per output):   lane <-> key
 //      S    = Q . K^T ,  dP = dO . V^T               (A = Q / dO rows from LDS, B = K / V in registers)
 //      P, dS with lse[q], D[q] per REGISTER row (read from LDS)
-//      dV^T += dO^T . P ,  dK^T += Q^T . dS          (A = dO^T / Q^T rows from LDS, B = P / dS)
-// K^T, Q^T, dO^T come from a3v_transpose into the caller's workspace; no atomics anywhere.
+//      dV^T += dO^T . P ,  dK^T += Q^T . dS          (A = dO^T / Q^T fragments by transpose reads of the dO / Q row tiles, B = P / dS)
+// No transposed copies of K, Q or dO exist (ds_read_b64_tr_b16 delivers the transposed MFMA operands); no atomics anywhere.
 #include "a3v_common.h"
 
 namespace {
 
 struct BwdArgs {
   const bf16_t* q; const bf16_t* k; const bf16_t* v; const bf16_t* dout;
-  const bf16_t* kt; const bf16_t* qt; const bf16_t* dot;      // [B,Hkv,hd,Sp], [B,H,hd,Sp], [B,H,hd,Sp]
   const float* lse; const float* D;                            // [B,H,S], [B,S,H]
   bf16_t* dq; bf16_t* dk; bf16_t* dv;
   int64_t k_sb, k_sh, v_sb, v_ss, v_sh;
@@ -45,34 +44,6 @@ __device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ base, int6
   }
 }
 
-// HD rows x 64 columns of a transposed operand [hd][Sp] -> LDS [HD][128 B] with the 8-B chunk swizzle of
-// the forward V^T tile; columns >= ncols are zero-filled (they multiply masked probabilities).
-template <int HD>
-__device__ __forceinline__ void stage_cols(const bf16_t* __restrict__ base, int64_t row_stride, int col0, int ncols, char* lds, int tid) {
-  constexpr int PER = HD * 8 / 256;
-#pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    const int id = tid + i * 256;
-    const int d = id >> 3, ch = id & 7;
-    const int c = col0 + ch * 8;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (c + 8 <= ncols) {
-      v = *reinterpret_cast<const u32x4*>(base + (int64_t)d * row_stride + c);
-    } else if (c < ncols) {
-      const unsigned short* src = reinterpret_cast<const unsigned short*>(base + (int64_t)d * row_stride + c);
-      unsigned short e[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) e[j] = (c + j < ncols) ? src[j] : (unsigned short)0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = (unsigned)e[2 * j] | ((unsigned)e[2 * j + 1] << 16);
-    }
-    const int g = (d >> 1) & 15;
-    const u32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
-    *reinterpret_cast<u32x2*>(lds + d * 128 + (((2 * ch) ^ g) << 3)) = lo;
-    *reinterpret_cast<u32x2*>(lds + d * 128 + (((2 * ch + 1) ^ g) << 3)) = hi;
-  }
-}
-
 // A operand fragment of a row tile: row (32 tb + lane&31), 16-B chunk 2 ks + hh
 template <int HD>
 __device__ __forceinline__ bf16x8 frag_rows(const char* lds, int tb, int ks, int ql, int hh) {
@@ -81,22 +52,8 @@ __device__ __forceinline__ bf16x8 frag_rows(const char* lds, int tb, int ks, int
   return *reinterpret_cast<const bf16x8*>(lds + row * (HD * 2) + (((2 * ks + hh) ^ sw) << 4));
 }
 
-// A operand fragment of a transposed tile for the accumulator-order contraction: row d = 32 db + lane&31,
-// elements at columns 32 tb + 16 c + 4 hh + {0..3, 8..11}
-__device__ __forceinline__ bf16x8 frag_cols(const char* lds, int db, int tb, int c, int ql, int hh) {
-  const int drow = db * 32 + ql;
-  const int g = (drow >> 1) & 15;
-  const char* vp = lds + drow * 128;
-  const int ca = 8 * tb + 4 * c + hh;
-  const u32x2 a0 = *reinterpret_cast<const u32x2*>(vp + ((ca ^ g) << 3));
-  const u32x2 a1 = *reinterpret_cast<const u32x2*>(vp + (((ca + 2) ^ g) << 3));
-  const u32x4 av = {a0[0], a0[1], a1[0], a1[1]};
-  bf16x8 f;
-  __builtin_memcpy(&f, &av, 16);
-  return f;
-}
-
-// The same A operand as frag_cols, taken from the ROW tile instead of a transposed copy: element e of lane (ql, hh) is
+// A operand of the accumulator-order contractions (dQ^T += K^T dS^T, dV^T += dO^T P^T, dK^T += Q^T dS^T), taken from the ROW tile
+// instead of a transposed copy: element e of lane (ql, hh) is
 // T[kv = 32 tb + 16 c + 4 hh + (e & 3) + 8 (e >> 2)][d = 32 db + ql], i.e. four consecutive rows of one column -- what gfx950's
 // ds_read_b64_tr_b16 delivers: the 16 lanes of a group pass the addresses of a 4 x 16 block (lane i: row i >> 2, columns
 // 4 (i & 3)..+3) and lane i receives column i (tools/ubench/trread.hip).  Rows r..r+3 carry different chunk swizzles, so the four
@@ -237,11 +194,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs p) {
 template <int HD, int WHICH>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs p) {
   constexpr int TILE = 64 * HD * 2;
-  constexpr int NT = WHICH == 0 ? 2 : 3;
+  constexpr int NT = 2;
   __shared__ __attribute__((aligned(16))) char lds[NT * TILE + 512];
-  char* Qs = lds;
-  char* T1 = lds + TILE;                    // dV: dO^T tile; dK: dO tile
-  char* T2 = lds + (NT - 1) * TILE;         // dK: Q^T tile
+  char* Qs = lds;                           // Q rows: S^T recompute (row fragments) and, for dK, the Q^T operand (transpose reads)
+  char* T1 = lds + TILE;                    // dO rows: dP^T (row fragments, dK) / the dO^T operand (transpose reads, dV)
   float* lse_s = reinterpret_cast<float*>(lds + NT * TILE);      // [64]
   float* D_s = lse_s + 64;                                       // [64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -272,8 +228,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs p) {
     const int h = hk * nrep + rep;
     const bf16_t* Q = p.q + ((int64_t)b * p.S * p.H + h) * HD;        // row stride H*HD
     const bf16_t* DO = p.dout + ((int64_t)b * p.S * p.H + h) * HD;
-    const bf16_t* QT = p.qt + ((int64_t)b * p.H + h) * HD * p.Sp;
-    const bf16_t* DOT = p.dot + ((int64_t)b * p.H + h) * HD * p.Sp;
     for (int t = q_begin; t < n_qt; ++t) {
       const int q0 = t * 64;
       __syncthreads();
@@ -282,14 +236,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs p) {
 #endif
       {
       stage_rows<HD>(Q, (int64_t)p.H * HD, q0, p.S, Qs, tid);
-      if (WHICH == 0) {
-        stage_cols<HD>(DOT, p.Sp, q0, p.S, T1, tid);
-      } else {
-        asm volatile("" ::: "memory");       // one tile's staging registers at a time (VGPR budget of two waves per SIMD)
-        stage_rows<HD>(DO, (int64_t)p.H * HD, q0, p.S, T1, tid);
-        asm volatile("" ::: "memory");
-        stage_cols<HD>(QT, p.Sp, q0, p.S, T2, tid);
-      }
+      asm volatile("" ::: "memory");         // one tile's staging registers at a time (VGPR budget of two waves per SIMD)
+      stage_rows<HD>(DO, (int64_t)p.H * HD, q0, p.S, T1, tid);
       }
       if (tid < 64) {
         const int qq = min(q0 + tid, p.S - 1);
@@ -324,14 +272,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs p) {
           }
         }
       }
-      const char* At = WHICH == 0 ? T1 : T2;
+      const char* At = WHICH == 0 ? T1 : Qs;      // dV^T += dO^T . P^T ; dK^T += Q^T . dS^T : transposed operands read out of the row tiles
 #pragma unroll
       for (int d = 0; d < HD / 32; ++d)
 #pragma unroll
         for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
           for (int c = 0; c < 2; ++c)
-            acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(At, d, tb, c, kl, hh), bf[tb][c], acc[d], 0, 0, 0);
+            acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_tr<HD>(At, d, tb, c, lane), bf[tb][c], acc[d], 0, 0, 0);
     }
   }
   if (kvrow < p.S) {
@@ -354,9 +302,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs p) {
 extern "C" int a3v_transpose(const void* src, int64_t ld_src, int64_t bs_src, void* dst, int64_t ld_dst, int64_t bs_dst,
                              int R, int C, int Rpad, int batch, int dtype, void* stream);
 
+// The MFMA path used to keep K^T / Q^T / dO^T images here; since the kernels read their transposed operands out of the row
+// tiles it needs no scratch.  A non-NULL `workspace` still selects the MFMA path (NULL = generic kernels): 256 bytes suffice.
 extern "C" int64_t a3v_attention_bwd_workspace_bytes(int B, int S, int H, int Hkv, int hd) {
-  const int64_t Sp = (S + 63) / 64 * 64;
-  return ((int64_t)B * Hkv + 2 * (int64_t)B * H) * hd * Sp * 2;
+  (void)B; (void)S; (void)H; (void)Hkv; (void)hd;
+  return 256;
 }
 
 // bf16 MFMA path of a3v_attention_bwd (called from a3v_train.hip); D must already hold rowsum(dO o O).
@@ -368,20 +318,11 @@ extern "C" int a3v_attention_bwd_mfma(const void* q, const void* k, int64_t k_sb
   if ((k_sb % 8) || (k_sh % 8) || (v_sb % 8) || (v_ss % 8) || (v_sh % 8)) return A3V_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   const int Sp = (S + 63) / 64 * 64;
-  bf16_t* kt = (bf16_t*)workspace;
-  bf16_t* qt = kt + (int64_t)B * Hkv * hd * Sp;
-  bf16_t* dot = qt + (int64_t)B * H * hd * Sp;
-  int rc;
-  // K^T / Q^T / dO^T: all (batch, head) matrices [S, hd] -> [hd, Sp] of a tensor in ONE launch (24 small launches before)
-  rc = a3v_transpose_2level((const bf16_t*)k, hd, k_sh, k_sb, kt, Sp, (int64_t)hd * Sp, (int64_t)Hkv * hd * Sp, S, hd, Sp, Hkv, B, stream);
-  if (rc) return rc;
-  rc = a3v_transpose_2level((const bf16_t*)q, (int64_t)H * hd, hd, (int64_t)S * H * hd, qt, Sp, (int64_t)hd * Sp, (int64_t)H * hd * Sp, S, hd, Sp, H, B, stream);
-  if (rc) return rc;
-  rc = a3v_transpose_2level((const bf16_t*)dout, (int64_t)H * hd, hd, (int64_t)S * H * hd, dot, Sp, (int64_t)hd * Sp, (int64_t)H * hd * Sp, S, hd, Sp, H, B, stream);
-  if (rc) return rc;
+  // (no transposed images: all three kernels take their transposed MFMA operands from the row tiles with ds_read_b64_tr_b16;
+  //  the workspace argument is kept for ABI stability and not touched)
   BwdArgs p;
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.dout = (const bf16_t*)dout;
-  p.kt = kt; p.qt = qt; p.dot = dot; p.lse = lse; p.D = D;
+  p.lse = lse; p.D = D;
   p.dq = (bf16_t*)dq; p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv;
   p.k_sb = k_sb; p.k_sh = k_sh; p.v_sb = v_sb; p.v_ss = v_ss; p.v_sh = v_sh;
   p.B = B; p.S = S; p.Sp = Sp; p.H = H; p.Hkv = Hkv; p.causal = causal;

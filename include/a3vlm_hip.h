@@ -305,8 +305,8 @@ int a3v_attention_bwd(const void* q, const void* k, int64_t k_sb, int64_t k_sh, 
                       int64_t v_sb, int64_t v_ss, int64_t v_sh, const void* out, const void* dout,
                       const float* lse, float* D, void* dq, void* dk, void* dv, void* workspace,
                       int B, int S, int H, int Hkv, int hd, int causal, int dtype, void* stream);
-/* bytes of `workspace` for the bf16 MFMA path (K^T, Q^T, dO^T images); workspace may be NULL, which
- * selects the generic (slow) kernels. */
+/* bytes of `workspace` for the bf16 MFMA path: a non-NULL workspace selects it (NULL = the generic, slow kernels).  The MFMA
+ * kernels no longer keep transposed K / Q / dO images there (transpose reads on the row tiles), so this is a token 256 bytes. */
 int64_t a3v_attention_bwd_workspace_bytes(int B, int S, int H, int Hkv, int hd);
 int a3v_attention_bwd_mfma(const void* q, const void* k, int64_t k_sb, int64_t k_sh, const void* v,
                            int64_t v_sb, int64_t v_ss, int64_t v_sh, const void* dout, const float* lse,
