@@ -22,6 +22,9 @@ struct BwdArgs {
   const bf16_t* q; const bf16_t* k; const bf16_t* v; const bf16_t* dout;
   const float* lse; const float* D;                            // [B,H,S], [B,S,H]
   bf16_t* dq; bf16_t* dk; bf16_t* dv;
+  // packed mode (dqkv != nullptr): the three kernels write straight into the gradient of the fused qkv activation
+  // [B*S, (H + 2 Hkv) * hd], q and k parts rotated back by -theta (the backward of apply_rotary_emb), instead of dq / dk / dv
+  bf16_t* dqkv; int64_t ld_qkv; const float* cos_sin; int rope_pos0;
   int64_t k_sb, k_sh, v_sb, v_ss, v_sh;
   int B, S, Sp, H, Hkv, causal;
   float scale;
@@ -73,6 +76,33 @@ __device__ __forceinline__ bf16x8 frag_rows_tr(const char* lds, int db, int tb, 
   const short v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   __builtin_memcpy(&f, v, 16);
   return f;
+}
+
+// Store one [32 x HD] accumulator set (lane: row `row`, 4 consecutive d at 32 db + 8 g4 + 4 hh) either as a plain [.., HD] row
+// (dst) or, in packed mode, into the fused-qkv gradient at column slot * HD with the inverse rotary rotation of position pos.
+template <int HD>
+__device__ __forceinline__ void store_grad_rows(const BwdArgs& p, f32x16 (&acc)[HD / 32], bf16_t* dst, int64_t prow, int slot, int pos,
+                                                bool rotate, int hh) {
+#pragma unroll
+  for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int dc = d * 32 + g4 * 8 + hh * 4;
+      float v0 = acc[d][g4 * 4 + 0], v1 = acc[d][g4 * 4 + 1], v2 = acc[d][g4 * 4 + 2], v3 = acc[d][g4 * 4 + 3];
+      bf16_t* o = dst + dc;
+      if (p.dqkv) {
+        o = p.dqkv + prow * p.ld_qkv + (int64_t)slot * HD + dc;
+        if (rotate) {      // dx = R(-theta) dy on the (even, odd) pairs (LLM/llama_ens5.py:123-135 backward)
+          const f32x4 cs = *reinterpret_cast<const f32x4*>(p.cos_sin + ((int64_t)pos * (HD / 2) + (dc >> 1)) * 2);
+          const float a0 = v0 * cs[0] + v1 * cs[1], a1 = -v0 * cs[1] + v1 * cs[0];
+          const float a2 = v2 * cs[2] + v3 * cs[3], a3 = -v2 * cs[3] + v3 * cs[2];
+          v0 = a0; v1 = a1; v2 = a2; v3 = a3;
+        }
+      }
+      bf16x4 ov;
+      ov[0] = f2bf(v0); ov[1] = f2bf(v1); ov[2] = f2bf(v2); ov[3] = f2bf(v3);
+      *reinterpret_cast<bf16x4*>(o) = ov;
+    }
 }
 
 // ------------------------------------------------------------------ dQ
@@ -172,18 +202,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs p) {
         for (int c = 0; c < 2; ++c)
           acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_tr<HD>(Ks, d, tb, c, lane), dsf[tb][c], acc[d], 0, 0, 0);
   }
-  if (qrow < p.S) {
-    bf16_t* O = p.dq + (((int64_t)b * p.S + qrow) * p.H + h) * HD;
-#pragma unroll
-    for (int d = 0; d < HD / 32; ++d)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        bf16x4 ov;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) ov[e] = f2bf(acc[d][g4 * 4 + e]);
-        *reinterpret_cast<bf16x4*>(O + d * 32 + g4 * 8 + hh * 4) = ov;
-      }
-  }
+  if (qrow < p.S)
+    store_grad_rows<HD>(p, acc, p.dq ? p.dq + (((int64_t)b * p.S + qrow) * p.H + h) * HD : nullptr, (int64_t)b * p.S + qrow, h,
+                        p.rope_pos0 + qrow, true, hh);
 }
 
 // ------------------------------------------------------------------ dK, dV
@@ -283,16 +304,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs p) {
     }
   }
   if (kvrow < p.S) {
-    bf16_t* O = (WHICH == 0 ? p.dv : p.dk) + (((int64_t)b * p.Hkv + hk) * p.S + kvrow) * HD;
-#pragma unroll
-    for (int d = 0; d < HD / 32; ++d)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        bf16x4 a;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) a[e] = f2bf(acc[d][g4 * 4 + e]);
-        *reinterpret_cast<bf16x4*>(O + d * 32 + g4 * 8 + hh * 4) = a;
-      }
+    bf16_t* base = WHICH == 0 ? p.dv : p.dk;
+    store_grad_rows<HD>(p, acc, base ? base + (((int64_t)b * p.Hkv + hk) * p.S + kvrow) * HD : nullptr, (int64_t)b * p.S + kvrow,
+                        WHICH == 0 ? p.H + p.Hkv + hk : p.H + hk, p.rope_pos0 + kvrow, WHICH == 1, hh);
   }
 }
 
@@ -309,12 +323,12 @@ extern "C" int64_t a3v_attention_bwd_workspace_bytes(int B, int S, int H, int Hk
   return 256;
 }
 
-// bf16 MFMA path of a3v_attention_bwd (called from a3v_train.hip); D must already hold rowsum(dO o O).
-extern "C" int a3v_attention_bwd_mfma(const void* q, const void* k, int64_t k_sb, int64_t k_sh, const void* v, int64_t v_sb,
-                                      int64_t v_ss, int64_t v_sh, const void* dout, const float* lse, const float* D, void* dq,
-                                      void* dk, void* dv, void* workspace, int B, int S, int H, int Hkv, int hd, int causal,
-                                      void* stream) {
-  if (!workspace || (hd != 64 && hd != 128)) return A3V_ERR_ARG;
+// the three MFMA kernels; D must already hold rowsum(dO o O)
+static int attention_bwd_mfma_impl(const void* q, const void* k, int64_t k_sb, int64_t k_sh, const void* v, int64_t v_sb,
+                                   int64_t v_ss, int64_t v_sh, const void* dout, const float* lse, const float* D, void* dq,
+                                   void* dk, void* dv, void* dqkv, int64_t ld_qkv, const float* cos_sin, int rope_pos0, int B, int S, int H,
+                                   int Hkv, int hd, int causal, void* stream) {
+  if (hd != 64 && hd != 128) return A3V_ERR_ARG;
   if ((k_sb % 8) || (k_sh % 8) || (v_sb % 8) || (v_ss % 8) || (v_sh % 8)) return A3V_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   const int Sp = (S + 63) / 64 * 64;
@@ -324,6 +338,7 @@ extern "C" int a3v_attention_bwd_mfma(const void* q, const void* k, int64_t k_sb
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.dout = (const bf16_t*)dout;
   p.lse = lse; p.D = D;
   p.dq = (bf16_t*)dq; p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv;
+  p.dqkv = (bf16_t*)dqkv; p.ld_qkv = ld_qkv; p.cos_sin = cos_sin; p.rope_pos0 = rope_pos0;
   p.k_sb = k_sb; p.k_sh = k_sh; p.v_sb = v_sb; p.v_ss = v_ss; p.v_sh = v_sh;
   p.B = B; p.S = S; p.Sp = Sp; p.H = H; p.Hkv = Hkv; p.causal = causal;
   p.scale = 1.0f / sqrtf((float)hd);
@@ -340,3 +355,25 @@ extern "C" int a3v_attention_bwd_mfma(const void* q, const void* k, int64_t k_sb
   A3V_LAUNCH_CHECK();
   return A3V_OK;
 }
+
+// bf16 MFMA path of a3v_attention_bwd (called from a3v_train.hip); D must already hold rowsum(dO o O).
+extern "C" int a3v_attention_bwd_mfma(const void* q, const void* k, int64_t k_sb, int64_t k_sh, const void* v, int64_t v_sb,
+                                      int64_t v_ss, int64_t v_sh, const void* dout, const float* lse, const float* D, void* dq,
+                                      void* dk, void* dv, void* workspace, int B, int S, int H, int Hkv, int hd, int causal,
+                                      void* stream) {
+  if (!workspace || !dq || !dk || !dv) return A3V_ERR_ARG;
+  return attention_bwd_mfma_impl(q, k, k_sb, k_sh, v, v_sb, v_ss, v_sh, dout, lse, D, dq, dk, dv, nullptr, 0, nullptr, 0, B, S, H, Hkv, hd,
+                                 causal, stream);
+}
+
+// Packed form: the gradient of the fused qkv activation in one go (dq | dk | dv columns of [B*S, (H + 2 Hkv) * hd], q and k parts
+// rotated back), i.e. a3v_attention_bwd + a3v_rope_bwd_pack without the dq / dk / dv round trip.  D as above.
+extern "C" int a3v_attention_bwd_mfma_packed(const void* q, const void* k, int64_t k_sb, int64_t k_sh, const void* v, int64_t v_sb,
+                                             int64_t v_ss, int64_t v_sh, const void* dout, const float* lse, const float* D, void* dqkv,
+                                             int64_t ld_qkv, const float* cos_sin, int rope_pos0, int B, int S, int H, int Hkv, int hd,
+                                             int causal, void* stream) {
+  if (!dqkv || !cos_sin || ld_qkv % 4 || rope_pos0 < 0) return A3V_ERR_ARG;
+  return attention_bwd_mfma_impl(q, k, k_sb, k_sh, v, v_sb, v_ss, v_sh, dout, lse, D, nullptr, nullptr, nullptr, dqkv, ld_qkv, cos_sin, rope_pos0,
+                                 B, S, H, Hkv, hd, causal, stream);
+}
+

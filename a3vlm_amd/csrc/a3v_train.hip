@@ -742,6 +742,32 @@ extern "C" int a3v_attention_bwd(const void* q, const void* k, int64_t k_sb, int
   return A3V_OK;
 }
 
+extern "C" int a3v_attention_bwd_mfma_packed(const void* q, const void* k, int64_t k_sb, int64_t k_sh, const void* v, int64_t v_sb,
+                                             int64_t v_ss, int64_t v_sh, const void* dout, const float* lse, const float* D, void* dqkv,
+                                             int64_t ld_qkv, const float* cos_sin, int rope_pos0, int B, int S, int H, int Hkv, int hd,
+                                             int causal, void* stream);
+
+// a3v_attention_bwd followed by a3v_rope_bwd_pack in one pass (bf16, hd 64 / 128 only: the MFMA kernels store the rotated-back
+// gradients straight into the fused-qkv gradient).  D: scratch [B, S, H] floats.
+extern "C" int a3v_attention_bwd_packed(const void* q, const void* k, int64_t k_sb, int64_t k_sh, const void* v, int64_t v_sb, int64_t v_ss,
+                                        int64_t v_sh, const void* out, const void* dout, const float* lse, float* D, void* dqkv,
+                                        int64_t ld_qkv, const float* cos_sin, int rope_pos0, int B, int S, int H, int Hkv, int hd, int causal,
+                                        int dtype, void* stream) {
+  if (!q || !k || !v || !out || !dout || !lse || !D || !dqkv || !cos_sin || B <= 0 || S <= 0) return A3V_ERR_ARG;
+  if (dtype != A3V_BF16) return A3V_ERR_DTYPE;
+  if ((hd != 64 && hd != 128) || (H % Hkv)) return A3V_ERR_SHAPE;
+  const int64_t rows = (int64_t)B * S * H;
+  if (((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(dout)) & 15) != 0)
+    hipLaunchKernelGGL(attn_rowdot_kernel<bf16_t>, dim3(B * S * H), dim3(64), 0, ST, (const bf16_t*)out, (const bf16_t*)dout, D, hd);
+  else if (hd == 128)
+    hipLaunchKernelGGL(attn_rowdot_vec_kernel<128>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, ST, (const bf16_t*)out, (const bf16_t*)dout, D, rows);
+  else
+    hipLaunchKernelGGL(attn_rowdot_vec_kernel<64>, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, ST, (const bf16_t*)out, (const bf16_t*)dout, D, rows);
+  A3V_LAUNCH_CHECK();
+  return a3v_attention_bwd_mfma_packed(q, k, k_sb, k_sh, v, v_sb, v_ss, v_sh, dout, lse, D, dqkv, ld_qkv, cos_sin, rope_pos0, B, S, H, Hkv, hd, causal,
+                                       stream);
+}
+
 extern "C" int a3v_embed_bwd(const int64_t* tokens, int64_t ld_tok, const float* dh, float* dtable, int B, int T, int W, int dim,
                              int vocab, void* stream) {
   if (!tokens || !dh || !dtable || B <= 0 || T <= 0) return A3V_ERR_ARG;

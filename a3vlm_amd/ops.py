@@ -421,6 +421,16 @@ def attention_bwd(q, k, k_sb, k_sh, v, v_sb, v_ss, v_sh, out, dout, lse, D, dq, 
     _l.check(rc, "a3v_attention_bwd")
 
 
+def attention_bwd_packed(q, k, k_sb, k_sh, v, v_sb, v_ss, v_sh, out, dout, lse, D, dqkv, cos_sin, B, S, H, Hkv, hd, causal: bool,
+                         rope_pos0: int = 0):
+    """attention backward + inverse RoPE + packing into the fused-qkv gradient in one pass (bf16, hd 64 / 128)."""
+    _dev(q, k, v, out, dout, lse, D, dqkv, cos_sin)
+    rc = _l.load().a3v_attention_bwd_packed(_p(q), _p(k), k_sb, k_sh, _p(v), v_sb, v_ss, v_sh, _p(out), _p(dout), _p(lse), _p(D),
+                                            _p(dqkv), dqkv.stride(0), _p(cos_sin), rope_pos0, B, S, H, Hkv, hd, 1 if causal else 0,
+                                            dt(q), _stream())
+    _l.check(rc, "a3v_attention_bwd_packed")
+
+
 def embed_bwd(tokens, dh, dtable, B, T, W, dim):
     _dev(tokens, dh, dtable)
     rc = _l.load().a3v_embed_bwd(_p(tokens), tokens.stride(0), _p(dh), _p(dtable), B, T, W, dim, dtable.shape[0], _stream())

@@ -31,6 +31,7 @@ class TrainEngine:
     fuse_qkv_rope = os.environ.get("A3V_FUSE_QKV_ROPE", "1") != "0"   # qkv GEMM with the RoPE / cache-write epilogue
     tn_wgrad = os.environ.get("A3V_TN_WGRAD", "1") != "0"              # weight gradients by a3v_gemm_tn (else transposes + NT)
     nn_dgrad = os.environ.get("A3V_NN_DGRAD", "1") != "0"              # input gradients by a3v_gemm_nn (else NT on W^T images)
+    packed_attn_bwd = os.environ.get("A3V_PACKED_ATTN_BWD", "1") != "0"  # attention backward writes the rotated-back qkv gradient itself
 
     def __init__(self, model, compute_dtype: torch.dtype = torch.bfloat16, recompute: Optional[bool] = None):
         """``recompute``: True = keep only each block's input and re-run the block in backward (the reference's
@@ -441,21 +442,26 @@ class TrainEngine:
         self._dgrad_w(dha, f"wo.{i}", datt)
         if self.lora:
             self._lora_bwd(i, f"wo.{i}", dha, k["att"], lt["wo"], datt)
-        dq = self._buf("dq", (rows, H * hd))
-        dk = self._buf("dk", (B, Hkv, S, hd))
-        dv = self._buf("dv", (B, Hkv, S, hd))
         D = self._buf("attn_D", (B, S, H), torch.float32)
         qkv = k["qkv"]
         ld = qkv.stride(0)
         vrows = qkv[:, (H + Hkv) * hd:]
         spad = k["spad"]
-        wsp = None
-        if self.act == torch.bfloat16 and hd in (64, 128):
-            wsp = self._buf("attn_bwd_ws", (ops.attention_bwd_workspace_bytes(B, S, H, Hkv, hd),), torch.uint8)
-        ops.attention_bwd(k["qrot"], k["kc"], Hkv * spad * hd, spad * hd, vrows, S * ld, ld, hd, k["att"], datt, k["lse"], D,
-                          dq, dk, dv, B, S, H, Hkv, hd, True, workspace=wsp)
         dqkv = self._buf("dqkv", (rows, (H + 2 * Hkv) * hd))
-        ops.rope_bwd_pack(dq, dk, dv, dqkv, m._cos_sin_dev(), B, S, H, Hkv, hd, 0)
+        if self.act == torch.bfloat16 and hd in (64, 128) and self.packed_attn_bwd:
+            # the MFMA kernels rotate dq / dk back and store [dq | dk | dv] straight into the fused-qkv gradient
+            ops.attention_bwd_packed(k["qrot"], k["kc"], Hkv * spad * hd, spad * hd, vrows, S * ld, ld, hd, k["att"], datt, k["lse"], D,
+                                     dqkv, m._cos_sin_dev(), B, S, H, Hkv, hd, True, 0)
+        else:
+            dq = self._buf("dq", (rows, H * hd))
+            dk = self._buf("dk", (B, Hkv, S, hd))
+            dv = self._buf("dv", (B, Hkv, S, hd))
+            wsp = None
+            if self.act == torch.bfloat16 and hd in (64, 128):
+                wsp = self._buf("attn_bwd_ws", (ops.attention_bwd_workspace_bytes(B, S, H, Hkv, hd),), torch.uint8)
+            ops.attention_bwd(k["qrot"], k["kc"], Hkv * spad * hd, spad * hd, vrows, S * ld, ld, hd, k["att"], datt, k["lse"], D,
+                              dq, dk, dv, B, S, H, Hkv, hd, True, workspace=wsp)
+            ops.rope_bwd_pack(dq, dk, dv, dqkv, m._cos_sin_dev(), B, S, H, Hkv, hd, 0)
         if self._has(pre + "attention.wq.weight", pre + "attention.wk.weight", pre + "attention.wv.weight"):
             self._wgrad(dqkv, k["xn"], self._gview(pre + "attention.wq.weight", pre + "attention.wv.weight"), "qkv",
                         (pre + "attention.wq.weight", pre + "attention.wk.weight", pre + "attention.wv.weight"))

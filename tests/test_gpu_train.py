@@ -306,6 +306,7 @@ def test_train_step_bf16_tn_weight_gradients():
         promote_trainable_params_to_fp32(m)
         eng = TrainEngine(m, BF)
         eng.tn_wgrad = eng.fuse_qkv_rope = eng.nn_dgrad = tn      # also: fused qkv / RoPE / cache epilogue, NN input gradients
+        # (packed_attn_bwd stays on in both: it moves a bf16 rounding point, see test_attention_bwd_packed_equals_bwd_then_rope_pack)
         for scale in (1.0, 0.5):
             eng.forward_loss(ex.to(DEV), lab.to(DEV), None)
             eng.backward(scale)
@@ -352,3 +353,40 @@ def test_metamodel_loss_backward_drop_in(golden_dir=None):
     opt.zero_grad()
     loss2, _ = mm(ex.to(DEV), lab.to(DEV))
     assert float(loss2) < float(loss)       # one AdamW step on the same batch reduces the loss
+
+
+@pytest.mark.parametrize("B,S,H,Hkv,hd", [(2, 150, 4, 4, 128), (1, 77, 4, 2, 64), (2, 1091, 4, 4, 128)])
+def test_attention_bwd_packed_equals_bwd_then_rope_pack(B, S, H, Hkv, hd):
+    """a3v_attention_bwd_packed == a3v_attention_bwd + a3v_rope_bwd_pack: the only difference allowed is the rounding point
+    (the packed form rotates the fp32 accumulator and rounds once; the two-pass form rounds dq / dk to bf16 first)."""
+    from a3vlm_amd.model.LLM.llama_ens5 import precompute_cos_sin
+    g = torch.Generator().manual_seed(B * 100 + S)
+    sp = (S + 63) // 64 * 64
+    q = (torch.randn(B, S, H, hd, generator=g)).to(BF).to(DEV)
+    kc = torch.zeros(B, Hkv, sp, hd, dtype=BF, device=DEV)
+    kc[:, :, :S] = torch.randn(B, Hkv, S, hd, generator=g).to(BF).to(DEV)
+    v = torch.randn(B, S, Hkv, hd, generator=g).to(BF).to(DEV)
+    vt = torch.zeros(B, Hkv, hd, sp, dtype=BF, device=DEV)
+    vt[:, :, :, :S] = v.permute(0, 2, 3, 1)
+    o = torch.empty_like(q)
+    lse = torch.empty(B, H, S, device=DEV)
+    st = (S * H * hd, H * hd, hd, Hkv * sp * hd, sp * hd, hd, Hkv * hd * sp, hd * sp, sp, S * H * hd, H * hd, hd)
+    ops.attention_lse(q, kc, vt, o, lse, B, S, S, H, Hkv, hd, st, True)
+    do = torch.randn(B, S, H, hd, generator=g).to(BF).to(DEV)
+    cs = precompute_cos_sin(hd, 2 * sp, 10000.0, None).to(DEV)
+    D = torch.empty(B, S, H, device=DEV)
+    N = (H + 2 * Hkv) * hd
+    dq = torch.empty_like(q)
+    dk = torch.empty(B, Hkv, S, hd, dtype=BF, device=DEV)
+    dv = torch.empty_like(dk)
+    ws = torch.empty(ops.attention_bwd_workspace_bytes(B, S, H, Hkv, hd), dtype=torch.uint8, device=DEV)
+    ops.attention_bwd(q, kc, Hkv * sp * hd, sp * hd, v, S * Hkv * hd, Hkv * hd, hd, o, do, lse, D, dq, dk, dv, B, S, H, Hkv, hd, True, workspace=ws)
+    ref = torch.zeros(B * S, N + 8, dtype=BF, device=DEV)
+    ops.rope_bwd_pack(dq, dk, dv, ref[:, :N], cs, B, S, H, Hkv, hd, 0)
+    got = torch.full((B * S, N + 8), 7.0, dtype=BF, device=DEV)
+    ops.attention_bwd_packed(q, kc, Hkv * sp * hd, sp * hd, v, S * Hkv * hd, Hkv * hd, hd, o, do, lse, D, got[:, :N], cs, B, S, H, Hkv, hd, True, 0)
+    assert float((got[:, N:].float() - 7.0).abs().max()) == 0                   # nothing written past the row
+    a, b = got[:, :N].float(), ref[:, :N].float()
+    scale = float(b.abs().max())
+    assert float((a - b).abs().max()) <= 2 ** -6 * scale
+    assert torch.equal(got[:, (H + Hkv) * hd:N], ref[:, (H + Hkv) * hd:N])       # dv is not rotated: identical
