@@ -160,6 +160,12 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GemmAr
           // v[] = the bf16 qkv values of token (b, s), columns n..n+3 of head slot n >> hd_shift: rotate the two (even, odd)
           // pairs of q / k by the token's position (LLM/llama_ens5.py:123-135 apply_rotary_emb); v passes through
           const RopeKvArgs& k = p.rk;
+          if (epi & A3V_EPI_RESIDUAL) {      // an additive term of the projection (the LoRA branch, model/peft.py:89-95): the
+            // reference adds it to the bf16 linear output and rounds, before the rotation
+            const bf16x4 rr = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(p.res) + (int64_t)m * p.ldr + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = rbf(bf2f(rr[r]) + v[r]);
+          }
           const int mg = m + k.m_off;
           const int sq = mg - (mg / k.S) * k.S;
           const int slot = n >> k.hd_shift, d = n & ((1 << k.hd_shift) - 1);
@@ -1829,16 +1835,18 @@ extern "C" int a3v_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ld
 // xq, xk, xv = wq(x), wk(x), wv(x); apply_rotary_emb; cache_k / cache_v[:bsz, start_pos:start_pos+seqlen] = xk / xv).
 // Same values as a3v_gemm_nt followed by a3v_rope_kvcache (the accumulator is rounded to the bf16 qkv value first).
 extern "C" int a3v_gemm_qkv_rope(const void* A, int64_t lda, const void* W, int64_t ldw, int K, void* q_out, int64_t ldq,
-                                 void* k_cache, void* vt_cache, void* v_rows, int64_t ldv, const float* cos_sin, int B, int S,
-                                 int H, int Hkv, int hd, int Smax, int start_pos, int rope_pos0, void* stream) {
+                                 void* k_cache, void* vt_cache, void* v_rows, int64_t ldv, const void* delta, int64_t ldd,
+                                 const float* cos_sin, int B, int S, int H, int Hkv, int hd, int Smax, int start_pos, int rope_pos0,
+                                 void* stream) {
   if (!q_out || !k_cache || !vt_cache || !cos_sin || B <= 0 || S <= 0 || H <= 0 || Hkv <= 0) return A3V_ERR_ARG;
-  if ((hd != 64 && hd != 128) || ldq % 4 || (v_rows && ldv % 4) || start_pos < 0 || start_pos + S > Smax) return A3V_ERR_SHAPE;
+  if ((hd != 64 && hd != 128) || ldq % 4 || (v_rows && ldv % 4) || (delta && ldd % 4) || start_pos < 0 || start_pos + S > Smax) return A3V_ERR_SHAPE;
   RopeKvArgs rk;
   rk.q_out = (bf16_t*)q_out; rk.k_cache = (bf16_t*)k_cache; rk.vt_cache = (bf16_t*)vt_cache; rk.cos_sin = cos_sin;
   rk.v_rows = (bf16_t*)v_rows; rk.ldv = ldv;
   rk.ldq = ldq; rk.S = S; rk.H = H; rk.Hkv = Hkv; rk.hd_shift = hd == 128 ? 7 : 6; rk.Smax = Smax;
   rk.start_pos = start_pos; rk.rope_pos0 = rope_pos0; rk.m_off = 0;
-  return gemm_nt_impl(A, lda, W, ldw, q_out, ldq, B * S, (H + 2 * Hkv) * hd, K, nullptr, nullptr, 0, 0, A3V_BF16, stream, &rk);
+  return gemm_nt_impl(A, lda, W, ldw, q_out, ldq, B * S, (H + 2 * Hkv) * hd, K, nullptr, delta, ldd, delta ? A3V_EPI_RESIDUAL : 0, A3V_BF16,
+                      stream, &rk);
 }
 
 // split-K factor of the DMA GEMV: enough blocks (row groups x S >= 1024) for 256 CUs, S <= 8, S <= number of ring stages

@@ -23,7 +23,7 @@ P, I, L, F = c_void_p, c_int, c_int64, c_float
 SIGNATURES = {
     "a3v_version": (I, []),
     "a3v_gemm_nt": (I, [P, L, P, L, P, L, I, I, I, P, P, L, I, I, P]),
-    "a3v_gemm_qkv_rope": (I, [P, L, P, L, I, P, L, P, P, P, L, P, I, I, I, I, I, I, I, I, P]),
+    "a3v_gemm_qkv_rope": (I, [P, L, P, L, I, P, L, P, P, P, L, P, L, P, I, I, I, I, I, I, I, I, P]),
     "a3v_gemm_nt_fp8": (I, [P, L, P, P, L, P, P, L, I, I, I, P, P, L, I, P]),
     "a3v_gemm_qkv_rope_fp8": (I, [P, L, P, P, L, P, I, P, L, P, P, P, I, I, I, I, I, I, I, I, P]),
     "a3v_quantize_rows_fp8": (I, [P, L, P, F, P, L, P, I, I, I, P]),

@@ -231,14 +231,15 @@ def rope_kvcache(qkv, q_out, k_cache, vt_cache, cos_sin, B, S, H, Hkv, hd, start
     _l.check(rc, "a3v_rope_kvcache")
 
 
-def gemm_qkv_rope(x, wqkv, qkv, k_cache, vt_cache, cos_sin, B, S, H, Hkv, hd, start_pos, rope_pos0, v_rows=None):
+def gemm_qkv_rope(x, wqkv, qkv, k_cache, vt_cache, cos_sin, B, S, H, Hkv, hd, start_pos, rope_pos0, v_rows=None, delta=None):
     """qkv GEMM with RoPE + KV-cache write in the epilogue: rotated q lands in qkv[:, :H*hd] (further columns are not
     written), rotated k in k_cache, v transposed in vt_cache (and token-major in v_rows if given) -- the values of gemm_nt
-    followed by rope_kvcache."""
-    _dev(x, wqkv, qkv, k_cache, vt_cache, cos_sin, v_rows)
+    followed by rope_kvcache.  ``delta`` [B*S, N] (bf16): added to the projection before the rotation (the LoRA branch)."""
+    _dev(x, wqkv, qkv, k_cache, vt_cache, cos_sin, v_rows, delta)
     assert x.shape[0] == B * S and wqkv.shape[0] == (H + 2 * Hkv) * hd and x.dtype == torch.bfloat16
     rc = _l.load().a3v_gemm_qkv_rope(_p(x), x.stride(0), _p(wqkv), wqkv.stride(0), x.shape[1], _p(qkv), qkv.stride(0),
                                      _p(k_cache), _p(vt_cache), _p(v_rows), v_rows.stride(0) if v_rows is not None else 0,
+                                     _p(delta), delta.stride(0) if delta is not None else 0,
                                      _p(cos_sin), B, S, H, Hkv, hd, k_cache.shape[2], start_pos, rope_pos0, _stream())
     _l.check(rc, "a3v_gemm_qkv_rope")
 

@@ -369,6 +369,17 @@ class TrainEngine:
             # RoPE + K / V^T writes in the GEMM epilogue; v also token-major in its qkv columns for the attention backward
             ops.gemm_qkv_rope(xn, im[f"qkv.{i}"], qrot, kc, vc, m._cos_sin_dev(), B, S, H, Hkv, hd, 0, 0,
                               v_rows=qkv[:, (H + Hkv) * hd:])
+        elif self.lora and self.act == torch.bfloat16 and hd in (64, 128) and rows > 16 and self.fuse_qkv_rope:
+            # adapters: the LoRA term t . B^T is written into the qkv buffer first and enters the fused GEMM as an additive term
+            # before the rotation (the reference's order: linear output + modification, rounded, then RoPE)
+            li = self._lora_step_images()
+            A, Bm = li[f"qkv.{i}.A"], li[f"qkv.{i}.B"]
+            t = self._buf("lora_t.qkv" + tag, (rows, A.shape[0]))
+            self._skinny(xn, A, t)
+            ops.gemm_nt(t, Bm, qkv)
+            ops.gemm_qkv_rope(xn, im[f"qkv.{i}"], qrot, kc, vc, m._cos_sin_dev(), B, S, H, Hkv, hd, 0, 0,
+                              v_rows=qkv[:, (H + Hkv) * hd:], delta=qkv)
+            lt["qkv"] = t
         else:
             ops.gemm_nt(xn, im[f"qkv.{i}"], qkv)
             if self.lora:

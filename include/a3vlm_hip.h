@@ -73,10 +73,13 @@ int a3v_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ldw, void* C,
  * a3v_gemm_nt on the fused [(H+2Hkv)*hd, K] weight followed by a3v_rope_kvcache, value for value (the accumulator is rounded
  * to the bf16 activation before the rotation), minus one HBM round trip of the [B*S, (H+2Hkv)*hd] activation.
  * A [B*S, K] bf16; q_out [B*S, ldq] receives the rotated q in columns 0..H*hd; caches as a3v_rope_kvcache; hd 64 or 128.
- * v_rows (optional, [B*S, ldv]): v also stored token-major, the layout the attention backward reads (training forward). */
+ * v_rows (optional, [B*S, ldv]): v also stored token-major, the layout the attention backward reads (training forward).
+ * delta (optional, bf16 [B*S, ldd]): an additive term of the projection -- the LoRA branch lora_b(lora_a(x)) of model/peft.py:89-95
+ * -- added to the bf16 linear output (and rounded, as the reference does) before the rotation; may alias v_rows' buffer. */
 int a3v_gemm_qkv_rope(const void* A, int64_t lda, const void* W, int64_t ldw, int K, void* q_out, int64_t ldq,
-                      void* k_cache, void* vt_cache, void* v_rows, int64_t ldv, const float* cos_sin, int B, int S,
-                      int H, int Hkv, int hd, int Smax, int start_pos, int rope_pos0, void* stream);
+                      void* k_cache, void* vt_cache, void* v_rows, int64_t ldv, const void* delta, int64_t ldd,
+                      const float* cos_sin, int B, int S, int H, int Hkv, int hd, int Smax, int start_pos, int rope_pos0,
+                      void* stream);
 
 /* fp8 (OCP e4m3fn) W8A8 prefill GEMM (BASELINE config 5 "quantised inference"; the reference's quantised path is bitsandbytes
  * NF4/INT8, util/quant.py:95-163, so there is no reference oracle: parity is stated against the exact product of the

@@ -627,3 +627,29 @@ def test_weight_and_input_gradient_gemms_at_7b_size():
     o3 = torch.empty(N, K, dtype=torch.float32, device=DEV)
     ops.gemm_tn((dy.float() * 2).to(BF), x, o3, epilogue=ops.EPI_OUT_F32)
     assert torch.equal(o3, got * 2)
+
+
+def test_gemm_qkv_rope_with_additive_term():
+    """The LoRA form of the fused projection: delta is added to the bf16 linear output (rounded) before the rotation ==
+    gemm_nt with the bf16 residual epilogue followed by rope_kvcache, bit for bit; delta may live in the buffer that receives
+    the token-major v (same element read, then written, by one lane)."""
+    from a3vlm_amd.model.LLM.llama_ens5 import precompute_cos_sin
+    B, S, H, Hkv, hd, K = 3, 211, 4, 2, 128, 256
+    rows, N = B * S, (H + 2 * Hkv) * hd
+    Smax = 256
+    x = gen(rows, K, seed=101).to(BF).to(DEV)
+    w = gen(N, K, seed=102, scale=0.05).to(BF).to(DEV)
+    delta = gen(rows, N, seed=103, scale=0.3).to(BF).to(DEV)
+    cs = precompute_cos_sin(hd, 2 * Smax, 10000.0, None).to(DEV)
+    qkv = delta.clone()
+    ops.gemm_nt(x, w, qkv, residual=qkv)                   # bf16(acc) + delta, rounded
+    kc0 = torch.zeros(B, Hkv, Smax, hd, dtype=BF, device=DEV)
+    vc0 = torch.zeros(B, Hkv, hd, Smax, dtype=BF, device=DEV)
+    ops.rope_kvcache(qkv, qkv, kc0, vc0, cs, B, S, H, Hkv, hd, 0, 0)
+    buf = delta.clone()
+    qrot = torch.zeros(rows, H * hd, dtype=BF, device=DEV)
+    kc1, vc1 = torch.zeros_like(kc0), torch.zeros_like(vc0)
+    ops.gemm_qkv_rope(x, w, qrot, kc1, vc1, cs, B, S, H, Hkv, hd, 0, 0, v_rows=buf[:, (H + Hkv) * hd:], delta=buf)
+    assert torch.equal(qrot, qkv[:, :H * hd]) and torch.equal(kc1, kc0) and torch.equal(vc1, vc0)
+    assert torch.equal(buf[:, (H + Hkv) * hd:], qkv[:, (H + Hkv) * hd:])
+    assert torch.equal(buf[:, :(H + Hkv) * hd], delta[:, :(H + Hkv) * hd])       # the q / k columns of delta are only read
