@@ -139,9 +139,19 @@ class Transformer(base.Transformer):
             kc, vc = k_caches[i], vt_caches[i]
             smax = kc.shape[2]
             ops.rmsnorm(h, lyr.attention_norm.weight, xn, a.norm_eps)
-            self._linear(xn, pk[f"wqkv.{i}"], qkv)
-            self._lora_add(f"qkv.{i}", xn, qkv)
-            ops.rope_kvcache(qkv, qkv, kc, vc, cs, B, S, H, Hkv, hd, start_pos, rope_pos0)
+            if rows > 16 and h.dtype == torch.bfloat16 and hd in (64, 128) and self._fuse_qkv_rope:
+                # prefill: the adapter term is written into the qkv buffer and enters the fused qkv / RoPE / cache GEMM as an
+                # additive term before the rotation (in place: a lane reads its delta before it stores the rotated q)
+                im = self.lora_images()
+                A, Bm = im[f"qkv.{i}.A"], im[f"qkv.{i}.B"]
+                t = self._buf("lora_t", (rows, A.shape[0]))
+                self._linear(xn, A, t)
+                self._linear(t, Bm, qkv)
+                ops.gemm_qkv_rope(xn, pk[f"wqkv.{i}"], qkv, kc, vc, cs, B, S, H, Hkv, hd, start_pos, rope_pos0, delta=qkv)
+            else:
+                self._linear(xn, pk[f"wqkv.{i}"], qkv)
+                self._lora_add(f"qkv.{i}", xn, qkv)
+                ops.rope_kvcache(qkv, qkv, kc, vc, cs, B, S, H, Hkv, hd, start_pos, rope_pos0)
             strides = (S * ldq, ldq, hd, Hkv * smax * hd, smax * hd, hd, Hkv * hd * smax, hd * smax, smax, S * H * hd, H * hd, hd)
             ops.attention(qkv, kc, vc, att, B, S, Sk, H, Hkv, hd, strides, causal and S > 1, scratch)
             # out = wo(att) + lora (rounded), then the residual add -- the reference's order (peft.py:95, llama_ens5.py:238)

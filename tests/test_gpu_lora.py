@@ -215,3 +215,35 @@ def test_lora_step_images_refresh_in_place_after_optimizer_step():
             assert set(li) == set(fresh)
             for k in li:
                 assert torch.equal(li[k], fresh[k]), k
+
+
+def test_lora_prefill_fused_qkv_matches_separate_kernels():
+    """peft plugin, head_dim 64, prefill of 61 tokens + two decode steps: with the adapter term folded into the fused qkv / RoPE /
+    cache GEMM the logits and caches are bit-identical to the separate kernels (same rounding points), and close to the oracle."""
+    big = dict(dim=256, n_layers=2, n_heads=4, n_kv_heads=2, vocab_size=320, multiple_of=256, max_seq_len=256)
+    oargs = ref_cpu.OracleArgs(**big)
+    sd = ref_cpu.make_decoder_weights(oargs, seed=3, std=0.05)
+    lsd = ref_cpu.make_lora_weights(oargs, RANK, seed=6, std_a=0.05, std_b=0.05)
+    m = peft.Transformer(peft.ModelArgs(**big, lora_rank=RANK), with_visual=False)
+    m.load_state_dict({**sd, **lsd}, strict=True)
+    m.to(BF).to(DEV)
+    g = torch.Generator().manual_seed(12)
+    B, T0 = 3, 61
+    ex = torch.randint(3, 320, (B, T0 + 2), generator=g)
+    ex[:, 0] = 1
+    exd = ex.to(DEV)
+    got = {}
+    for fuse in (True, False):
+        m._fuse_qkv_rope = fuse
+        lg = [m.forward_inference(exd[:, :T0], 0).float().clone()]
+        for t in range(T0, T0 + 2):
+            lg.append(m.forward_inference(exd[:, t:t + 1], t).float().clone())
+        got[fuse] = (lg, [k.clone() for k in m._k_cache], [v.clone() for v in m._vt_cache])
+    for a, b in zip(got[True][0], got[False][0]):
+        assert torch.equal(a, b)
+    for l in range(2):
+        assert torch.equal(got[True][1][l][:, :, :T0 + 2], got[False][1][l][:, :, :T0 + 2])
+        assert torch.equal(got[True][2][l][:, :, :, :T0 + 2], got[False][2][l][:, :, :, :T0 + 2])
+    dec = ref_cpu.OracleDecoder(oargs, {k: v.to(BF) for k, v in {**sd, **lsd}.items()})
+    want = dec.forward_inference(ex[:, :T0], 0).float()
+    assert float((got[True][0][0].cpu() - want).abs().max()) / float(want.abs().max()) < 4e-2
