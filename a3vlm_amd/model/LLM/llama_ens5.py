@@ -429,7 +429,6 @@ class Transformer(nn.Module):
         The single-call decode step streams them weight-only (half the bytes, bf16 activations).  ``prefill=True`` also runs
         the multi-token forward W8A8 (a3v_gemm_nt_fp8: activations quantised per token on the fly); otherwise prefill keeps
         the bf16 weights.  ``mode=None`` drops the images.  Re-run after the weights change."""
-        from ...quant import quantize_rows_fp8
         self._q8 = None
         self._fp8_prefill = bool(prefill) and mode is not None
         self._layer_tab_key = None
@@ -442,10 +441,16 @@ class Transformer(nn.Module):
             raise ValueError("fp8 decode weights need bf16 parameters and dim, ffn, n_heads*head_dim multiples of 256")
         pk = self._pack(check=True)
         q8 = []
+
+        def quant(w):                      # per-row e4m3 image + fp32 scales by the HIP quantiser (a3v_quantize_rows_fp8)
+            q = torch.empty(w.shape, dtype=torch.uint8, device=w.device)
+            sc = torch.empty(w.shape[0], dtype=torch.float32, device=w.device)
+            ops.quantize_rows_fp8(w, q, sc)
+            return q, sc
         with torch.no_grad():
             for i, lyr in enumerate(self.layers):
-                q8.append(tuple(quantize_rows_fp8(w) for w in (pk[f"wqkv.{i}"], lyr.attention.wo.weight, pk[f"w13.{i}"],
-                                                               lyr.feed_forward.w2.weight)))
+                q8.append(tuple(quant(w) for w in (pk[f"wqkv.{i}"], lyr.attention.wo.weight, pk[f"w13.{i}"],
+                                                   lyr.feed_forward.w2.weight)))
         self._q8 = (self._packed_version, q8)
 
     def _decode_step(self, h: torch.Tensor, B: int, pos: int) -> None:
