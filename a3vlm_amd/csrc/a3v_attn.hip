@@ -555,7 +555,12 @@ __global__ __launch_bounds__(64) void attn_generic_kernel(AttnArgs p, int hd, in
 }
 
 inline void decode_plan(int B, int H, int Sk, int* nsplit, int* chunk) {
-  int want = (1024 + B * H - 1) / (B * H);
+  // ~768 blocks: at B*H = 256 three splits of the context beat four by 5-8 % for 600..1500 keys (larger chunks fill the 64 lanes of
+  // the V^T scan and the K scan's 128-row passes; sweep with tools/attn_decode_bench.py under -DA3V_ABLATION, A3V_DECODE_WANT)
+#ifndef A3V_DECODE_BLOCKS
+#define A3V_DECODE_BLOCKS 768
+#endif
+  int want = (A3V_DECODE_BLOCKS + B * H - 1) / (B * H);
 #ifdef A3V_ABLATION
   { static const char* e = getenv("A3V_DECODE_WANT"); if (e) want = atoi(e); }
 #endif
