@@ -1858,11 +1858,16 @@ extern "C" int a3v_gemm_qkv_rope(const void* A, int64_t lda, const void* W, int6
                       stream, &rk);
 }
 
-// split-K factor of the DMA GEMV: enough blocks (row groups x S >= 1024) for 256 CUs, S <= 8, S <= number of ring stages
+// split-K factor of the DMA GEMV: enough blocks (row groups x S >= A3V_GEMV_BLOCKS) for 256 CUs, S <= 8, S <= number of ring stages
 static int gemv_split(int N, int K, bool w8) {
   const int tgs = (N + 63) / 64, nst = K / (w8 ? 256 : 128);
+// block target of the split: 768 measured best in the decode bench of the 7B geometry (qkv: 4 slices instead of 8, LM head 2 instead
+// of 4; +2-3 % decode tok/s, +6 % with fp8 weights; 640 / 896 / 1024 / 1536 all slower) -- sweep with -DA3V_GEMV_BLOCKS=n
+#ifndef A3V_GEMV_BLOCKS
+#define A3V_GEMV_BLOCKS 768
+#endif
   int S = 1;
-  while (S < 8 && tgs * S < 1024 && S * 2 <= nst) S *= 2;
+  while (S < 8 && tgs * S < A3V_GEMV_BLOCKS && S * 2 <= nst) S *= 2;
   return S;
 }
 
