@@ -22,7 +22,10 @@
 namespace {
 
 constexpr int BK = 64;
-constexpr int GROUP_M = 8;
+#ifndef A3V_GROUP_M
+#define A3V_GROUP_M 8
+#endif
+constexpr int GROUP_M = A3V_GROUP_M;
 constexpr int GEMM_EPI_RAW = 1 << 20;     // internal: fp32 output without the bf16 rounding of the accumulator
 constexpr int GEMM_EPI_SCALE = 1 << 22;   // internal: fp8 operands -- accumulator *= sa[m] * sw[n] (per-row scales of A and W) first
 constexpr int GEMM_EPI_ROPEKV = 1 << 21;  // internal: fused-qkv epilogue (a3v_gemm_qkv_rope): RoPE on q / k, k -> K cache, v -> V^T cache
@@ -1866,8 +1869,11 @@ static int gemv_split(int N, int K, bool w8) {
 #ifndef A3V_GEMV_BLOCKS
 #define A3V_GEMV_BLOCKS 768
 #endif
+#ifndef A3V_GEMV_MAXS
+#define A3V_GEMV_MAXS 8
+#endif
   int S = 1;
-  while (S < 8 && tgs * S < A3V_GEMV_BLOCKS && S * 2 <= nst) S *= 2;
+  while (S < A3V_GEMV_MAXS && tgs * S < A3V_GEMV_BLOCKS && S * 2 <= nst) S *= 2;
   return S;
 }
 
