@@ -382,14 +382,15 @@ __global__ __launch_bounds__(64) void attn_rowdot_kernel(const TA* __restrict__ 
 // form above moved 142 MB in 63 us; this one streams it at HBM rate)
 template <int HD>
 __global__ __launch_bounds__(256) void attn_rowdot_vec_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
-                                                              float* __restrict__ D, int64_t rows) {
+                                                              float* __restrict__ D, int64_t rows, int H = 1, int64_t ld_o = HD) {
   constexpr int LPR = HD / 8;                       // lanes per row: 16 (hd 128) or 8 (hd 64)
   const int64_t row = (int64_t)blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
   const int sub = threadIdx.x % LPR;
   float a = 0.f;
   if (row < rows) {
     float x[8], y[8];
-    load8(o + row * HD + sub * 8, x);
+    const int64_t tok = row / H;                    // o may have a padded token stride (ld_o >= H * HD); dout is contiguous
+    load8(o + tok * ld_o + (row - tok * H) * HD + sub * 8, x);
     load8(dout + row * HD + sub * 8, y);
 #pragma unroll
     for (int e = 0; e < 8; ++e) a = fmaf(x[e], y[e], a);
@@ -750,19 +751,18 @@ extern "C" int a3v_attention_bwd_mfma_packed(const void* q, const void* k, int64
 // a3v_attention_bwd followed by a3v_rope_bwd_pack in one pass (bf16, hd 64 / 128 only: the MFMA kernels store the rotated-back
 // gradients straight into the fused-qkv gradient).  D: scratch [B, S, H] floats.
 extern "C" int a3v_attention_bwd_packed(const void* q, const void* k, int64_t k_sb, int64_t k_sh, const void* v, int64_t v_sb, int64_t v_ss,
-                                        int64_t v_sh, const void* out, const void* dout, const float* lse, float* D, void* dqkv,
+                                        int64_t v_sh, const void* out, int64_t ld_out, const void* dout, const float* lse, float* D, void* dqkv,
                                         int64_t ld_qkv, const float* cos_sin, int rope_pos0, int B, int S, int H, int Hkv, int hd, int causal,
                                         int dtype, void* stream) {
   if (!q || !k || !v || !out || !dout || !lse || !D || !dqkv || !cos_sin || B <= 0 || S <= 0) return A3V_ERR_ARG;
   if (dtype != A3V_BF16) return A3V_ERR_DTYPE;
-  if ((hd != 64 && hd != 128) || (H % Hkv)) return A3V_ERR_SHAPE;
+  if ((hd != 64 && hd != 128) || (H % Hkv) || ld_out < (int64_t)H * hd || ld_out % 8) return A3V_ERR_SHAPE;
+  if (((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(dout)) & 15) != 0) return A3V_ERR_SHAPE;
   const int64_t rows = (int64_t)B * S * H;
-  if (((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(dout)) & 15) != 0)
-    hipLaunchKernelGGL(attn_rowdot_kernel<bf16_t>, dim3(B * S * H), dim3(64), 0, ST, (const bf16_t*)out, (const bf16_t*)dout, D, hd);
-  else if (hd == 128)
-    hipLaunchKernelGGL(attn_rowdot_vec_kernel<128>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, ST, (const bf16_t*)out, (const bf16_t*)dout, D, rows);
+  if (hd == 128)
+    hipLaunchKernelGGL(attn_rowdot_vec_kernel<128>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, ST, (const bf16_t*)out, (const bf16_t*)dout, D, rows, H, ld_out);
   else
-    hipLaunchKernelGGL(attn_rowdot_vec_kernel<64>, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, ST, (const bf16_t*)out, (const bf16_t*)dout, D, rows);
+    hipLaunchKernelGGL(attn_rowdot_vec_kernel<64>, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, ST, (const bf16_t*)out, (const bf16_t*)dout, D, rows, H, ld_out);
   A3V_LAUNCH_CHECK();
   return a3v_attention_bwd_mfma_packed(q, k, k_sb, k_sh, v, v_sb, v_ss, v_sh, dout, lse, D, dqkv, ld_qkv, cos_sin, rope_pos0, B, S, H, Hkv, hd, causal,
                                        stream);

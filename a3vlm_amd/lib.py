@@ -28,7 +28,7 @@ SIGNATURES = {
     "a3v_gemm_qkv_rope_fp8": (I, [P, L, P, P, L, P, I, P, L, P, P, P, I, I, I, I, I, I, I, I, P]),
     "a3v_quantize_rows_fp8": (I, [P, L, P, F, P, L, P, I, I, I, P]),
     "a3v_gemm_tn_splitk": (I, [P, L, P, L, P, I, I, I, I, P]),
-    "a3v_attention_bwd_packed": (I, [P, P, L, L, P, L, L, L, P, P, P, P, P, L, P, I, I, I, I, I, I, I, I, P]),
+    "a3v_attention_bwd_packed": (I, [P, P, L, L, P, L, L, L, P, L, P, P, P, P, L, P, I, I, I, I, I, I, I, I, P]),
     "a3v_lora_refresh": (I, [P, P, I, I, I, P, L, P, L, P, L, P, L, I, I, P]),
     "a3v_adamw": (I, [P, P, P, P, L, F, F, F, F, F, L, P, P]),
     "a3v_gemm_nn": (I, [P, L, P, L, P, L, I, I, I, P, L, I, P]),

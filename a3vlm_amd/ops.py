@@ -426,7 +426,8 @@ def attention_bwd_packed(q, k, k_sb, k_sh, v, v_sb, v_ss, v_sh, out, dout, lse, 
                          rope_pos0: int = 0):
     """attention backward + inverse RoPE + packing into the fused-qkv gradient in one pass (bf16, hd 64 / 128)."""
     _dev(q, k, v, out, dout, lse, D, dqkv, cos_sin)
-    rc = _l.load().a3v_attention_bwd_packed(_p(q), _p(k), k_sb, k_sh, _p(v), v_sb, v_ss, v_sh, _p(out), _p(dout), _p(lse), _p(D),
+    ld_out = out.stride(-2) if out.dim() == 2 else out.stride(1)      # token stride of out ([rows, H*hd (+pad)] or [B, S, H, hd])
+    rc = _l.load().a3v_attention_bwd_packed(_p(q), _p(k), k_sb, k_sh, _p(v), v_sb, v_ss, v_sh, _p(out), ld_out, _p(dout), _p(lse), _p(D),
                                             _p(dqkv), dqkv.stride(0), _p(cos_sin), rope_pos0, B, S, H, Hkv, hd, 1 if causal else 0,
                                             dt(q), _stream())
     _l.check(rc, "a3v_attention_bwd_packed")

@@ -32,6 +32,7 @@ class TrainEngine:
     tn_wgrad = os.environ.get("A3V_TN_WGRAD", "1") != "0"              # weight gradients by a3v_gemm_tn (else transposes + NT)
     nn_dgrad = os.environ.get("A3V_NN_DGRAD", "1") != "0"              # input gradients by a3v_gemm_nn (else NT on W^T images)
     packed_attn_bwd = os.environ.get("A3V_PACKED_ATTN_BWD", "1") != "0"  # attention backward writes the rotated-back qkv gradient itself
+    lora_kext = os.environ.get("A3V_LORA_KEXT", "1") != "0"            # adapters inside the main GEMMs: [x | t] . [W | B]^T (K extended by Rp)
 
     def __init__(self, model, compute_dtype: torch.dtype = torch.bfloat16, recompute: Optional[bool] = None):
         """``recompute``: True = keep only each block's input and re-run the block in backward (the reference's
@@ -72,6 +73,20 @@ class TrainEngine:
 
     def images_adopted(self, written_ids) -> None:
         self._images().adopted(written_ids)
+
+    def _kext_cols(self, key: str) -> int:
+        """Width of the adapter block appended to the image / input of decoder GEMM ``key`` (0: adapters not folded in)."""
+        if not self._kext() or not key.startswith(("qkv.", "wo.", "w13.", "w2.")):
+            return 0
+        n = {"qkv": 3, "wo": 1, "w13": 2, "w2": 1}[key.split(".")[0]]
+        return _pad64(n * int(self.m.lora_rank))
+
+    def _kext(self) -> int:
+        """Columns appended to the inputs / weight images of the four decoder GEMMs when the adapters ride inside them
+        (LoRA, bf16): y = [x | t] . [W | B]^T with t = x . A^T -- no separate read-modify-write pass over y."""
+        if not (self.lora and self.lora_kext and self.act == torch.bfloat16):
+            return 0
+        return _pad64(3 * int(self.m.lora_rank))          # the widest group (wq|wk|wv) sets one width for all four
 
     def _check_dtypes(self):
         for n, p in self.m.get_trainable_params().items():
@@ -304,6 +319,15 @@ class TrainEngine:
                 vp = v
             ops.transpose(vp, vt, _pad64(R), C, _pad64(R))
             li[k + "t"] = vt
+        if self._kext():
+            im = self._images()
+            for i in range(m.n_layers):
+                for key, _, _ in m.lora_groups(i):
+                    full = im[key + ".x"]                      # [N, K + Rp]
+                    Rp = li[key + ".A"].shape[0]
+                    blk = full[:, full.shape[1] - Rp:]
+                    blk.copy_(li[key + ".B"])
+                    li[key + ".B"] = blk                        # refreshed in place from now on (row stride K + Rp)
         self._li, self._li_ver, self._li_act = li, ver, self.act
         return li
 
@@ -356,12 +380,23 @@ class TrainEngine:
         rows = B * S
         l = m.layers[i]
         spad = _pad64(S)
-        xn = self._buf("xn" + tag, (rows, dim))
+        kx = self._kext() > 0 and rows > 16 and hd in (64, 128) and self.fuse_qkv_rope
+        li = self._lora_step_images() if kx else None
+
+        def xbuf(name, cols, key):      # activation buffer with the adapter block t = x . A^T appended (K_ext): full, x view, t view
+            ext = li[key + ".A"].shape[0]
+            full = self._buf(name + tag, (rows, cols + ext))
+            return full, full[:, :cols], full[:, cols:]
+        if kx:
+            xn_full, xn, t_qkv = xbuf("xn", dim, f"qkv.{i}")
+            att_full, att, t_wo = xbuf("att", H * hd, f"wo.{i}")
+        else:
+            xn = self._buf("xn" + tag, (rows, dim))
+            att = self._buf("att" + tag, (rows, H * hd))
         qkv = self._buf("qkv" + tag, (rows, (H + 2 * Hkv) * hd))
         qrot = self._buf("qrot" + tag, (rows, H * hd))
         kc = self._buf("kc" + tag, (B, Hkv, spad, hd))
         vc = self._buf("vc", (B, Hkv, hd, spad))
-        att = self._buf("att" + tag, (rows, H * hd))
         lse = self._buf("lse" + tag, (B, H, S), torch.float32)
         ops.rmsnorm(h, l.attention_norm.weight, xn, a.norm_eps)
         lt = {}
@@ -369,6 +404,12 @@ class TrainEngine:
             # RoPE + K / V^T writes in the GEMM epilogue; v also token-major in its qkv columns for the attention backward
             ops.gemm_qkv_rope(xn, im[f"qkv.{i}"], qrot, kc, vc, m._cos_sin_dev(), B, S, H, Hkv, hd, 0, 0,
                               v_rows=qkv[:, (H + Hkv) * hd:])
+        elif kx:
+            # adapters inside the GEMM: t = x . A^T goes into the tail columns of the input, B sits in the tail columns of the image
+            self._skinny(xn, li[f"qkv.{i}.A"], t_qkv)
+            ops.gemm_qkv_rope(xn_full, im[f"qkv.{i}.x"], qrot, kc, vc, m._cos_sin_dev(), B, S, H, Hkv, hd, 0, 0,
+                              v_rows=qkv[:, (H + Hkv) * hd:])
+            lt["qkv"] = t_qkv
         elif self.lora and self.act == torch.bfloat16 and hd in (64, 128) and rows > 16 and self.fuse_qkv_rope:
             # adapters: the LoRA term t . B^T is written into the qkv buffer first and enters the fused GEMM as an additive term
             # before the rotation (the reference's order: linear output + modification, rounded, then RoPE)
@@ -385,33 +426,50 @@ class TrainEngine:
             if self.lora:
                 lt["qkv"] = self._lora_fwd(f"qkv.{i}", xn, qkv, tag)
             ops.rope_kvcache(qkv, qrot, kc, vc, m._cos_sin_dev(), B, S, H, Hkv, hd, 0, 0)
-        strides = (S * H * hd, H * hd, hd, Hkv * spad * hd, spad * hd, hd, Hkv * hd * spad, hd * spad, spad, S * H * hd, H * hd, hd)
+        ldo = att.stride(0)
+        strides = (S * H * hd, H * hd, hd, Hkv * spad * hd, spad * hd, hd, Hkv * hd * spad, hd * spad, spad, S * ldo, ldo, hd)
         ops.attention_lse(qrot, kc, vc, att, lse, B, S, S, H, Hkv, hd, strides, True)
         res_flag = ops.EPI_RES_F32 if self.act == torch.bfloat16 else 0
-        if keep:
-            h_mid = self._buf("h_mid" + tag, (rows, dim), torch.float32)
-            ops.gemm_nt(att, im[f"wo.{i}"], h_mid, residual=h, epilogue=res_flag)
+        h_mid = self._buf("h_mid" + tag, (rows, dim), torch.float32) if keep else h
+        if kx:
+            self._skinny(att, li[f"wo.{i}.A"], t_wo)
+            ops.gemm_nt(att_full, im[f"wo.{i}.x"], h_mid, residual=h, epilogue=res_flag)
+            lt["wo"] = t_wo
         else:
-            h_mid = h
-            ops.gemm_nt(att, im[f"wo.{i}"], h, residual=h, epilogue=res_flag)
-        if self.lora:
-            lt["wo"] = self._lora_fwd(f"wo.{i}", att, h_mid, tag)
-        xn2 = self._buf("xn2" + tag, (rows, dim))
+            ops.gemm_nt(att, im[f"wo.{i}"], h_mid, residual=h, epilogue=res_flag)
+            if self.lora:
+                lt["wo"] = self._lora_fwd(f"wo.{i}", att, h_mid, tag)
         gu = self._buf("gu" + tag, (rows, 2 * F))
-        actb = self._buf("act" + tag, (rows, F))
+        if kx:
+            xn2_full, xn2, t_w13 = xbuf("xn2", dim, f"w13.{i}")
+            act_full, actb, t_w2 = xbuf("act", F, f"w2.{i}")
+        else:
+            xn2 = self._buf("xn2" + tag, (rows, dim))
+            actb = self._buf("act" + tag, (rows, F))
         ops.rmsnorm(h_mid, l.ffn_norm.weight, xn2, a.norm_eps)
-        ops.gemm_nt(xn2, im[f"w13.{i}"], gu)
-        if self.lora:
-            lt["w13"] = self._lora_fwd(f"w13.{i}", xn2, gu, tag)
+        if kx:
+            self._skinny(xn2, li[f"w13.{i}.A"], t_w13)
+            ops.gemm_nt(xn2_full, im[f"w13.{i}.x"], gu)
+            lt["w13"] = t_w13
+        else:
+            ops.gemm_nt(xn2, im[f"w13.{i}"], gu)
+            if self.lora:
+                lt["w13"] = self._lora_fwd(f"w13.{i}", xn2, gu, tag)
         ops.swiglu_fwd(gu, actb, F, interleaved=False)
-        if self.lora:                                     # t = lora_a(act) of w2 is needed by the backward even without the output
-            li = self._lora_step_images()
-            lt["w2"] = self._buf("lora_t.w2" + tag, (rows, li[f"w2.{i}.A"].shape[0]))
-            self._skinny(actb, li[f"w2.{i}.A"], lt["w2"])
+        if kx:
+            self._skinny(actb, li[f"w2.{i}.A"], t_w2)
+            lt["w2"] = t_w2
+        elif self.lora:                                   # t = lora_a(act) of w2 is needed by the backward even without the output
+            li2 = self._lora_step_images()
+            lt["w2"] = self._buf("lora_t.w2" + tag, (rows, li2[f"w2.{i}.A"].shape[0]))
+            self._skinny(actb, li2[f"w2.{i}.A"], lt["w2"])
         kept = dict(xn=xn, qkv=qkv, qrot=qrot, kc=kc, att=att, lse=lse, h_mid=h_mid, xn2=xn2, gu=gu, act=actb, spad=spad, lt=lt)
         if keep and h_out is None:
             return kept                                   # recompute inside backward: the block output is not needed
         out = h_out if keep else h
+        if kx:
+            ops.gemm_nt(act_full, im[f"w2.{i}.x"], out, residual=h_mid, epilogue=res_flag)
+            return kept
         ops.gemm_nt(actb, im[f"w2.{i}"], out, residual=h_mid, epilogue=res_flag)
         if self.lora:
             f32 = out.dtype == torch.float32 and self.act == torch.bfloat16
@@ -470,7 +528,8 @@ class TrainEngine:
             wsp = None
             if self.act == torch.bfloat16 and hd in (64, 128):
                 wsp = self._buf("attn_bwd_ws", (ops.attention_bwd_workspace_bytes(B, S, H, Hkv, hd),), torch.uint8)
-            ops.attention_bwd(k["qrot"], k["kc"], Hkv * spad * hd, spad * hd, vrows, S * ld, ld, hd, k["att"], datt, k["lse"], D,
+            att_c = k["att"] if k["att"].is_contiguous() else k["att"].contiguous()      # (K_ext keeps att inside a wider buffer)
+            ops.attention_bwd(k["qrot"], k["kc"], Hkv * spad * hd, spad * hd, vrows, S * ld, ld, hd, att_c, datt, k["lse"], D,
                               dq, dk, dv, B, S, H, Hkv, hd, True, workspace=wsp)
             ops.rope_bwd_pack(dq, dk, dv, dqkv, m._cos_sin_dev(), B, S, H, Hkv, hd, 0)
         if self._has(pre + "attention.wq.weight", pre + "attention.wk.weight", pre + "attention.wv.weight"):
@@ -631,7 +690,15 @@ class _Images:
         return "vp" if key.startswith("vp") else "out"
 
     def _both(self, key, w):      # forward image W [N,K] now; W^T [K, N padded to 64] only when somebody asks for key + ".t"
-        self.store[key] = w.to(self.eng.act).contiguous()
+        ext = self.eng._kext_cols(key)
+        if ext:                   # LoRA inside the GEMM: [W | B] with the adapter block written by _lora_step_images / a3v_lora_refresh
+            N, K = w.shape
+            full = torch.zeros(N, K + ext, dtype=self.eng.act, device=w.device)
+            full[:, :K] = w.to(self.eng.act)
+            self.store[key] = full[:, :K]
+            self.store[key + ".x"] = full
+        else:
+            self.store[key] = w.to(self.eng.act).contiguous()
 
     def _transposed(self, key: str, ver) -> torch.Tensor:
         if self.tver.get(key) != ver:

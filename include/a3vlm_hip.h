@@ -310,9 +310,10 @@ int a3v_attention_bwd(const void* q, const void* k, int64_t k_sb, int64_t k_sh, 
                       int B, int S, int H, int Hkv, int hd, int causal, int dtype, void* stream);
 /* a3v_attention_bwd + a3v_rope_bwd_pack in one pass (bf16, hd 64 / 128): the gradient of the fused qkv activation
  * dqkv [B*S, ld_qkv] = [dq | dk | dv] with the q / k parts rotated back by -theta (autograd of apply_rotary_emb and of the
- * xq / xk / xv views, LLM/llama_ens5.py:112-118); no dq / dk / dv buffers.  D: scratch [B, S, H] floats. */
+ * xq / xk / xv views, LLM/llama_ens5.py:112-118); no dq / dk / dv buffers.  out [B*S, ld_out] (token stride ld_out >= H*hd, 16-B
+ * aligned), dout contiguous.  D: scratch [B, S, H] floats. */
 int a3v_attention_bwd_packed(const void* q, const void* k, int64_t k_sb, int64_t k_sh, const void* v, int64_t v_sb,
-                             int64_t v_ss, int64_t v_sh, const void* out, const void* dout, const float* lse, float* D,
+                             int64_t v_ss, int64_t v_sh, const void* out, int64_t ld_out, const void* dout, const float* lse, float* D,
                              void* dqkv, int64_t ld_qkv, const float* cos_sin, int rope_pos0, int B, int S, int H, int Hkv,
                              int hd, int causal, int dtype, void* stream);
 /* bytes of `workspace` for the bf16 MFMA path: a non-NULL workspace selects it (NULL = the generic, slow kernels).  The MFMA

@@ -247,3 +247,51 @@ def test_lora_prefill_fused_qkv_matches_separate_kernels():
     dec = ref_cpu.OracleDecoder(oargs, {k: v.to(BF) for k, v in {**sd, **lsd}.items()})
     want = dec.forward_inference(ex[:, :T0], 0).float()
     assert float((got[True][0][0].cpu() - want).abs().max()) / float(want.abs().max()) < 4e-2
+
+
+def test_lora_kext_adapters_inside_the_gemms_match_oracle_and_separate_path():
+    """head_dim 64: the adapters ride inside the four decoder GEMMs ([x | t] . [W | B]^T, K extended by the padded rank).
+    Loss and every trainable gradient agree with the oracle's autograd (bf16 level) and with the separate-pass path; the
+    extended weight images carry B in their tail columns after an optimizer step (refreshed in place)."""
+    from a3vlm_amd.optim import FusedAdamW
+    big = dict(dim=256, n_layers=2, n_heads=4, n_kv_heads=2, vocab_size=320, multiple_of=256, max_seq_len=256)
+    oargs = ref_cpu.OracleArgs(**big)
+    sd = ref_cpu.make_decoder_weights(oargs, seed=3, std=0.05)
+    lsd = ref_cpu.make_lora_weights(oargs, RANK, seed=6, std_a=0.05, std_b=0.05)
+    g = torch.Generator().manual_seed(13)
+    B, T = 3, 47
+    ex = torch.randint(3, 320, (B, T), generator=g)
+    ex[:, 0] = 1
+    lab = ex.clone()
+    lab[:, :6] = 0
+    got, losses = {}, {}
+    for kext in (True, False):
+        m = peft.Transformer(peft.ModelArgs(**big, lora_rank=RANK), with_visual=False)
+        m.load_state_dict({**sd, **lsd}, strict=True)
+        train = m.get_trainable_params()
+        for n, p in m.named_parameters():
+            p.requires_grad = n in train
+        m.to(BF).to(DEV)
+        promote_trainable_params_to_fp32(m)
+        eng = TrainEngine(m, BF)
+        eng.lora_kext = kext
+        assert (eng._kext() > 0) == kext
+        losses[kext] = float(eng.forward_loss(ex.to(DEV), lab.to(DEV), None))
+        eng.backward(1.0)
+        got[kext] = {n: p.grad.float().cpu().clone() for n, p in train.items()}
+        if kext:      # one optimizer step, then the B blocks inside the extended images equal the updated adapters
+            opt = FusedAdamW([p for p in m.parameters() if p.requires_grad], lr=1e-2, betas=(0.9, 0.95), weight_decay=0.0)
+            opt.step()
+            eng.forward_loss(ex.to(DEV), lab.to(DEV), None)
+            full = eng._images()["wo.0.x"]
+            wb = m.layers[0].attention.wo.lora_b.weight
+            assert torch.equal(full[:, 256:256 + RANK], wb.detach().to(BF)) and float(full[:, 256 + RANK:].float().abs().sum()) == 0
+    tr = {n for n in got[True]}
+    osd = {k: v.clone().requires_grad_(k in tr) for k, v in {**sd, **lsd}.items()}
+    want_loss = ref_cpu.meta_forward_loss(ref_cpu.OracleDecoder(oargs, osd), ex, lab, None)
+    want_loss.backward()
+    assert abs(losses[True] - float(want_loss)) < 2e-2 * abs(float(want_loss)) and abs(losses[True] - losses[False]) < 1e-2 * abs(losses[False])
+    for n in got[True]:
+        a, b, c = got[True][n].flatten(), got[False][n].flatten(), osd[n].grad.flatten()
+        cos = lambda x, y: float(torch.dot(x, y) / (x.norm() * y.norm() + 1e-20))
+        assert cos(a, b) > 0.995 and cos(a, c) > 0.98, (n, cos(a, b), cos(a, c))
