@@ -323,11 +323,14 @@ class TrainEngine:
             im = self._images()
             for i in range(m.n_layers):
                 for key, _, _ in m.lora_groups(i):
-                    full = im[key + ".x"]                      # [N, K + Rp]
+                    fx, fy = im[key + ".x"], im[key + ".y"]   # [N, K + Rp] = [W | B],  [N + Rp, K] = [W ; A]
                     Rp = li[key + ".A"].shape[0]
-                    blk = full[:, full.shape[1] - Rp:]
+                    blk = fx[:, fx.shape[1] - Rp:]
                     blk.copy_(li[key + ".B"])
                     li[key + ".B"] = blk                        # refreshed in place from now on (row stride K + Rp)
+                    rows_a = fy[fy.shape[0] - Rp:]
+                    rows_a.copy_(li[key + ".A"])
+                    li[key + ".A"] = rows_a
         self._li, self._li_ver, self._li_act = li, ver, self.act
         return li
 
@@ -341,7 +344,16 @@ class TrainEngine:
         ops.gemm_nt(t, Bm, y, residual=y, epilogue=ops.EPI_RES_F32 if f32 else 0)
         return t
 
-    def _lora_bwd(self, i: int, key: str, dy: torch.Tensor, x: torch.Tensor, t: torch.Tensor, dx: Optional[torch.Tensor]):
+    def _kx_group_bwd(self, i: int, key: str, dy_full: torch.Tensor, N: int, x: torch.Tensor, t: torch.Tensor, dx: torch.Tensor):
+        """Input gradient of a decoder GEMM with the adapters inside it: dy_full = [dy | dt] (dt = dy . B in the tail columns)
+        times [W ; A] in ONE NN GEMM (dx = dy W + dt A), then the adapter weight gradients."""
+        li = self._lora_step_images()
+        dy, dt = dy_full[:, :N], dy_full[:, N:]
+        self._dgrad(dy, li[key + ".Bt"], dt)
+        ops.gemm_nn(dy_full, self._images()[key + ".y"], dx)
+        self._lora_bwd(i, key, dy, x, t, None, dt=dt)
+
+    def _lora_bwd(self, i: int, key: str, dy: torch.Tensor, x: torch.Tensor, t: torch.Tensor, dx: Optional[torch.Tensor], dt=None):
         """Adapter gradients of a fused group and the adapter term of the input gradient (dx += (dy B) A)."""
         m = self.m
         li = self._lora_step_images()
@@ -349,8 +361,9 @@ class TrainEngine:
         Bt, At = li[key + ".Bt"], li[key + ".At"]          # [Rp, Npad], [in, Rp]
         M, N = dy.shape
         Rp = t.shape[1]
-        dt = self._buf("lora_dt", (M, Rp))
-        self._dgrad(dy, Bt, dt)                              # dt = dy @ B
+        if dt is None:
+            dt = self._buf("lora_dt", (M, Rp))
+            self._dgrad(dy, Bt, dt)                          # dt = dy @ B
         g = key.split(".")[0]
         gB = self._buf("lora_gB." + g, (N, Rp), torch.float32)
         gA = self._buf("lora_gA." + g, (Rp, x.shape[1]), torch.float32)
@@ -484,39 +497,61 @@ class TrainEngine:
         pre = f"layers.{i}."
         k = self._saved["kept"][i] if self._saved.get("kept") else self._block_forward(i, h_in, B, S, keep=True)
         # ---- FFN: out = h_mid + w2(silu(g) * u)
-        dha = self._buf("dh_act", (rows, dim))
-        ops.cast(dh, dha)
         lt = k.get("lt", {})
+        kx = self._kext() > 0 and rows > 16 and hd in (64, 128) and self.fuse_qkv_rope       # as in _block_forward
+        li = self._lora_step_images() if kx else None
+
+        def ybuf(name, cols, key):      # gradient buffer with room for dt = dy . B behind it: full, dy view
+            full = self._buf(name, (rows, cols + li[key + ".A"].shape[0]))
+            return full, full[:, :cols]
+        if kx:
+            dha_full, dha = ybuf("dh_act.x", dim, f"w2.{i}")
+        else:
+            dha = self._buf("dh_act", (rows, dim))
+        ops.cast(dh, dha)
         if self._has(pre + "feed_forward.w2.weight"):
             self._wgrad(dha, k["act"], self._views[pre + "feed_forward.w2.weight"], "w2", (pre + "feed_forward.w2.weight",))
         dact = self._buf("dact", (rows, F))
-        self._dgrad_w(dha, f"w2.{i}", dact)
-        if self.lora:
-            self._lora_bwd(i, f"w2.{i}", dha, k["act"], lt["w2"], dact)
-        dgu = self._buf("dgu", (rows, 2 * F))
+        if kx:
+            self._kx_group_bwd(i, f"w2.{i}", dha_full, dim, k["act"], lt["w2"], dact)
+            dgu_full, dgu = ybuf("dgu.x", 2 * F, f"w13.{i}")
+        else:
+            self._dgrad_w(dha, f"w2.{i}", dact)
+            if self.lora:
+                self._lora_bwd(i, f"w2.{i}", dha, k["act"], lt["w2"], dact)
+            dgu = self._buf("dgu", (rows, 2 * F))
         ops.swiglu_bwd(k["gu"], dact, dgu, F, interleaved=False)
         if self._has(pre + "feed_forward.w1.weight", pre + "feed_forward.w3.weight"):
             self._wgrad(dgu, k["xn2"], self._gview(pre + "feed_forward.w1.weight", pre + "feed_forward.w3.weight"), "w13",
                         (pre + "feed_forward.w1.weight", pre + "feed_forward.w3.weight"))
         dxn = self._buf("dxn", (rows, dim))
-        self._dgrad_w(dgu, f"w13.{i}", dxn)
-        if self.lora:
-            self._lora_bwd(i, f"w13.{i}", dgu, k["xn2"], lt["w13"], dxn)
+        if kx:
+            self._kx_group_bwd(i, f"w13.{i}", dgu_full, 2 * F, k["xn2"], lt["w13"], dxn)
+        else:
+            self._dgrad_w(dgu, f"w13.{i}", dxn)
+            if self.lora:
+                self._lora_bwd(i, f"w13.{i}", dgu, k["xn2"], lt["w13"], dxn)
         ops.rmsnorm_bwd(k["h_mid"], l.ffn_norm.weight, dxn, dh, self._views.get(pre + "ffn_norm.weight"), a.norm_eps)
         # ---- attention: h_mid = h_in + wo(attn(rope(qkv(norm(h_in)))))
         ops.cast(dh, dha)
         if self._has(pre + "attention.wo.weight"):
             self._wgrad(dha, k["att"], self._views[pre + "attention.wo.weight"], "wo", (pre + "attention.wo.weight",))
         datt = self._buf("datt", (rows, H * hd))
-        self._dgrad_w(dha, f"wo.{i}", datt)
-        if self.lora:
-            self._lora_bwd(i, f"wo.{i}", dha, k["att"], lt["wo"], datt)
+        if kx:
+            self._kx_group_bwd(i, f"wo.{i}", dha_full, dim, k["att"], lt["wo"], datt)
+        else:
+            self._dgrad_w(dha, f"wo.{i}", datt)
+            if self.lora:
+                self._lora_bwd(i, f"wo.{i}", dha, k["att"], lt["wo"], datt)
         D = self._buf("attn_D", (B, S, H), torch.float32)
         qkv = k["qkv"]
         ld = qkv.stride(0)
         vrows = qkv[:, (H + Hkv) * hd:]
         spad = k["spad"]
-        dqkv = self._buf("dqkv", (rows, (H + 2 * Hkv) * hd))
+        if kx:
+            dqkv_full, dqkv = ybuf("dqkv.x", (H + 2 * Hkv) * hd, f"qkv.{i}")
+        else:
+            dqkv = self._buf("dqkv", (rows, (H + 2 * Hkv) * hd))
         if self.act == torch.bfloat16 and hd in (64, 128) and self.packed_attn_bwd:
             # the MFMA kernels rotate dq / dk back and store [dq | dk | dv] straight into the fused-qkv gradient
             ops.attention_bwd_packed(k["qrot"], k["kc"], Hkv * spad * hd, spad * hd, vrows, S * ld, ld, hd, k["att"], datt, k["lse"], D,
@@ -535,9 +570,12 @@ class TrainEngine:
         if self._has(pre + "attention.wq.weight", pre + "attention.wk.weight", pre + "attention.wv.weight"):
             self._wgrad(dqkv, k["xn"], self._gview(pre + "attention.wq.weight", pre + "attention.wv.weight"), "qkv",
                         (pre + "attention.wq.weight", pre + "attention.wk.weight", pre + "attention.wv.weight"))
-        self._dgrad_w(dqkv, f"qkv.{i}", dxn)
-        if self.lora:
-            self._lora_bwd(i, f"qkv.{i}", dqkv, k["xn"], lt["qkv"], dxn)
+        if kx:
+            self._kx_group_bwd(i, f"qkv.{i}", dqkv_full, (H + 2 * Hkv) * hd, k["xn"], lt["qkv"], dxn)
+        else:
+            self._dgrad_w(dqkv, f"qkv.{i}", dxn)
+            if self.lora:
+                self._lora_bwd(i, f"qkv.{i}", dqkv, k["xn"], lt["qkv"], dxn)
         ops.rmsnorm_bwd(h_in, l.attention_norm.weight, dxn, dh, self._views.get(pre + "attention_norm.weight"), a.norm_eps)
 
     # ------------------------------------------------------------------ forward (loss) and backward
@@ -691,12 +729,13 @@ class _Images:
 
     def _both(self, key, w):      # forward image W [N,K] now; W^T [K, N padded to 64] only when somebody asks for key + ".t"
         ext = self.eng._kext_cols(key)
-        if ext:                   # LoRA inside the GEMM: [W | B] with the adapter block written by _lora_step_images / a3v_lora_refresh
-            N, K = w.shape
-            full = torch.zeros(N, K + ext, dtype=self.eng.act, device=w.device)
-            full[:, :K] = w.to(self.eng.act)
-            self.store[key] = full[:, :K]
-            self.store[key + ".x"] = full
+        if ext:                   # LoRA inside the GEMMs: one [N + Rp, K + Rp] image = [[W, B], [A, 0]]; forward reads [W | B] (rows 0..N),
+            N, K = w.shape        # the input gradient reads [W ; A] (columns 0..K); A / B blocks written by _lora_step_images / a3v_lora_refresh
+            full = torch.zeros(N + ext, K + ext, dtype=self.eng.act, device=w.device)
+            full[:N, :K] = w.to(self.eng.act)
+            self.store[key] = full[:N, :K]
+            self.store[key + ".x"] = full[:N]
+            self.store[key + ".y"] = full[:, :K]
         else:
             self.store[key] = w.to(self.eng.act).contiguous()
 
