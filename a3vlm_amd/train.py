@@ -147,8 +147,10 @@ class TrainEngine:
             for name, (o, p) in offs.items():
                 self._views[name] = self._flat[o:o + p.numel()].view(p.shape)
             self._params = {name: p for name, (o, p) in offs.items()}
+            self._offs = {name: (o, (p.numel() + 63) // 64 * 64) for name, (o, p) in offs.items()}
             self._gemm_written = {n for n in self._params if n == "output.weight" or (n.startswith("layers.") and n.endswith(
                 ("wq.weight", "wk.weight", "wv.weight", "wo.weight", "w1.weight", "w2.weight", "w3.weight")) and "lora_" not in n)}
+        runs = []                     # [start, end) float ranges of the flat buffer to zero, adjacent ones merged (one fill per run)
         for name, p in self._params.items():
             if not p.requires_grad:
                 if p.grad is not None and p.grad.data_ptr() == self._views[name].data_ptr():
@@ -161,10 +163,16 @@ class TrainEngine:
                 if name in self._gemm_written:
                     self._fresh.add(name)
                 else:
-                    v.zero_()
+                    o, n = self._offs[name]
+                    if runs and runs[-1][1] == o:
+                        runs[-1][1] = o + n
+                    else:
+                        runs.append([o, o + n])
                 p.grad = v
             elif p.grad.data_ptr() != v.data_ptr():
                 raise RuntimeError(f"{name}.grad was replaced by a foreign tensor; use zero_grad(set_to_none=True) or keep the views")
+        for o, e in runs:
+            self._flat[o:e].zero_()
 
     def grad_ranges(self):
         return list(self._ranges)
