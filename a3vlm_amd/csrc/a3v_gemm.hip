@@ -2065,8 +2065,42 @@ extern "C" int a3v_gemm_tn(const void* At, int64_t lda, const void* Wt, int64_t 
   p.A = (const bf16_t*)At; p.W = (const bf16_t*)Wt; p.C = C; p.bias = nullptr; p.res = residual;
   p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr;
   p.M = M; p.N = N; p.K = K; p.epi = epilogue; p.dbg = 0;
-  p.tiles_m = (M + 255) / 256; p.tiles_n = (N + 255) / 256;
-  hipLaunchKernelGGL(gemm_tn_bf16_pp_kernel<false>, dim3(p.tiles_m * p.tiles_n), dim3(512), 0, (hipStream_t)stream, p);
+  p.tiles_n = (N + 255) / 256;
+  hipStream_t st = (hipStream_t)stream;
+  // rows of C beyond whole tile rounds (e.g. dW of w1|w3: 86 x 16 tiles = 5.4 rounds): split over the contracted index into fp32
+  // planes + the reduce epilogue, as in a3v_gemm_nn / a3v_gemm_nt (needs the registered workspace; otherwise one plain launch)
+  const int ncu = cu_count();
+  const int tm_all = (M + 255) / 256;
+  const long total = (long)tm_all * p.tiles_n;
+  const long mt_h = (total / ncu) * ncu / p.tiles_n;
+  const long rem_tiles = total - mt_h * p.tiles_n;
+  int S = 1;
+  while (rem_tiles * S * 2 <= ncu && S < 8 && ((K + 63) / 64) >= 16 * S) S *= 2;
+  const int m_big = (int)(mt_h * 256);
+  static const bool tail_on = [] { const char* e = getenv("A3V_TN_TAIL"); return !(e && e[0] == '0'); }();
+  if (tail_on && mt_h >= 1 && m_big < M && S > 1 && rem_tiles * 4 < 3 * ncu && g_gemm_ws && (int64_t)S * (M - m_big) * N * 4 <= g_gemm_ws_bytes) {
+    GemmArgs q = p;
+    q.M = m_big; q.tiles_m = (int)mt_h;
+    hipLaunchKernelGGL(gemm_tn_bf16_pp_kernel<false>, dim3(q.tiles_m * q.tiles_n), dim3(512), 0, st, q);
+    GemmArgs t = p;
+    t.M = M - m_big;
+    t.A = p.A + m_big;                      // At is [K][lda] with the C-row index contiguous: the tail rows of C are columns m_big.. of At
+    t.C = g_gemm_ws; t.ldc = N; t.res = nullptr;
+    t.epi = A3V_EPI_OUT_F32 | GEMM_EPI_RAW;
+    t.tiles_m = (t.M + 255) / 256;
+    t.c_split = (int64_t)t.M * N * 4;
+    hipLaunchKernelGGL(gemm_tn_bf16_pp_kernel<false>, dim3(t.tiles_m * t.tiles_n, S), dim3(512), 0, st, t);
+    const int esz = (epilogue & (A3V_EPI_OUT_F32 | A3V_EPI_RES_F32)) ? 4 : 2;
+    void* Ct = (char*)C + (int64_t)m_big * ldc * esz;
+    const void* Rt = residual ? (const char*)residual + (int64_t)m_big * ldr * ((epilogue & A3V_EPI_RES_F32) ? 4 : 2) : nullptr;
+    const int64_t n4 = (int64_t)t.M * (N / 4);
+    const int rb = (int)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256);
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(rb), dim3(256), 0, st, g_gemm_ws, S, (int64_t)t.M * N, t.M, N, Ct, ldc, Rt, ldr, epilogue);
+    A3V_LAUNCH_CHECK();
+    return A3V_OK;
+  }
+  p.tiles_m = tm_all;
+  hipLaunchKernelGGL(gemm_tn_bf16_pp_kernel<false>, dim3(p.tiles_m * p.tiles_n), dim3(512), 0, st, p);
   A3V_LAUNCH_CHECK();
   return A3V_OK;
 }

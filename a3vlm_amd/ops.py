@@ -75,6 +75,7 @@ def gemm_tn(at, wt, out, *, residual=None, epilogue: int = 0):
     K, M = at.shape
     N = wt.shape[1]
     assert wt.shape[0] == K and at.stride(1) == 1 and wt.stride(1) == 1 and out.stride(1) == 1
+    _ensure_gemm_workspace(at.device)
     ep = epilogue
     if residual is not None and not (ep & EPI_RES_F32):
         ep |= EPI_RESIDUAL

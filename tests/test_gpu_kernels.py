@@ -653,3 +653,27 @@ def test_gemm_qkv_rope_with_additive_term():
     assert torch.equal(qrot, qkv[:, :H * hd]) and torch.equal(kc1, kc0) and torch.equal(vc1, vc0)
     assert torch.equal(buf[:, (H + Hkv) * hd:], qkv[:, (H + Hkv) * hd:])
     assert torch.equal(buf[:, :(H + Hkv) * hd], delta[:, :(H + Hkv) * hd])       # the q / k columns of delta are only read
+
+
+@pytest.mark.parametrize("M,N,K,mode", [(22016, 4096, 1100, "store"), (4456, 4096, 2048, "acc"), (4456, 4096, 2048, "bf16")])
+def test_gemm_tn_split_tail(M, N, K, mode):
+    """dW-shaped TN products whose tile count leaves a partial round (86 x 16 / 18 x 16 tiles on 256 CUs): the rows beyond whole
+    rounds go through split-K planes + the reduce epilogue; same values as one plain launch up to fp32 summation order."""
+    g = torch.Generator(device=DEV).manual_seed(M + K)
+    at = (torch.randn(K, M, device=DEV, generator=g) * 0.1).to(BF)
+    wt = (torch.randn(K, N, device=DEV, generator=g) * 0.5).to(BF)
+    want = (at.float().t() @ wt.float())
+    scale = float(want.abs().max())
+    if mode == "store":
+        out = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+        ops.gemm_tn(at, wt, out, epilogue=ops.EPI_OUT_F32)
+        assert float((out - want).abs().max()) <= 2 ** -7 * scale
+    elif mode == "acc":
+        acc0 = torch.randn(M, N, device=DEV, generator=g)
+        out = acc0.clone()
+        ops.gemm_tn(at, wt, out, residual=out, epilogue=ops.EPI_RES_F32)
+        assert float((out - acc0 - want).abs().max()) <= 2 ** -7 * scale + 1e-5
+    else:
+        out = torch.empty(M, N, dtype=BF, device=DEV)
+        ops.gemm_tn(at, wt, out)
+        assert float((out.float() - want).abs().max()) <= 2 ** -7 * scale
