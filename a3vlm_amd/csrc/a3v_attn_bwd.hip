@@ -78,30 +78,43 @@ __device__ __forceinline__ bf16x8 frag_rows_tr(const char* lds, int db, int tb, 
   return f;
 }
 
-// Store one [32 x HD] accumulator set (lane: row `row`, 4 consecutive d at 32 db + 8 g4 + 4 hh) either as a plain [.., HD] row
-// (dst) or, in packed mode, into the fused-qkv gradient at column slot * HD with the inverse rotary rotation of position pos.
-template <int HD>
-__device__ __forceinline__ void store_grad_rows(const BwdArgs& p, f32x16 (&acc)[HD / 32], bf16_t* dst, int64_t prow, int slot, int pos,
+// Store one [32 x HD] accumulator set (lane: one row, 4 consecutive d at 32 db + 8 g4 + 4 hh): as a plain [.., HD] row at `plain`,
+// or (packed mode) into the fused-qkv gradient row `prow` at column slot * HD, with the inverse rotary rotation of position pos
+// when `rotate`.  The mode is a template parameter of the kernels: with a run-time test (or per-store pointer selects) the dK
+// kernel went from 240 VGPRs to 256 + 18 spills inside its query loop (two waves per SIMD leave no slack).
+template <int HD, bool PACKED>
+__device__ __forceinline__ void store_grad_rows(const BwdArgs& p, f32x16 (&acc)[HD / 32], bf16_t* plain, int64_t prow, int slot, int pos,
                                                 bool rotate, int hh) {
+  if constexpr (!PACKED) {
+    bf16_t* O = plain;
+#pragma unroll
+    for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        bf16x4 ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ov[e] = f2bf(acc[d][g4 * 4 + e]);
+        *reinterpret_cast<bf16x4*>(O + d * 32 + g4 * 8 + hh * 4) = ov;
+      }
+    return;
+  }
+  bf16_t* O = p.dqkv + prow * p.ld_qkv + (int64_t)slot * HD;
+  const float* CS = p.cos_sin + (int64_t)pos * HD;             // [pos][HD / 2][cos, sin]
 #pragma unroll
   for (int d = 0; d < HD / 32; ++d)
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       const int dc = d * 32 + g4 * 8 + hh * 4;
       float v0 = acc[d][g4 * 4 + 0], v1 = acc[d][g4 * 4 + 1], v2 = acc[d][g4 * 4 + 2], v3 = acc[d][g4 * 4 + 3];
-      bf16_t* o = dst + dc;
-      if (p.dqkv) {
-        o = p.dqkv + prow * p.ld_qkv + (int64_t)slot * HD + dc;
-        if (rotate) {      // dx = R(-theta) dy on the (even, odd) pairs (LLM/llama_ens5.py:123-135 backward)
-          const f32x4 cs = *reinterpret_cast<const f32x4*>(p.cos_sin + ((int64_t)pos * (HD / 2) + (dc >> 1)) * 2);
-          const float a0 = v0 * cs[0] + v1 * cs[1], a1 = -v0 * cs[1] + v1 * cs[0];
-          const float a2 = v2 * cs[2] + v3 * cs[3], a3 = -v2 * cs[3] + v3 * cs[2];
-          v0 = a0; v1 = a1; v2 = a2; v3 = a3;
-        }
+      if (rotate) {        // dx = R(-theta) dy on the (even, odd) pairs (LLM/llama_ens5.py:123-135 backward)
+        const f32x4 cs = *reinterpret_cast<const f32x4*>(CS + dc);
+        const float a0 = v0 * cs[0] + v1 * cs[1], a1 = -v0 * cs[1] + v1 * cs[0];
+        const float a2 = v2 * cs[2] + v3 * cs[3], a3 = -v2 * cs[3] + v3 * cs[2];
+        v0 = a0; v1 = a1; v2 = a2; v3 = a3;
       }
       bf16x4 ov;
       ov[0] = f2bf(v0); ov[1] = f2bf(v1); ov[2] = f2bf(v2); ov[3] = f2bf(v3);
-      *reinterpret_cast<bf16x4*>(o) = ov;
+      *reinterpret_cast<bf16x4*>(O + dc) = ov;
     }
 }
 
@@ -116,7 +129,7 @@ __device__ __forceinline__ void xcd_head_tile(int nt, int& head_slot, int& t) {
   t = vb - head_slot * nt;
 }
 
-template <int HD>
+template <int HD, bool PACKED>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs p) {
   constexpr int TILE = 64 * HD * 2;                 // bytes of one 64-row tile (== HD x 128 B)
   __shared__ __attribute__((aligned(16))) char lds[2 * TILE];
@@ -202,9 +215,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs p) {
         for (int c = 0; c < 2; ++c)
           acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_tr<HD>(Ks, d, tb, c, lane), dsf[tb][c], acc[d], 0, 0, 0);
   }
-  if (qrow < p.S)
-    store_grad_rows<HD>(p, acc, p.dq ? p.dq + (((int64_t)b * p.S + qrow) * p.H + h) * HD : nullptr, (int64_t)b * p.S + qrow, h,
-                        p.rope_pos0 + qrow, true, hh);
+  int q_e = qrow, hh_e = hh;                 // opaque copies: keeps the store's address arithmetic out of the key loop (see dK below)
+  asm volatile("" : "+v"(q_e), "+v"(hh_e));
+  if (q_e < p.S)
+    store_grad_rows<HD, PACKED>(p, acc, p.dq + (((int64_t)b * p.S + q_e) * p.H + h) * HD, (int64_t)b * p.S + q_e, h, p.rope_pos0 + q_e, true, hh_e);
 }
 
 // ------------------------------------------------------------------ dK, dV
@@ -212,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs p) {
 // accumulates dK (needs S and dP).  Each keeps ONE [HD x 32-key] accumulator set (64 VGPRs) instead of two, which brings
 // the kernel under 256 VGPRs = two waves per SIMD and cuts the LDS tiles staged per query tile from four to two / three;
 // the price is one extra S^T recompute (5 instead of 4 tile products), paid back ~1.5x by the doubled occupancy.
-template <int HD, int WHICH>
+template <int HD, int WHICH, bool PACKED>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs p) {
   constexpr int TILE = 64 * HD * 2;
   constexpr int NT = 2;
@@ -303,10 +317,40 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs p) {
             acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_tr<HD>(At, d, tb, c, lane), bf[tb][c], acc[d], 0, 0, 0);
     }
   }
+  // (the stores are written out here rather than through store_grad_rows: routed through the helper, this kernel went from
+  //  240 VGPRs to 256 + 18 spills inside the query loop -- two waves per SIMD leave the allocator no slack)
   if (kvrow < p.S) {
-    bf16_t* base = WHICH == 0 ? p.dv : p.dk;
-    store_grad_rows<HD>(p, acc, base ? base + (((int64_t)b * p.Hkv + hk) * p.S + kvrow) * HD : nullptr, (int64_t)b * p.S + kvrow,
-                        WHICH == 0 ? p.H + p.Hkv + hk : p.H + hk, p.rope_pos0 + kvrow, WHICH == 1, hh);
+    if constexpr (!PACKED) {
+      bf16_t* O = (WHICH == 0 ? p.dv : p.dk) + (((int64_t)b * p.Hkv + hk) * p.S + kvrow) * HD;
+#pragma unroll
+      for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          bf16x4 a;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a[e] = f2bf(acc[d][g4 * 4 + e]);
+          *reinterpret_cast<bf16x4*>(O + d * 32 + g4 * 8 + hh * 4) = a;
+        }
+    } else {
+      bf16_t* O = p.dqkv + ((int64_t)b * p.S + kvrow) * p.ld_qkv + (int64_t)(WHICH == 0 ? p.H + p.Hkv + hk : p.H + hk) * HD;
+      const float* CS = p.cos_sin + (int64_t)(p.rope_pos0 + kvrow) * HD;      // [pos][HD / 2][cos, sin]
+#pragma unroll
+      for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int dc = d * 32 + g4 * 8 + hh * 4;
+          float v0 = acc[d][g4 * 4 + 0], v1 = acc[d][g4 * 4 + 1], v2 = acc[d][g4 * 4 + 2], v3 = acc[d][g4 * 4 + 3];
+          if (WHICH == 1) {      // dK: rotate back, dx = R(-theta) dy on the (even, odd) pairs (LLM/llama_ens5.py:123-135 backward)
+            const f32x4 cs = *reinterpret_cast<const f32x4*>(CS + dc);
+            const float a0 = v0 * cs[0] + v1 * cs[1], a1 = -v0 * cs[1] + v1 * cs[0];
+            const float a2 = v2 * cs[2] + v3 * cs[3], a3 = -v2 * cs[3] + v3 * cs[2];
+            v0 = a0; v1 = a1; v2 = a2; v3 = a3;
+          }
+          bf16x4 ov;
+          ov[0] = f2bf(v0); ov[1] = f2bf(v1); ov[2] = f2bf(v2); ov[3] = f2bf(v3);
+          *reinterpret_cast<bf16x4*>(O + dc) = ov;
+        }
+    }
   }
 }
 
@@ -343,15 +387,18 @@ static int attention_bwd_mfma_impl(const void* q, const void* k, int64_t k_sb, i
   p.B = B; p.S = S; p.Sp = Sp; p.H = H; p.Hkv = Hkv; p.causal = causal;
   p.scale = 1.0f / sqrtf((float)hd);
   dim3 gq(((S + 127) / 128) * H * B), gk(((S + 127) / 128) * Hkv * B);
+#define A3V_BWD_LAUNCH(HDV, PK)                                                                  \
+  do {                                                                                           \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<HDV, PK>), gq, dim3(256), 0, st, p);                  \
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDV, 0, PK>), gk, dim3(256), 0, st, p);              \
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDV, 1, PK>), gk, dim3(256), 0, st, p);              \
+  } while (0)
   if (hd == 128) {
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, gq, dim3(256), 0, st, p);
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 0>), gk, dim3(256), 0, st, p);
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 1>), gk, dim3(256), 0, st, p);
+    if (dqkv) A3V_BWD_LAUNCH(128, true); else A3V_BWD_LAUNCH(128, false);
   } else {
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, gq, dim3(256), 0, st, p);
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, 0>), gk, dim3(256), 0, st, p);
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, 1>), gk, dim3(256), 0, st, p);
+    if (dqkv) A3V_BWD_LAUNCH(64, true); else A3V_BWD_LAUNCH(64, false);
   }
+#undef A3V_BWD_LAUNCH
   A3V_LAUNCH_CHECK();
   return A3V_OK;
 }
