@@ -47,6 +47,39 @@ __device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ base, int6
   }
 }
 
+// Asynchronous form of stage_rows: a 64-row tile goes global -> LDS by LDS-DMA without passing through VGPRs; it has landed after
+// `s_waitcnt vmcnt(0)` + a workgroup barrier.  One wave instruction writes 1 KiB (lane-linear), so the chunk swizzle is applied on
+// the SOURCE side: thread id -> (row id / KCH, physical chunk id % KCH) fetches logical chunk (physical ^ swizzle(row)).  Buffer-
+// descriptor form: the per-lane byte offsets (dma_lane_offsets) are loop constants shared by every tile with the same row stride;
+// the tile's first row goes into the descriptor base and the bytes left up to the end of the last valid row into num_records, so
+// rows past the end read as zeros (their scores are masked).  Same LDS image as stage_rows for the valid rows.
+__device__ __forceinline__ void buf_dma16(__amdgpu_buffer_rsrc_t rs, char* lds_dst, unsigned voff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, 0, 0, 0);
+}
+__device__ __forceinline__ void buf_dma4(__amdgpu_buffer_rsrc_t rs, void* lds_dst, unsigned voff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_dst, 4, voff, 0, 0, 0);
+}
+template <int HD>
+__device__ __forceinline__ void dma_lane_offsets(unsigned (&voff)[64 * (HD / 8) / 256], int64_t row_stride, int tid) {
+  constexpr int KCH = HD / 8;
+#pragma unroll
+  for (int i = 0; i < 64 * KCH / 256; ++i) {
+    const int id = tid + i * 256;
+    const int row = id / KCH, pc = id % KCH;
+    const int sw = (HD == 128) ? (row & 15) : ((row >> 1) & 7);
+    voff[i] = (unsigned)((row * row_stride + ((pc ^ sw) << 3)) * 2);
+  }
+}
+// rows [row0, row0 + 64) of a [nrows, HD] matrix with `row_stride` elements between rows
+template <int HD>
+__device__ __forceinline__ void stage_rows_dma(const bf16_t* base, int64_t row_stride, int row0, int nrows, char* lds,
+                                               const unsigned (&voff)[64 * (HD / 8) / 256], int wave) {
+  const int64_t left = ((int64_t)(nrows - 1 - row0) * row_stride + HD) * 2;          // bytes from the tile's first row to the end of the last valid row
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(base + (int64_t)row0 * row_stride), 0, (int)(left < 0x7fffffff ? left : 0x7fffffff), 0x00020000);
+#pragma unroll
+  for (int i = 0; i < 64 * (HD / 8) / 256; ++i) buf_dma16(rs, lds + (wave * 64 + i * 256) * 16, voff[i]);
+}
+
 // A operand fragment of a row tile: row (32 tb + lane&31), 16-B chunk 2 ks + hh
 template <int HD>
 __device__ __forceinline__ bf16x8 frag_rows(const char* lds, int tb, int ks, int ql, int hh) {
@@ -132,9 +165,10 @@ __device__ __forceinline__ void xcd_head_tile(int nt, int& head_slot, int& t) {
 template <int HD, bool PACKED>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs p) {
   constexpr int TILE = 64 * HD * 2;                 // bytes of one 64-row tile (== HD x 128 B)
-  __shared__ __attribute__((aligned(16))) char lds[2 * TILE];
-  char* Ks = lds; char* Vs = lds + TILE;        // dQ^T += K^T . dS^T reads K^T fragments out of the K row tile (transpose reads)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // two (K, V) tile pairs: tile t+1 streams in by LDS-DMA while tile t is consumed (one barrier per tile; the synchronous
+  // global -> VGPR -> LDS staging was ~16 % of the kernel, profiles/r01l_attn_bwd_staging_variants.txt)
+  __shared__ __attribute__((aligned(1024))) char lds[4 * TILE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nqt = (p.S + 127) / 128;
   int head_slot, ti;
   xcd_head_tile(nqt, head_slot, ti);
@@ -164,17 +198,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs p) {
   int kv_end = p.S;
   if (p.causal) kv_end = min(p.S, min(qt * 128 + 127, p.S - 1) + 1);
   const int n_tiles = (kv_end + 63) / 64;
+  unsigned koff[64 * (HD / 8) / 256], voff[64 * (HD / 8) / 256];
+  dma_lane_offsets<HD>(koff, HD, tid);
+  dma_lane_offsets<HD>(voff, p.v_ss, tid);
+  stage_rows_dma<HD>(K, HD, 0, p.S, lds, koff, wave);
+  stage_rows_dma<HD>(V, p.v_ss, 0, p.S, lds + TILE, voff, wave);
   for (int t = 0; t < n_tiles; ++t) {
     const int kv0 = t * 64;
-    __syncthreads();
-#ifdef AB_NO_STAGE      // timing experiment: tiles staged once (results wrong by construction)
-    if (t == 0)
-#endif
-    {
-      stage_rows<HD>(K, HD, kv0, p.S, Ks, tid);
-      stage_rows<HD>(V, p.v_ss, kv0, p.S, Vs, tid);
+    const char* Ks = lds + (t & 1) * 2 * TILE;    // dQ^T += K^T . dS^T reads K^T fragments out of the K row tile (transpose reads)
+    const char* Vs = Ks + TILE;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                              // tile t has landed; every wave is done with the other pair (tile t - 1)
+    if (t + 1 < n_tiles) {
+      char* nx = lds + ((t + 1) & 1) * 2 * TILE;
+      stage_rows_dma<HD>(K, HD, kv0 + 64, p.S, nx, koff, wave);
+      stage_rows_dma<HD>(V, p.v_ss, kv0 + 64, p.S, nx + TILE, voff, wave);
     }
-    __syncthreads();
     // one 32-key block at a time: S^T and dP^T accumulators (32 VGPRs) are dead before the next block starts, which keeps
     // the kernel under 256 VGPRs = two waves per SIMD
     bf16x8 dsf[2][2];
@@ -229,13 +268,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs p) {
 template <int HD, int WHICH, bool PACKED>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs p) {
   constexpr int TILE = 64 * HD * 2;
-  constexpr int NT = 2;
-  __shared__ __attribute__((aligned(16))) char lds[NT * TILE + 512];
-  char* Qs = lds;                           // Q rows: S^T recompute (row fragments) and, for dK, the Q^T operand (transpose reads)
-  char* T1 = lds + TILE;                    // dO rows: dP^T (row fragments, dK) / the dO^T operand (transpose reads, dV)
-  float* lse_s = reinterpret_cast<float*>(lds + NT * TILE);      // [64]
-  float* D_s = lse_s + 64;                                       // [64]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // two (Q, dO) tile pairs + their lse / D rows: pair i+1 streams in by LDS-DMA while pair i is consumed (see the dQ kernel)
+  __shared__ __attribute__((aligned(1024))) char lds[4 * TILE + 1024];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int head_slot, kt_;
   xcd_head_tile((p.S + 127) / 128, head_slot, kt_);
   const int b = head_slot / p.Hkv, hk = head_slot - b * p.Hkv;
@@ -259,27 +294,42 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs p) {
   const float sl2 = p.scale * 1.4426950408889634f;
   const int q_begin = p.causal ? (kt_ * 128) / 64 : 0;      // first q tile that can see this block's keys
   const int n_qt = (p.S + 63) / 64;
-  for (int rep = 0; rep < nrep; ++rep) {
-    const int h = hk * nrep + rep;
-    const bf16_t* Q = p.q + ((int64_t)b * p.S * p.H + h) * HD;        // row stride H*HD
-    const bf16_t* DO = p.dout + ((int64_t)b * p.S * p.H + h) * HD;
-    for (int t = q_begin; t < n_qt; ++t) {
-      const int q0 = t * 64;
-      __syncthreads();
-#ifdef AB_NO_STAGE
-      if (t == q_begin)
-#endif
-      {
-      stage_rows<HD>(Q, (int64_t)p.H * HD, q0, p.S, Qs, tid);
-      asm volatile("" ::: "memory");         // one tile's staging registers at a time (VGPR budget of two waves per SIMD)
-      stage_rows<HD>(DO, (int64_t)p.H * HD, q0, p.S, T1, tid);
-      }
-      if (tid < 64) {
-        const int qq = min(q0 + tid, p.S - 1);
-        lse_s[tid] = p.lse[((int64_t)b * p.H + h) * p.S + qq] * 1.4426950408889634f;
-        if (WHICH == 1) D_s[tid] = p.D[((int64_t)b * p.S + qq) * p.H + h];
-      }
-      __syncthreads();
+  const int n_it = n_qt - q_begin, total = nrep * n_it;
+  // pair `it` = (head repetition it / n_it, query tile q_begin + it % n_it) -> buffer it & 1:
+  //   [Q rows | dO rows] (S^T recompute from row fragments; Q^T for dK / dO^T for dV by transpose reads) + lse[64] | D[64]
+  auto issue = [&](int it) {
+    // per-lane offsets recomputed per issue from an opaque copy of the thread id (a dozen VALU ops per ~1.5 us iteration): as
+    // loop constants they would be live across the whole query loop, and the dK kernel has no VGPR to spare
+    int tid_o = tid;
+    asm volatile("" : "+v"(tid_o));
+    const int lane = tid_o & 63;
+    unsigned qoff[64 * (HD / 8) / 256];          // Q and dO rows share the row stride H*HD
+    dma_lane_offsets<HD>(qoff, (int64_t)p.H * HD, tid_o);
+    const int h = hk * nrep + it / n_it, q0 = (q_begin + it % n_it) * 64;
+    char* buf = lds + (it & 1) * 2 * TILE;
+    stage_rows_dma<HD>(p.q + ((int64_t)b * p.S * p.H + h) * HD, (int64_t)p.H * HD, q0, p.S, buf, qoff, wave);
+    stage_rows_dma<HD>(p.dout + ((int64_t)b * p.S * p.H + h) * HD, (int64_t)p.H * HD, q0, p.S, buf + TILE, qoff, wave);
+    float* sm = reinterpret_cast<float*>(lds + 4 * TILE) + (it & 1) * 128;
+    if (wave == 0) {
+      const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.lse + ((int64_t)b * p.H + h) * p.S + q0), 0, (p.S - q0) * 4, 0x00020000);
+      buf_dma4(rs, sm, lane * 4);
+    }
+    if (WHICH == 1 && wave == 1) {
+      const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.D + ((int64_t)b * p.S + q0) * p.H + h), 0, ((p.S - 1 - q0) * p.H + 1) * 4, 0x00020000);
+      buf_dma4(rs, sm + 64, lane * p.H * 4);
+    }
+  };
+  if (total > 0) issue(0);
+  for (int it = 0; it < total; ++it) {
+    {
+      const int q0 = (q_begin + it % n_it) * 64;
+      const char* Qs = lds + (it & 1) * 2 * TILE;
+      const char* T1 = Qs + TILE;
+      const float* lse_s = reinterpret_cast<const float*>(lds + 4 * TILE) + (it & 1) * 128;
+      const float* D_s = lse_s + 64;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                       // pair `it` has landed; every wave is done with the other buffer (pair it - 1)
+      if (it + 1 < total) issue(it + 1);
       bf16x8 bf[2][2];                       // P (dV) or dS (dK) as the B operand of the accumulation products
 #pragma unroll
       for (int tb = 0; tb < 2; ++tb) {
@@ -294,7 +344,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs p) {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
           const int qb = tb * 32 + 8 * g4 + 4 * hh;                       // 4 consecutive query rows of the tile
-          const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qb);   // lse * log2(e)
+          f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qb);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) l4[e] *= 1.4426950408889634f;       // lse * log2(e)
           f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
           if (WHICH == 1) d4 = *reinterpret_cast<const f32x4*>(D_s + qb);
 #pragma unroll
