@@ -331,6 +331,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs p) {
       __syncthreads();                       // pair `it` has landed; every wave is done with the other buffer (pair it - 1)
       if (it + 1 < total) issue(it + 1);
       bf16x8 bf[2][2];                       // P (dV) or dS (dK) as the B operand of the accumulation products
+      const int kv_hi = kt_ * 128 + wave * 32 + 31;                        // last key of this wave (wave-uniform)
+      const bool interior = (q0 + 64 <= p.S) && (kv_hi < p.S) && (!p.causal || q0 >= kv_hi);
 #pragma unroll
       for (int tb = 0; tb < 2; ++tb) {
         f32x16 s, dp;
@@ -349,13 +351,26 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs p) {
           for (int e = 0; e < 4; ++e) l4[e] *= 1.4426950408889634f;       // lse * log2(e)
           f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
           if (WHICH == 1) d4 = *reinterpret_cast<const f32x4*>(D_s + qb);
+          // interior pairs (all 64 query rows exist and see all 32 keys of this wave): no compare / select per element; on
+          // the others the exponential is evaluated unconditionally and selected (an `ok ? exp : 0` form compiles to one
+          // exec-mask branch per element: 32 per tile)
+          if (interior) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int r = g4 * 4 + e;
-            const int qg = q0 + qb + e;
-            const bool ok = (qg < p.S) && (kvrow < p.S) && (!p.causal || kvrow <= qg);
-            const float pr = ok ? __builtin_amdgcn_exp2f(fmaf(s[r], sl2, -l4[e])) : 0.f;
-            bf[tb][r >> 3][r & 7] = WHICH == 0 ? f2bf(pr) : f2bf(pr * (dp[r] - d4[e]) * p.scale);
+            for (int e = 0; e < 4; ++e) {
+              const int r = g4 * 4 + e;
+              const float pr = __builtin_amdgcn_exp2f(fmaf(s[r], sl2, -l4[e]));
+              bf[tb][r >> 3][r & 7] = WHICH == 0 ? f2bf(pr) : f2bf(pr * (dp[r] - d4[e]) * p.scale);
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int r = g4 * 4 + e;
+              const int qg = q0 + qb + e;
+              const bool ok = (qg < p.S) && (kvrow < p.S) && (!p.causal || kvrow <= qg);
+              const float ev = __builtin_amdgcn_exp2f(fmaf(s[r], sl2, -l4[e]));
+              const float pr = ok ? ev : 0.f;
+              bf[tb][r >> 3][r & 7] = WHICH == 0 ? f2bf(pr) : f2bf(ok ? pr * (dp[r] - d4[e]) * p.scale : 0.f);
+            }
           }
         }
       }
