@@ -235,8 +235,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs p) {
         for (int r = 0; r < 16; ++r) {
           const int kv = kv0 + tb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
           const bool ok = (kv < p.S) && (!p.causal || kv <= qrow);
-          const float pr = ok ? __builtin_amdgcn_exp2f(fmaf(s[r], sl2, -lse2)) : 0.f;
-          dsf[tb][r >> 3][r & 7] = f2bf(pr * (dp[r] - Dq) * p.scale);
+          const float ev = __builtin_amdgcn_exp2f(fmaf(s[r], sl2, -lse2));      // unconditional + select: no exec branch per element
+          dsf[tb][r >> 3][r & 7] = f2bf(ok ? ev * (dp[r] - Dq) * p.scale : 0.f);
         }
       } else {
 #pragma unroll
