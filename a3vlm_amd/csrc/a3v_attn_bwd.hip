@@ -368,8 +368,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs p) {
               const int qg = q0 + qb + e;
               const bool ok = (qg < p.S) && (kvrow < p.S) && (!p.causal || kvrow <= qg);
               const float ev = __builtin_amdgcn_exp2f(fmaf(s[r], sl2, -l4[e]));
-              const float pr = ok ? ev : 0.f;
-              bf[tb][r >> 3][r & 7] = WHICH == 0 ? f2bf(pr) : f2bf(ok ? pr * (dp[r] - d4[e]) * p.scale : 0.f);
+              const float val = WHICH == 0 ? ev : ev * (dp[r] - d4[e]) * p.scale;
+              bf[tb][r >> 3][r & 7] = f2bf(ok ? val : 0.f);
             }
           }
         }
