@@ -794,11 +794,15 @@ extern "C" int a3v_rows_sum(const void* src, int64_t ld, const int32_t* row_idx,
 namespace {
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, int64_t n4, int64_t n, float decay, float b1, float b2,
-                                                    float step_size, float inv_bc2_sqrt, float eps, bf16_t* __restrict__ img) {
+                                                    float step_size, float inv_bc2_sqrt, float eps, bf16_t* __restrict__ img,
+                                                    const float* __restrict__ gscale) {
+  const float gs = gscale ? *gscale : 1.f;       // clip coefficient (device scalar): g * coef rounded to fp32 = the value grad.mul_(coef) stores
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
     f32x4 pp = reinterpret_cast<const f32x4*>(p)[i];
-    const f32x4 gg = reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 gg = reinterpret_cast<const f32x4*>(g)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) gg[e] = __fmul_rn(gg[e], gs);      // rounded product (never contracted into the fma below)
     f32x4 mm = reinterpret_cast<const f32x4*>(m)[i];
     f32x4 vv = reinterpret_cast<const f32x4*>(v)[i];
 #pragma unroll
@@ -822,7 +826,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   if (blockIdx.x == 0 && threadIdx.x < (int)(n - n4 * 4)) {
     const int64_t i = n4 * 4 + threadIdx.x;
     float pp = p[i] * decay;
-    const float gg = g[i];
+    const float gg = __fmul_rn(g[i], gs);
     const float mm = m[i] + (1.f - b1) * (gg - m[i]);
     const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
     pp -= step_size * mm / (sqrtf(vv) * inv_bc2_sqrt + eps);
@@ -832,8 +836,19 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 }
 }  // namespace
 
+extern "C" int a3v_adamw_scaled(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                                float beta2, float eps, float weight_decay, int64_t step, void* bf16_image, const float* grad_scale,
+                                void* stream);
 extern "C" int a3v_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                          float beta2, float eps, float weight_decay, int64_t step, void* bf16_image, void* stream) {
+  return a3v_adamw_scaled(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, bf16_image, nullptr, stream);
+}
+
+// a3v_adamw with the gradient multiplied by a DEVICE scalar on the way in (the global-norm clip coefficient of
+// util/clip_grad.py:187-193 without the separate grad.mul_ pass over every gradient and without a host read of the norm)
+extern "C" int a3v_adamw_scaled(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                                float beta2, float eps, float weight_decay, int64_t step, void* bf16_image, const float* grad_scale,
+                                void* stream) {
   if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || step < 1) return A3V_ERR_ARG;
   if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return A3V_ERR_SHAPE;
   if (bf16_image && ((uintptr_t)bf16_image & 7)) return A3V_ERR_SHAPE;
@@ -845,7 +860,7 @@ extern "C" int a3v_adamw(float* param, const float* grad, float* exp_avg, float*
   if (blocks > 256 * 16) blocks = 256 * 16;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n4, n, decay,
-                     beta1, beta2, step_size, inv_bc2_sqrt, eps, (bf16_t*)bf16_image);
+                     beta1, beta2, step_size, inv_bc2_sqrt, eps, (bf16_t*)bf16_image, grad_scale);
   A3V_LAUNCH_CHECK();
   return A3V_OK;
 }

@@ -87,15 +87,32 @@ class GradReducer:
         self.finish()
 
 
-def clip_grad_norm(parameters, max_norm: float) -> torch.Tensor:
-    """util/clip_grad.py:59-210 for pure DP: fp32 global L2 norm, coef = max_norm/(norm+1e-6) clamped to 1."""
+def clip_grad_norm(parameters, max_norm: float, flat: Optional[torch.Tensor] = None, defer: bool = False):
+    """util/clip_grad.py:59-210 for pure DP: fp32 global L2 norm, coef = max_norm/(norm+1e-6) clamped to 1, every gradient
+    multiplied by coef.  Returns the norm.
+
+    ``flat``: the training engine's flat gradient buffer (``TrainEngine.flat_grads()``); when every gradient is a view into
+    it the norm is ONE reduction over the buffer instead of one per parameter (its padding is zero).  ``defer=True`` returns
+    ``(norm, coef)`` and leaves the gradients untouched: the caller hands ``coef`` (a device scalar) to
+    ``FusedAdamW.step(grad_scale=coef)``, which multiplies as it reads -- no separate read + write of every gradient."""
     grads = [p.grad for p in parameters if p.grad is not None]
     if not grads:
-        return torch.zeros(())
-    norm = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(g.float()) for g in grads]))
+        z = torch.zeros(())
+        return (z, torch.ones(())) if defer else z
+    in_flat = flat is not None and flat.dtype == torch.float32 and all(
+        g.dtype == torch.float32 and g.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() for g in grads)
+    if in_flat:
+        norm = torch.linalg.vector_norm(flat)
+    else:
+        norm = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(g.float()) for g in grads]))
     coef = torch.clamp(max_norm / (norm + 1e-6), max=1.0)
-    for g in grads:
-        g.mul_(coef.to(g.dtype))
+    if defer:
+        return norm, coef.to(torch.float32)
+    if in_flat:
+        flat.mul_(coef)
+    else:
+        for g in grads:
+            g.mul_(coef.to(g.dtype))
     return norm
 
 

@@ -58,9 +58,18 @@ def train_one_epoch(model, data_loader, optimizer, epoch: int, start_iter: int, 
                     reducer.reduce_all_now()
                 else:
                     reducer.finish()
+            eng = getattr(optimizer, "engine", None)
             if getattr(args, "clip_grad", -1) and args.clip_grad > 0:
-                stats["grad_norm"] = clip_grad_norm(params, args.clip_grad)
-            optimizer.step()
+                if eng is not None:
+                    # one norm over the engine's flat gradient buffer; the coefficient stays on the device and is applied by the
+                    # optimizer kernel as it reads the gradients (a3v_adamw_scaled): no grad.mul_ pass, no host sync
+                    stats["grad_norm"], coef = clip_grad_norm(params, args.clip_grad, flat=eng.flat_grads(), defer=True)
+                    optimizer.step(grad_scale=coef)
+                else:
+                    stats["grad_norm"] = clip_grad_norm(params, args.clip_grad)
+                    optimizer.step()
+            else:
+                optimizer.step()
             model.zero_grad(set_to_none=True)
         boundary_idx = (step + 1) // accum_iter
         if update_grad and (boundary_idx % print_freq == 0 or step + 1 == n_iter + start_iter):

@@ -31,6 +31,7 @@ SIGNATURES = {
     "a3v_attention_bwd_packed": (I, [P, P, L, L, P, L, L, L, P, L, P, P, P, P, L, P, I, I, I, I, I, I, I, I, P]),
     "a3v_lora_refresh": (I, [P, P, I, I, I, P, L, P, L, P, L, P, L, I, I, P]),
     "a3v_adamw": (I, [P, P, P, P, L, F, F, F, F, F, L, P, P]),
+    "a3v_adamw_scaled": (I, [P, P, P, P, L, F, F, F, F, F, L, P, P, P]),
     "a3v_gemm_nn": (I, [P, L, P, L, P, L, I, I, I, P, L, I, P]),
     "a3v_gemm_tn": (I, [P, L, P, L, P, L, I, I, I, P, L, I, P]),
     "a3v_gemm_set_workspace": (I, [P, L]),

@@ -30,13 +30,18 @@ class FusedAdamW(torch.optim.Optimizer):
         self.image_of = image_of if engine is None else engine.image_sink
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, grad_scale: Optional[torch.Tensor] = None):
+        """``grad_scale``: optional fp32 device scalar every gradient is multiplied by as it is read (the clip coefficient of
+        ``dp.clip_grad_norm(..., defer=True)``): same update as ``grad.mul_(coef)`` + ``step()``; ``p.grad`` is left unscaled."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
         lib = _l.load()
         stream = torch.cuda.current_stream().cuda_stream
+        if grad_scale is not None and (not grad_scale.is_cuda or grad_scale.dtype != torch.float32 or grad_scale.numel() != 1):
+            raise RuntimeError("grad_scale must be a one-element fp32 device tensor")
+        gs_ptr = grad_scale.data_ptr() if grad_scale is not None else None
         written = set()
         for group in self.param_groups:
             b1, b2 = group["betas"]
@@ -55,10 +60,10 @@ class FusedAdamW(torch.optim.Optimizer):
                 img = self.image_of(p) if self.image_of is not None else None
                 if img is not None and (img.dtype != torch.bfloat16 or img.shape != p.shape or not img.is_contiguous()):
                     raise RuntimeError("image_of must return a contiguous bf16 tensor of the parameter's shape")
-                rc = lib.a3v_adamw(p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(),
-                                   float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
-                                   int(st["step"].item()), img.data_ptr() if img is not None else None, stream)
-                _l.check(rc, "a3v_adamw")
+                rc = lib.a3v_adamw_scaled(p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(),
+                                          float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
+                                          int(st["step"].item()), img.data_ptr() if img is not None else None, gs_ptr, stream)
+                _l.check(rc, "a3v_adamw_scaled")
                 # the kernel wrote through raw pointers: tell autograd / version-keyed caches (the engine's bf16 weight images)
                 torch.autograd.graph.increment_version(p)
                 if img is not None:

@@ -169,7 +169,7 @@ def train_leg(m, args, B, T, image, tokens, steps, dist, dev):
     gradient buckets are all-reduced over RCCL on a side stream while earlier layers still back-propagate."""
     from a3vlm_amd.train import TrainEngine
     from a3vlm_amd.util import promote_trainable_params_to_fp32
-    from a3vlm_amd.dp import GradReducer
+    from a3vlm_amd.dp import GradReducer, clip_grad_norm
     for n, p in m.named_parameters():
         p.requires_grad = not n.startswith("clip.")
     m._ws.clear(); m._packed.clear(); m._packed_version = None; m._destroy_kv_cache()
@@ -180,6 +180,7 @@ def train_leg(m, args, B, T, image, tokens, steps, dist, dev):
     promote_trainable_params_to_fp32(m)
     eng = TrainEngine(m, torch.bfloat16)
     params = [p for p in m.parameters() if p.requires_grad]
+    params_list = params
     from a3vlm_amd.optim import FusedAdamW
     opt = FusedAdamW(params, lr=2e-5, betas=(0.9, 0.95), weight_decay=0.0, engine=eng)
     # bf16 on the wire = the reference's FSDP MixedPrecision(reduce_dtype=bf16) (main_finetune.py:251-255); fp32 accumulation buffers
@@ -192,7 +193,10 @@ def train_leg(m, args, B, T, image, tokens, steps, dist, dev):
         eng.backward(1.0)
         if red is not None:
             red.finish()
-        opt.step()
+        # global-norm clip of the reference recipe (--clip_grad 8, a3vlm_train.sh:47-55; util/misc.py:302-315): one reduction
+        # over the flat gradient buffer, coefficient applied inside the optimizer kernel
+        _, coef = clip_grad_norm(params_list, 8.0, flat=eng.flat_grads(), defer=True)
+        opt.step(grad_scale=coef)
         opt.zero_grad(set_to_none=True)
         return loss
 
@@ -222,7 +226,7 @@ def lora_leg(m, args, B, T, image, tokens, steps, dist, dev, rank=16):
     from a3vlm_amd.model.LLM import llama_ens5_peft as peft
     from a3vlm_amd.train import TrainEngine
     from a3vlm_amd.util import promote_trainable_params_to_fp32
-    from a3vlm_amd.dp import GradReducer
+    from a3vlm_amd.dp import GradReducer, clip_grad_norm
     torch.cuda.reset_peak_memory_stats()
     pargs = peft.ModelArgs(**dataclasses.asdict(args), lora_rank=rank)
     with torch.device("meta"):
@@ -248,7 +252,8 @@ def lora_leg(m, args, B, T, image, tokens, steps, dist, dev, rank=16):
     n_train = sum(p.numel() for p in pm.parameters() if p.requires_grad)
     eng = TrainEngine(pm, torch.bfloat16)
     from a3vlm_amd.optim import FusedAdamW
-    opt = FusedAdamW([p for p in pm.parameters() if p.requires_grad], lr=2e-5, betas=(0.9, 0.95), weight_decay=0.0, engine=eng)
+    params_list = [p for p in pm.parameters() if p.requires_grad]
+    opt = FusedAdamW(params_list, lr=2e-5, betas=(0.9, 0.95), weight_decay=0.0, engine=eng)
     # bf16 on the wire = the reference's FSDP MixedPrecision(reduce_dtype=bf16) (main_finetune.py:251-255); fp32 accumulation buffers
     red = GradReducer(eng, dist, reduce_dtype=torch.bfloat16) if dist is not None else None
     labels = tokens.clone()
@@ -259,7 +264,10 @@ def lora_leg(m, args, B, T, image, tokens, steps, dist, dev, rank=16):
         eng.backward(1.0)
         if red is not None:
             red.finish()
-        opt.step()
+        # global-norm clip of the reference recipe (--clip_grad 8, a3vlm_train.sh:47-55; util/misc.py:302-315): one reduction
+        # over the flat gradient buffer, coefficient applied inside the optimizer kernel
+        _, coef = clip_grad_norm(params_list, 8.0, flat=eng.flat_grads(), defer=True)
+        opt.step(grad_scale=coef)
         opt.zero_grad(set_to_none=True)
         return loss
 
@@ -519,7 +527,7 @@ def main():
                      "hbm_gib": round(mem, 1), "tflops": round((3 * fl_t["total"]) * world / sec / 1e12, 1),
                      "mfma_frac": round(3 * fl_t["total"] / sec / MFMA_PEAK_BF16, 4),
                      "config": f"full fine-tune of decoder+projector (6.7 G trainable), bs={B}/GPU, {T}-token prompts + 579 image words, fp32 masters + "
-                               f"bf16 GEMMs, block activations kept in HBM (no recompute), AdamW (a3v_adamw), dp{world}"
+                               f"bf16 GEMMs, block activations kept in HBM (no recompute), global-norm clip 8 + AdamW (a3v_adamw_scaled), dp{world}"
                                + (" with RCCL all-reduce of per-layer fp32 grad buckets overlapped with backward" if world > 1 else ""),
                      "flop_convention": "3 x forward FLOPs of the step (SURVEY 8(d)); LM head on all text positions and the frozen ViT counted once are ignored"}
         except Exception as e:

@@ -346,6 +346,13 @@ int a3v_rows_sum(const void* src, int64_t ld, const int32_t* row_idx, int n_rows
 int a3v_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
               float eps, float weight_decay, int64_t step, void* bf16_image, void* stream);
 
+/* a3v_adamw with the gradient multiplied by *grad_scale (a DEVICE fp32 scalar, NULL = 1) as it is read: the clip of
+ * NativeScalerWithGradNormCount.__call__ (util/misc.py:302-315) / clip_grad_norm (util/clip_grad.py:187-193: coef =
+ * max_norm / (norm + 1e-6) clamped to 1, every gradient multiplied by it) folded into the optimizer pass -- same values as
+ * grad.mul_(coef) followed by a3v_adamw, without the extra read + write of every gradient and without a host read of the norm. */
+int a3v_adamw_scaled(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                     float eps, float weight_decay, int64_t step, void* bf16_image, const float* grad_scale, void* stream);
+
 /* Re-write one adapter's rows / columns of a fused LoRA group's bf16 images from its fp32 parameters (model/peft.py:40-64
  * lora_a [r, in], lora_b [nj, r]): A[col0+i, :] and At[:, col0+i] from lora_a, B[row0+n, col0+i] and Bt[col0+i, row0+n] from lora_b. */
 int a3v_lora_refresh(const float* lora_a, const float* lora_b, int r, int in_f, int nj, void* A, int64_t lda, void* At, int64_t ldat,

@@ -390,3 +390,59 @@ def test_attention_bwd_packed_equals_bwd_then_rope_pack(B, S, H, Hkv, hd):
     scale = float(b.abs().max())
     assert float((a - b).abs().max()) <= 2 ** -6 * scale
     assert torch.equal(got[:, (H + Hkv) * hd:N], ref[:, (H + Hkv) * hd:N])       # dv is not rotated: identical
+
+
+@pytest.mark.gpu
+def test_fused_adamw_grad_scale_equals_scaled_gradients():
+    """FusedAdamW.step(grad_scale=coef) (a3v_adamw_scaled: the clip coefficient applied as the gradient is read) is the same
+    update, bit for bit, as grad.mul_(coef) followed by step() (util/clip_grad.py:187-193 + engine_finetune.py:63)."""
+    import copy
+    from a3vlm_amd.optim import FusedAdamW
+    from a3vlm_amd.dp import clip_grad_norm
+    g = torch.Generator(device=DEV).manual_seed(5)
+    shapes = [(257, 131), (64,), (1000, 7)]
+    pa = [torch.nn.Parameter(torch.randn(*s, device=DEV, generator=g)) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa = FusedAdamW(pa, lr=1e-2, betas=(0.9, 0.95), weight_decay=0.1)
+    ob = FusedAdamW(pb, lr=1e-2, betas=(0.9, 0.95), weight_decay=0.1)
+    for it in range(3):
+        grads = [torch.randn(*s, device=DEV, generator=g) * (10.0 if it == 0 else 1e-4) for s in shapes]
+        for p, q, gr in zip(pa, pb, grads):
+            p.grad = gr.clone()
+            q.grad = gr.clone()
+        na, coef = clip_grad_norm(pa, 1.0, defer=True)
+        assert coef.dtype == torch.float32 and coef.is_cuda
+        oa.step(grad_scale=coef)
+        nb = clip_grad_norm(pb, 1.0)               # scales pb's gradients in place
+        ob.step()
+        assert torch.equal(na, nb)
+        assert (float(coef) < 1.0) == (it == 0)
+        for p, q in zip(pa, pb):
+            assert torch.equal(p, q)
+            assert torch.equal(oa.state[p]["exp_avg"], ob.state[q]["exp_avg"])
+            assert torch.equal(oa.state[p]["exp_avg_sq"], ob.state[q]["exp_avg_sq"])
+
+
+@pytest.mark.gpu
+def test_clip_grad_norm_on_flat_buffer_matches_per_parameter_form():
+    from a3vlm_amd.dp import clip_grad_norm
+    g = torch.Generator(device=DEV).manual_seed(6)
+    flat = torch.randn(5000, device=DEV, generator=g)
+    views = [flat[0:1200].view(30, 40), flat[1200:1264], flat[2048:5000].view(-1, 8)]
+    flat[1264:2048] = 0                                    # padding between views is zero in the engine's buffer
+    ps = [torch.nn.Parameter(torch.zeros_like(v)) for v in views]
+    for p, v in zip(ps, views):
+        p.grad = v
+    ref = [torch.nn.Parameter(torch.zeros_like(v)) for v in views]
+    for p, v in zip(ref, views):
+        p.grad = v.clone()
+    n_ref = clip_grad_norm(ref, 0.5)
+    n_flat, coef = clip_grad_norm(ps, 0.5, flat=flat, defer=True)
+    assert abs(float(n_flat) - float(n_ref)) <= 1e-5 * float(n_ref)
+    assert abs(float(coef) - 0.5 / (float(n_ref) + 1e-6)) <= 1e-6
+    before = flat.clone()
+    n2 = clip_grad_norm(ps, 0.5, flat=flat)                # in-place form on the flat buffer
+    assert torch.equal(n2, n_flat)
+    assert torch.allclose(flat, before * coef, rtol=1e-6, atol=0)
+    for p, q in zip(ps, ref):
+        assert torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-8)
