@@ -30,29 +30,13 @@ struct BwdArgs {
   float scale;
 };
 
-// 64-row x HD tile of row-major bf16 rows -> LDS with the 16-B chunk XOR swizzle of the forward K tile
-template <int HD>
-__device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ base, int64_t row_stride, int row0, int nrows, char* lds, int tid) {
-  constexpr int KCH = HD / 8;
-  constexpr int PER = 64 * KCH / 256;
-#pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    const int id = tid + i * 256;
-    const int row = id / KCH, ch = id % KCH;
-    int r = row0 + row;
-    r = r < nrows ? r : nrows - 1;
-    const u32x4 val = *reinterpret_cast<const u32x4*>(base + (int64_t)r * row_stride + ch * 8);
-    const int sw = (HD == 128) ? (row & 15) : ((row >> 1) & 7);
-    *reinterpret_cast<u32x4*>(lds + row * (HD * 2) + ((ch ^ sw) << 4)) = val;
-  }
-}
-
-// Asynchronous form of stage_rows: a 64-row tile goes global -> LDS by LDS-DMA without passing through VGPRs; it has landed after
+// Tile staging: a 64-row x HD tile of row-major bf16 rows goes global -> LDS by LDS-DMA (16-B chunk XOR swizzle of the forward K
+// tile: logical chunk ch of row r sits at physical chunk ch ^ swizzle(r)) without passing through VGPRs; it has landed after
 // `s_waitcnt vmcnt(0)` + a workgroup barrier.  One wave instruction writes 1 KiB (lane-linear), so the chunk swizzle is applied on
 // the SOURCE side: thread id -> (row id / KCH, physical chunk id % KCH) fetches logical chunk (physical ^ swizzle(row)).  Buffer-
 // descriptor form: the per-lane byte offsets (dma_lane_offsets) are loop constants shared by every tile with the same row stride;
 // the tile's first row goes into the descriptor base and the bytes left up to the end of the last valid row into num_records, so
-// rows past the end read as zeros (their scores are masked).  Same LDS image as stage_rows for the valid rows.
+// rows past the end read as zeros (their scores are masked).
 __device__ __forceinline__ void buf_dma16(__amdgpu_buffer_rsrc_t rs, char* lds_dst, unsigned voff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, 0, 0, 0);
 }
