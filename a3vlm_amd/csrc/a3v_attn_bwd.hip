@@ -30,6 +30,18 @@ struct BwdArgs {
   float scale;
 };
 
+// 16-B chunk swizzle of a row tile: logical chunk c of row r sits at physical chunk c ^ tile_swz(r).  Two access patterns must
+// both be conflict-free: (a) row fragments, ds_read_b128 by 16 lanes on 16 consecutive rows at one logical chunk -> the swizzle
+// must be a bijection on 16 consecutive rows; (b) transpose reads (ds_read_b64_tr_b16), where one half-wave reads 64 B (four
+// chunks) of each of FOUR consecutive rows -> the four rows must differ in the upper two chunk bits.  HD 128 (16 chunks = one
+// 256-B bank row per tile row): the row's two low bits go to the upper chunk bits and bits 2-3 to the lower ones.  With the
+// plain `r & 15` the four rows of (b) shared their 64 banks: 4-way conflicts on every transpose read (17.7 M conflict cycles per
+// launch in profiles/r01t_pmc_attention.txt, ~6 extra cycles per read).
+template <int HD>
+__device__ __forceinline__ int tile_swz(int row) {
+  return (HD == 128) ? (((row & 3) << 2) | ((row >> 2) & 3)) : ((row >> 1) & 7);
+}
+
 // Tile staging: a 64-row x HD tile of row-major bf16 rows goes global -> LDS by LDS-DMA (16-B chunk XOR swizzle of the forward K
 // tile: logical chunk ch of row r sits at physical chunk ch ^ swizzle(r)) without passing through VGPRs; it has landed after
 // `s_waitcnt vmcnt(0)` + a workgroup barrier.  One wave instruction writes 1 KiB (lane-linear), so the chunk swizzle is applied on
@@ -50,7 +62,7 @@ __device__ __forceinline__ void dma_lane_offsets(unsigned (&voff)[64 * (HD / 8) 
   for (int i = 0; i < 64 * KCH / 256; ++i) {
     const int id = tid + i * 256;
     const int row = id / KCH, pc = id % KCH;
-    const int sw = (HD == 128) ? (row & 15) : ((row >> 1) & 7);
+    const int sw = tile_swz<HD>(row);
     voff[i] = (unsigned)((row * row_stride + ((pc ^ sw) << 3)) * 2);
   }
 }
@@ -68,7 +80,7 @@ __device__ __forceinline__ void stage_rows_dma(const bf16_t* base, int64_t row_s
 template <int HD>
 __device__ __forceinline__ bf16x8 frag_rows(const char* lds, int tb, int ks, int ql, int hh) {
   const int row = tb * 32 + ql;
-  const int sw = (HD == 128) ? (row & 15) : ((row >> 1) & 7);
+  const int sw = tile_swz<HD>(row);
   return *reinterpret_cast<const bf16x8*>(lds + row * (HD * 2) + (((2 * ks + hh) ^ sw) << 4));
 }
 
@@ -85,8 +97,7 @@ __device__ __forceinline__ bf16x8 frag_rows_tr(const char* lds, int db, int tb, 
   const int chunk16 = ((db * 32 + 16 * (ql >> 4)) >> 3) + ((i & 3) >> 1);
   const int row0 = 32 * tb + 16 * c + 4 * hh + (i >> 2);
   const int row1 = row0 + 8;
-  const int sw0 = (HD == 128) ? (row0 & 15) : ((row0 >> 1) & 7);
-  const int sw1 = (HD == 128) ? (row1 & 15) : ((row1 >> 1) & 7);
+  const int sw0 = tile_swz<HD>(row0), sw1 = tile_swz<HD>(row1);
   const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(lds + row0 * (HD * 2) + ((chunk16 ^ sw0) << 4) + (i & 1) * 8));
   const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(lds + row1 * (HD * 2) + ((chunk16 ^ sw1) << 4) + (i & 1) * 8));
   bf16x8 f;
