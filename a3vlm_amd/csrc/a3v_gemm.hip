@@ -1383,7 +1383,11 @@ __global__ __launch_bounds__(256) void gemv_dma_bf16_kernel(GemvArgs p) {
   for (int s4 = 0; s4 < 4; ++s4) foff[s4] = (((4 * s4 + fg) ^ fr) & 15) * 16;
   int aoff[4];
 #pragma unroll
-  for (int s4 = 0; s4 < 4; ++s4) aoff[s4] = (((4 * s4 + fg) ^ arow) & 15) * 16;
+  // AROWS == 8: lanes fr >= 8 feed accumulator columns 8..15, which are never stored.  Pointing them at the SAME address as lane
+  // fr - 8 made every A fragment read a 2-way bank conflict (b128 reads do not merge duplicates: PMC conflict cycles = 2x the
+  // active LDS cycles); with the lane's own fr in the swizzle they read the other half-row of the same row instead (any finite
+  // data will do) and the 16 lanes of a group cover 16 distinct slots.
+  for (int s4 = 0; s4 < 4; ++s4) aoff[s4] = (((4 * s4 + fg) ^ fr) & 15) * 16;
   for (int st = 0; st < nst; ++st) {
     const int slot = st & 1;
     if (st + 2 <= nst) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
