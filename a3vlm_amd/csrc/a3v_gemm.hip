@@ -18,6 +18,7 @@
 //  * gemm_nt_f32_kernel : fp32 parity path (plain FMA, 64x64x16 tile).
 #include "a3v_common.h"
 #include <algorithm>
+#include <type_traits>
 
 namespace {
 
@@ -677,6 +678,262 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_pp_kernel(GemmArgs p) {
 #undef PP_STAMP
 #undef PP_READ_FRAGS
 #undef PP_MFMA_ALL
+}
+
+// ------------------------------------------------------------------------------------
+// "Ring" form of the ping-pong kernel: the same tile, fragments, MFMA stream and epilogue, but the LDS is cut into three
+// rings that together use all 160 KiB of the CU, so every LDS-DMA piece has THREE OR FOUR intervals (1.5 - 2 K-tile periods)
+// to land instead of two.  The two-stage kernel above waits ~2600 cycles for a stage that it issued one K-tile period
+// (2176 cycles of MFMA) earlier: the k-loop runs at the DMA's completion latency, not at the matrix pipe's rate.
+//
+//   A_top ring : rows   0..127 of the A tile (only group 0 reads them), 2 slots x 16 KiB   slot(t) = t & 1
+//   A_bot ring : rows 128..255 of the A tile (only group 1 reads them), 2 slots x 16 KiB   slot(t) = t & 1
+//   W ring     : the 256 W rows (both groups read them),                3 slots x 32 KiB   slot(t) = t % 3
+//
+//   interval I:   2t             2t+1            2t+2            2t+3
+//   group 0:      L(t)           M(t)            L(t+1)          M(t+1)
+//   group 1:      M(t-1)         L(t)            M(t)            L(t+1)
+//   freed at the barrier that ENDS the interval:
+//                 A_top(t)       A_bot(t), W(t)
+//   issued in L (the wave's partner on the SIMD is in its MFMA interval), 8 pieces per wave per K-tile:
+//     group 0 in L(t)  : A_bot(t+1) -> needed I = 2t+3 (3 intervals),   W rows 0..127 of tile t+2   -> needed I = 2t+4 (4)
+//     group 1 in L(t)  : W rows 128..255 of tile t+2 and A_top(t+2)     -> needed I = 2t+4 (3 intervals)
+//   counted waits (loads retire in order; a wave only ever waits for its OWN pieces, the barrier publishes them):
+//     group 0, end of L(t): vmcnt(12) = A_bot(t), the first 4 pieces of its previous burst, has landed (group 1 reads it next)
+//              end of M(t): vmcnt(8)  = the rest of that burst (W half of tile t+1) has landed
+//     group 1, end of L(t): vmcnt(8)  = its previous burst (W half and A_top of tile t+1) has landed
+//   The last two K-tiles issue shorter bursts, so their counts shrink accordingly (the switch below).
+// ------------------------------------------------------------------------------------
+// EARLY: the barrier that ends an MFMA interval is executed EARLY tile-rows before the interval's last MFMA.  Nothing after it
+// needs the barrier (the tail MFMAs read registers only), and the partner wave on the SIMD -- released by the same barrier --
+// starts its own MFMA stream while this wave is still feeding the pipe: no matrix-pipe bubble at the hand-over.
+template <int DBG, bool M32, int EARLY>   // M32: v_mfma_f32_32x32x16_bf16 (4x2 tiles per wave) instead of 16x16x32 (8x4)
+__global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
+  constexpr int TBM = 256, TBN = 256, WTM = 128, WTN = 64, TM = M32 ? 4 : 8, TN = M32 ? 2 : 4;
+  constexpr int AH = 128 * BK * 2;                      // 16 KiB: one group's half of an A K-tile
+  constexpr int WT = TBN * BK * 2;                      // 32 KiB: a W K-tile
+  constexpr int ATOP = 0, ABOT = 2 * AH, WB = 4 * AH;   // ring bases
+  __shared__ __attribute__((aligned(1024))) char lds[4 * AH + 3 * WT];   // 163840 B = all of the CU's LDS
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  const int ntiles = p.tiles_m * p.tiles_n;
+  auto tile_of = [&](int vb, int& tm0, int& tn0) {
+    const int xcd = vb & 7, q = ntiles >> 3, r = ntiles & 7;
+    const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
+    const int per_group = GROUP_M * p.tiles_n;
+    const int group = bid / per_group;
+    const int first_m = group * GROUP_M;
+    const int gsz = min(p.tiles_m - first_m, GROUP_M);
+    const int in_g = bid - group * per_group;
+    tm0 = (first_m + in_g % gsz) * TBM;
+    tn0 = (in_g / gsz) * TBN;
+  };
+  int m0, n0, sm0, sn0;     // tile being computed / tile being staged
+  tile_of(blockIdx.x, m0, n0);
+  sm0 = m0; sn0 = n0;
+  typedef typename std::conditional<M32, f32x16, f32x4>::type acc_t;
+  acc_t acc[TM][TN];
+
+  const int nk = p.K / BK;
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)(((int64_t)(p.M - 1) * p.lda + p.K) * 2), 0x00020000);
+  const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)(((int64_t)(p.N - 1) * p.ldw + p.K) * 2), 0x00020000);
+  // per-lane byte offset inside an 8-row chunk: row = lane/8, 16-B slot = (lane%8) ^ ((chunk*4 + lane/16) & 7)
+  const unsigned lr = lane >> 3;
+  unsigned voA[2], voW[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par) {
+    const unsigned sl = (lane & 7) ^ ((par * 4 + (lane >> 4)) & 7);
+    voA[par] = (unsigned)((lr * p.lda + sl * 8) * 2);
+    voW[par] = (unsigned)((lr * p.ldw + sl * 8) * 2);
+  }
+  // one 1-KiB piece = 8 rows x 128 B; `row` = first row inside the A (W) tile, `par` = its chunk index & 1 (swizzle key)
+  auto piece_a = [&](int row, int t, int par, char* dst) {
+    const unsigned so = (unsigned)(((int64_t)(sm0 + row) * p.lda + t * BK) * 2);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)dst, 16, voA[par] + so, 0, 0, 0);
+  };
+  auto piece_w = [&](int row, int t, int par, char* dst) {
+    const unsigned so = (unsigned)(((int64_t)(sn0 + row) * p.ldw + t * BK) * 2);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)dst, 16, voW[par] + so, 0, 0, 0);
+  };
+  // tile prologue (all 8 waves, 14 pieces each): K-tile 0 whole, A_top and W of K-tile 1
+  auto prologue = [&]() {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int ch = wave * 4 + c;                      // 32 chunks of A(0): waves 0-3 -> A_top, waves 4-7 -> A_bot
+      piece_a(ch * 8, 0, c & 1, lds + (wr ? ABOT : ATOP) + (ch & 15) * 1024);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) piece_w((wave * 4 + c) * 8, 0, c & 1, lds + WB + (wave * 4 + c) * 1024);
+    if (nk > 1) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) piece_a((wave * 2 + c) * 8, 1, c & 1, lds + ATOP + AH + (wave * 2 + c) * 1024);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) piece_w((wave * 4 + c) * 8, 1, c & 1, lds + WB + WT + (wave * 4 + c) * 1024);
+    }
+  };
+  prologue();
+
+  // fragments.  16x16x32: lane -> row (lane&15), 16-B slots (lane>>4) and 4 + (lane>>4) of the 64-k row (two MFMAs per tile);
+  // 32x32x16: lane -> row (lane&31), slots 2 kk + (lane>>5), kk = 0..3 (four MFMAs per tile).  24 ds_read_b128 either way.
+  const int frow = M32 ? (lane & 31) : (lane & 15), fsw = (lane >> 1) & 7;
+  constexpr int NKK = M32 ? 4 : 2;
+  int offk[NKK];
+#pragma unroll
+  for (int kk = 0; kk < NKK; ++kk) offk[kk] = (M32 ? ((kk * 2 + (lane >> 5)) ^ fsw) : ((kk * 4 + (lane >> 4)) ^ fsw)) << 4;
+  const int a_base = frow * 128;                        // inside the group's own A ring slot
+  const int w_base = (wc * WTN + frow) * 128;
+  constexpr int TSTRIDE = (M32 ? 32 : 16) * 128;        // bytes between the row tiles of a fragment set
+  bf16x8 af[NKK][TM], wf[NKK][TN];
+
+#define RG_READ_FRAGS(aslot, wslot)                                                                  \
+  do {                                                                                               \
+    const char* At_ = (aslot) + a_base;                                                              \
+    const char* Wt_ = (wslot) + w_base;                                                              \
+    _Pragma("unroll") for (int kk = 0; kk < NKK; ++kk)                                               \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                 \
+        wf[kk][j] = *reinterpret_cast<const bf16x8*>(Wt_ + j * TSTRIDE + offk[kk]);                  \
+    _Pragma("unroll") for (int kk = 0; kk < NKK; ++kk)                                               \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                 \
+        af[kk][i] = *reinterpret_cast<const bf16x8*>(At_ + i * TSTRIDE + offk[kk]);                  \
+  } while (0)
+
+#define RG_MFMA_PART(tail)                                                                           \
+  do {                                                                                               \
+    _Pragma("unroll") for (int kk = 0; kk < NKK; ++kk)                                               \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                               \
+        const bool in_tail = (kk == NKK - 1) && (i >= TM - EARLY);                                   \
+        if (in_tail == (tail)) {                                                                     \
+          _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                           \
+            if constexpr (M32) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][j], af[kk][i], acc[i][j], 0, 0, 0); \
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][j], af[kk][i], acc[i][j], 0, 0, 0);               \
+          }                                                                                          \
+        }                                                                                            \
+      }                                                                                              \
+  } while (0)
+#define RG_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+  // DBG == 4: cycle stamps (s_memtime) of block 0, waves 0 and 4, into the buffer passed as `bias`
+  unsigned long long* stamps = (DBG == 4 && blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0)
+                                   ? (unsigned long long*)p.bias + (wave ? 1 : 0) * 64 * 8 : nullptr;
+#define RG_STAMP(t, k) do { if (DBG == 4 && stamps && (t) < 64) stamps[(t) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+  const int g4 = wave & 3;
+  int tile_no = 0;
+  // tile-level stamps (DBG == 4), column 7 of rows 5 n .. 5 n + 4 for the block's n-th tile: k-loop entry, k-loop exit,
+  // next tile's prologue issued, epilogue issued, (next row group) next k-loop entry
+#define RG_TSTAMP(k) do { if (DBG == 4 && stamps && tile_no < 12) stamps[(tile_no * 5 + (k)) * 8 + 7] = __builtin_amdgcn_s_memtime(); } while (0)
+  for (int vb = blockIdx.x;;) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = acc_t{};
+    A3V_WAIT_VM0();
+    A3V_BARRIER();
+    int wcur = 0;                                        // W ring slot of K-tile t
+    RG_TSTAMP(0);
+    if (wr == 0) {
+      for (int t = 0; t < nk; ++t) {
+        RG_STAMP(t, 0);
+        const int wn2 = wcur == 0 ? 2 : wcur - 1;        // slot of K-tile t + 2
+        if (t + 1 < nk) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) piece_a(128 + (g4 * 4 + c) * 8, t + 1, c & 1, lds + ABOT + ((t + 1) & 1) * AH + (g4 * 4 + c) * 1024);
+        }
+        if (t + 2 < nk) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) piece_w((g4 * 4 + c) * 8, t + 2, c & 1, lds + WB + wn2 * WT + (g4 * 4 + c) * 1024);
+        }
+        RG_READ_FRAGS(lds + ATOP + (t & 1) * AH, lds + WB + wcur * WT);
+        A3V_WAIT_LGKM0();
+        RG_STAMP(t, 1);
+        if (t + 2 < nk) RG_VMCNT(12);
+        else if (t + 2 == nk) RG_VMCNT(8);
+        else RG_VMCNT(0);
+        RG_STAMP(t, 2);
+        A3V_BARRIER();
+        RG_STAMP(t, 3);
+        __builtin_amdgcn_s_setprio(1);
+        RG_MFMA_PART(false);
+        __builtin_amdgcn_s_setprio(0);                 // never wait (vmcnt / barrier) at raised priority: measured -20 %
+        RG_STAMP(t, 4);
+        if (t + 2 < nk) RG_VMCNT(8);
+        else if (t + 2 == nk) RG_VMCNT(4);
+        else RG_VMCNT(0);
+        RG_STAMP(t, 5);
+        if constexpr (EARLY > 0) __builtin_amdgcn_sched_barrier(0);   // keep the tail MFMAs behind the barrier, the others before it
+        A3V_BARRIER();
+        if constexpr (EARLY > 0) __builtin_amdgcn_sched_barrier(0);
+        RG_STAMP(t, 6);
+        if constexpr (EARLY > 0) {
+          __builtin_amdgcn_s_setprio(1);
+          RG_MFMA_PART(true);
+          __builtin_amdgcn_s_setprio(0);
+        }
+        wcur = wcur == 2 ? 0 : wcur + 1;
+      }
+      A3V_BARRIER();
+    } else {
+      A3V_BARRIER();
+      for (int t = 0; t < nk; ++t) {
+        RG_STAMP(t, 0);
+        const int wn2 = wcur == 0 ? 2 : wcur - 1;
+        if (t + 2 < nk) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) piece_w(128 + (g4 * 4 + c) * 8, t + 2, c & 1, lds + WB + wn2 * WT + AH + (g4 * 4 + c) * 1024);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) piece_a((g4 * 4 + c) * 8, t + 2, c & 1, lds + ATOP + (t & 1) * AH + (g4 * 4 + c) * 1024);
+        }
+        RG_READ_FRAGS(lds + ABOT + (t & 1) * AH, lds + WB + wcur * WT);
+        A3V_WAIT_LGKM0();
+        RG_STAMP(t, 1);
+        if (t + 2 < nk) RG_VMCNT(8);
+        else RG_VMCNT(0);
+        RG_STAMP(t, 2);
+        A3V_BARRIER();
+        RG_STAMP(t, 3);
+        __builtin_amdgcn_s_setprio(1);
+        RG_MFMA_PART(false);
+        __builtin_amdgcn_s_setprio(0);                 // never wait (vmcnt / barrier) at raised priority: measured -20 %
+        RG_STAMP(t, 4);
+        RG_STAMP(t, 5);
+        if constexpr (EARLY > 0) __builtin_amdgcn_sched_barrier(0);   // keep the tail MFMAs behind the barrier, the others before it
+        A3V_BARRIER();
+        if constexpr (EARLY > 0) __builtin_amdgcn_sched_barrier(0);
+        RG_STAMP(t, 6);
+        if constexpr (EARLY > 0) {
+          __builtin_amdgcn_s_setprio(1);
+          RG_MFMA_PART(true);
+          __builtin_amdgcn_s_setprio(0);
+        }
+        wcur = wcur == 2 ? 0 : wcur + 1;
+      }
+    }
+    // every read of the rings is behind the last barrier: stage the next tile now, store this one after
+    const int nb = vb + (int)gridDim.x;
+    RG_TSTAMP(1);
+    if (nb < ntiles) {
+      tile_of(nb, sm0, sn0);
+      prologue();
+    }
+    RG_TSTAMP(2);
+    {
+      int lane_e = lane;
+      asm volatile("" : "+v"(lane_e));
+      if constexpr (M32) gemm_epilogue32<TM, TN>(acc, p, m0 + wr * WTM, n0 + wc * WTN, lane_e);
+      else gemm_epilogue<TM, TN>(acc, p, m0 + wr * WTM, n0 + wc * WTN, lane_e);
+    }
+    RG_TSTAMP(3);
+    ++tile_no;
+    if (nb >= ntiles) break;
+    vb = nb; m0 = sm0; n0 = sn0;
+  }
+#undef RG_TSTAMP
+#undef RG_STAMP
+#undef RG_VMCNT
+#undef RG_READ_FRAGS
+#undef RG_MFMA_PART
 }
 
 // ------------------------------------------------------------------------------------
@@ -1714,6 +1971,12 @@ static bool pp_persistent() {
   return v != 0;
 }
 
+static bool pp_ring() {       // A3V_GEMM_RING=1: the 160-KiB ring form of the ping-pong kernel (default off until measured)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("A3V_GEMM_RING"); v = (e && e[0] == '1') ? 1 : 0; }
+  return v != 0;
+}
+
 static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
                         int M, int N, int K, const void* bias, const void* residual, int64_t ldr,
                         int epilogue, int dtype, void* stream, const RopeKvArgs* rk) {
@@ -1762,8 +2025,18 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
     if (cfg == 256) hipLaunchKernelGGL((gemm_nt_bf16_kernel<256, 256, 2, 4>), g, b, 0, st, q);
     else if (cfg == 258) hipLaunchKernelGGL(gemm_nt_bf16_pp32_kernel<0>, g, b, 0, st, q);
     else {
-      switch (q.dbg) {
+      int dbg = q.dbg;
+      if (dbg == 0 && pp_ring()) dbg = 5;
+      switch (dbg) {
         case 0: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<0, 0>), g, b, 0, st, q); break;
+        case 5: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0>), g, b, 0, st, q); break;
+        case 11: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 1>), g, b, 0, st, q); break;   // barrier 4 MFMAs early
+        case 12: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 2>), g, b, 0, st, q); break;   // 8 early
+        case 13: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 4>), g, b, 0, st, q); break;   // 16 early
+        case 7: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<0, 0>), g, b, 0, st, q); break;   // two-stage kernel, for A/B runs
+        case 9: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, true, 0>), g, b, 0, st, q); break;   // ring, 32x32x16 MFMA
+        case 10: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<4, true, 0>), g, b, 0, st, q); break;   // 32x32x16, stamps
+        case 6: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<4, false, 0>), g, b, 0, st, q); break;   // cycle stamps (tools/ring_stamps.py)
 #ifdef A3V_ABLATION
         case 1: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<1, 0>), g, b, 0, st, q); break;
         case 2: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<2, 0>), g, b, 0, st, q); break;

@@ -574,6 +574,44 @@ extern "C" int a3v_cast(const void* src, int64_t ld_src, int src_dtype, void* ds
   return A3V_OK;
 }
 
+// dst[i] = (TD)(src[i] * scale): the DP reducer's wire-dtype conversions (fp32 gradient bucket -> bf16 wire bucket pre-scaled by
+// 1/world, and back) in one pass each instead of mul_ + to() + copy_ (dp.py GradReducer; reference: FSDP reduce_dtype,
+// main_finetune.py:251-255).  16-B accesses on the wider side, every line touched once.
+namespace {
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void scale_cast_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int64_t n, float scale) {
+  const int64_t n8 = n / 8, stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += stride) {
+    float v[8];
+    load8(src + i * 8, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= scale;
+    store8(dst + i * 8, v);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n - n8 * 8)) {
+    const int64_t i = n8 * 8 + threadIdx.x;
+    Cvt<TD>::st(dst + i, Cvt<TS>::ld(src + i) * scale);
+  }
+}
+}  // namespace
+
+extern "C" int a3v_scale_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, float scale, void* stream) {
+  if (!src || !dst || n <= 0) return A3V_ERR_ARG;
+  if (((uintptr_t)src | (uintptr_t)dst) & 15) return A3V_ERR_SHAPE;
+  int64_t blocks = (n / 8 + 255) / 256;
+  blocks = blocks > 8192 ? 8192 : (blocks < 1 ? 1 : blocks);
+  dim3 g((unsigned)blocks), b(256);
+  switch (src_dtype * 2 + dst_dtype) {
+    case 2: hipLaunchKernelGGL((scale_cast_kernel<float, bf16_t>), g, b, 0, ST, (const float*)src, (bf16_t*)dst, n, scale); break;
+    case 1: hipLaunchKernelGGL((scale_cast_kernel<bf16_t, float>), g, b, 0, ST, (const bf16_t*)src, (float*)dst, n, scale); break;
+    case 3: hipLaunchKernelGGL((scale_cast_kernel<float, float>), g, b, 0, ST, (const float*)src, (float*)dst, n, scale); break;
+    case 0: hipLaunchKernelGGL((scale_cast_kernel<bf16_t, bf16_t>), g, b, 0, ST, (const bf16_t*)src, (bf16_t*)dst, n, scale); break;
+    default: return A3V_ERR_DTYPE;
+  }
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}
+
 extern "C" int a3v_transpose(const void* src, int64_t ld_src, int64_t bs_src, void* dst, int64_t ld_dst, int64_t bs_dst,
                              int R, int C, int Rpad, int batch, int dtype, void* stream) {
   if (!src || !dst || R <= 0 || C <= 0 || Rpad < R || batch <= 0) return A3V_ERR_ARG;
@@ -797,6 +835,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                                                     float step_size, float inv_bc2_sqrt, float eps, bf16_t* __restrict__ img,
                                                     const float* __restrict__ gscale) {
   const float gs = gscale ? *gscale : 1.f;       // clip coefficient (device scalar): g * coef rounded to fp32 = the value grad.mul_(coef) stores
+  if (!(gs >= 0.f)) return;                      // negative or NaN: the caller's "this step saw a non-finite loss / gradient norm" flag
+                                                 // -> the update is a no-op (masters, moments and bf16 images stay as they were)
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
     f32x4 pp = reinterpret_cast<const f32x4*>(p)[i];

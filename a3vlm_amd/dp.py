@@ -1,24 +1,37 @@
 """Data-parallel fine-tuning over RCCL/xGMI (one process per GPU, ``torch.distributed`` backend "nccl").
 
 Replaces the reference's FSDP(SHARD_GRAD_OP) wrap (main_finetune.py:241-263) by pure DP replicas:
-  * ``GradReducer`` -- bucketed SUM all-reduce (pre-scaled by 1/world = FSDP's gradient average) of the
-    training engine's flat fp32 gradient buffer.  Buckets are the engine's per-layer ranges; a bucket is
-    handed to RCCL on a dedicated side HIP stream the moment that layer's backward has produced it
-    (``TrainEngine.on_layer_grads_ready``), so the transfer overlaps the back-propagation of the earlier
-    layers.  Gradient accumulation = ``reducer.enabled = False`` on non-boundary micro-steps (the
-    reference's ``no_sync``, util/misc.py:311-313).
-  * ``FinetuneDistSampler`` -- the reference's sharding contract (data/alpaca.py:246-328).
-  * ``clip_grad_norm`` -- global L2 clip with the reference's coefficient (util/clip_grad.py:187-193); no
-    collective is needed in pure DP because post-reduce gradients are identical on every rank.
+  * ``GradReducer`` -- bucketed gradient AVERAGE (= FSDP's gradient reduction) of the training engine's flat fp32 gradient
+    buffer.  Buckets are the engine's per-layer ranges; a bucket is handed to RCCL on a dedicated side HIP stream the moment
+    that layer's backward has produced it (``TrainEngine.on_layer_grads_ready``), so the transfer overlaps the
+    back-propagation of the earlier layers.  Gradient accumulation = ``reducer.enabled = False`` on every micro-step but the
+    LAST of a cycle (the reference's ``no_sync``, util/misc.py:311-313): the flat buffer accumulates in place, so on the last
+    micro-step a layer's bucket already holds the cycle's sum when its backward finishes, and the reduction overlaps that
+    backward exactly as without accumulation.
+    Passes over the gradient buffer: fp32 wire = none besides the collective (``ReduceOp.AVG`` on RCCL); bf16 wire (the
+    reference's FSDP ``reduce_dtype``) = one fused scale+cast kernel into a persistent bf16 bucket before, one widening cast
+    after (``a3v_scale_cast``).
+  * ``FinetuneDistSampler`` -- the reference's sharding contract (data/alpaca.py:246-328), pinned by
+    ``tests/golden/host_tiny.json``.
+  * ``clip_grad_norm`` -- global L2 clip with the reference's coefficient (util/clip_grad.py:187-193); no collective is
+    needed in pure DP because post-reduce gradients are identical on every rank.
 xGMI is point-to-point: large (per-layer, ~0.8 GB fp32) buckets keep every link busy with few launches.
 """
 from __future__ import annotations
 
-import copy
-from typing import Iterator, List, Optional
+from typing import Dict, Iterator, List, Optional, Tuple
 
 import numpy as np
 import torch
+
+
+def _scale_cast(src: torch.Tensor, dst: torch.Tensor, scale: float) -> None:
+    """dst = (dst.dtype)(src * scale) in ONE pass (HIP kernel on device tensors; torch on the CPU tensors of the gloo tests)."""
+    if src.is_cuda:
+        from . import ops
+        ops.scale_cast(src, dst, scale)
+    else:
+        torch.mul(src, scale, out=dst) if dst.dtype == src.dtype else dst.copy_(src * scale)
 
 
 class GradReducer:
@@ -28,9 +41,14 @@ class GradReducer:
         self.group = group
         self.world = dist.get_world_size(group) if group is not None else dist.get_world_size()
         self.enabled = True
-        self.reduce_dtype = reduce_dtype          # None: reduce the fp32 buffer in place; bf16: halve wire bytes
+        self.reduce_dtype = reduce_dtype          # None: reduce the fp32 buffer in place; bf16: halve the wire bytes
         self._pending: List = []
         self._stream = None
+        self._wire: Dict[Tuple[int, int], torch.Tensor] = {}      # persistent low-precision buckets, keyed by flat range
+        try:                                       # RCCL averages in the collective; gloo (CPU tests) only sums
+            self._avg = dist.get_backend(group) == "nccl" and hasattr(dist.ReduceOp, "AVG")
+        except Exception:
+            self._avg = False
         engine.on_layer_grads_ready = self._on_ready
 
     def _side_stream(self, device):
@@ -48,27 +66,35 @@ class GradReducer:
             ev.record(torch.cuda.current_stream(seg.device))
             st.wait_event(ev)                      # the bucket's producers have finished
             with torch.cuda.stream(st):
-                self._launch(seg)
+                self._launch(seg, (start, end))
         else:
-            self._launch(seg)
+            self._launch(seg, (start, end))
 
-    def _launch(self, seg: torch.Tensor) -> None:
-        seg.mul_(1.0 / self.world)
+    def _launch(self, seg: torch.Tensor, key: Tuple[int, int]) -> None:
+        dist = self.dist
         if self.reduce_dtype is not None and self.reduce_dtype != seg.dtype:
-            low = seg.to(self.reduce_dtype)
-            work = self.dist.all_reduce(low, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+            low = self._wire.get(key)
+            if low is None or low.device != seg.device:
+                low = self._wire[key] = torch.empty(seg.numel(), dtype=self.reduce_dtype, device=seg.device)
+            _scale_cast(seg, low, 1.0 if self._avg else 1.0 / self.world)
+            op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+            work = dist.all_reduce(low, op=op, group=self.group, async_op=True)
             self._pending.append((work, seg, low))
+        elif self._avg:
+            work = dist.all_reduce(seg, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+            self._pending.append((work, None, None))
         else:
-            work = self.dist.all_reduce(seg, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+            seg.mul_(1.0 / self.world)
+            work = dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._pending.append((work, None, None))
 
     def finish(self) -> None:
         """Join every outstanding bucket (call before clipping / optimizer.step)."""
         for work, seg, low in self._pending:
             if seg is not None and seg.is_cuda:
-                with torch.cuda.stream(self._stream):     # the copy-back runs on the side stream: THAT stream must wait for the collective
+                with torch.cuda.stream(self._stream):     # the widening runs on the side stream: THAT stream must wait for the collective
                     work.wait()
-                    seg.copy_(low)
+                    _scale_cast(low, seg, 1.0)
             else:
                 work.wait()
                 if seg is not None:
@@ -78,7 +104,7 @@ class GradReducer:
             torch.cuda.current_stream().wait_stream(self._stream)
 
     def reduce_all_now(self) -> None:
-        """Reduce every bucket (used at an accumulation boundary when earlier micro-steps ran with enabled=False)."""
+        """Reduce every bucket at once (no overlap): for callers that ran the whole cycle with ``enabled = False``."""
         was = self.enabled
         self.enabled = True
         for name, st, en in self.eng.grad_ranges():
@@ -117,45 +143,50 @@ def clip_grad_norm(parameters, max_norm: float, flat: Optional[torch.Tensor] = N
 
 
 class FinetuneDistSampler(torch.utils.data.Sampler):
-    """data/alpaca.py:246-328: every GLOBAL batch (batch_size x replicas x acc_grad consecutive indices of one
-    group) is homogeneous in data type; global batches are shuffled with default_rng(seed + epoch); rank r takes
-    rows [r*bs + k*replicas*bs, +bs); resumable through set_epoch(epoch, start_iter)."""
+    """Which dataset indices a DP rank sees, in which order (the sharding contract of the path's training side).
+
+    * A *global batch* = ``batch_size * num_replicas * acc_grad`` consecutive members of ONE dataset group (``dataset.groups()``),
+      so every optimizer step is homogeneous in data type; a group's ragged tail is dropped.
+    * Per epoch the global batches (not the samples) are permuted with ``numpy.random.default_rng(seed + epoch)``.
+    * Inside the flattened order, micro-batch ``k`` of rank ``r`` is the ``batch_size`` indices starting at
+      ``(k * num_replicas + r) * batch_size``.
+    * ``set_epoch(epoch, start_iter)`` resumes inside an epoch: the first ``start_iter`` micro-batches are skipped
+      (``__len__`` keeps reporting the full epoch, which the trainer's LR schedule relies on)."""
 
     def __init__(self, dataset, num_replicas: Optional[int] = None, rank: Optional[int] = None, shuffle: bool = True,
                  seed: int = 0, batch_size=None, acc_grad: int = 1) -> None:
-        if num_replicas is None or rank is None or rank >= num_replicas or rank < 0:
+        if num_replicas is None or rank is None or not 0 <= rank < num_replicas:
             raise ValueError(f"Invalid num_replicas ({num_replicas}) or rank ({rank})")
         assert batch_size is not None
-        self.batch_size, self.dataset, self.num_replicas, self.rank, self.acc_grad = batch_size, dataset, num_replicas, rank, acc_grad
+        self.dataset, self.num_replicas, self.rank = dataset, num_replicas, rank
+        self.batch_size, self.acc_grad, self.shuffle, self.seed = batch_size, acc_grad, shuffle, seed
         self.epoch, self.start_iter = 0, 0
-        group_indices = dataset.groups()
-        global_bsz = batch_size * num_replicas * acc_grad
-        group_indices = [ind[: len(ind) // global_bsz * global_bsz] for ind in group_indices]
-        group_n_batch = [len(g) // batch_size for g in group_indices]
-        assert all(n % num_replicas == 0 for n in group_n_batch)
-        n_total_batch = sum(group_n_batch)
-        self.group_indices = group_indices
-        self.total_size = n_total_batch * batch_size
+        per_step = self._per_step
+        self.group_indices = [list(members[:len(members) - len(members) % per_step]) for members in dataset.groups()]
+        self.total_size = sum(len(members) for members in self.group_indices)
         self.num_samples = self.total_size // num_replicas
-        self.shuffle, self.seed = shuffle, seed
 
-    def __iter__(self) -> Iterator:
-        gbs = self.batch_size * self.num_replicas * self.acc_grad
-        groups = copy.deepcopy(self.group_indices)
-        if self.shuffle:
-            rng = np.random.default_rng(self.seed + self.epoch)
-            batches = [g[i:i + gbs] for g in groups for i in range(0, len(g), gbs)]
-            rng.shuffle(batches)
-            indices = [i for b in batches for i in b]
-        else:
-            indices = [i for g in groups for i in g]
-        assert len(indices) == self.total_size
-        own: List[int] = []
-        for start in range(self.rank * self.batch_size, len(indices), self.num_replicas * self.batch_size):
-            own += indices[start:start + self.batch_size]
-        assert len(own) == self.num_samples
-        own = [] if self.start_iter * self.batch_size > len(own) else own[self.start_iter * self.batch_size:]
-        return iter(own)
+    @property
+    def _per_step(self) -> int:
+        return self.batch_size * self.num_replicas * self.acc_grad
+
+    def _epoch_order(self) -> np.ndarray:
+        """All kept indices of the epoch as an array [global batch][per_step]."""
+        per_step = self._per_step
+        table = np.asarray([i for members in self.group_indices for i in members], dtype=np.int64).reshape(-1, per_step)
+        if self.shuffle and len(table):
+            order = list(range(len(table)))
+            np.random.default_rng(self.seed + self.epoch).shuffle(order)     # a Python list: the generic Fisher-Yates path
+            table = table[order]
+        return table
+
+    def __iter__(self) -> Iterator[int]:
+        table = self._epoch_order()
+        assert table.size == self.total_size
+        # [global batch, micro-step of the accumulation cycle, rank, sample of the micro-batch] -> this rank's column
+        mine = table.reshape(-1, self.acc_grad, self.num_replicas, self.batch_size)[:, :, self.rank, :].reshape(-1)
+        assert mine.size == self.num_samples
+        return iter(mine[self.start_iter * self.batch_size:].tolist())
 
     def __len__(self) -> int:
         return self.num_samples

@@ -1,15 +1,25 @@
 """``train_one_epoch`` with the semantics of the reference's engine (model/accessory/engine_finetune.py:13-105)
 on top of the HIP training engine and the DP reducer.
 
-Kept: 3/4/5-tuple batches, LR set per accumulation boundary by FRACTIONAL epoch, ``loss / accum_iter``,
-non-finite loss -> ``sys.exit(1)``, clip (global L2, reference coefficient) then ``optimizer.step()`` only on
-boundary micro-steps, ``zero_grad(set_to_none=True)``, gradient all-reduce skipped on non-boundary micro-steps
-(the reference's ``no_sync``, util/misc.py:311-313).
-Changed: no per-iteration ``cuda.synchronize()`` and no per-meter all-reduce with host sync every iteration
-(engine_finetune.py:79,87-91) -- the loss is read back once per ``print_freq`` boundary steps.
+Kept: 3/4/5-tuple batches, LR set per accumulation boundary by FRACTIONAL epoch, ``loss / accum_iter``, clip (global L2,
+reference coefficient) then ``optimizer.step()`` only on boundary micro-steps, ``zero_grad(set_to_none=True)``, gradient
+all-reduce skipped on non-boundary micro-steps (the reference's ``no_sync``, util/misc.py:311-313), a non-finite loss ends
+the run with ``sys.exit(1)`` and never reaches the weights.
+
+Changed:
+  * no per-iteration ``cuda.synchronize()`` and no per-meter all-reduce with host sync every iteration
+    (engine_finetune.py:79,87-91): the loss is read back once per ``print_freq`` boundary steps;
+  * the reference reads ``loss.item()`` every micro-step and exits BEFORE backward (engine_finetune.py:54-58).  Here the check
+    stays on the device: a sticky flag ``bad |= !isfinite(loss) | !isfinite(grad_norm)`` is folded into the optimizer's
+    gradient coefficient (negative coefficient = ``a3v_adamw_scaled`` does nothing), so a bad step is a no-op on masters,
+    moments and bf16 weight images, and the host reads the flag at every logging boundary, before every checkpoint callback
+    and at the end of the epoch -- exiting then, before anything poisoned can be written;
+  * with ``accum_iter > 1`` the DP all-reduce still overlaps the backward: the reducer is enabled on the LAST micro-step of a
+    cycle, when each layer's bucket holds the cycle's accumulated sum as soon as that layer's backward is done.
 """
 from __future__ import annotations
 
+import inspect
 import math
 import sys
 from typing import Callable, Dict, Optional
@@ -20,6 +30,18 @@ from .dp import GradReducer, clip_grad_norm
 from .util import adjust_learning_rate_epoch
 
 
+def _unpack(batch):
+    """(examples, labels, images, depth images) of a 3 / 4 / 5-tuple (engine_finetune.py:30-39)."""
+    if len(batch) == 5:
+        examples, labels, _mask, imgs, depth = batch
+        return examples, labels, imgs, depth
+    if len(batch) == 4:
+        examples, labels, _mask, imgs = batch
+        return examples, labels, imgs, None
+    examples, labels, _mask = batch
+    return examples, labels, None, None
+
+
 def train_one_epoch(model, data_loader, optimizer, epoch: int, start_iter: int, args, reducer: Optional[GradReducer] = None,
                     log: Callable[[str], None] = print, on_save: Optional[Callable[[int], None]] = None) -> Dict[str, float]:
     model.train(True)
@@ -27,53 +49,69 @@ def train_one_epoch(model, data_loader, optimizer, epoch: int, start_iter: int, 
     print_freq = getattr(args, "print_freq", 10)
     model.zero_grad(set_to_none=True)
     dev = next(model.parameters()).device
-    n_iter = len(data_loader)
+    n_iter = len(data_loader)                      # the FULL epoch, also when resuming at start_iter (sampler contract)
     stats = {"closs": 0.0, "n": 0, "grad_norm": 0.0, "lr": 0.0}
     params = [p for p in model.parameters() if p.requires_grad]
+    clip = getattr(args, "clip_grad", -1) or -1
+    bad = torch.zeros((), dtype=torch.bool, device=dev)          # sticky: some loss / gradient norm of this epoch was not finite
+    takes_scale = hasattr(optimizer, "engine")                   # FusedAdamW: device-scalar coefficient, negative = skip
+
+    def stop_if_bad(step: int) -> None:
+        if bool(bad):                              # host read: only at logging / checkpoint / epoch boundaries
+            log(f"Loss or gradient norm became non-finite at or before step {step}, stopping training")
+            sys.exit(1)
+
+    # our MetaModel: trim the batch on the host tensors (no device read) and tell the HIP engine the loss scale up front
+    trim = getattr(type(model), "_trim", None) if "trimmed" in inspect.signature(model.forward).parameters else None
+    engine = model.train_engine() if hasattr(model, "train_engine") and dev.type == "cuda" and params else None
+    if engine is not None:
+        engine.static_grad_scale = 1.0 / accum_iter
     for step, batch in enumerate(data_loader, start=start_iter):
-        if len(batch) == 5:
-            examples, labels, _mask, imgs, depth = batch
-        elif len(batch) == 4:
-            examples, labels, _mask, imgs = batch
-            depth = None
-        else:
-            examples, labels, _mask = batch
-            imgs = depth = None
+        examples, labels, imgs, depth = _unpack(batch)
+        if trim is not None and not examples.is_cuda:
+            examples, labels = trim(examples, labels)
         if step % accum_iter == 0:
             stats["lr"] = adjust_learning_rate_epoch(optimizer, step / n_iter + epoch, lr=args.lr, min_lr=args.min_lr,
                                                      warmup_epochs=args.warmup_epochs, epochs=args.epochs)
         update_grad = (step + 1) % accum_iter == 0
         if reducer is not None:
-            reducer.enabled = update_grad and accum_iter == 1      # with accumulation the whole buffer is reduced at the boundary
+            reducer.enabled = update_grad
         examples, labels = examples.to(dev, non_blocking=True), labels.to(dev, non_blocking=True)
         imgs = imgs.to(dev, non_blocking=True) if imgs is not None else None
-        c_loss, extra = model(examples, labels, images=imgs, depth_imgs=depth)
+        if trim is not None:
+            c_loss, extra = model(examples, labels, images=imgs, depth_imgs=depth, trimmed=True)
+        else:
+            c_loss, extra = model(examples, labels, images=imgs, depth_imgs=depth)
         loss = c_loss
         for add_loss, weight in extra.values():
             loss = loss + add_loss * weight
+        bad |= ~torch.isfinite(loss.detach())
         (loss / accum_iter).backward()
         if update_grad:
             if reducer is not None:
-                if accum_iter > 1:
-                    reducer.reduce_all_now()
-                else:
-                    reducer.finish()
-            eng = getattr(optimizer, "engine", None)
-            if getattr(args, "clip_grad", -1) and args.clip_grad > 0:
-                if eng is not None:
+                reducer.finish()
+            coef = None
+            if clip > 0:
+                if takes_scale:
                     # one norm over the engine's flat gradient buffer; the coefficient stays on the device and is applied by the
                     # optimizer kernel as it reads the gradients (a3v_adamw_scaled): no grad.mul_ pass, no host sync
-                    stats["grad_norm"], coef = clip_grad_norm(params, args.clip_grad, flat=eng.flat_grads(), defer=True)
-                    optimizer.step(grad_scale=coef)
+                    eng = optimizer.engine
+                    stats["grad_norm"], coef = clip_grad_norm(params, clip, flat=eng.flat_grads() if eng is not None else None, defer=True)
                 else:
-                    stats["grad_norm"] = clip_grad_norm(params, args.clip_grad)
-                    optimizer.step()
+                    stats["grad_norm"] = clip_grad_norm(params, clip)
+                bad |= ~torch.isfinite(torch.as_tensor(stats["grad_norm"]).to(dev))
+            if takes_scale:
+                one = coef if coef is not None else torch.ones((), dtype=torch.float32, device=dev)
+                optimizer.step(grad_scale=torch.where(bad, -one.new_ones(()), one).reshape(1))
             else:
+                stop_if_bad(step)                  # a stock optimizer cannot skip on a device flag: pay the host read
                 optimizer.step()
             model.zero_grad(set_to_none=True)
         boundary_idx = (step + 1) // accum_iter
-        if update_grad and (boundary_idx % print_freq == 0 or step + 1 == n_iter + start_iter):
-            lv = float(c_loss.detach())            # the only host sync of the loop
+        last = step + 1 == n_iter
+        if update_grad and (boundary_idx % print_freq == 0 or last):
+            stop_if_bad(step)
+            lv = float(c_loss.detach())            # the loop's host sync: once per print_freq optimizer steps
             if not math.isfinite(lv):
                 log(f"Loss is {lv}, stopping training")
                 sys.exit(1)
@@ -83,5 +121,9 @@ def train_one_epoch(model, data_loader, optimizer, epoch: int, start_iter: int, 
             log(f"Epoch: [{epoch}] [{step + 1}/{n_iter}] lr: {stats['lr']:.6f} closs: {lv:.4f} grad_norm: {gn:.4f}")
         if on_save is not None and update_grad and getattr(args, "save_iteration_interval", 0):
             if boundary_idx % max(args.save_iteration_interval // accum_iter, 1) == 0:
+                stop_if_bad(step)                  # never checkpoint past a bad step
                 on_save(step)
+    if engine is not None:
+        engine.static_grad_scale = None
+    stop_if_bad(n_iter - 1)                        # the caller writes the epoch-end checkpoint next
     return {"closs": stats["closs"] / max(stats["n"], 1), "lr": stats["lr"]}

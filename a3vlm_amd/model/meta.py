@@ -123,9 +123,13 @@ class MetaModel(nn.Module):
             self._anchor = torch.zeros((), dtype=torch.float32, device=self._device, requires_grad=True)
         return self._engine
 
-    def forward(self, examples, labels, images=None, depth_imgs=None):
-        with torch.no_grad():
-            examples, labels = self._trim(examples, labels)
+    def forward(self, examples, labels, images=None, depth_imgs=None, trimmed: bool = False):
+        """``trimmed=True`` (not in the reference's signature): the caller already cut the batch after its last labelled column
+        (``MetaModel._trim`` on the CPU batch, as ``engine_finetune.train_one_epoch`` does) -- skips the host read of the
+        per-column label counts that the trim needs on device tensors."""
+        if not trimmed:
+            with torch.no_grad():
+                examples, labels = self._trim(examples, labels)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.llma.parameters()):
             # training: loss and gradients through the HIP backward (loss.backward() fills param.grad)
             from ..train import step_loss

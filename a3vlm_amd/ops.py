@@ -353,6 +353,15 @@ def cast(src, dst):
     return dst
 
 
+def scale_cast(src, dst, scale: float = 1.0):
+    """dst = (dst.dtype)(src * scale) over contiguous 1-D buffers of equal length (DP gradient wire conversions)."""
+    _dev(src, dst)
+    assert src.is_contiguous() and dst.is_contiguous() and src.numel() == dst.numel()
+    rc = _l.load().a3v_scale_cast(_p(src), dt(src), _p(dst), dt(dst), src.numel(), float(scale), _stream())
+    _l.check(rc, "a3v_scale_cast")
+    return dst
+
+
 def add2d(dst, src):
     """dst += src (2-D blocks of one dtype, arbitrary row strides)."""
     _dev(dst, src)

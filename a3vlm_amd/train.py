@@ -52,6 +52,7 @@ class TrainEngine:
         self._fresh: set = set()                            # grads attached this step whose storage is still undefined
         self._gemm_written: set = set()                     # names whose gradient comes from exactly one wgrad GEMM per micro-step
         self.on_layer_grads_ready: Optional[Callable[[str, int, int], None]] = None
+        self.static_grad_scale: Optional[float] = None      # set by a trainer that knows d(total)/d(loss) (1 / accum_iter)
         self._saved = None
 
     # ------------------------------------------------------------------ buffers
@@ -851,7 +852,10 @@ class _StepLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
-        ctx.engine.backward(float(grad_out))
+        # the incoming gradient of the loss is the caller's 1 / accum_iter: a trainer that knows it sets
+        # engine.static_grad_scale and spares the host read of a device scalar on every micro-step
+        hint = getattr(ctx.engine, "static_grad_scale", None)
+        ctx.engine.backward(float(grad_out) if hint is None else float(hint))
         return torch.zeros((), device=grad_out.device), None, None, None, None
 
 

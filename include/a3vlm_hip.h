@@ -350,8 +350,16 @@ int a3v_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq
  * NativeScalerWithGradNormCount.__call__ (util/misc.py:302-315) / clip_grad_norm (util/clip_grad.py:187-193: coef =
  * max_norm / (norm + 1e-6) clamped to 1, every gradient multiplied by it) folded into the optimizer pass -- same values as
  * grad.mul_(coef) followed by a3v_adamw, without the extra read + write of every gradient and without a host read of the norm. */
+/* A NEGATIVE or NaN *grad_scale makes the call a no-op: the trainer folds "loss and gradient norm of this step are finite" into
+ * the coefficient on the device, so a bad step never reaches the fp32 masters, the moments or the bf16 weight images (the
+ * reference stops before backward on a non-finite loss, engine_finetune.py:56-58; here the host reads the flag later). */
 int a3v_adamw_scaled(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
                      float eps, float weight_decay, int64_t step, void* bf16_image, const float* grad_scale, void* stream);
+
+/* dst[i] = (dst_dtype)(src[i] * scale), n contiguous elements, both 16-B aligned: the wire-dtype conversions of the DP gradient
+ * reducer (fp32 bucket -> bf16 wire bucket pre-scaled by 1/world, and back) -- FSDP's reduce_dtype = bf16 averaging
+ * (main_finetune.py:251-255) without separate scale / cast / copy passes over the gradient buffer. */
+int a3v_scale_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, float scale, void* stream);
 
 /* Re-write one adapter's rows / columns of a fused LoRA group's bf16 images from its fp32 parameters (model/peft.py:40-64
  * lora_a [r, in], lora_b [nj, r]): A[col0+i, :] and At[:, col0+i] from lora_a, B[row0+n, col0+i] and Bt[col0+i, row0+n] from lora_b. */

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""A/B of the two-stage ping-pong GEMM (dbg 7) against its 160-KiB ring forms: bit equality on ragged / short-K shapes,
+then interleaved timing rounds in ONE process on the bench step's shapes (guide rules 24, 25: random data).
+  dbg 5  ring, barrier at the end of the MFMA interval      dbg 11 / 12 / 13  barrier 4 / 8 / 16 MFMAs before the end
+  dbg 9  ring on v_mfma_f32_32x32x16_bf16                   dbg 10            ... barrier 2 MFMAs before the end"""
+import sys, os, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from a3vlm_amd import ops, lib
+
+dev = "cuda"
+T = lib.EPI_TILE_256PP
+VARIANTS = {"pp": 7, "ring": 5, "e4": 11, "e8": 12, "e16": 13, "ring32": 9, "r32e": 10}
+if len(sys.argv) > 1:
+    VARIANTS = {k: v for k, v in VARIANTS.items() if k in sys.argv[1].split(",") or k == "pp"}
+flag = {k: T | (v << 24) for k, v in VARIANTS.items()}
+ok = True
+for (M, N, K) in [(256, 256, 64), (256, 256, 128), (256, 256, 192), (300, 260, 256), (1000, 520, 320), (2048, 2048, 4096),
+                  (8728, 4096, 4096), (4616, 3072, 1024), (700, 4100, 11008)]:
+    g = torch.Generator(device=dev).manual_seed(M + N + K)
+    a = torch.randn(M, K, device=dev, dtype=torch.bfloat16, generator=g)
+    w = torch.randn(N, K, device=dev, dtype=torch.bfloat16, generator=g) * 0.05
+    ref = (a.float() @ w.float().t())
+    o0 = torch.full((M, N), 7.0, device=dev, dtype=torch.bfloat16)
+    ops.gemm_nt(a, w, o0, epilogue=flag["pp"])
+    row = {"shape": [M, N, K], "rel_err_vs_fp32": round(((o0.float() - ref).abs().max() / ref.abs().max()).item(), 5)}
+    for name, f in flag.items():
+        if name == "pp":
+            continue
+        outs = []
+        for rep in range(3):        # repeated launches: a DMA / read race shows as a run-to-run difference
+            o1 = torch.full((M, N), 9.0 + rep, device=dev, dtype=torch.bfloat16)
+            ops.gemm_nt(a, w, o1, epilogue=f)
+            outs.append(o1)
+        rep_ok = all(torch.equal(outs[0], o) for o in outs[1:])
+        if name in ("ring32", "r32e"):      # another MFMA shape = another summation order: tolerance, not bit equality
+            e = ((outs[0].float() - ref).abs().max() / ref.abs().max()).item()
+            good = rep_ok and e < 2 * row["rel_err_vs_fp32"] + 1e-3
+        else:
+            good = rep_ok and torch.equal(outs[0], o0)
+        row[name] = "ok" if good else "MISMATCH"
+        ok = ok and good
+    print(json.dumps(row), flush=True)
+print("EQUALITY", "OK" if ok else "FAILED", flush=True)
+
+shapes = [(8728, 12288, 4096, 0), (8728, 4096, 4096, 0), (8728, 22016, 4096, ops.EPI_SWIGLU),
+          (8728, 4096, 11008, 0), (8192, 8192, 8192, 0), (4096, 4096, 4096, 0), (4616, 4096, 1024, 0)]
+rounds, reps = 6, 4
+for (M, N, K, epi) in shapes:
+    a = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
+    w = torch.randn(N, K, device=dev, dtype=torch.bfloat16) * 0.02
+    ncol = N // 2 if epi & ops.EPI_SWIGLU else N
+    out = torch.zeros(M, ncol, device=dev, dtype=torch.bfloat16)
+    times = {k: [] for k in flag}
+    for r in range(rounds):
+        for k, f in flag.items():
+            ops.gemm_nt(a, w, out, epilogue=epi | f)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                ops.gemm_nt(a, w, out, epilogue=epi | f)
+            e1.record()
+            torch.cuda.synchronize()
+            times[k].append(e0.elapsed_time(e1) * 1e-3 / reps)
+    fl = 2.0 * M * N * K
+    row = {"M": M, "N": N, "K": K}
+    for k in flag:
+        t = sorted(times[k])
+        row[k + "_tf"] = round(fl / t[len(t) // 2] / 1e12, 1)
+    for k in flag:
+        if k != "pp":
+            row[k + "/pp"] = round(row[k + "_tf"] / row["pp_tf"], 3)
+    print(json.dumps(row), flush=True)
