@@ -4,7 +4,8 @@ Writer  : ``save_checkpoint``  -- util/misc.py:324-438 at MP = 1: ``epoch{E}[-it
           = ``{"model": {"llma.<key>": tensor in the save dtype}}``, ``tokenizer.model``, ``config.json``
           (= dataclasses.asdict(model.llma.args)), ``meta.json`` ({"llama_type": ...}), ``...optimizer.pth``,
           ``...other.pth`` and ``rank-specific-{rank:05d}-of-{ws:05d}.pth``.
-Reader  : ``load_tensor_parallel_model_list`` -- util/tensor_parallel.py:425-485: format / MP-size inference from the
+Reader  : ``load_tensor_parallel_model_list`` -- util/tensor_parallel.py:425-485 incl. the add-to-existing semantics of
+          ``consolidated_diff`` folders (:387-423) and the MP split (:133-161, ``split_tensor_parallel_state_dict``): format / MP-size inference from the
           file names (:40-45, :333-384), ``meta_ori`` key prefixing (:223-225), merge of MP > 1 shards along the
           tensor-parallel dim of each weight (Column -> 0, Row -> 1, Embedding -> 1, :34-38; key table
           tools/convert_weights_to_hf.py:101-115), replicated params taken from shard 0 with a consistency warning
@@ -103,21 +104,73 @@ def load_merged_state_dict(path: str, known_keys=None) -> "OrderedDict[str, torc
     return merged
 
 
+def split_tensor_parallel_state_dict(state_dict: Dict[str, torch.Tensor], mp_size: int) -> List[Dict[str, torch.Tensor]]:
+    """The inverse of the shard merge (util/tensor_parallel.py:133-161): MP = 1 tensors cut into ``mp_size`` shards along each
+    weight's tensor-parallel dim, replicated parameters copied to every shard -- what a reference MP = ``mp_size`` job loads."""
+    shards: List[Dict[str, torch.Tensor]] = [OrderedDict() for _ in range(mp_size)]
+    for key, value in state_dict.items():
+        d = merge_dim(key)
+        if d < 0 or mp_size == 1:
+            for sh in shards:
+                sh[key] = value
+            continue
+        if value.shape[d] % mp_size:
+            raise ValueError(f"{key}: dim {d} of size {value.shape[d]} does not split into {mp_size} shards")
+        for sh, piece in zip(shards, torch.chunk(value, mp_size, dim=d)):
+            sh[key] = piece.contiguous()
+    return shards
+
+
+def _load_filtered(model, sd: Dict[str, torch.Tensor], own: Dict[str, torch.Tensor], mismatched: List[str]):
+    """load_state_dict(strict=False) that REPORTS shape-mismatched keys instead of raising from inside torch (a checkpoint of the
+    full 4-encoder ensemble has e.g. visual_proj.0.weight [dim, 5632] against a CLIP-only build's [dim, 1024])."""
+    ok = {}
+    for k, v in sd.items():
+        if k not in own:
+            continue
+        if tuple(v.shape) != tuple(own[k].shape):
+            mismatched.append(f"{k}: checkpoint {tuple(v.shape)} vs model {tuple(own[k].shape)}")
+            continue
+        ok[k] = v
+    return model.load_state_dict(ok, strict=False)
+
+
 def load_tensor_parallel_model_list(model, paths: List[str], verbose: bool = False) -> Dict[str, List[str]]:
-    """Loads one or more checkpoint folders sequentially into a MetaModel-like module whose parameters carry the
-    ``llma.`` prefix; returns the keys still missing after the last path and the union of unexpected keys."""
-    existing = set(model.state_dict().keys())
-    missing, unexpected = set(existing), set()
-    for path in paths:
+    """Loads one or more checkpoint folders sequentially into a MetaModel-like module whose parameters carry the ``llma.``
+    prefix (util/tensor_parallel.py:425-485).  A base folder (``meta_ori`` / ``consolidated``) overrides what earlier folders
+    set; a ``consolidated_diff`` folder ADDS its tensors to the values already loaded from earlier folders and plainly sets keys
+    no earlier folder provided (load_diff_checkpoint, :387-423 -- implemented as documented there; the reference's own call site
+    :470-472 omits the ``existing_keys`` argument and cannot run).  Returns the keys still missing after the last folder and the
+    union of unexpected keys; shape-mismatched keys are skipped and listed under ``mismatched_keys`` when there are any."""
+    if isinstance(paths, str):
+        paths = [paths]
+    own = model.state_dict()
+    existing = set(own.keys())
+    seen: set = set()
+    missing, unexpected, mismatched = set(existing), set(), []
+    for i, path in enumerate(paths):
+        fmt, _ = infer_checkpoint_format_and_mp_size(path)
+        assert i != 0 or not fmt.endswith("_diff"), "The first checkpoint in the list cannot be a *_diff checkpoint."
         sd = load_merged_state_dict(path)
-        res = model.load_state_dict({k: v for k, v in sd.items() if k in existing}, strict=False)
+        if fmt.endswith("_diff"):
+            cur = model.state_dict()
+            for k in list(sd.keys()):
+                if k in seen and k in cur and tuple(cur[k].shape) == tuple(sd[k].shape):
+                    sd[k] = cur[k].detach().to("cpu") + sd[k].to(cur[k].dtype)
+        res = _load_filtered(model, sd, own, mismatched)
         unexpected |= {k for k in sd if k not in existing}
-        missing &= set(res.missing_keys)
+        step_missing = set(res.missing_keys)
+        missing = {k for k in missing if k in step_missing}
+        seen |= set(sd.keys())
         if verbose:
-            print(f"loaded {path}: {len(sd)} tensors")
+            print(f"loaded {path} ({fmt}): {len(sd)} tensors")
     if hasattr(getattr(model, "llma", None), "invalidate_packed_weights"):
         model.llma.invalidate_packed_weights()
-    return {"missing_keys": sorted(missing), "unexpected_keys": sorted(unexpected)}
+    out = {"missing_keys": sorted(missing), "unexpected_keys": sorted(unexpected)}
+    if mismatched:
+        warnings.warn("checkpoint tensors skipped because their shapes differ from the model's:\n  " + "\n  ".join(mismatched))
+        out["mismatched_keys"] = mismatched
+    return out
 
 
 def save_checkpoint(output_dir: str, args, model, optimizer=None, loss_scaler=None, dataset_state=None, epoch=None,

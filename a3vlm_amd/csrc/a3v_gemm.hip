@@ -92,8 +92,13 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, int64_t
 
 // Epilogue shared by the tile kernels.  The lane holds, for each (i, j) MFMA tile,
 // C[m = mbase + 16 i + (lane&15)][n = nbase + 16 j + 4 (lane>>4) + 0..3].
+// `stage`: optional wave-private 4-KiB LDS scratch (32 rows x 128 B).  With it, bf16 row-major outputs leave the wave as whole
+// 128-byte rows (16 B per lane, 8 rows per store instruction) instead of 8 B per lane scattered over 16 rows: the accumulator
+// layout gives every lane 4 consecutive n of ONE row, so the direct form writes each 128-B line of C in four separate
+// 32-B pieces from four instructions -- measured 31-33 k cycles per 256x256 tile (15 % of a K = 4096 tile, half of a K = 1024
+// one) against ~8 k through the LDS transpose.
 template <int TM, int TN, bool F8 = false>
-__device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GemmArgs& p, int mbase, int nbase, int lane) {
+__device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GemmArgs& p, int mbase, int nbase, int lane, char* stage = nullptr) {
   // ---- epilogue: lane holds C[m][n..n+3], m = .. + (lane&15), n = .. + (lane>>4)*4 ----
   const int epi = p.epi;
   const int mrow = lane & 15;
@@ -212,6 +217,35 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GemmAr
     }
   }
   // Phase 2 -- stores only
+  if (TN == 4 && TM % 2 == 0 && stage && !(epi & (GEMM_EPI_ROPEKV | A3V_EPI_RES_F32 | A3V_EPI_OUT_F32)) && !(p.ldc & 7) && !(p.N & 7) &&
+      !(reinterpret_cast<uintptr_t>(p.C) & 15)) {
+    // chunk = two 16-row tiles x 64 columns of bf16 = 32 rows x 128 B.  8-byte slot s of row r sits at slot s ^ (r & 14): the 16
+    // lanes of a ds_write_b64 group (16 rows, one slot) spread over the banks (2-way at worst), and the pair structure survives,
+    // so a lane reads back 16 contiguous bytes: pair q of row r from physical pair q ^ ((r >> 1) & 7) (conflict-free b128 reads).
+    bf16_t* const Cb = reinterpret_cast<bf16_t*>(p.C);
+#pragma unroll
+    for (int ic = 0; ic < TM / 2; ++ic) {
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        const int r = ii * 16 + mrow;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          bf16x4 o;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o[q] = f2bf(acc[2 * ic + ii][j][q]);
+          *reinterpret_cast<bf16x4*>(stage + r * 128 + (((j * 4 + (lane >> 4)) ^ (r & 14)) << 3)) = o;
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int r = it * 8 + (lane >> 3), q = lane & 7;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(stage + r * 128 + ((q ^ ((r >> 1) & 7)) << 4));
+        const int m = mbase + ic * 32 + r, n = nbase + q * 8;
+        if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(Cb + (int64_t)m * p.ldc + n) = v;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int m = mbase + i * 16 + mrow;
@@ -707,7 +741,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_pp_kernel(GemmArgs p) {
 // EARLY: the barrier that ends an MFMA interval is executed EARLY tile-rows before the interval's last MFMA.  Nothing after it
 // needs the barrier (the tail MFMAs read registers only), and the partner wave on the SIMD -- released by the same barrier --
 // starts its own MFMA stream while this wave is still feeding the pipe: no matrix-pipe bubble at the hand-over.
-template <int DBG, bool M32, int EARLY>   // M32: v_mfma_f32_32x32x16_bf16 (4x2 tiles per wave) instead of 16x16x32 (8x4)
+template <int DBG, bool M32, int EARLY, bool STAGED = true>   // M32: v_mfma_f32_32x32x16_bf16 (4x2 tiles per wave) instead of 16x16x32 (8x4)
 __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
   constexpr int TBM = 256, TBN = 256, WTM = 128, WTN = 64, TM = M32 ? 4 : 8, TN = M32 ? 2 : 4;
   constexpr int AH = 128 * BK * 2;                      // 16 KiB: one group's half of an A K-tile
@@ -922,7 +956,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
       int lane_e = lane;
       asm volatile("" : "+v"(lane_e));
       if constexpr (M32) gemm_epilogue32<TM, TN>(acc, p, m0 + wr * WTM, n0 + wc * WTN, lane_e);
-      else gemm_epilogue<TM, TN>(acc, p, m0 + wr * WTM, n0 + wc * WTN, lane_e);
+      else gemm_epilogue<TM, TN>(acc, p, m0 + wr * WTM, n0 + wc * WTN, lane_e, STAGED ? lds + WB + 2 * WT + wave * 4096 : nullptr);
     }
     RG_TSTAMP(3);
     ++tile_no;
@@ -1971,9 +2005,9 @@ static bool pp_persistent() {
   return v != 0;
 }
 
-static bool pp_ring() {       // A3V_GEMM_RING=1: the 160-KiB ring form of the ping-pong kernel (default off until measured)
+static bool pp_ring() {       // the 160-KiB ring form of the ping-pong kernel (A3V_GEMM_RING=0: the two-stage kernel, for A/B runs)
   static int v = -1;
-  if (v < 0) { const char* e = getenv("A3V_GEMM_RING"); v = (e && e[0] == '1') ? 1 : 0; }
+  if (v < 0) { const char* e = getenv("A3V_GEMM_RING"); v = (e && e[0] == '0') ? 0 : 1; }
   return v != 0;
 }
 
@@ -2030,9 +2064,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
       switch (dbg) {
         case 0: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<0, 0>), g, b, 0, st, q); break;
         case 5: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0>), g, b, 0, st, q); break;
-        case 11: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 1>), g, b, 0, st, q); break;   // barrier 4 MFMAs early
-        case 12: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 2>), g, b, 0, st, q); break;   // 8 early
-        case 13: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 4>), g, b, 0, st, q); break;   // 16 early
+        case 11: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0, false>), g, b, 0, st, q); break;   // ring, direct (unstaged) epilogue stores
         case 7: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<0, 0>), g, b, 0, st, q); break;   // two-stage kernel, for A/B runs
         case 9: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, true, 0>), g, b, 0, st, q); break;   // ring, 32x32x16 MFMA
         case 10: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<4, true, 0>), g, b, 0, st, q); break;   // 32x32x16, stamps

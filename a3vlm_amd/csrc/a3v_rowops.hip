@@ -443,6 +443,81 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
   }
 }
 
+// ---------------------------------------------------------------- one step of MetaModel.generate's token bookkeeping
+// model/meta.py:456-477 for one batch row per block, after the row's argmax (temperature 0, :460) or with an externally
+// sampled id (top-p branch, :457-459):
+//   next = text_mask[row, cur] ? tokens[row, cur] : next          (prompts longer than the shortest one are teacher-forced, :463-465)
+//   tokens[row, cur] = next
+//   stop_pos[row] = stopped[row] ? stop_pos[row] : cur + 1
+//   for every stop sequence st (in order), n = len(st), if cur + 1 - n >= 0:
+//       hit = tokens[row, cur+1-n : cur+1] == st  &&  !text_mask[row, cur]  &&  !stopped[row]
+//       if hit: stop_pos[row] = cur + 1 - n; stopped[row] = 1
+// `live` counts the rows still running (the host polls that ONE word every few steps instead of `stopped.all()` every step).
+__global__ __launch_bounds__(1024) void generate_step_kernel(const float* __restrict__ logits, int64_t ld, const int64_t* __restrict__ sampled,
+                                                             int V, int64_t* __restrict__ tokens, int64_t ld_tok,
+                                                             const uint8_t* __restrict__ text_mask, int64_t ld_mask, int cur,
+                                                             const int64_t* __restrict__ stop_seq, const int32_t* __restrict__ stop_off,
+                                                             int n_stop, uint8_t* __restrict__ stopped, int64_t* __restrict__ stop_pos,
+                                                             int32_t* __restrict__ live) {
+  __shared__ float bv[16];
+  __shared__ int bi[16];
+  const int row = blockIdx.x;
+  float best = -INFINITY;
+  int idx = 0x7fffffff;
+  if (!sampled) {
+    const float* r = logits + (int64_t)row * ld;
+    auto take = [&](float v, int i) { if (v > best || (v == best && i < idx)) { best = v; idx = i; } };
+    const bool vec = ((reinterpret_cast<uintptr_t>(r) & 15) == 0);
+    const int V4 = vec ? V / 4 : 0;
+    for (int i0 = threadIdx.x; i0 < V4; i0 += 4 * 1024) {
+      f32x4 x[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = i0 + q * 1024;
+        x[q] = i < V4 ? reinterpret_cast<const f32x4*>(r)[i] : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) take(x[q][e], (i0 + q * 1024) * 4 + e);
+    }
+    for (int i = V4 * 4 + threadIdx.x; i < V; i += 1024) take(r[i], i);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(idx, o, 64);
+      if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = idx; }
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  int64_t next;
+  if (sampled) {
+    next = sampled[row];
+  } else {
+    for (int w = 1; w < 16; ++w)
+      if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+    next = idx == 0x7fffffff ? 0 : idx;
+  }
+  int64_t* trow = tokens + (int64_t)row * ld_tok;
+  const bool forced = text_mask[(int64_t)row * ld_mask + cur] != 0;
+  if (forced) next = trow[cur];
+  trow[cur] = next;
+  bool st = stopped[row] != 0;
+  int64_t sp = st ? stop_pos[row] : (int64_t)cur + 1;
+  for (int s = 0; s < n_stop; ++s) {
+    const int o = stop_off[s], n = stop_off[s + 1] - o;
+    if (cur + 1 - n < 0 || forced || st) continue;
+    bool hit = true;
+    for (int k = 0; k < n && hit; ++k) hit = trow[cur + 1 - n + k] == stop_seq[o + k];
+    if (hit) { sp = cur + 1 - n; st = true; }
+  }
+  if (st && !stopped[row] && live) atomicSub(live, 1);
+  stopped[row] = st ? 1 : 0;
+  stop_pos[row] = sp;
+}
+
 __global__ __launch_bounds__(256) void count_valid_kernel(const int64_t* __restrict__ labels, int rows, int32_t* __restrict__ out) {
   __shared__ float red[4];
   float c = 0.f;
@@ -638,6 +713,17 @@ extern "C" int a3v_split_views(const void* img, void* out, int B, int crop, int 
     case 3: hipLaunchKernelGGL((split_views_kernel<float, float>), g, b, 0, ST, (const float*)img, (float*)out, B, crop); break;
     default: return A3V_ERR_DTYPE;
   }
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}
+
+extern "C" int a3v_generate_step(const float* logits, int64_t ld, const int64_t* sampled, int B, int V, int64_t* tokens, int64_t ld_tok,
+                                 const uint8_t* text_mask, int64_t ld_mask, int cur_pos, const int64_t* stop_seq, const int32_t* stop_off,
+                                 int n_stop, uint8_t* stopped, int64_t* stop_pos, int32_t* live, void* stream) {
+  if ((!logits && !sampled) || !tokens || !text_mask || !stopped || !stop_pos || B <= 0 || V <= 0 || cur_pos < 0 || n_stop < 0) return A3V_ERR_ARG;
+  if (n_stop > 0 && (!stop_seq || !stop_off)) return A3V_ERR_ARG;
+  hipLaunchKernelGGL(generate_step_kernel, dim3(B), dim3(1024), 0, ST, logits, ld, sampled, V, tokens, ld_tok, text_mask, ld_mask, cur_pos,
+                     stop_seq, stop_off, n_stop, stopped, stop_pos, live);
   A3V_LAUNCH_CHECK();
   return A3V_OK;
 }

@@ -57,7 +57,7 @@ class GradReducer:
         return self._stream
 
     def _on_ready(self, name: str, start: int, end: int) -> None:
-        if not self.enabled or self.world == 1:
+        if not self.enabled or self.world == 1 or end <= start:      # (a bucket is empty when all its parameters are frozen)
             return
         seg = self.eng.flat_grads()[start:end]
         if seg.is_cuda:

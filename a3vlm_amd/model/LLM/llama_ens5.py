@@ -425,7 +425,7 @@ class Transformer(nn.Module):
             self._linear(act, lyr.feed_forward.w2.weight, h, residual=h)
 
     def quantize_decode_weights(self, mode: str = "fp8", prefill: bool = False) -> None:
-        """Opt-in fp8 images of the four decoder matrices of every layer (a3vlm_amd/quant.py; BASELINE config 5).
+        """Opt-in fp8 images of the four decoder matrices of every layer (BASELINE config 5; quantiser = a3v_quantize_rows_fp8).
         The single-call decode step streams them weight-only (half the bytes, bf16 activations).  ``prefill=True`` also runs
         the multi-token forward W8A8 (a3v_gemm_nt_fp8: activations quantised per token on the fly); otherwise prefill keeps
         the bf16 weights.  ``mode=None`` drops the images.  Re-run after the weights change."""

@@ -68,6 +68,64 @@ class MetaModel(nn.Module):
         self._set_default_trainability(pretrain_stage)
         self.is_peft = getattr(model, "is_peft", False)
 
+    # ------------------------------------------------------------------ construction from a checkpoint folder
+    @classmethod
+    def from_pretrained(cls, pretrained_path, llama_type: Optional[str] = None, llama_config=None,
+                        tokenizer_path: Optional[str] = None, with_visual: bool = False, max_seq_len: int = 4096,
+                        mp_group=None, dtype=torch.bfloat16, device="cuda", quant=False) -> "MetaModel":
+        """Build the model a checkpoint folder describes and load it (reference: model/meta.py:88-222).
+
+        What is not given is looked up in the LAST folder of ``pretrained_path``: ``llama_type`` in ``meta.json``,
+        ``llama_config`` in ``config.json`` (absent: ModelArgs defaults), the tokenizer as ``tokenizer.model`` or an HF pair.
+        Folders are loaded in order (``consolidated`` / ``meta_ori`` override, ``consolidated_diff`` adds).  Differences to the
+        reference, all forced by the DP-replica design: no process group is created (``mp_group`` must be None or of size 1;
+        TP-sharded folders are merged on load), ``hf://`` ids need a network and are refused, and ``quant=True`` selects this
+        package's weight-only fp8 decoder images (``Transformer.quantize_decode_weights("fp8")``) instead of bitsandbytes NF4."""
+        import os
+        import warnings
+        from ..checkpoint import load_tensor_parallel_model_list
+        paths = [pretrained_path] if isinstance(pretrained_path, str) else list(pretrained_path or [])
+        if not paths:
+            raise ValueError("pretrained_path should be specified")
+        for path in paths:
+            if path.startswith("hf://"):
+                raise NotImplementedError(f"{path}: downloading from the hub is not available here; pass a local folder")
+        if mp_group is not None:
+            import torch.distributed as dist
+            if dist.get_world_size(mp_group) != 1:
+                raise NotImplementedError("model parallel size > 1 is replaced by DP replicas; TP-sharded folders are merged on load")
+        last = paths[-1]
+        if llama_type is None:
+            meta_file = os.path.join(last, "meta.json")
+            if not os.path.exists(meta_file):
+                raise ValueError("Cannot determine llama_type")
+            with open(meta_file) as f:
+                llama_type = json.load(f)["llama_type"]
+        if llama_config is None:
+            cfg_file = os.path.join(last, "config.json")
+            llama_config = [cfg_file] if os.path.exists(cfg_file) else []
+        if tokenizer_path is None:
+            tokenizer_path = probe_tokenizer_path_from_pretrained(last)
+            if tokenizer_path is None:
+                raise FileNotFoundError("No tokenizer available")
+        old = torch.get_default_dtype()
+        torch.set_default_dtype(dtype)
+        try:
+            with torch.device(device):
+                model = cls(llama_type, llama_config, tokenizer_path, with_visual, max_seq_len)
+        finally:
+            torch.set_default_dtype(old)
+        print(f"Loading pretrained weights from {paths} ...")
+        load_result = load_tensor_parallel_model_list(model, paths)
+        if load_result != {"missing_keys": [], "unexpected_keys": []}:
+            warnings.warn(f"checkpoint and model mismatch: \n{load_result}")
+        else:
+            print("all params match perfectly!")
+        if quant:
+            model.llma.quantize_decode_weights("fp8")
+        model.eval()
+        return model
+
     # ------------------------------------------------------------------ trainability
     def get_trainable_params(self, pretrain_stage: bool = False):
         return {"llma." + n: p for n, p in self.llma.get_trainable_params(pretrain_stage).items()}
@@ -226,14 +284,22 @@ class MetaModel(nn.Module):
         text_mask = mask_cpu.to(dev)
         start_pos, prev_pos = min_prompt, 0
 
+        # stop sequences: EOS, then each extra stop string tokenised as a word-initial and as a word-internal piece (:438-444)
         l_stop = [[self.tokenizer.eos_id]]
         l_stop += [self.tokenizer.encode_segment(s) for s in additional_stop_symbols]
         l_stop += [self.tokenizer.encode_wo_prefix_space(s) for s in additional_stop_symbols]
-        l_stop = [torch.tensor(s, dtype=torch.long, device=dev) for s in l_stop]
+        offs = [0]
+        for st in l_stop:
+            offs.append(offs[-1] + len(st))
+        stop_seq = torch.tensor([t for st in l_stop for t in st], dtype=torch.long, device=dev)
+        stop_off = torch.tensor(offs, dtype=torch.int32, device=dev)
         stopped = torch.zeros(bsz, dtype=torch.bool, device=dev)
         stop_pos = torch.full((bsz,), start_pos + 1, dtype=torch.long, device=dev)
-        next_token = torch.empty(bsz, dtype=torch.long, device=dev)
+        live = torch.full((1,), bsz, dtype=torch.int32, device=dev)      # rows still generating (device counter)
 
+        # One iteration = the model step (one C call for a decode step) + ONE launch of a3v_generate_step, which does everything
+        # meta.py:456-477 does with a dozen small torch ops: argmax, teacher forcing of longer prompts, the tokens[:, cur_pos]
+        # write, stop_pos / stopped bookkeeping and the multi-token stop match.  The host only reads `live` every poll_every steps.
         for cur_pos in range(start_pos, total_len):
             if depth_images is not None:                     # two-image plugin (meta.py:447-451)
                 if prev_pos == 0:
@@ -243,23 +309,12 @@ class MetaModel(nn.Module):
             else:
                 logits = self.llma.forward_inference(tokens[:, prev_pos:cur_pos], prev_pos,
                                                      images if prev_pos == 0 else None)
+            sampled = None
             if temperature > 0:
                 probs = torch.softmax(logits / temperature, dim=-1)
-                nt = self.sample_top_p(probs, top_p).reshape(-1)
-            else:
-                nt = ops.argmax(logits, next_token)
-            nt = torch.where(text_mask[:, cur_pos], tokens[:, cur_pos], nt)
-            tokens[:, cur_pos] = nt
-            stop_pos = torch.where(stopped, stop_pos, cur_pos + 1)
-            for st in l_stop:
-                n = len(st)
-                if cur_pos + 1 - n >= 0:
-                    c1 = (tokens[:, cur_pos + 1 - n:cur_pos + 1] == st.unsqueeze(0)).all(dim=-1)
-                    c2 = ~text_mask[:, cur_pos]
-                    new = c1 & c2 & (~stopped)
-                    stop_pos = torch.where(new, cur_pos + 1 - n, stop_pos)
-                    stopped = torch.logical_or(new, stopped)
-            if ((cur_pos - start_pos) % poll_every == poll_every - 1 or cur_pos == total_len - 1) and bool(stopped.all()):
+                sampled = self.sample_top_p(probs, top_p).reshape(-1).contiguous()
+            ops.generate_step(logits, sampled, tokens, text_mask, cur_pos, stop_seq, stop_off, len(l_stop), stopped, stop_pos, live)
+            if ((cur_pos - start_pos) % poll_every == poll_every - 1 or cur_pos == total_len - 1) and int(live.item()) == 0:
                 break
             prev_pos = cur_pos
 

@@ -304,6 +304,24 @@ def vit_embed(patch, cls, pos, x, N, T, width):
     _l.check(rc, "a3v_vit_embed")
 
 
+def generate_step(logits, sampled, tokens, text_mask, cur_pos: int, stop_seq, stop_off, n_stop: int, stopped, stop_pos, live):
+    """One launch = one step of MetaModel.generate's bookkeeping (a3v_generate_step): argmax (or the sampled ids), teacher
+    forcing, tokens[:, cur_pos] write, stop-sequence match, stop_pos / stopped / live update."""
+    _dev(tokens, text_mask, stopped, stop_pos, live)
+    B = tokens.shape[0]
+    assert tokens.dtype == torch.int64 and text_mask.dtype == torch.bool and stopped.dtype == torch.bool and stop_pos.dtype == torch.int64
+    assert tokens.stride(1) == 1 and text_mask.stride(1) == 1 and live.dtype == torch.int32
+    if sampled is None:
+        assert logits.dtype == torch.float32 and logits.stride(1) == 1 and logits.shape[0] == B
+        lp, ld, V = _p(logits), logits.stride(0), logits.shape[1]
+    else:
+        assert sampled.dtype == torch.int64 and sampled.is_contiguous() and sampled.numel() == B
+        lp, ld, V = None, 0, 1
+    rc = _l.load().a3v_generate_step(lp, ld, _p(sampled), B, V, _p(tokens), tokens.stride(0), _p(text_mask), text_mask.stride(0), int(cur_pos),
+                                     _p(stop_seq), _p(stop_off), int(n_stop), _p(stopped), _p(stop_pos), _p(live), _stream())
+    _l.check(rc, "a3v_generate_step")
+
+
 def argmax(logits, out):
     _dev(logits, out)
     assert logits.dtype == torch.float32 and out.dtype == torch.int64

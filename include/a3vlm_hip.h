@@ -215,6 +215,17 @@ int a3v_split_views(const void* img, void* out, int B, int crop, int in_dtype, i
 int a3v_vit_embed(const void* patch, const void* cls, const void* pos, void* x, int N, int T,
                   int width, int dtype, void* stream);
 
+/* One step of the token bookkeeping of MetaModel.generate (model/meta.py:456-477), one launch for the whole batch: greedy argmax of
+ * logits [B, V] (fp32, row stride ld) -- or, when `sampled` is non-NULL, the externally sampled ids of the top-p branch (:457-459) --
+ * then, per row: teacher forcing of prompt positions (text_mask[row, cur_pos], :463-465), tokens[row, cur_pos] = next,
+ * stop_pos / stopped update and the multi-token stop-sequence match (:468-475; stop_seq = all sequences concatenated, stop_off =
+ * n_stop + 1 offsets, tried in order).  text_mask / stopped are one byte per element (torch.bool).  `live` (optional): device
+ * counter of rows still running, decremented when a row stops -- the host reads that one word every k steps instead of
+ * `stopped.all()` every step (:476).  Values are bit-identical to the reference's torch ops (integer work). */
+int a3v_generate_step(const float* logits, int64_t ld, const int64_t* sampled, int B, int V, int64_t* tokens, int64_t ld_tok,
+                      const uint8_t* text_mask, int64_t ld_mask, int cur_pos, const int64_t* stop_seq, const int32_t* stop_off,
+                      int n_stop, uint8_t* stopped, int64_t* stop_pos, int32_t* live, void* stream);
+
 /* torch.argmax(logits, -1) with first-index tie break (model/meta.py:460).  fp32 [B,V]. */
 int a3v_argmax(const float* logits, int64_t ld, int64_t* out, int B, int V, void* stream);
 

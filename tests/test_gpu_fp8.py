@@ -10,7 +10,7 @@ import torch.nn.functional as F
 
 from a3vlm_amd import ops
 from a3vlm_amd.model.LLM import llama_ens5 as plugin
-from a3vlm_amd.quant import dequantize_rows_fp8, quantize_rows_fp8
+from oracle.quant_fp8 import W8A8OracleDecoder, dequantize_rows_fp8, quantize_rows_fp8
 from oracle import ref_cpu
 
 pytestmark = pytest.mark.gpu
@@ -110,7 +110,7 @@ def test_fp8_decode_step_vs_bf16(heads, kv, dim, B):
         err = float((base[i] - q8[i]).abs().max()) / scale
         assert 0 < err < 0.25, (i, err)                                  # really quantised; random N(0, 0.05) weights are a worst case for e4m3
     # oracle on the DEQUANTISED weights (what the fp8 step computes): tight(er) agreement
-    from a3vlm_amd.quant import dequantize_rows_fp8, quantize_rows_fp8
+    from oracle.quant_fp8 import W8A8OracleDecoder, dequantize_rows_fp8, quantize_rows_fp8
     sdq = dict(sd)
     for k in list(sd):
         if k.startswith("layers.") and k.endswith((".wq.weight", ".wk.weight", ".wv.weight", ".wo.weight", ".w1.weight", ".w2.weight", ".w3.weight")):
@@ -127,18 +127,7 @@ def test_fp8_decode_step_vs_bf16(heads, kv, dim, B):
     assert torch.equal(again[1], base[1])
 
 
-class _W8A8Oracle(ref_cpu.OracleDecoder):
-    """The CPU restatement with the W8A8 arithmetic of the prefill path spelled out: per-row fp8 weights (dequantised), the
-    input of every decoder linear fake-quantised per token (scale = max|x| / 448), fp32 product, one bf16 rounding."""
-
-    def lin(self, x, name):
-        if not name.startswith("layers."):
-            return super().lin(x, name)
-        w = dequantize_rows_fp8(*quantize_rows_fp8(self.sd[name + ".weight"]))
-        xf = x.float()
-        sc = xf.abs().amax(dim=-1, keepdim=True).clamp_min(1e-12) / 448.0
-        xq = (xf / sc).clamp(-448, 448).to(torch.float8_e4m3fn).float() * sc
-        return F.linear(xq, w).to(x.dtype)
+_W8A8Oracle = W8A8OracleDecoder.make(ref_cpu.OracleDecoder)
 
 
 @pytest.mark.parametrize("heads,kv,dim,B,T0,L", [(4, 4, 512, 4, 33, 1), (8, 2, 1024, 3, 150, 1), (4, 4, 512, 4, 33, 3)])
@@ -220,7 +209,7 @@ def test_quantize_rows_fp8(rows, dim, norm):
 def test_gemm_nt_fp8(M, N, K, epi):
     """MX-scaled fp8 MFMA GEMM == the fp32 product of the dequantised operands (fp8 x fp8 products are exact in fp32), then
     the same rounding points as the bf16 kernel's epilogues; partial tiles in M and N, one to eight k-tiles."""
-    from a3vlm_amd.quant import quantize_rows_fp8 as qhost
+    from oracle.quant_fp8 import quantize_rows_fp8 as qhost
     a, w = gen(M, K, seed=71), gen(N, K, seed=72, scale=0.05)
     aq, sa = qhost(a)
     wq, sw = qhost(w)
@@ -259,7 +248,7 @@ def test_gemm_nt_fp8_split_tail(M, N, K, mode):
     """18 x 16 (35 x 16) tiles on 256 CUs: the tile rows that fill whole rounds run as one launch, the remaining rows as split-K
     planes + the reduce epilogue -- same values as the un-split kernel up to fp32 summation order before the bf16 rounding.
     Reference: fp32 torch matmul of the dequantised operands on the device (exact products)."""
-    from a3vlm_amd.quant import quantize_rows_fp8 as qhost
+    from oracle.quant_fp8 import quantize_rows_fp8 as qhost
     a, w = gen(M, K, seed=81), gen(N, K, seed=82, scale=0.05)
     aq, sa = qhost(a)
     wq, sw = qhost(w)

@@ -1,0 +1,165 @@
+"""-m gpu: the HIP plugin against the round-2 fixtures captured from the reference (``oracle/gen_golden_r2.py``):
+the head_dim-128 / GQA decoder -- the geometry at which the bf16 build runs its MFMA attention, the fused qkv / RoPE / KV-cache GEMM
+epilogue and the one-call decode step, i.e. the kernels ``bench.py`` times -- in fp32 (1e-3, ids bit-exact) and in bf16 (tolerance
+stated against the reference's OWN bf16-vs-fp32 deviation; greedy ids compared wherever the fp32 top-2 margin exceeds the bf16
+noise); linear RoPE scaling; the ``openai`` CLIP activation (QuickGELU)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from a3vlm_amd.model.LLM import llama_ens5 as plugin  # noqa: E402
+from a3vlm_amd.model.meta import MetaModel  # noqa: E402
+from oracle import ref_cpu  # noqa: E402
+from oracle.gen_golden import TINY, synth_image  # noqa: E402
+from oracle.gen_golden_r2 import MID  # noqa: E402
+
+DEV, BF, REL = "cuda", torch.bfloat16, 1e-3
+P, NDEC = 41, 6
+
+
+def rel_err(got, want):
+    got = got.detach().float().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    want = np.asarray(want, dtype=np.float32)
+    return float(np.abs(got - want).max() / (np.abs(want).max() + 1e-12))
+
+
+@pytest.fixture(scope="module")
+def mid(golden_dir):
+    j = json.load(open(os.path.join(golden_dir, "mid_meta.json")))
+    fx = np.load(os.path.join(golden_dir, "decoder_mid.npz"))
+    oargs = ref_cpu.OracleArgs(vocab_size=j["vocab_size"], **MID)
+    sd = ref_cpu.make_decoder_weights(oargs, seed=21, std=0.04)
+    return dict(fx=fx, j=j, sd=sd, oargs=oargs, dir=golden_dir)
+
+
+def _model(mid, dtype):
+    m = plugin.Transformer(plugin.ModelArgs(vocab_size=mid["j"]["vocab_size"], **MID))
+    m.load_state_dict(mid["sd"])
+    return m.to(dtype).to(DEV)
+
+
+def _run_inference(m, ex):
+    lg = [m.forward_inference(ex[:, :P], 0).float().clone()]
+    for t in range(P, P + NDEC):
+        lg.append(m.forward_inference(ex[:, t:t + 1], t).float().clone())
+    return torch.stack(lg)
+
+
+def test_mid_fp32_matches_reference(mid):
+    fx = mid["fx"]
+    m = _model(mid, torch.float32)
+    ex = torch.from_numpy(fx["examples"]).to(DEV)
+    out = m(ex)
+    assert rel_err(out, fx["logits"]) < REL
+    assert (out.argmax(-1).cpu().numpy() == fx["logits"].argmax(-1)).all()
+    inf = _run_inference(m, ex)
+    assert rel_err(inf, fx["inf_logits"]) < REL
+    assert (inf.argmax(-1).cpu().numpy() == fx["inf_logits"].argmax(-1)).all()
+    k1 = m._k_cache[1][:, :, :P + NDEC].permute(0, 2, 1, 3)
+    assert rel_err(k1, fx["kcache_l1"]) < REL
+
+
+def test_mid_bf16_mfma_path_matches_reference(mid):
+    """bf16 storage + MFMA kernels (attention hd = 128, fused qkv/RoPE/cache epilogue, fused decode step) against the reference's
+    fp32 and bf16 logits.  Bound: 2.5 x the reference's own bf16-vs-fp32 deviation on the same inputs (same rounding points,
+    different accumulation order), and greedy ids equal wherever the fp32 margin between the two best tokens exceeds twice the
+    measured error."""
+    fx = mid["fx"]
+    scale = np.abs(fx["logits"]).max()
+    ref_dev = np.abs(fx["logits_bf16"] - fx["logits"]).max() / scale
+    m = _model(mid, BF)
+    assert m.head_dim == 128
+    ex = torch.from_numpy(fx["examples"]).to(DEV)
+    out = m(ex).float().cpu().numpy()
+    err = np.abs(out - fx["logits"]).max() / scale
+    assert err < 2.5 * ref_dev, (err, ref_dev)
+    assert np.abs(out - fx["logits_bf16"]).max() / scale < 2.5 * ref_dev
+    inf = _run_inference(m, ex).cpu().numpy()
+    scale_i = np.abs(fx["inf_logits"]).max()
+    err_i = np.abs(inf - fx["inf_logits"]).max() / scale_i
+    assert err_i < 2.5 * max(ref_dev, np.abs(fx["inf_logits_bf16"] - fx["inf_logits"]).max() / scale_i), err_i
+    # greedy ids on the bf16 path
+    compared = agree = 0
+    for got, want in ((out, fx["logits"]), (inf, fx["inf_logits"])):
+        noise = np.abs(got - want).max()
+        top2 = np.sort(want, axis=-1)[..., -2:]
+        decided = (top2[..., 1] - top2[..., 0]) > 2 * noise
+        compared += int(decided.sum())
+        agree += int((got.argmax(-1) == want.argmax(-1))[decided].sum())
+        total = decided.size
+    assert agree == compared, (agree, compared)
+    assert compared >= 0.5 * (out.shape[0] * out.shape[1]), f"only {compared} positions had a decisive fp32 margin"
+
+
+def test_mid_generate_greedy_ids(mid):
+    """``MetaModel.generate(temperature=0)`` on the hd-128 geometry: fp32 ids bit-exact with the reference's; bf16 ids equal up to the
+    first step whose fp32 top-2 margin (teacher-forced along the reference's ids, CPU oracle) is inside the bf16 noise."""
+    j = mid["j"]
+
+    def build(dtype):
+        mm = MetaModel("llama_ens5", os.path.join(mid["dir"], "mid_params.json"), os.path.join(mid["dir"], "tokenizer.model"),
+                       with_visual=False, max_seq_len=128)
+        mm.llma.load_state_dict(mid["sd"])
+        return mm.to(dtype).to(DEV)
+    texts, ids = build(torch.float32).generate(j["prompts"], None, max_gen_len=24, temperature=0.0, return_ids=True)
+    assert ids == j["gen24_ids"] and texts == j["gen24_text"]
+    _, ids_bf = build(BF).generate(j["prompts"], None, max_gen_len=24, temperature=0.0, return_ids=True)
+    dec = ref_cpu.OracleDecoder(mid["oargs"], mid["sd"])
+    fx = mid["fx"]
+    noise = 2.0 * float(np.abs(fx["logits_bf16"] - fx["logits"]).max())
+    compared = total = 0
+    for pid, want, got in zip(j["prompt_ids"], j["gen24_ids"], ids_bf):
+        seq = torch.tensor([pid + want])
+        lg = dec.forward(seq)[0]                                   # teacher-forced fp32 logits along the reference's output
+        for k, tok in enumerate(want):
+            total += 1
+            row = lg[len(pid) + k - 1]
+            top2 = torch.topk(row, 2).values
+            if float(top2[0] - top2[1]) <= noise:
+                break                                              # from here on the bf16 run may legitimately branch off
+            assert k < len(got) and got[k] == tok, (k, got[:k + 1], want[:k + 1])
+            compared += 1
+    assert compared >= 0.5 * total, f"{compared} of {total} generated tokens had a decisive margin"
+
+
+def test_rope_scaling_fp32_matches_hf_pin(golden_dir):
+    fx = np.load(os.path.join(golden_dir, "rope_scaling.npz"))
+    s = float(fx["rope_scaling"])
+    V = fx["hf_logits"].shape[-1]
+    sd = ref_cpu.make_decoder_weights(ref_cpu.OracleArgs(vocab_size=V, **TINY), seed=0, std=0.08)
+    m = plugin.Transformer(plugin.ModelArgs(vocab_size=V, rope_scaling=s, **TINY))
+    m.load_state_dict(sd)
+    m.to(DEV)
+    ex = torch.from_numpy(fx["examples"]).to(DEV)
+    out = m(ex)
+    assert rel_err(out, fx["hf_logits"]) < REL and rel_err(out, fx["ref_logits"]) < REL
+    # cached inference uses the same scaled table at the decode positions
+    lg = m.forward_inference(ex[:, :15], 0).clone()
+    assert rel_err(lg, fx["hf_logits"][:, 14]) < REL
+    lg = m.forward_inference(ex[:, 15:16], 15).clone()
+    assert rel_err(lg, fx["hf_logits"][:, 15]) < REL
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (BF, 3e-2)])
+def test_vit_quick_gelu_matches_oracle(dtype, tol):
+    """``vit_quick_gelu`` = the activation of open_clip's ``openai``-pretrained ViT-L/14 config (x * sigmoid(1.702 x)); the default
+    build uses erf-GELU.  The flag switches the epilogue of the ViT's c_fc GEMM; ``clip_encode_image`` (LLM/llama_ens5.py:351-375)
+    is checked against the oracle's ViT with the same flag, on weights wide enough for the two activations to differ visibly."""
+    kw = dict(dim=128, n_layers=1, n_heads=2, vocab_size=256, multiple_of=64, max_seq_len=1024)
+    vsd = ref_cpu.make_vision_weights(128, width=128, layers=2, patch=14, grid=24, seed=4, std=0.25)
+    sd = ref_cpu.make_decoder_weights(ref_cpu.OracleArgs(**kw), seed=3, std=0.05)
+    img = synth_image(2, size=336, seed=9)
+    want = {q: ref_cpu.clip_encode_image(img, vsd, 2, 2, 14, quick_gelu=q) for q in (True, False)}
+    assert rel_err(want[True], want[False].numpy()) > 0.1, "the two activations must be distinguishable on this input"
+    for q in (True, False):
+        args = plugin.ModelArgs(**kw, vit_width=128, vit_layers=2, vit_heads=2, vit_crop=336, n_views=1, vit_quick_gelu=q)
+        m = plugin.Transformer(args, with_visual=True)
+        m.load_state_dict({**sd, **vsd})
+        m.to(dtype).to(DEV)
+        got = m.clip_encode_image(img.to(dtype).to(DEV)).view(2, 577, 128)
+        assert rel_err(got, want[q].numpy()) < tol, q

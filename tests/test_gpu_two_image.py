@@ -127,3 +127,55 @@ def test_two_image_generate_matches_oracle(golden_dir):
     pt = [mm.tokenizer.encode(p, bos=True, eos=False) for p in prompts]
     _, want = ref_cpu.generate_greedy(dec, pt, image_tokens=itok, image_words=itok.shape[1], max_gen_len=12, eos_id=mm.tokenizer.eos_id)
     assert ids == want
+
+
+def test_two_image_fp8_weights_1024_context():
+    """BASELINE configs[4]: RGB + depth images, 1024-token prompt, fp8 weight path -- the combination, on one model.
+    ``llama_ens5_2images`` in bf16 with ``quantize_decode_weights("fp8", prefill=True)``: W8A8 prefill over
+    [BOS | RGB words | depth words | 1023 text tokens], then weight-only fp8 decode steps on the cache it wrote.
+    No reference oracle exists for fp8: checked against the W8A8 restatement of the oracle
+    (oracle/quant_fp8.py) fed the SAME two-image token assembly, and against the bf16 run of the same plugin."""
+    from oracle.quant_fp8 import W8A8OracleDecoder
+    kw = dict(dim=512, n_layers=2, n_heads=4, n_kv_heads=2, vocab_size=640, multiple_of=256, max_seq_len=2048)
+    args = plugin2.ModelArgs(**kw, vit_width=64, vit_layers=2, vit_heads=4, vit_crop=112, n_views=1)
+    m = plugin2.Transformer(args, with_visual=True)
+    oargs = ref_cpu.OracleArgs(**kw)
+    sd = ref_cpu.make_decoder_weights(oargs, seed=31, std=0.05)
+    vsd = ref_cpu.make_vision_weights(512, width=64, layers=2, patch=14, grid=8, seed=1, std=0.05)
+    sdi, edi = depth_tags(dim=512)
+    m.load_state_dict({**sd, **vsd, "start_depth_img": sdi, "end_depth_img": edi})
+    m.to(torch.bfloat16).to(DEV)
+    assert m.image_words == 2 * (64 + 1 + 2)
+    B, T = 2, 1024
+    g = torch.Generator().manual_seed(17)
+    ex = torch.randint(3, 640, (B, T + 2), generator=g)
+    ex[:, 0] = 1
+    img, depth = synth_image(B, size=112, seed=3), synth_image(B, size=112, seed=4)
+    exd, imgd, depd = ex.to(DEV), img.to(DEV), depth.to(DEV)
+    base = m.forward_inference(exd[:, :T], 0, imgd, depd).float().clone()
+    base_next = m.forward_inference(exd[:, T:T + 1], T).float().clone()
+    m.quantize_decode_weights("fp8", prefill=True)
+    got = m.forward_inference(exd[:, :T], 0, imgd, depd).float().clone()
+    assert m.cache_image_words == m.image_words
+    nxt = [m.forward_inference(exd[:, t:t + 1], t).float().clone() for t in range(T, T + 2)]
+    # oracle: bf16 weights, the same image words, W8A8 arithmetic in the decoder linears
+    bf = torch.bfloat16
+    vb = {k: v.to(bf) for k, v in vsd.items()}
+    kwv = dict(vit_layers=2, vit_heads=4, n_views=1)
+    itok = torch.cat([ref_cpu.assemble_image_tokens(ref_cpu.encode_image(img.to(bf), vb, **kwv), vb["start_img"], vb["end_img"]),
+                      ref_cpu.assemble_image_tokens(ref_cpu.encode_image(depth.to(bf), vb, **kwv), sdi.to(bf), edi.to(bf))], dim=1)
+    dec = W8A8OracleDecoder.make(ref_cpu.OracleDecoder)(oargs, {k: v.to(bf) for k, v in sd.items()})
+    want = dec.forward_inference(ex[:, :T], 0, itok).float()
+
+    def rms(a, b):
+        a, b = a.float().cpu(), b.float().cpu()
+        return float((a - b).norm() / b.norm())
+    e_bf, e_or = rms(got, base), rms(got, want)
+    print(f"2 images + fp8 @ T=1024: rms vs bf16 plugin {e_bf:.4f}, vs W8A8 oracle {e_or:.4f}")
+    assert 0 < e_bf < 0.4 and e_or < 0.7 * e_bf, (e_bf, e_or)
+    assert rms(nxt[0], base_next) < 0.4
+    for i, t in enumerate(range(T, T + 2)):
+        w2 = dec.forward_inference(ex[:, t:t + 1], t).float()
+        assert rms(nxt[i], w2) < 0.25, (i, rms(nxt[i], w2))
+    m.quantize_decode_weights(None)
+    assert torch.equal(m.forward_inference(exd[:, :T], 0, imgd, depd).float(), base)

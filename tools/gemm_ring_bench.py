@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """A/B of the two-stage ping-pong GEMM (dbg 7) against its 160-KiB ring forms: bit equality on ragged / short-K shapes,
 then interleaved timing rounds in ONE process on the bench step's shapes (guide rules 24, 25: random data).
-  dbg 5  ring, barrier at the end of the MFMA interval      dbg 11 / 12 / 13  barrier 4 / 8 / 16 MFMAs before the end
-  dbg 9  ring on v_mfma_f32_32x32x16_bf16                   dbg 10            ... barrier 2 MFMAs before the end"""
+  dbg 5  ring, epilogue stores staged through LDS (whole 128-B rows)      dbg 11  ring, direct 8-B-per-lane epilogue stores
+  dbg 9  ring on v_mfma_f32_32x32x16_bf16 (direct stores)"""
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,7 +10,7 @@ from a3vlm_amd import ops, lib
 
 dev = "cuda"
 T = lib.EPI_TILE_256PP
-VARIANTS = {"pp": 7, "ring": 5, "e4": 11, "e8": 12, "e16": 13, "ring32": 9, "r32e": 10}
+VARIANTS = {"pp": 7, "ring": 5, "ring_direct": 11, "ring32": 9}
 if len(sys.argv) > 1:
     VARIANTS = {k: v for k, v in VARIANTS.items() if k in sys.argv[1].split(",") or k == "pp"}
 flag = {k: T | (v << 24) for k, v in VARIANTS.items()}
@@ -41,6 +41,25 @@ for (M, N, K) in [(256, 256, 64), (256, 256, 128), (256, 256, 192), (300, 260, 2
         row[name] = "ok" if good else "MISMATCH"
         ok = ok and good
     print(json.dumps(row), flush=True)
+# epilogue modes through the staged store path: bias + GELU, bf16 residual (in place), ragged N / M
+for (M, N, K) in [(520, 776, 256), (2048, 1024, 512)]:
+    g = torch.Generator(device=dev).manual_seed(7)
+    a = torch.randn(M, K, device=dev, dtype=torch.bfloat16, generator=g)
+    w = torch.randn(N, K, device=dev, dtype=torch.bfloat16, generator=g) * 0.05
+    bias = torch.randn(N, device=dev, dtype=torch.bfloat16, generator=g)
+    res = torch.randn(M, N, device=dev, dtype=torch.bfloat16, generator=g)
+    for mode in ("bias_gelu", "residual", "bias_residual"):
+        outs = {}
+        for name in ("pp", "ring", "ring_direct"):
+            if name not in flag:
+                continue
+            o = res.clone() if "residual" in mode else torch.full((M, N), 2.0, device=dev, dtype=torch.bfloat16)
+            ops.gemm_nt(a, w, o, bias=bias if "bias" in mode else None, residual=o if "residual" in mode else None,
+                        epilogue=flag[name] | (ops.EPI_GELU if "gelu" in mode else 0))
+            outs[name] = o
+        good = all(torch.equal(outs["pp"], v) for v in outs.values())
+        ok = ok and good
+        print(json.dumps({"shape": [M, N, K], "epilogue": mode, "equal": good}), flush=True)
 print("EQUALITY", "OK" if ok else "FAILED", flush=True)
 
 shapes = [(8728, 12288, 4096, 0), (8728, 4096, 4096, 0), (8728, 22016, 4096, ops.EPI_SWIGLU),
