@@ -246,6 +246,27 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GemmAr
     }
     return;
   }
+  if (TN == 4 && stage && (epi & (A3V_EPI_RES_F32 | A3V_EPI_OUT_F32)) && !(epi & GEMM_EPI_ROPEKV) && !(p.ldc & 3) && !(p.N & 3) &&
+      !(reinterpret_cast<uintptr_t>(p.C) & 15)) {
+    // fp32 outputs (weight gradients, fp32 residual stream): chunk = one 16-row tile x 64 columns = 16 rows x 256 B; the lane's
+    // 16-B slot s of row r sits at slot s ^ r (conflict-free for the 8-lane ds_write_b128 groups and for the row-contiguous reads);
+    // read back 4 rows x 256 B per instruction, stored as whole 256-B row segments.
+    float* const Cf = reinterpret_cast<float*>(p.C);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        *reinterpret_cast<f32x4*>(stage + mrow * 256 + (((j * 4 + (lane >> 4)) ^ mrow) << 4)) = acc[i][j];
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int r = it * 4 + (lane >> 4), q = lane & 15;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(stage + r * 256 + ((q ^ r) << 4));
+        const int m = mbase + i * 16 + r, n = nbase + q * 4;
+        if (m < p.M && n < p.N) *reinterpret_cast<f32x4*>(Cf + (int64_t)m * p.ldc + n) = v;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int m = mbase + i * 16 + mrow;
@@ -369,7 +390,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_bf16_kernel(Ge
     __syncthreads();
   }
 
-  gemm_epilogue<TM, TN>(acc, p, m0 + wm * WTM, n0 + wn * WTN, lane);
+  // the loop's last __syncthreads() is behind every read of the stage buffers: a private 4 KiB per wave for whole-row stores
+  gemm_epilogue<TM, TN>(acc, p, m0 + wm * WTM, n0 + wn * WTN, lane, nk > 0 ? lds + wave * 4096 : nullptr);
 }
 
 // Epilogue for v_mfma_f32_32x32x16 accumulators (D = W_frag x A_frag): for tile (i, j) the lane holds
@@ -1261,9 +1283,16 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_pp_kernel(GemmArgs p) {
   }
 #undef TN_READ_FRAGS
 #undef TN_MFMA_ALL
-  if (active) gemm_epilogue<TM, TN>(acc, p, m0 + wr * WTM, n0 + wc * WTN, lane);
+  // every read of the stage buffers is behind the last barrier: each wave takes a private 4 KiB of them for the row-contiguous stores
+  if (active) gemm_epilogue<TM, TN>(acc, p, m0 + wr * WTM, n0 + wc * WTN, lane, lds + wave * 4096);
 }
 
+// A ring form of this kernel (A_top / A_bot / W rings over all 160 KiB as in gemm_nt_bf16_ring_kernel; for TN the A halves as
+// [64 k][128 m] tiles with 256-B rows and key(k) & 7) was built and measured in round 2: bit-identical, but NN +1..3 % and TN -7..9 %
+// against this two-stage form (gpurun_out/tn_ring_b.log) -- the transpose-read L interval, not the DMA flight time, paces these
+// loops -- so it was not kept.  One finding worth keeping: with ds_read_tr builtins in the loop, hipcc orders every fragment read
+// behind ALL outstanding LDS-DMA builtins (a compiler-inserted s_waitcnt vmcnt(0)); LDS-DMA that must stay in flight across
+// transpose reads has to be issued from inline asm (s_mov_b32 m0 / buffer_load_dwordx4 ... offen lds).
 // Same schedule with v_mfma_f32_32x32x16_bf16 (8-pass, higher sustained rate than 16x16x32):
 // wave tile 128x64 = 4x2 tiles of 32x32, 4 k-steps of 16 per K-tile, 32 MFMAs per interval.
 template <int DBG>
@@ -1546,7 +1575,7 @@ constexpr int GEMV_EPI_SSQ = 1 << 25;
 // W8: the weight rows are OCP fp8 e4m3fn (weight-only quantisation, one fp32 scale per row applied to the summed
 // accumulator).  A ring stage is still 16 rows x 256 B, i.e. 256 k instead of 128; fragments are read 8 B per lane and
 // widened fp8 -> f32 -> bf16 in registers (exact), so the arithmetic is the bf16 MFMA on dequantised weights.
-template <int AROWS, bool PRO, bool W8>
+template <int AROWS, bool PRO, bool W8, int WAUX = 0>   // WAUX: cache-policy bits of the weight-stream LDS-DMA (2 = nt: streamed once)
 __global__ __launch_bounds__(256) void gemv_dma_bf16_kernel(GemvArgs p) {
   extern __shared__ __attribute__((aligned(1024))) char gemv_lds[];
   __shared__ float rinv_s[16];
@@ -1589,7 +1618,7 @@ __global__ __launch_bounds__(256) void gemv_dma_bf16_kernel(GemvArgs p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wrow[i] + st * 256),
-                                       (__attribute__((address_space(3))) void*)(Wring + slot * 4096 + i * 1024), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(Wring + slot * 4096 + i * 1024), 16, 0, WAUX);
   };
   if (PRO) {
     // RMSNorm of the block's K slice of A (model/components.py:39,52-53 rounding: fp32 x*rinv -> bf16 -> * weight -> bf16),
@@ -2006,9 +2035,13 @@ static bool pp_persistent() {
 }
 
 static bool pp_ring() {       // the 160-KiB ring form of the ping-pong kernel (A3V_GEMM_RING=0: the two-stage kernel, for A/B runs)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("A3V_GEMM_RING"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v != 0;
+  const char* e = getenv("A3V_GEMM_RING");         // read per launch: tuning scripts flip it inside one process
+  return !(e && e[0] == '0');
+}
+
+template <bool A_ROWS>
+static void launch_tn(dim3 grid, hipStream_t st, const GemmArgs& q) {
+  hipLaunchKernelGGL(gemm_tn_bf16_pp_kernel<A_ROWS>, grid, dim3(512), 0, st, q);
 }
 
 static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
@@ -2210,12 +2243,18 @@ static bool gemv_launch(GemvArgs& g, void* ws, hipStream_t st) {
   const int blocks = ((g.tgs + 7) / 8) * 8 * g.S;
   const bool pro = g.norm_w != nullptr;
   void (*kern)(GemvArgs);
-  if (w8) kern = arows == 8 ? (pro ? gemv_dma_bf16_kernel<8, true, true> : gemv_dma_bf16_kernel<8, false, true>)
-                            : (pro ? gemv_dma_bf16_kernel<16, true, true> : gemv_dma_bf16_kernel<16, false, true>);
-  else kern = arows == 8 ? (pro ? gemv_dma_bf16_kernel<8, true, false> : gemv_dma_bf16_kernel<8, false, false>)
-                         : (pro ? gemv_dma_bf16_kernel<16, true, false> : gemv_dma_bf16_kernel<16, false, false>);
-  static bool attr_done[8] = {false, false, false, false, false, false, false, false};
-  const int ki = (w8 ? 4 : 0) + (arows == 16 ? 2 : 0) + (pro ? 1 : 0);
+  // weights are streamed once per step by ONE CU each: non-temporal policy on their LDS-DMA (A3V_GEMV_NT=0: default policy, A/B)
+  const char* nte = getenv("A3V_GEMV_NT");
+  const bool nt = !(nte && nte[0] == '0');
+#define GEMV_PICK(AUX)                                                                                                      \
+  (w8 ? (arows == 8 ? (pro ? gemv_dma_bf16_kernel<8, true, true, AUX> : gemv_dma_bf16_kernel<8, false, true, AUX>)          \
+                    : (pro ? gemv_dma_bf16_kernel<16, true, true, AUX> : gemv_dma_bf16_kernel<16, false, true, AUX>))       \
+      : (arows == 8 ? (pro ? gemv_dma_bf16_kernel<8, true, false, AUX> : gemv_dma_bf16_kernel<8, false, false, AUX>)        \
+                    : (pro ? gemv_dma_bf16_kernel<16, true, false, AUX> : gemv_dma_bf16_kernel<16, false, false, AUX>)))
+  kern = nt ? GEMV_PICK(2) : GEMV_PICK(0);
+#undef GEMV_PICK
+  static bool attr_done[16] = {};
+  const int ki = (nt ? 8 : 0) + (w8 ? 4 : 0) + (arows == 16 ? 2 : 0) + (pro ? 1 : 0);
   if (!attr_done[ki]) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_done[ki] = true; }
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), ldsb, st, g);
   return true;
@@ -2399,7 +2438,7 @@ extern "C" int a3v_gemm_tn(const void* At, int64_t lda, const void* Wt, int64_t 
   if (tail_on && mt_h >= 1 && m_big < M && S > 1 && rem_tiles * 4 < 3 * ncu && g_gemm_ws && (int64_t)S * (M - m_big) * N * 4 <= g_gemm_ws_bytes) {
     GemmArgs q = p;
     q.M = m_big; q.tiles_m = (int)mt_h;
-    hipLaunchKernelGGL(gemm_tn_bf16_pp_kernel<false>, dim3(q.tiles_m * q.tiles_n), dim3(512), 0, st, q);
+    launch_tn<false>(dim3(q.tiles_m * q.tiles_n), st, q);
     GemmArgs t = p;
     t.M = M - m_big;
     t.A = p.A + m_big;                      // At is [K][lda] with the C-row index contiguous: the tail rows of C are columns m_big.. of At
@@ -2407,7 +2446,7 @@ extern "C" int a3v_gemm_tn(const void* At, int64_t lda, const void* Wt, int64_t 
     t.epi = A3V_EPI_OUT_F32 | GEMM_EPI_RAW;
     t.tiles_m = (t.M + 255) / 256;
     t.c_split = (int64_t)t.M * N * 4;
-    hipLaunchKernelGGL(gemm_tn_bf16_pp_kernel<false>, dim3(t.tiles_m * t.tiles_n, S), dim3(512), 0, st, t);
+    launch_tn<false>(dim3(t.tiles_m * t.tiles_n, S), st, t);
     const int esz = (epilogue & (A3V_EPI_OUT_F32 | A3V_EPI_RES_F32)) ? 4 : 2;
     void* Ct = (char*)C + (int64_t)m_big * ldc * esz;
     const void* Rt = residual ? (const char*)residual + (int64_t)m_big * ldr * ((epilogue & A3V_EPI_RES_F32) ? 4 : 2) : nullptr;
@@ -2418,7 +2457,7 @@ extern "C" int a3v_gemm_tn(const void* At, int64_t lda, const void* Wt, int64_t 
     return A3V_OK;
   }
   p.tiles_m = tm_all;
-  hipLaunchKernelGGL(gemm_tn_bf16_pp_kernel<false>, dim3(p.tiles_m * p.tiles_n), dim3(512), 0, st, p);
+  launch_tn<false>(dim3(p.tiles_m * p.tiles_n), st, p);
   A3V_LAUNCH_CHECK();
   return A3V_OK;
 }
@@ -2437,7 +2476,7 @@ extern "C" int a3v_gemm_tn_splitk(const void* At, int64_t lda, const void* Wt, i
   p.M = M; p.N = N; p.K = K; p.epi = A3V_EPI_OUT_F32 | GEMM_EPI_RAW; p.dbg = 0;
   p.tiles_m = (M + 255) / 256; p.tiles_n = (N + 255) / 256;
   p.c_split = (int64_t)M * N * 4;
-  hipLaunchKernelGGL(gemm_tn_bf16_pp_kernel<false>, dim3(p.tiles_m * p.tiles_n, S), dim3(512), 0, (hipStream_t)stream, p);
+  launch_tn<false>(dim3(p.tiles_m * p.tiles_n, S), (hipStream_t)stream, p);
   A3V_LAUNCH_CHECK();
   return A3V_OK;
 }
@@ -2551,7 +2590,7 @@ extern "C" int a3v_gemm_nn(const void* A, int64_t lda, const void* Wt, int64_t l
   if (mt_h >= 1 && m_big < M && S > 1 && rem_tiles * 4 < 3 * ncu && g_gemm_ws && (int64_t)S * (M - m_big) * N * 4 <= g_gemm_ws_bytes) {
     GemmArgs q = p;
     q.M = m_big; q.tiles_m = (int)mt_h;
-    hipLaunchKernelGGL(gemm_tn_bf16_pp_kernel<true>, dim3(q.tiles_m * q.tiles_n), dim3(512), 0, st, q);
+    launch_tn<true>(dim3(q.tiles_m * q.tiles_n), st, q);
     GemmArgs t = p;
     t.M = M - m_big;
     t.A = p.A + (int64_t)m_big * lda;
@@ -2559,7 +2598,7 @@ extern "C" int a3v_gemm_nn(const void* A, int64_t lda, const void* Wt, int64_t l
     t.epi = A3V_EPI_OUT_F32 | GEMM_EPI_RAW;
     t.tiles_m = (t.M + 255) / 256;
     t.c_split = (int64_t)t.M * N * 4;
-    hipLaunchKernelGGL(gemm_tn_bf16_pp_kernel<true>, dim3(t.tiles_m * t.tiles_n, S), dim3(512), 0, st, t);
+    launch_tn<true>(dim3(t.tiles_m * t.tiles_n, S), st, t);
     const int esz = (epilogue & (A3V_EPI_OUT_F32 | A3V_EPI_RES_F32)) ? 4 : 2;
     void* Ct = (char*)C + (int64_t)m_big * ldc * esz;
     const void* Rt = residual ? (const char*)residual + (int64_t)m_big * ldr * ((epilogue & A3V_EPI_RES_F32) ? 4 : 2) : nullptr;
@@ -2570,7 +2609,7 @@ extern "C" int a3v_gemm_nn(const void* A, int64_t lda, const void* Wt, int64_t l
     return A3V_OK;
   }
   p.tiles_m = tm_all;
-  hipLaunchKernelGGL(gemm_tn_bf16_pp_kernel<true>, dim3(p.tiles_m * p.tiles_n), dim3(512), 0, st, p);
+  launch_tn<true>(dim3(p.tiles_m * p.tiles_n), st, p);
   A3V_LAUNCH_CHECK();
   return A3V_OK;
 }

@@ -538,7 +538,9 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const T* __restrict_
   const int row = blockIdx.x, tid = threadIdx.x;
   const T* lr = logits + (int64_t)row * ld;
   const int64_t lab = labels[row];
-  if (lab == 0) {
+  // 0 = pad = CrossEntropyLoss(ignore_index=0) (model/meta.py:67).  A label outside [0, V) would index past the logits row
+  // (torch raises on it): it is treated like an ignored position -- zero loss, zero gradient -- never read.
+  if (lab <= 0 || lab >= V) {
     if (tid == 0) row_loss[row] = 0.f;
     if (dlogits)
       for (int i = tid; i < V; i += 256) Cvt<T>::st(dlogits + (int64_t)row * ldd + i, 0.f);
@@ -713,6 +715,80 @@ extern "C" int a3v_split_views(const void* img, void* out, int B, int crop, int 
     case 3: hipLaunchKernelGGL((split_views_kernel<float, float>), g, b, 0, ST, (const float*)img, (float*)out, B, crop); break;
     default: return A3V_ERR_DTYPE;
   }
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}
+
+// ---------------------------------------------------------------- image preprocessing (data/transform.py:13-68 on the device)
+// PadToSquare(fill) -> bicubic resize -> ToTensor -> Normalize, with Pillow's 8-bit resampling arithmetic (the reference transform
+// is torchvision on PIL images = Pillow's ImagingResample): two separable passes, each output sample
+//   clip8((2^21 + sum_k pixel[lo + k] * coef[k]) >> 22)      coef = round(weight * 2^22) (host-computed table, Resample.c)
+// horizontal pass first (uint8 intermediate), then vertical; the padded square is never materialised (pixels outside the image
+// rectangle read as the fill colour).  The vertical pass finishes with ((v / 255) - mean) / std in fp32 and writes CHW.
+namespace {
+__device__ __forceinline__ int clip8(int v) { v >>= 22; return v < 0 ? 0 : (v > 255 ? 255 : v); }
+
+__global__ __launch_bounds__(256) void resample_h_kernel(const uint8_t* __restrict__ src, int H, int W, int side, int px, int py, int fill_r,
+                                                         int fill_g, int fill_b, const int32_t* __restrict__ kx, const int32_t* __restrict__ bx,
+                                                         int ksize, int out, uint8_t* __restrict__ tmp) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= side * out) return;
+  const int y = i / out, x = i - y * out;
+  const int lo = bx[2 * x], n = bx[2 * x + 1];
+  const int32_t* k = kx + (int64_t)x * ksize;
+  int sr = 1 << 21, sg = 1 << 21, sb = 1 << 21;
+  const int sy = y - py;
+  const bool row_in = sy >= 0 && sy < H;
+  for (int t = 0; t < n; ++t) {
+    const int sx = lo + t - px;
+    int r = fill_r, g = fill_g, b = fill_b;
+    if (row_in && sx >= 0 && sx < W) {
+      const uint8_t* q = src + ((int64_t)sy * W + sx) * 3;
+      r = q[0]; g = q[1]; b = q[2];
+    }
+    sr += r * k[t]; sg += g * k[t]; sb += b * k[t];
+  }
+  uint8_t* o = tmp + (int64_t)i * 3;
+  o[0] = (uint8_t)clip8(sr); o[1] = (uint8_t)clip8(sg); o[2] = (uint8_t)clip8(sb);
+}
+
+template <typename TO>
+__global__ __launch_bounds__(256) void resample_v_norm_kernel(const uint8_t* __restrict__ tmp, int side, int out, const int32_t* __restrict__ ky,
+                                                              const int32_t* __restrict__ by, int ksize, float m0, float m1, float m2,
+                                                              float s0, float s1, float s2, TO* __restrict__ dst) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= out * out) return;
+  const int y = i / out, x = i - y * out;
+  const int lo = by[2 * y], n = by[2 * y + 1];
+  const int32_t* k = ky + (int64_t)y * ksize;
+  int sr = 1 << 21, sg = 1 << 21, sb = 1 << 21;
+  for (int t = 0; t < n; ++t) {
+    const uint8_t* q = tmp + ((int64_t)(lo + t) * out + x) * 3;
+    sr += q[0] * k[t]; sg += q[1] * k[t]; sb += q[2] * k[t];
+  }
+  const int64_t plane = (int64_t)out * out;
+  // ToTensor: uint8 -> float / 255 (a correctly rounded fp32 division); Normalize: (x - mean) / std, both fp32 (torch ops)
+  Cvt<TO>::st(dst + i, __fdiv_rn(__fsub_rn(__fdiv_rn((float)clip8(sr), 255.f), m0), s0));
+  Cvt<TO>::st(dst + plane + i, __fdiv_rn(__fsub_rn(__fdiv_rn((float)clip8(sg), 255.f), m1), s1));
+  Cvt<TO>::st(dst + 2 * plane + i, __fdiv_rn(__fsub_rn(__fdiv_rn((float)clip8(sb), 255.f), m2), s2));
+}
+}  // namespace
+
+extern "C" int a3v_preprocess_image(const uint8_t* src, int H, int W, int side, int pad_x, int pad_y, const int* fill_rgb,
+                                    const int32_t* kx, const int32_t* bx, int ksize_x, const int32_t* ky, const int32_t* by, int ksize_y,
+                                    int out_size, uint8_t* tmp, void* dst, int dst_dtype, const float* mean, const float* std_, void* stream) {
+  if (!src || !kx || !bx || !ky || !by || !tmp || !dst || !fill_rgb || !mean || !std_) return A3V_ERR_ARG;
+  if (H <= 0 || W <= 0 || side < H || side < W || out_size <= 0 || pad_x < 0 || pad_y < 0 || pad_x + W > side || pad_y + H > side) return A3V_ERR_SHAPE;
+  const int n1 = side * out_size, n2 = out_size * out_size;
+  hipLaunchKernelGGL(resample_h_kernel, dim3((n1 + 255) / 256), dim3(256), 0, ST, src, H, W, side, pad_x, pad_y, fill_rgb[0], fill_rgb[1],
+                     fill_rgb[2], kx, bx, ksize_x, out_size, tmp);
+  if (dst_dtype == A3V_F32)
+    hipLaunchKernelGGL(resample_v_norm_kernel<float>, dim3((n2 + 255) / 256), dim3(256), 0, ST, tmp, side, out_size, ky, by, ksize_y, mean[0],
+                       mean[1], mean[2], std_[0], std_[1], std_[2], (float*)dst);
+  else if (dst_dtype == A3V_BF16)
+    hipLaunchKernelGGL(resample_v_norm_kernel<bf16_t>, dim3((n2 + 255) / 256), dim3(256), 0, ST, tmp, side, out_size, ky, by, ksize_y, mean[0],
+                       mean[1], mean[2], std_[0], std_[1], std_[2], (bf16_t*)dst);
+  else return A3V_ERR_DTYPE;
   A3V_LAUNCH_CHECK();
   return A3V_OK;
 }

@@ -108,3 +108,88 @@ def get_transform(transform_type: str, size: int = 224):
     if transform_type == "padded_resize":
         return T_padded_resize(size)
     raise ValueError("unknown transform type: transform_type")
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# The same padded-resize transform on the device (a3v_preprocess_image): Pillow's 8-bit two-pass bicubic resampling with
+# host-computed fixed-point coefficient tables, the padded square never materialised, normalisation fused into the second pass.
+# ------------------------------------------------------------------------------------------------------------------------
+_PRECISION_BITS = 32 - 8 - 2          # Pillow Resample.c: 8-bit samples, 2 bits of headroom for the bicubic overshoot
+
+
+def _bicubic(x: float, a: float = -0.5) -> float:
+    x = abs(x)
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+def pillow_bicubic_coeffs(in_size: int, out_size: int):
+    """(coefficients int32 [out_size, ksize], bounds int32 [out_size, 2] = (first input index, tap count)) of one resampling pass
+    from ``in_size`` to ``out_size`` samples, as Pillow's ``precompute_coeffs`` + ``normalize_coeffs_8bpc`` build them: filter
+    support 2 (x the down-scaling factor), weights normalised in double precision, then rounded half away from zero to 2^22."""
+    import math
+    scale = in_size / out_size
+    filterscale = max(scale, 1.0)
+    support = 2.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    kk = np.zeros((out_size, ksize), dtype=np.int32)
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        w = [_bicubic((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+        ww = sum(w)                                   # Pillow accumulates in this order, in double
+        if ww != 0.0:
+            w = [v / ww for v in w]
+        for x, v in enumerate(w):
+            kk[xx, x] = int(-0.5 + v * (1 << _PRECISION_BITS)) if v < 0 else int(0.5 + v * (1 << _PRECISION_BITS))
+        bounds[xx] = (xmin, xmax)
+    return kk, bounds
+
+
+class GpuPaddedResize:
+    """``T_padded_resize`` evaluated on the device: takes a decoded RGB image (PIL image, HWC uint8 array or tensor) and returns the
+    normalised ``[3, size, size]`` tensor on ``device`` -- bit-identical to the PIL path (tests/test_gpu_preprocess.py).  The
+    coefficient tables depend only on (padded side, size) and are cached on the device."""
+
+    def __init__(self, size: int = 224, device="cuda", dtype: torch.dtype = torch.float32):
+        self.size, self.device, self.dtype = size, torch.device(device), dtype
+        self.fill = tuple(int(x * 255) for x in CLIP_MEAN)
+        self._tables = {}
+
+    def _table(self, side: int):
+        if side not in self._tables:
+            kk, bounds = pillow_bicubic_coeffs(side, self.size)
+            self._tables[side] = (torch.from_numpy(kk).to(self.device), torch.from_numpy(bounds).to(self.device), kk.shape[1])
+        return self._tables[side]
+
+    def __call__(self, img) -> torch.Tensor:
+        import ctypes
+        from .. import lib as _l
+        from ..ops import dt
+        if isinstance(img, Image.Image):
+            img = np.asarray(img.convert("RGB"), dtype=np.uint8)
+        src = torch.as_tensor(img)
+        if src.dtype != torch.uint8 or src.dim() != 3 or src.shape[2] != 3:
+            raise TypeError("GpuPaddedResize takes one RGB image as uint8 [H, W, 3]")
+        src = src.to(self.device, non_blocking=True).contiguous()
+        H, W = int(src.shape[0]), int(src.shape[1])
+        side = max(H, W)
+        px, py = ((side - W) // 2, 0) if H > W else (0, (side - H) // 2)      # PadToSquare: centred on the shorter axis
+        kk, bounds, ksize = self._table(side)
+        tmp = torch.empty(side, self.size, 3, dtype=torch.uint8, device=self.device)
+        out = torch.empty(3, self.size, self.size, dtype=self.dtype, device=self.device)
+        fill = (ctypes.c_int * 3)(*self.fill)
+        mean = (ctypes.c_float * 3)(*CLIP_MEAN)
+        std = (ctypes.c_float * 3)(*CLIP_STD)
+        rc = _l.load().a3v_preprocess_image(src.data_ptr(), H, W, side, px, py, ctypes.cast(fill, ctypes.c_void_p), kk.data_ptr(), bounds.data_ptr(),
+                                            ksize, kk.data_ptr(), bounds.data_ptr(), ksize, self.size, tmp.data_ptr(), out.data_ptr(), dt(out),
+                                            ctypes.cast(mean, ctypes.c_void_p), ctypes.cast(std, ctypes.c_void_p),
+                                            torch.cuda.current_stream().cuda_stream)
+        _l.check(rc, "a3v_preprocess_image")
+        return out

@@ -684,30 +684,61 @@ class TrainEngine:
 
     # ------------------------------------------------------------------ vision (frozen ViT, trainable projector)
     def _encode_image_train(self, h, image, B, S, qformer_feats, extra_feats):
+        """Image words of the training forward (LLM/llama_ens5.py:377-458, 471-478): frozen CLIP ViT on the HIP path, then the two
+        TRAINABLE projectors -- visual_proj over the concat [CLIP | ConvNeXt-XXL | DINOv2] (5632 wide in the reference configuration)
+        and qformer_proj over the 32 Q-Former tokens.  The three out-of-scope encoders are frozen and run under no_grad in the
+        reference (:399): their outputs are INPUTS here (``extra_feats`` / ``qformer_feats`` or the plugin's provider hooks), and
+        only the projectors are differentiated (_encode_image_backward)."""
         m, a = self.m, self.m.args
         im = self._images()
-        if a.extra_feat_dim or a.qformer_tokens:
-            raise NotImplementedError("training with the hook-fed encoder streams is not wired yet (next: SURVEY 8(f) N4)")
         _, _, L = m._vit_geometry()
         images = list(image) if isinstance(image, (list, tuple)) else [image]
         slots = tuple(range(len(images)))
         views = m._gather_views(images, B, m.clip.visual.conv1.weight.dtype)
         N = len(images) * a.n_views * B
         feats = m.clip_encode_image(views)                      # frozen, compute dtype of the clip params
-        if feats.dtype != self.act:
+        if extra_feats is None and getattr(m, "extra_feat_fns", None):
+            extra_feats = [fn(views) for fn in m.extra_feat_fns]
+        if qformer_feats is None and getattr(m, "qformer_fn", None) is not None:
+            qformer_feats = m.qformer_fn(views)
+        if a.extra_feat_dim:
+            if extra_feats is None:
+                raise ValueError("extra_feat_dim is set but no ConvNeXt / DINOv2 features were given (extra_feats= or provider hooks)")
+            cat = self._buf("feats_cat", (N * L, a.vit_width + a.extra_feat_dim))
+            cat[:, :a.vit_width] = feats                        # data movement only (concat, llama_ens5.py:436-440)
+            o = a.vit_width
+            for e in extra_feats:
+                e2 = e.reshape(N * L, -1)
+                cat[:, o:o + e2.shape[1]] = e2
+                o += e2.shape[1]
+            assert o == cat.shape[1], "extra feature widths do not add up to extra_feat_dim"
+            feats = cat
+        elif feats.dtype != self.act:
             f2 = self._buf("feats_act", tuple(feats.shape))
             ops.cast(feats, f2)
             feats = f2
         proj = self._buf("proj", (N * L, a.dim))
         ops.gemm_nt(feats, im["vp"], proj, bias=im["vp.b"])
         vp1 = getattr(m.visual_proj, "1")
-        clip_map, _, start_rows, end_rows = m._image_row_maps(B, S, slots)
+        clip_map, qf_map, start_rows, end_rows = m._image_row_maps(B, S, slots)
         ops.layernorm(proj, vp1.weight, vp1.bias, h, row_map=clip_map)
+        out = dict(feats=feats, proj=proj, clip_map=clip_map, start_rows=start_rows, end_rows=end_rows, N=N, L=L, slots=slots)
+        if a.qformer_tokens:
+            if qformer_feats is None:
+                raise ValueError("qformer_tokens is set but no Q-Former features were given (qformer_feats= or provider hook)")
+            Q = a.qformer_tokens
+            qin = self._buf("qf_in", (N * Q, 768))
+            qin.copy_(qformer_feats.reshape(N * Q, 768))
+            qout = self._buf("qf_out", (N * Q, a.dim))
+            ops.gemm_nt(qin, im["vq"], qout, bias=im["vq.b"])
+            qp1 = getattr(m.qformer_proj, "1")
+            ops.layernorm(qout, qp1.weight, qp1.bias, h, row_map=qf_map)
+            out.update(qin=qin, qout=qout, qf_map=qf_map, Q=Q)
         tags = m._image_slots()
         for j, sl in enumerate(slots):
             ops.fill_rows(tags[sl][0].view(-1), h, start_rows[j])
             ops.fill_rows(tags[sl][1].view(-1), h, end_rows[j])
-        return dict(feats=feats, proj=proj, clip_map=clip_map, start_rows=start_rows, end_rows=end_rows, N=N, L=L, slots=slots)
+        return out
 
     def _encode_image_backward(self, dh, vis, B, S):
         m, a = self.m, self.m.args
@@ -718,6 +749,14 @@ class TrainEngine:
                           self._views["visual_proj.1.bias"])
         self._wgrad(dproj, vis["feats"], self._views["visual_proj.0.weight"], "vp")
         ops.rows_sum(dproj, None, rowsv, self._views["visual_proj.0.bias"])
+        if "qin" in vis:
+            qp1 = getattr(m.qformer_proj, "1")
+            rowsq = vis["N"] * vis["Q"]
+            dq = self._buf("dqf", (rowsq, a.dim))
+            ops.layernorm_bwd(vis["qout"], qp1.weight, dh, vis["qf_map"], dq, self._views["qformer_proj.1.weight"],
+                              self._views["qformer_proj.1.bias"])
+            self._wgrad(dq, vis["qin"], self._views["qformer_proj.0.weight"], "vq")
+            ops.rows_sum(dq, None, rowsq, self._views["qformer_proj.0.bias"])
         names = [("start_img", "end_img"), ("start_depth_img", "end_depth_img")]
         for j, sl in enumerate(vis["slots"]):
             ops.rows_sum(dh, vis["start_rows"][j], vis["start_rows"][j].numel(), self._views[names[sl][0]].view(-1))
@@ -737,7 +776,7 @@ class _Images:
     def _group(self, key: str):
         if key.startswith(("qkv.", "wo.", "w13.", "w2.")):
             return "L" + key.split(".")[1]
-        return "vp" if key.startswith("vp") else "out"
+        return "vp" if key.startswith(("vp", "vq")) else "out"
 
     def _both(self, key, w):      # forward image W [N,K] now; W^T [K, N padded to 64] only when somebody asks for key + ".t"
         ext = self.eng._kext_cols(key)
@@ -783,6 +822,9 @@ class _Images:
         if g == "out":
             return (m.output.weight,), (("out", 0),)
         vp0 = getattr(m.visual_proj, "0")
+        if getattr(m.args, "qformer_tokens", 0):
+            qp0 = getattr(m.qformer_proj, "0")
+            return (vp0.weight, vp0.bias, qp0.weight, qp0.bias), (("vp", 0), ("vp.b", 0), ("vq", 0), ("vq.b", 0))
         return (vp0.weight, vp0.bias), (("vp", 0), ("vp.b", 0))
 
     def _key(self, ps) -> tuple:
@@ -836,6 +878,9 @@ class _Images:
                 else:
                     self._both("vp", ps[0])
                     self.store["vp.b"] = ps[1].to(eng.act)
+                    if len(ps) == 4:
+                        self._both("vq", ps[2])
+                        self.store["vq.b"] = ps[3].to(eng.act)
             self.ver[g] = ver
         if key.endswith(".t"):
             return self._transposed(key, ver)

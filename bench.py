@@ -4,18 +4,28 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-Workload (BASELINE.json configs[1], geometry S of SURVEY.md 8(d)): ViT-L/14 @ 336x336 single crop
-(577 + 2 image words) + Llama-2-7B decoder, bf16, batch 8 per GPU, 512-token prompts, synthetic
-data, N(0, 0.02) random weights.  One "step" = ONE pass of the multimodal forward hot path over one
-batch: patch-embed + 24 ViT blocks + projector + [BOS|image|text] assembly + 32 decoder blocks over
-8 x 1091 positions (KV cache written) + final norm + LM head on the last position.
-`value` = image-text samples/s (whole job).  The same JSON line carries the greedy-decode rate
-(`decode_tok_s`, HBM-bound, its own roofline in `decode_roofline`), the MFMA roofline of the dominant
-kernel (gemm_nt_bf16_kernel) and the CPU oracle timed on the host cores.
+Headline (`metric` / `value`, BASELINE.json: "image-text samples/sec (train) + articulation-decode tok/s"): ONE step = one FULL
+FINE-TUNING step of the configs[1] backbone (ViT-L/14 @ 336x336 single crop, 577 + 2 image words, + Llama-2-7B; bf16 GEMMs,
+fp32 masters) on this rank's micro-batch of 8 image + 512-token samples: multimodal forward (frozen ViT, projector, 32 decoder
+blocks over 8 x 1091 positions, LM head, CE), backward through the HIP kernels, DP all-reduce of the gradient buckets (N > 1;
+RCCL, overlapped with the backward), global-norm clip, fused AdamW.  W warm-up steps, then EXACTLY K timed steps between
+barrier + synchronize pairs, max over ranks; `value` = samples of ALL ranks per second.  Synthetic data, N(0, 0.02) weights.
+
+Named legs on the same JSON line (same inputs, each with its own warm-up and barrier-bracketed timing):
+  forward        configs[1]: the inference forward (prefill) step, samples/s and fraction of the MFMA peak
+  decode         greedy decode model step (tok/s, HBM roofline); generate = MetaModel.generate() END TO END (tokenise ... stop match)
+  decode_fp8     configs[4] semantics on the base plugin: weight-only fp8 decode, W8A8 prefill
+  train_lora     configs[2]: LoRA r = 16 step
+  geometry_R     the reference-faithful geometry (448x448 -> 5 x 224 crops, 1455 image words, S = 1967) next to the headline's S
+  m13b           configs[3] shapes: 13B forward + decode, and ONE DP replica of the 13B full fine-tune (288 GB sizing)
+  config5        configs[4]: RGB + depth, 1024-token prompt, fp8 weights (and its bf16 twin)
+  roofline       dominant kernel family of the headline step (MFMA GEMMs: NT forward, NN input-gradient, TN weight-gradient), HIP events
+  cpu_baseline   the oracle on the host cores: one forward sample + 16 decode steps, and configs[0] (C1) greedy ids GPU == CPU
 """
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -27,7 +37,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_PEAK_BF16 = 2.5e15      # dense, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_PEAK_FP8 = 5.0e15
 HBM_PEAK = 8.0e12            # spec; 6.3e12 achievable
+
+ALL_LEGS = ("forward", "decode", "generate", "fp8", "geometry_r", "config5", "lora", "train", "m13b", "cpu")
+CORE_LEGS = ("forward", "decode", "lora", "train")
 
 
 def parse():
@@ -38,10 +52,12 @@ def parse():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--prompt", type=int, default=512)
     ap.add_argument("--decode-steps", type=int, default=32)
+    ap.add_argument("--gen-len", type=int, default=64, help="new tokens of the end-to-end generate() leg")
     ap.add_argument("--model", default="7b", choices=["7b", "13b", "tiny"])
+    ap.add_argument("--legs", default=None, help="comma list of " + ",".join(ALL_LEGS) + " (default: all at 1 GPU, core legs at N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-train", action="store_true", help="skip the fine-tuning step measurement")
-    ap.add_argument("--train-steps", type=int, default=3)
+    ap.add_argument("--no-train", action="store_true", help="skip the fine-tuning legs (profiling runs); the headline is then the forward step")
+    ap.add_argument("--train-steps", type=int, default=None, help="(deprecated) the training legs use --steps / --warmup")
     ap.add_argument("--cpu-seconds", type=float, default=30.0)
     return ap.parse_args()
 
@@ -53,19 +69,12 @@ GEOM = {
 }
 
 
-def build_model(name, dev, max_seq_len):
-    from a3vlm_amd.model.LLM import llama_ens5 as plugin
-    vit = dict(vit_width=1024, vit_layers=24, vit_heads=16) if name != "tiny" else dict(vit_width=128, vit_layers=2, vit_heads=2)
-    args = plugin.ModelArgs(vocab_size=32000 if name != "tiny" else 512, max_seq_len=max_seq_len,
-                            vit_patch=14, vit_crop=336, n_views=1, **GEOM[name], **vit)
-    old = torch.get_default_dtype()
-    torch.set_default_dtype(torch.bfloat16)
-    try:
-        with torch.device(dev):
-            m = plugin.Transformer(args, with_visual=True)
-    finally:
-        torch.set_default_dtype(old)
-    g = torch.Generator(device=dev).manual_seed(0)      # identical weights on every rank
+def _vit(name):
+    return dict(vit_width=1024, vit_layers=24, vit_heads=16) if name != "tiny" else dict(vit_width=128, vit_layers=2, vit_heads=2)
+
+
+def _init_params(m, dev, seed=0):
+    g = torch.Generator(device=dev).manual_seed(seed)      # identical weights on every rank
     with torch.no_grad():
         for n, p in m.named_parameters():
             if n.endswith("norm.weight") or (".ln_" in n and n.endswith("weight")) or n.endswith(".1.weight"):
@@ -74,18 +83,68 @@ def build_model(name, dev, max_seq_len):
                 p.zero_()
             else:
                 p.normal_(0.0, 0.02, generator=g)
+
+
+def build_model(name, dev, max_seq_len):
+    from a3vlm_amd.model.LLM import llama_ens5 as plugin
+    args = plugin.ModelArgs(vocab_size=32000 if name != "tiny" else 512, max_seq_len=max_seq_len,
+                            vit_patch=14, vit_crop=336, n_views=1, **GEOM[name], **_vit(name))
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        with torch.device(dev):
+            m = plugin.Transformer(args, with_visual=True)
+    finally:
+        torch.set_default_dtype(old)
+    _init_params(m, dev)
     return m, args
 
 
-def flops_forward(args, B, T, W):
-    """Algorithmic FLOPs of one step (SURVEY.md 8(d) conventions: 2 FLOP/MAC, causal attention at
-    1/2, LM head on the positions actually computed -- the last one for the inference step)."""
+def share_into(cls, new_args, base_model, dev, seed=7):
+    """A second plugin instance (another geometry / the two-image / adapter plugin) built around the SAME parameter tensors as
+    ``base_model`` wherever name and shape agree (no second copy of the 7B weights); the rest is N(0, 0.02) bf16."""
+    with torch.device("meta"):
+        m = cls(new_args, with_visual=True)
+    base = dict(base_model.named_parameters())
+    g = torch.Generator(device=dev).manual_seed(seed)
+    for name, p in list(m.named_parameters()):
+        mod = m
+        parts = name.split(".")
+        for q in parts[:-1]:
+            mod = getattr(mod, q)
+        if name in base and tuple(base[name].shape) == tuple(p.shape):
+            setattr(mod, parts[-1], base[name])
+        else:
+            t = torch.empty(p.shape, dtype=torch.bfloat16, device=dev)
+            if name.endswith(".1.weight"):
+                t.fill_(1.0)
+            elif name.endswith("bias"):
+                t.zero_()
+            else:
+                t.normal_(0.0, 0.02, generator=g)
+            setattr(mod, parts[-1], torch.nn.Parameter(t))
+    from a3vlm_amd.model.LLM.llama_ens5 import precompute_cos_sin
+    if new_args.max_seq_len == base_model.args.max_seq_len:
+        m._cos_sin_cpu = base_model._cos_sin_cpu
+    else:
+        m._cos_sin_cpu = precompute_cos_sin(m.head_dim, new_args.max_seq_len * 2, new_args.rope_theta, new_args.rope_scaling)
+    return m
+
+
+def _ffn(args):
+    from a3vlm_amd.model.LLM.llama_ens5 import _ffn_hidden
+    return _ffn_hidden(args.dim, args.multiple_of, args.ffn_dim_multiplier)
+
+
+def flops_forward(args, B, T, W, n_images=1):
+    """Algorithmic FLOPs of one forward step (SURVEY.md 8(d) conventions: 2 FLOP/MAC, causal attention at 1/2, LM head on the
+    positions actually computed -- the last one for the inference step).  Vision: ``n_views`` crops of ``vit_crop`` per image
+    through the frozen ViT, projector Linear(vit_width + extra_feat_dim -> dim) on every ViT token, Q-Former projector if present."""
     S = T + W
-    d, L, ffn = args.dim, args.n_layers, None
+    d, L = args.dim, args.n_layers
     hd = d // args.n_heads
     nkv = args.n_kv_heads or args.n_heads
-    from a3vlm_amd.model.LLM.llama_ens5 import _ffn_hidden
-    ffn = _ffn_hidden(d, args.multiple_of, args.ffn_dim_multiplier)
+    ffn = _ffn(args)
     p_layer = d * (args.n_heads + 2 * nkv) * hd + d * d + 3 * d * ffn
     f_lin = 2 * p_layer * L * S * B
     f_att = L * 4 * S * S * d * 0.5 * B
@@ -93,100 +152,129 @@ def flops_forward(args, B, T, W):
     w, Lv = args.vit_width, args.vit_layers
     g = args.vit_crop // args.vit_patch
     Ltok = g * g + 1
-    f_vit = B * (2 * 3 * args.vit_patch ** 2 * w * g * g + Lv * (2 * 12 * w * w * Ltok + 4 * Ltok * Ltok * w))
-    f_proj = 2 * w * d * Ltok * B
-    gemm = f_lin + f_head + f_proj + B * (2 * 3 * args.vit_patch ** 2 * w * g * g + Lv * 2 * 12 * w * w * Ltok)
-    return dict(total=f_lin + f_att + f_head + f_vit + f_proj, gemm=gemm, att=f_att + B * Lv * 4 * Ltok * Ltok * w)
+    crops = B * args.n_views * n_images
+    f_vit_gemm = crops * (2 * 3 * args.vit_patch ** 2 * w * g * g + Lv * 2 * 12 * w * w * Ltok)
+    f_vit_att = crops * Lv * 4 * Ltok * Ltok * w
+    extra = getattr(args, "extra_feat_dim", 0)
+    f_proj = 2 * (w + extra) * d * Ltok * crops + 2 * 768 * d * getattr(args, "qformer_tokens", 0) * crops
+    gemm = f_lin + f_head + f_proj + f_vit_gemm
+    return dict(total=gemm + f_att + f_vit_att, gemm=gemm, att=f_att + f_vit_att, vit=f_vit_gemm + f_vit_att)
 
 
-def bytes_decode_step(args, B, ctx):
-    from a3vlm_amd.model.LLM.llama_ens5 import _ffn_hidden
+def p_decoder(args):
     d, L = args.dim, args.n_layers
     hd = d // args.n_heads
     nkv = args.n_kv_heads or args.n_heads
-    ffn = _ffn_hidden(d, args.multiple_of, args.ffn_dim_multiplier)
-    p_dec = L * (d * (args.n_heads + 2 * nkv) * hd + d * d + 3 * d * ffn)
-    return 2 * (p_dec + d * args.vocab_size) + B * 2 * L * ctx * nkv * hd * 2
+    return L * (d * (args.n_heads + 2 * nkv) * hd + d * d + 3 * d * _ffn(args))
+
+
+def bytes_decode_step(args, B, ctx):
+    d, L = args.dim, args.n_layers
+    hd = d // args.n_heads
+    nkv = args.n_kv_heads or args.n_heads
+    return 2 * (p_decoder(args) + d * args.vocab_size) + B * 2 * L * ctx * nkv * hd * 2
 
 
 def bytes_decoder_matrices(args):
     """bytes SAVED per decode step by 1-byte decoder matrices (wqkv, wo, w1|w3, w2 of every layer) relative to bf16"""
-    from a3vlm_amd.model.LLM.llama_ens5 import _ffn_hidden
-    d, L = args.dim, args.n_layers
-    hd = d // args.n_heads
-    nkv = args.n_kv_heads or args.n_heads
-    ffn = _ffn_hidden(d, args.multiple_of, args.ffn_dim_multiplier)
-    return L * (d * (args.n_heads + 2 * nkv) * hd + d * d + 3 * d * ffn)
+    return p_decoder(args)
 
 
-def time_gemm_shapes(m, args, B, T, W, dev):
-    """Event-time every distinct gemm_nt_bf16_kernel shape of one step (same stream the step uses);
-    returns (flops per step in that kernel, seconds per step in that kernel, per-shape rows)."""
+class Timer:
+    """W warm-up calls, then K calls between (barrier + synchronize) pairs; seconds per call, max over ranks."""
+
+    def __init__(self, dist, dev):
+        self.dist, self.dev = dist, dev
+
+    def sync(self):
+        torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def __call__(self, fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        self.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        self.sync()
+        el = time.perf_counter() - t0
+        if self.dist is not None:
+            t = torch.tensor([el], device=self.dev, dtype=torch.float64)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el / steps
+
+
+def _events(fn, reps=5, warm=2):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / reps
+
+
+def time_gemm_shapes(args, B, T, W, dev, train=True):
+    """HIP-event time of every distinct MFMA GEMM shape of one step on the stream the step uses (torch's current stream):
+    NT = forward linears (a3v_gemm_nt: ring ping-pong kernel / 128x128 kernel), and for the training step NN = input gradients
+    (a3v_gemm_nn) and TN = weight gradients (a3v_gemm_tn) of the trainable decoder linears.  Returns per-family
+    (FLOP per step, seconds per step) and the per-shape rows."""
     from a3vlm_amd import ops
-    from a3vlm_amd.model.LLM.llama_ens5 import _ffn_hidden
     S = T + W
     rows = B * S
-    d, Lyr = args.dim, args.n_layers
-    ffn = _ffn_hidden(d, args.multiple_of, args.ffn_dim_multiplier)
+    d, Lyr, ffn = args.dim, args.n_layers, _ffn(args)
     w, Lv = args.vit_width, args.vit_layers
     g = args.vit_crop // args.vit_patch
     vr = B * (g * g + 1)
-    shapes = [  # (M, N, K, count per step, epilogue)
+    nt_shapes = [  # (M, N, K, count per step, epilogue)
         (rows, 3 * d, d, Lyr, 0), (rows, d, d, Lyr, ops.EPI_RESIDUAL), (rows, 2 * ffn, d, Lyr, ops.EPI_SWIGLU),
         (rows, d, ffn, Lyr, ops.EPI_RESIDUAL),
         (vr, 3 * w, w, Lv, 0), (vr, w, w, Lv, ops.EPI_RESIDUAL), (vr, 4 * w, w, Lv, ops.EPI_GELU), (vr, w, 4 * w, Lv, ops.EPI_RESIDUAL),
         (vr, d, w, 1, 0), (B * g * g, w, 640, 1, 0),
     ]
-    tot_f, tot_t, table = 0.0, 0.0, []
-    for (M, N, K, cnt, epi) in shapes:
+    fam = {"nt": [0.0, 0.0], "nn": [0.0, 0.0], "tn": [0.0, 0.0]}
+    table = []
+    for (M, N, K, cnt, epi) in nt_shapes:
         a = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
         wt = torch.randn(N, K, device=dev, dtype=torch.bfloat16) * 0.02
-        ncol = N // 2 if epi & ops.EPI_SWIGLU else N
-        out = torch.zeros(M, ncol, device=dev, dtype=torch.bfloat16)
+        out = torch.zeros(M, N // 2 if epi & ops.EPI_SWIGLU else N, device=dev, dtype=torch.bfloat16)
         res = out if epi & ops.EPI_RESIDUAL else None
-        e = epi & ~ops.EPI_RESIDUAL
-        for _ in range(2):
-            ops.gemm_nt(a, wt, out, residual=res, epilogue=e)
-        reps = 5
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            ops.gemm_nt(a, wt, out, residual=res, epilogue=e)
-        e1.record()
-        torch.cuda.synchronize()
-        dt = e0.elapsed_time(e1) * 1e-3 / reps
+        dt = _events(lambda: ops.gemm_nt(a, wt, out, residual=res, epilogue=epi & ~ops.EPI_RESIDUAL))
         fl = 2.0 * M * N * K
-        tot_f += fl * cnt
-        tot_t += dt * cnt
-        table.append(dict(M=M, N=N, K=K, count=cnt, us=round(dt * 1e6, 1), tflops=round(fl / dt / 1e12, 1)))
+        fam["nt"][0] += fl * cnt
+        fam["nt"][1] += dt * cnt
+        table.append(dict(kind="nt", M=M, N=N, K=K, count=cnt, us=round(dt * 1e6, 1), tflops=round(fl / dt / 1e12, 1)))
         del a, wt, out
-    return tot_f, tot_t, table
+    if train:
+        # decoder linears only (the ViT is frozen: no gradient GEMMs); (rows, out features, in features)
+        for (M, N, K) in [(rows, 3 * d, d), (rows, d, d), (rows, 2 * ffn, d), (rows, d, ffn)]:
+            dy = torch.randn(M, N, device=dev, dtype=torch.bfloat16)
+            x = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
+            wimg = torch.randn(N, K, device=dev, dtype=torch.bfloat16) * 0.02
+            dx = torch.empty(M, K, device=dev, dtype=torch.bfloat16)
+            gw = torch.zeros(N, K, device=dev, dtype=torch.float32)
+            fl = 2.0 * M * N * K
+            dt = _events(lambda: ops.gemm_nn(dy, wimg, dx))
+            fam["nn"][0] += fl * Lyr
+            fam["nn"][1] += dt * Lyr
+            table.append(dict(kind="nn", M=M, N=K, K=N, count=Lyr, us=round(dt * 1e6, 1), tflops=round(fl / dt / 1e12, 1)))
+            dt = _events(lambda: ops.gemm_tn(dy, x, gw, epilogue=ops.EPI_OUT_F32))
+            fam["tn"][0] += fl * Lyr
+            fam["tn"][1] += dt * Lyr
+            table.append(dict(kind="tn", M=N, N=K, K=M, count=Lyr, us=round(dt * 1e6, 1), tflops=round(fl / dt / 1e12, 1)))
+            del dy, x, wimg, dx, gw
+    return fam, table
 
 
-def train_leg(m, args, B, T, image, tokens, steps, dist, dev):
-    """Full fine-tune step of configs[2]/[3] semantics on this rank's micro-batch: fp32 masters for the trainables
-    (decoder + projector), frozen bf16 ViT, bf16 GEMMs, per-block recompute, AdamW(0.9, 0.95); with N > 1 the
-    gradient buckets are all-reduced over RCCL on a side stream while earlier layers still back-propagate."""
-    from a3vlm_amd.train import TrainEngine
-    from a3vlm_amd.util import promote_trainable_params_to_fp32
-    from a3vlm_amd.dp import GradReducer, clip_grad_norm
-    for n, p in m.named_parameters():
-        p.requires_grad = not n.startswith("clip.")
-    m._ws.clear(); m._packed.clear(); m._packed_version = None; m._destroy_kv_cache()
-    import gc
-    gc.collect()
-    torch.cuda.empty_cache()
-    torch.cuda.reset_peak_memory_stats()
-    promote_trainable_params_to_fp32(m)
-    eng = TrainEngine(m, torch.bfloat16)
-    params = [p for p in m.parameters() if p.requires_grad]
-    params_list = params
-    from a3vlm_amd.optim import FusedAdamW
-    opt = FusedAdamW(params, lr=2e-5, betas=(0.9, 0.95), weight_decay=0.0, engine=eng)
-    # bf16 on the wire = the reference's FSDP MixedPrecision(reduce_dtype=bf16) (main_finetune.py:251-255); fp32 accumulation buffers
-    red = GradReducer(eng, dist, reduce_dtype=torch.bfloat16) if dist is not None else None
-    labels = tokens.clone()
-    labels[:, :T // 2] = 0
+# ---------------------------------------------------------------------------------------------------------------- training legs
+def _train_step_fn(eng, opt, red, params, tokens, labels, image):
+    from a3vlm_amd.dp import clip_grad_norm
 
     def one():
         loss = eng.forward_loss(tokens, labels, image)
@@ -195,117 +283,252 @@ def train_leg(m, args, B, T, image, tokens, steps, dist, dev):
             red.finish()
         # global-norm clip of the reference recipe (--clip_grad 8, a3vlm_train.sh:47-55; util/misc.py:302-315): one reduction
         # over the flat gradient buffer, coefficient applied inside the optimizer kernel
-        _, coef = clip_grad_norm(params_list, 8.0, flat=eng.flat_grads(), defer=True)
+        _, coef = clip_grad_norm(params, 8.0, flat=eng.flat_grads(), defer=True)
         opt.step(grad_scale=coef)
         opt.zero_grad(set_to_none=True)
-        return loss
-
-    one()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = one()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    el = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([el], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
-    return el / steps, float(loss), torch.cuda.max_memory_allocated() / 2 ** 30
+        one.loss = loss
+    return one
 
 
-def lora_leg(m, args, B, T, image, tokens, steps, dist, dev, rank=16):
+def train_leg(m, B, T, image, tokens, steps, warmup, timer, recompute=None):
+    """Full fine-tune step on this rank's micro-batch: fp32 masters for the trainables (decoder + projector), frozen bf16 ViT,
+    bf16 GEMMs, AdamW(0.9, 0.95), clip 8; with N > 1 the per-layer gradient buckets are averaged over RCCL (bf16 on the wire =
+    the reference's FSDP reduce_dtype, main_finetune.py:251-255) on a side stream while earlier layers still back-propagate.
+    DESTRUCTIVE for ``m`` (its trainable parameters become fp32)."""
+    from a3vlm_amd.train import TrainEngine
+    from a3vlm_amd.util import promote_trainable_params_to_fp32
+    from a3vlm_amd.dp import GradReducer
+    from a3vlm_amd.optim import FusedAdamW
+    for n, p in m.named_parameters():
+        p.requires_grad = not n.startswith("clip.")
+    m._ws.clear(); m._packed.clear(); m._packed_version = None; m._destroy_kv_cache()
+    gc.collect()
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
+    promote_trainable_params_to_fp32(m)
+    eng = TrainEngine(m, torch.bfloat16) if recompute is None else TrainEngine(m, torch.bfloat16, recompute=recompute)
+    params = [p for p in m.parameters() if p.requires_grad]
+    opt = FusedAdamW(params, lr=2e-5, betas=(0.9, 0.95), weight_decay=0.0, engine=eng)
+    red = GradReducer(eng, timer.dist, reduce_dtype=torch.bfloat16) if timer.dist is not None else None
+    labels = tokens.clone()
+    labels[:, :T // 2] = 0
+    one = _train_step_fn(eng, opt, red, params, tokens, labels, image)
+    sec = timer(one, steps, max(1, warmup))
+    return sec, float(one.loss), torch.cuda.max_memory_allocated() / 2 ** 30, sum(p.numel() for p in params), bool(eng.recompute)
+
+
+def lora_leg(m, args, B, T, image, tokens, steps, warmup, timer, dev, rank=16):
     """configs[2]: LoRA fine-tune step (rank-16 adapters on the seven decoder linears of every block + norms + projector
-    trainable, base matrices frozen in bf16) on this rank's micro-batch.  The adapter plugin is built around the SAME base
-    parameter tensors as ``m`` (no second copy of the 7B weights)."""
+    trainable, base matrices frozen in bf16) on this rank's micro-batch; adapter plugin built around the SAME base parameters."""
     import dataclasses
     from a3vlm_amd.model.LLM import llama_ens5_peft as peft
     from a3vlm_amd.train import TrainEngine
     from a3vlm_amd.util import promote_trainable_params_to_fp32
-    from a3vlm_amd.dp import GradReducer, clip_grad_norm
+    from a3vlm_amd.dp import GradReducer
+    from a3vlm_amd.optim import FusedAdamW
     torch.cuda.reset_peak_memory_stats()
-    pargs = peft.ModelArgs(**dataclasses.asdict(args), lora_rank=rank)
-    with torch.device("meta"):
-        pm = peft.Transformer(pargs, with_visual=True)
-    base = dict(m.named_parameters())
-    g = torch.Generator(device=dev).manual_seed(7)
-    for name, p in list(pm.named_parameters()):
-        mod = pm
-        parts = name.split(".")
-        for q in parts[:-1]:
-            mod = getattr(mod, q)
-        if name in base:
-            setattr(mod, parts[-1], base[name])                      # shared storage
-        else:
-            t = torch.empty(p.shape, dtype=torch.bfloat16, device=dev)
-            t.normal_(0.0, 0.02, generator=g)                        # B != 0 so that every adapter GEMM does real work
-            setattr(mod, parts[-1], torch.nn.Parameter(t))
-    pm._cos_sin_cpu = m._cos_sin_cpu
+    pm = share_into(peft.Transformer, peft.ModelArgs(**dataclasses.asdict(args), lora_rank=rank), m, dev)   # B != 0: every adapter GEMM works
     train = pm.get_trainable_params()
     for n, p in pm.named_parameters():
         p.requires_grad = n in train
     promote_trainable_params_to_fp32(pm)
     n_train = sum(p.numel() for p in pm.parameters() if p.requires_grad)
     eng = TrainEngine(pm, torch.bfloat16)
-    from a3vlm_amd.optim import FusedAdamW
-    params_list = [p for p in pm.parameters() if p.requires_grad]
-    opt = FusedAdamW(params_list, lr=2e-5, betas=(0.9, 0.95), weight_decay=0.0, engine=eng)
-    # bf16 on the wire = the reference's FSDP MixedPrecision(reduce_dtype=bf16) (main_finetune.py:251-255); fp32 accumulation buffers
-    red = GradReducer(eng, dist, reduce_dtype=torch.bfloat16) if dist is not None else None
+    params = [p for p in pm.parameters() if p.requires_grad]
+    opt = FusedAdamW(params, lr=2e-5, betas=(0.9, 0.95), weight_decay=0.0, engine=eng)
+    red = GradReducer(eng, timer.dist, reduce_dtype=torch.bfloat16) if timer.dist is not None else None
     labels = tokens.clone()
     labels[:, :T // 2] = 0
-
-    def one():
-        loss = eng.forward_loss(tokens, labels, image)
-        eng.backward(1.0)
-        if red is not None:
-            red.finish()
-        # global-norm clip of the reference recipe (--clip_grad 8, a3vlm_train.sh:47-55; util/misc.py:302-315): one reduction
-        # over the flat gradient buffer, coefficient applied inside the optimizer kernel
-        _, coef = clip_grad_norm(params_list, 8.0, flat=eng.flat_grads(), defer=True)
-        opt.step(grad_scale=coef)
-        opt.zero_grad(set_to_none=True)
-        return loss
-
-    one()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = one()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    el = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([el], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+    one = _train_step_fn(eng, opt, red, params, tokens, labels, image)
+    sec = timer(one, steps, max(1, warmup))
     mem = torch.cuda.max_memory_allocated() / 2 ** 30
-    # restore the shared parameters' state for the legs that follow
-    for n, p in m.named_parameters():
+    loss = float(one.loss)
+    for n, p in m.named_parameters():      # restore the shared parameters' state for the legs that follow
         p.grad = None
     del eng, opt, red, pm, one
-    import gc
-    gc.collect()                        # the engine holds lazy weight-image objects that point back at it: a cycle, not a leak
+    gc.collect()                           # the engine holds lazy weight-image objects that point back at it: a cycle, not a leak
     torch.cuda.empty_cache()
-    return el / steps, float(loss), mem, n_train
+    return sec, loss, mem, n_train
 
 
-def cpu_baseline(args, T, W, seconds):
-    """The CPU oracle (oracle/ref_cpu.py, kind "port") on the host cores, bf16, ONE sample of the same
-    workload: full ViT-L/14@336 + projector + all decoder layers over 1091 positions + LM head.  To keep
-    host RAM bounded every decoder layer aliases ONE set of N(0,0.02) weights (identical FLOPs/bytes per
-    layer); if the time budget runs out the decoder is cut after k layers and the rate is reported for the
-    layers actually run, scaled by the algorithmic FLOP ratio (stated in `sample`)."""
+# ---------------------------------------------------------------------------------------------------------------- inference legs
+def decode_leg(m, fwd_prefill, B, T, n_steps, timer, dev, image_words=None):
+    """Greedy decode MODEL steps after a prefill (KV cache holds T + W positions): argmax + one-token forward_inference."""
+    from a3vlm_amd import ops
+    nt = torch.empty(B, dtype=torch.long, device=dev)
+    cur = torch.empty(B, 1, dtype=torch.long, device=dev)
+    state = {"logits": fwd_prefill(), "pos": T}
+
+    def one():
+        ops.argmax(state["logits"], nt)
+        cur[:, 0] = nt
+        state["logits"] = m.forward_inference(cur, state["pos"], None)
+        state["pos"] += 1
+    return timer(one, n_steps, 2)
+
+
+class _SynthTokenizer:
+    """Stands in for a 32000-word SentencePiece model (none ships with the repo, no network): deterministic ids per string.
+    Only the generate() leg uses it; what is timed is MetaModel.generate's own loop, whatever the ids are."""
+    bos_id, eos_id, n_words = 1, 2, 32000
+
+    def __init__(self, prompt_len):
+        self.prompt_len = prompt_len
+
+    def encode(self, s, bos, eos):
+        import zlib
+        g = torch.Generator().manual_seed(zlib.crc32(s.encode()) & 0x7fffffff)
+        ids = torch.randint(3, self.n_words, (self.prompt_len - 1,), generator=g).tolist()
+        return ([self.bos_id] if bos else []) + ids + ([self.eos_id] if eos else [])
+
+    def encode_segment(self, s):
+        return self.encode(s, False, False)[:2]
+
+    def encode_wo_prefix_space(self, s):
+        return self.encode(s, False, False)[1:3]
+
+    def decode(self, t):
+        return " ".join(map(str, t))
+
+
+def generate_leg(m, B, T, image, gen_len, timer, dev):
+    """MetaModel.generate(temperature=0) end to end: tokenise, left-truncate, prefill (image + T-token prompts), gen_len greedy
+    steps with teacher forcing / stop matching / stop_pos bookkeeping (one a3v_generate_step launch per token), detokenise."""
+    from a3vlm_amd.model.meta import MetaModel
+    mm = MetaModel.__new__(MetaModel)
+    torch.nn.Module.__init__(mm)
+    mm.llma, mm.tokenizer, mm.llama_type = m, _SynthTokenizer(T), "llama_ens5"
+    prompts = [f"synthetic prompt {i}" for i in range(B)]
+    out = {}
+
+    def one():
+        _, ids = mm.generate(prompts, image, max_gen_len=gen_len, temperature=0.0, additional_stop_symbols=["###"], return_ids=True)
+        out["n"] = sum(len(t) for t in ids)
+    sec = timer(one, 2, 1)
+    # the prefill's share, timed alone, so that the decode-phase rate can be stated next to the model-step number
+    tok = torch.tensor([mm.tokenizer.encode(p, True, False) for p in prompts], device=dev)
+    pre = timer(lambda: m.forward_inference(tok, 0, image), 2, 1)
+    mm.llma = None
+    return sec, pre, out["n"]
+
+
+def geometry_r_leg(m, args, B, T, steps, warmup, timer, dev):
+    """Reference-faithful geometry R: 448x448 input -> bicubic 224 global view + 4 quadrant crops through the ViT,
+    32 Q-Former tokens + 257 ViT tokens + 2 tags per view = 1455 image words, visual_proj over the 5632-wide feature concat.  The
+    three out-of-scope encoders (Q-Former / ConvNeXt-XXL / DINOv2) enter as synthetic feature tensors through the plugin hooks."""
+    import dataclasses
+    from a3vlm_amd.model.LLM import llama_ens5 as plugin
+    ra = plugin.ModelArgs(**{**dataclasses.asdict(args), "vit_crop": 224, "n_views": 5, "extra_feat_dim": 3072 + 1536, "qformer_tokens": 32})
+    mr = share_into(plugin.Transformer, ra, m, dev)
+    W = mr.image_words
+    g = torch.Generator(device=dev).manual_seed(3)
+    img = torch.randn(B, 3, 448, 448, device=dev, generator=g).bfloat16()
+    tok = torch.randint(3, args.vocab_size, (B, T), device=dev, generator=g)
+    tok[:, 0] = 1
+    qf = torch.randn(5 * B, 32, 768, device=dev, generator=g).bfloat16()
+    extra = [torch.randn(5 * B, 257, 3072, device=dev, generator=g).bfloat16(), torch.randn(5 * B, 257, 1536, device=dev, generator=g).bfloat16()]
+    fwd = lambda: mr.forward_inference(tok, 0, img, qformer_feats=qf, extra_feats=extra)  # noqa: E731
+    sec = timer(fwd, steps, warmup)
+    dsec = decode_leg(mr, fwd, B, T, 16, timer, dev)
+    fl = flops_forward(ra, B, T, W)
+    res = {"image_words": W, "seq_len": T + W, "forward_samples_s": round(B * timer_world(timer) / sec, 2), "forward_ms": round(sec * 1e3, 2),
+           "forward_mfma_frac": round(fl["total"] / sec / MFMA_PEAK_BF16, 4), "decode_tok_s": round(B * timer_world(timer) / dsec, 1),
+           "decode_ms_per_step": round(dsec * 1e3, 3),
+           "decode_hbm_frac": round(bytes_decode_step(ra, B, T + W + 10) / dsec / HBM_PEAK, 4),
+           "note": "geometry R: image_size 448, 5 x 224 crops, W = 1455 (CLIP ViT-L/14 on the HIP path; Q-Former / ConvNeXt-XXL / DINOv2 "
+                   "features synthetic, injected through the plugin hooks: out-of-scope frozen encoders)"}
+    mr._ws.clear(); mr._destroy_kv_cache()
+    del mr
+    gc.collect(); torch.cuda.empty_cache()
+    return res
+
+
+def timer_world(timer):
+    return timer.dist.get_world_size() if timer.dist is not None else 1
+
+
+def config5_leg(m, args, B, steps, warmup, timer, dev):
+    """BASELINE configs[4]: RGB + depth images (two-image plugin), 1024-token prompt, fp8 weight path (W8A8 prefill, weight-only
+    fp8 decode); the bf16 run of the same workload beside it."""
+    import dataclasses
+    from a3vlm_amd.model.LLM import llama_ens5_2images as p2
+    a2 = p2.ModelArgs(**{**dataclasses.asdict(args), "max_seq_len": 4096})
+    m2 = share_into(p2.Transformer, a2, m, dev)
+    T = 1024
+    g = torch.Generator(device=dev).manual_seed(5)
+    img = torch.randn(B, 3, 336, 336, device=dev, generator=g).bfloat16()
+    dep = torch.randn(B, 3, 336, 336, device=dev, generator=g).bfloat16()
+    tok = torch.randint(3, args.vocab_size, (B, T), device=dev, generator=g)
+    tok[:, 0] = 1
+    W = m2.image_words
+    fl = flops_forward(a2, B, T, W, n_images=2)
+    world = timer_world(timer)
+    res = {"image_words": W, "seq_len": T + W}
+    fwd = lambda: m2.forward_inference(tok, 0, img, dep)  # noqa: E731
+    for tag in ("bf16", "fp8"):
+        if tag == "fp8":
+            m2.quantize_decode_weights("fp8", prefill=True)
+        sec = timer(fwd, steps, warmup)
+        dsec = decode_leg(m2, fwd, B, T, 16, timer, dev)
+        db = bytes_decode_step(a2, B, T + W + 10) - (bytes_decoder_matrices(a2) if tag == "fp8" else 0)
+        res[tag] = {"forward_samples_s": round(B * world / sec, 2), "forward_ms": round(sec * 1e3, 2),
+                    "forward_tflops": round(fl["total"] * world / sec / 1e12, 1), "decode_tok_s": round(B * world / dsec, 1),
+                    "decode_ms_per_step": round(dsec * 1e3, 3), "decode_hbm_frac": round(db / dsec / HBM_PEAK, 4)}
+    res["fp8"]["forward_frac_of_fp8_peak"] = round(fl["total"] / (res["fp8"]["forward_ms"] * 1e-3) / MFMA_PEAK_FP8, 4)
+    res["note"] = ("configs[4]: llama_ens5_2images, one 336x336 crop per image (2 x 579 words), 1024-token prompt; fp8 = "
+                   "quantize_decode_weights('fp8', prefill=True): W8A8 decoder GEMMs on the MX-scaled MFMA + weight-only fp8 decode. "
+                   "No reference oracle exists for fp8 (SURVEY 8(a) row Q); parity: tests/test_gpu_two_image.py, tests/test_gpu_fp8.py")
+    m2.quantize_decode_weights(None)
+    m2._ws.clear(); m2._destroy_kv_cache()
+    del m2
+    gc.collect(); torch.cuda.empty_cache()
+    return res
+
+
+def m13b_leg(B, T, steps, warmup, timer, dev):
+    """configs[3] shapes: Llama-2-13B geometry.  Inference forward + decode at bs 8, then ONE DP replica of the full fine-tune
+    (every rank of a DP = 8 job holds exactly this: fp32 masters + flat fp32 grads + AdamW state + bf16 images ~ 234 GB, block
+    activations recomputed) at micro-batch 4."""
+    world = timer_world(timer)
+    m, args = build_model("13b", dev, 2048)
+    W = m.image_words
+    g = torch.Generator(device=dev).manual_seed(1)
+    img = torch.randn(B, 3, 336, 336, device=dev, generator=g).bfloat16()
+    tok = torch.randint(3, args.vocab_size, (B, T), device=dev, generator=g)
+    tok[:, 0] = 1
+    fwd = lambda: m.forward_inference(tok, 0, img)  # noqa: E731
+    sec = timer(fwd, max(2, steps // 2), 1)
+    dsec = decode_leg(m, fwd, B, T, 16, timer, dev)
+    fl = flops_forward(args, B, T, W)
+    res = {"forward_samples_s": round(B * world / sec, 2), "forward_ms": round(sec * 1e3, 1), "forward_mfma_frac": round(fl["total"] / sec / MFMA_PEAK_BF16, 4),
+           "decode_tok_s": round(B * world / dsec, 1), "decode_ms_per_step": round(dsec * 1e3, 3),
+           "decode_hbm_frac": round(bytes_decode_step(args, B, T + W + 10) / dsec / HBM_PEAK, 4)}
+    mb = 4
+    try:
+        tsec, loss, mem, ntr, rec = train_leg(m, mb, T, img[:mb].contiguous(), tok[:mb].contiguous(), 2, 1, timer, recompute=True)
+        flt = flops_forward(args, mb, T, W)
+        res["train_replica"] = {"micro_batch": mb, "samples_s": round(mb * world / tsec, 2), "ms_per_step": round(tsec * 1e3, 1), "loss": round(loss, 4),
+                                "hbm_gib": round(mem, 1), "trainable_params": ntr, "recompute": rec,
+                                "mfma_frac_3x": round(3 * flt["total"] / tsec / MFMA_PEAK_BF16, 4),
+                                "note": "one pure-DP replica of configs[3] (13B full fine-tune) in 288 GB HBM; gradients would be "
+                                        "all-reduced in bf16 per layer bucket exactly as in the 7B headline leg"}
+    except Exception as e:
+        res["train_replica"] = {"samples_s": None, "error": repr(e)[:300]}
+    del m
+    gc.collect(); torch.cuda.empty_cache()
+    return res
+
+
+# ---------------------------------------------------------------------------------------------------------------- CPU baseline
+def cpu_baseline(args, T, W, seconds, dev):
+    """The CPU oracle (oracle/ref_cpu.py, kind "port": the reference has no compiled code and cannot travel) on the host cores,
+    bf16: (i) ONE sample of the headline workload's forward (full ViT-L/14@336 + projector + all decoder layers over 1091
+    positions + LM head) and 16 greedy decode steps on the cache it leaves; every decoder layer aliases ONE set of weights so the
+    host RAM stays bounded (identical FLOPs / bytes per layer); if the time budget runs out the decoder is cut after k layers and
+    the rate scaled by the layer ratio (stated in `sample`).  (ii) configs[0] (C1): tiny weights, one 336x336 image + 64-token
+    prompt, greedy decode on the CPU oracle and through the HIP path in fp32 -- token ids must be identical."""
     from oracle import ref_cpu
     ncpu = os.cpu_count() or 1
-    # pick the fastest (threads, dtype) for torch's CPU kernels on this host with one FFN-sized matmul
     xs = torch.randn(T + W, args.dim)
     ws = torch.randn(4096, args.dim) * 0.02
     best = None
@@ -349,24 +572,82 @@ def cpu_baseline(args, T, W, seconds):
                 break
         hn = ref_cpu.rmsnorm(h, sd1["norm.weight"], oargs.norm_eps)
         _ = torch.nn.functional.linear(hn[:, -1, :], sd1["output.weight"]).float()
-    el = time.perf_counter() - t0
+        el = time.perf_counter() - t0
+        # 16 decode steps: one new token against S cached positions; the same aliased layer n_layers times per step
+        dec.allocate_kv_cache(1)
+        dec.k_cache[0] = torch.randn(dec.k_cache[0].shape).to(dt)      # a context of S positions (contents irrelevant for timing)
+        dec.v_cache[0] = torch.randn(dec.v_cache[0].shape).to(dt)
+        t1 = time.perf_counter()
+        nd = 0
+        for stp in range(16):
+            x = dec.embed(tok[:, :1])
+            for i in range(args.n_layers):
+                x = dec.block(0, x, S + stp, dec.freqs_cis[S + stp:S + stp + 1], None)
+            _ = torch.nn.functional.linear(ref_cpu.rmsnorm(x, sd1["norm.weight"], oargs.norm_eps)[:, -1, :], sd1["output.weight"]).float()
+            nd += 1
+            if time.perf_counter() - t1 > seconds / 2:
+                break
+        d_el = (time.perf_counter() - t1) / nd
     t_dec = el - t_vit
     full = t_vit + t_dec * (args.n_layers / done)
-    return dict(value=round(1.0 / full, 5), unit="samples/s", cores=cores, kind="port",
-                sample=(f"oracle/ref_cpu.py {str(dt).split('.')[-1]} on {cores} of {ncpu} host threads (fastest of a threads x dtype probe), 1 sample (336x336 image, {T}-token prompt, S={S}): ViT-L/14 24 blocks "
-                        f"{t_vit:.1f}s + {done}/{args.n_layers} decoder layers {t_dec:.1f}s (weights aliased across layers)"
-                        + ("" if done == args.n_layers else f"; decoder time scaled x{args.n_layers / done:.2f} by layer count")),
-                seconds=round(el, 1))
+    out = dict(value=round(1.0 / full, 5), unit="samples/s", cores=cores, kind="port",
+               sample=(f"oracle/ref_cpu.py {str(dt).split('.')[-1]} on {cores} of {ncpu} host threads (fastest of a threads x dtype probe), 1 sample "
+                       f"(336x336 image, {T}-token prompt, S={S}): ViT-L/14 24 blocks {t_vit:.1f}s + {done}/{args.n_layers} decoder layers {t_dec:.1f}s "
+                       f"(weights aliased across layers)" + ("" if done == args.n_layers else f"; decoder time scaled x{args.n_layers / done:.2f} by layer count")
+                       + f"; then {nd} greedy decode steps at context {S} (batch 1)"),
+               seconds=round(el, 1), decode_tok_s=round(1.0 / d_el, 3), decode_ms_per_step=round(d_el * 1e3, 1))
+    out["c1"] = c1_check(dev)
+    return out
+
+
+def c1_check(dev):
+    """configs[0]: single 336x336 render + 64-token prompt through the CPU eager path (the oracle), greedy decode; the HIP path in
+    fp32 must produce the same ids (north_star: token ids bit-exact under greedy decode)."""
+    from a3vlm_amd.model.LLM import llama_ens5 as plugin
+    from oracle import ref_cpu
+    kw = dict(dim=128, n_layers=2, n_heads=2, vocab_size=256, multiple_of=64, max_seq_len=1024)
+    oargs = ref_cpu.OracleArgs(**kw)
+    sd = ref_cpu.make_decoder_weights(oargs, seed=3, std=0.05)
+    vsd = ref_cpu.make_vision_weights(128, width=128, layers=2, patch=14, grid=24, seed=4, std=0.05)
+    g = torch.Generator().manual_seed(0)
+    img = torch.randn(1, 3, 336, 336, generator=g).half().float()
+    tok = torch.randint(3, 256, (1, 64), generator=g)
+    tok[:, 0] = 1
+    n_new = 16
+    t0 = time.perf_counter()
+    dec = ref_cpu.OracleDecoder(oargs, sd)
+    itok = ref_cpu.assemble_image_tokens(ref_cpu.encode_image(img, vsd, vit_layers=2, vit_heads=2, n_views=1), vsd["start_img"], vsd["end_img"])
+    lg = dec.forward_inference(tok, 0, itok)
+    want = []
+    for i in range(n_new):
+        nt = int(lg.argmax(-1))
+        want.append(nt)
+        lg = dec.forward_inference(torch.tensor([[nt]]), 64 + i)
+    cpu_s = time.perf_counter() - t0
+    m = plugin.Transformer(plugin.ModelArgs(**kw, vit_width=128, vit_layers=2, vit_heads=2, vit_crop=336, n_views=1), with_visual=True)
+    m.load_state_dict({**sd, **vsd})
+    m.to(dev)
+    lg = m.forward_inference(tok.to(dev), 0, img.to(dev))
+    got = []
+    for i in range(n_new):
+        nt = int(lg.argmax(-1))
+        got.append(nt)
+        lg = m.forward_inference(torch.tensor([[nt]], device=dev), 64 + i)
+    return {"config": "configs[0]: 336x336 image + 64-token prompt, tiny weights, greedy, fp32", "ids_equal": got == want, "n_tokens": n_new,
+            "cpu_seconds": round(cpu_s, 2)}
 
 
 def pmc_traffic():
-    """HBM-side bytes per launch of the dominant GEMM from the committed rocprofv3 PMC passes (counters cannot be read
-    from inside the process); None when the summary is absent."""
+    """HBM-side bytes per launch of the dominant GEMM from the newest committed rocprofv3 PMC summary (counters cannot be read
+    from inside the process: separate --pmc passes, tools/pmc_gemm.sh); None when no summary is there."""
     try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01i_pmc_traffic.json")) as f:
+        import glob
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+        with open(files[-1]) as f:
             d = json.load(f)
         return {"bytes_per_launch": d["traffic_bytes_per_launch"], "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
-                "shape": d["shape"], "source": d["source"]}
+                "shape": d["shape"], "kernel": d.get("kernel"), "l2_hit_rate": d.get("l2_hit_rate"), "source": d["source"],
+                "file": os.path.basename(files[-1])}
     except Exception:
         return None
 
@@ -388,10 +669,17 @@ def main():
         dist = None
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local if world > 1 else 0)
+    timer = Timer(dist, dev)
+    legs = set((a.legs.split(",") if a.legs else (ALL_LEGS if world == 1 else CORE_LEGS)))
+    if a.model != "7b":
+        legs -= {"m13b", "geometry_r", "config5"} if a.model == "13b" else {"m13b"}
+    if a.no_train:
+        legs -= {"train", "lora", "m13b"}
+    if a.no_cpu_baseline:
+        legs.discard("cpu")
 
     B, T = a.batch, a.prompt
-    max_seq = 2048
-    m, args = build_model(a.model, dev, max_seq)
+    m, args = build_model(a.model, dev, 2048)
     W = m.image_words
     S = T + W
     gen = torch.Generator(device=dev).manual_seed(100 + rank)
@@ -401,170 +689,134 @@ def main():
     image = ((img_u8 / 255.0 - mean) / std).contiguous()          # transform.py:59-68 (resize is a no-op at 336)
     tokens = torch.randint(3, args.vocab_size, (B, T), device=dev, generator=gen)
     tokens[:, 0] = 1
+    fl = flops_forward(args, B, T, W)
+    res = {}
 
-    def step():
-        return m.forward_inference(tokens, 0, image)
-
-    def sync_all():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(a.warmup):
-        step()
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    sync_all()
-    el = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([el], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
-    ms_step = el / a.steps * 1e3
-    value = B * world * a.steps / el
-
-    # ---- decode: greedy steps after the prefill above (KV cache holds S positions) ----
-    nt = torch.empty(B, dtype=torch.long, device=dev)
-    from a3vlm_amd import ops
-    logits = step()
-    cur = torch.empty(B, 1, dtype=torch.long, device=dev)
-    for _ in range(2):
-        ops.argmax(logits, nt)
-        cur[:, 0] = nt
-        logits = m.forward_inference(cur, T, None)
-    sync_all()
-    t0 = time.perf_counter()
-    for i in range(a.decode_steps):
-        ops.argmax(logits, nt)
-        cur[:, 0] = nt
-        logits = m.forward_inference(cur, T + 2 + i, None)
-    sync_all()
-    d_el = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([d_el], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        d_el = float(t.item())
-    dec_ms = d_el / a.decode_steps * 1e3
-    dec_tok_s = B * world * a.decode_steps / d_el
-    ctx = S + 2 + a.decode_steps // 2
-    dec_bytes = bytes_decode_step(args, B, ctx)
-
-    # ---- decode with weight-only fp8 images of the decoder matrices (BASELINE config 5 semantics; opt-in, separate from the
-    # bf16 headline: the reference has no fp8 path, so this leg is reported beside it, never instead of it)
-    fp8 = None
-    try:
-        m.quantize_decode_weights("fp8")
-        logits = step()
-        for _ in range(2):
-            ops.argmax(logits, nt)
-            cur[:, 0] = nt
-            logits = m.forward_inference(cur, T, None)
-        sync_all()
-        t0 = time.perf_counter()
-        for i in range(a.decode_steps):
-            ops.argmax(logits, nt)
-            cur[:, 0] = nt
-            logits = m.forward_inference(cur, T + 2 + i, None)
-        sync_all()
-        f_el = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([f_el], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            f_el = float(t.item())
-        f_ms = f_el / a.decode_steps * 1e3
-        f_bytes = bytes_decode_step(args, B, ctx) - bytes_decoder_matrices(args)          # the four matrices per layer at 1 B/weight
-        fp8 = {"tok_s": round(B * world * a.decode_steps / f_el, 1), "ms_per_step": round(f_ms, 3),
-               "hbm_frac": round(f_bytes / (f_ms * 1e-3) / HBM_PEAK, 4), "bytes_per_step": f_bytes,
-               "note": "weight-only OCP e4m3fn decoder matrices with per-row fp32 scales (embeddings, norms, LM head, KV cache bf16); "
-                       "no reference oracle exists for fp8 (SURVEY 8(a) row Q): parity is stated against the bf16 kernels on the "
-                       "dequantised weights (tests/test_gpu_fp8.py)"}
-        # W8A8 prefill: the same forward step with every decoder GEMM on fp8 operands (MX-scaled MFMA); ViT and LM head bf16
-        m.quantize_decode_weights("fp8", prefill=True)
-        for _ in range(2):
-            step()
-        sync_all()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            step()
-        sync_all()
-        p_el = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([p_el], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            p_el = float(t.item())
-        fp8["forward_w8a8"] = {"samples_s": round(B * world * a.steps / p_el, 2), "ms_per_step": round(p_el / a.steps * 1e3, 2),
-                               "tflops": round(flops_forward(args, B, T, W)["total"] * world * a.steps / p_el / 1e12, 1),
-                               "note": "opt-in quantize_decode_weights('fp8', prefill=True): per-token dynamic e4m3 activations x "
-                                       "per-row e4m3 weights, fp32 accumulate; never the headline value"}
-    except Exception as e:
-        fp8 = dict(fp8 or {}, error=repr(e)[:300])
-    finally:
-        m.quantize_decode_weights(None)
-
-    lora = None
-    if not a.no_train and a.model != "13b":
+    def guarded(name, fn):
         try:
-            sec, tl, mem, ntr = lora_leg(m, args, B, T, image, tokens, a.train_steps, dist, dev)
-            fl_t = flops_forward(args, B, T, W)
-            lora = {"samples_s": round(B * world / sec, 2), "ms_per_step": round(sec * 1e3, 1), "loss": round(tl, 4), "hbm_gib": round(mem, 1),
-                    "trainable_params": ntr, "tflops": round(2 * fl_t["total"] * world / sec / 1e12, 1),
-                    "mfma_frac": round(2 * fl_t["total"] / sec / MFMA_PEAK_BF16, 4),
+            return fn()
+        except Exception as e:             # a failing side leg must never hide the headline
+            return {"error": f"{name}: {e!r}"[:400]}
+
+    fwd = lambda: m.forward_inference(tokens, 0, image)  # noqa: E731
+    if "forward" in legs:
+        sec = timer(fwd, a.steps, a.warmup)
+        res["forward"] = {"samples_s": round(B * world / sec, 3), "ms_per_step": round(sec * 1e3, 3), "tflops": round(fl["total"] * world / sec / 1e12, 1),
+                          "mfma_frac": round(fl["total"] / sec / MFMA_PEAK_BF16, 4),
+                          "config": f"configs[1]: ViT-L/14@336 (577+2 image words) + Llama-2-{a.model.upper()} bf16 inference forward, bs={B}/GPU, {T}-token prompt, S={S}"}
+    if "decode" in legs:
+        dsec = decode_leg(m, fwd, B, T, a.decode_steps, timer, dev)
+        ctx = S + 2 + a.decode_steps // 2
+        db = bytes_decode_step(args, B, ctx)
+        res["decode"] = {"tok_s": round(B * world / dsec, 1), "ms_per_step": round(dsec * 1e3, 3), "steps": a.decode_steps,
+                         "roofline": {"bound": "hbm", "achieved": round(db / dsec / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                      "frac": round(db / dsec / HBM_PEAK, 4), "bytes_per_step": db,
+                                      "note": "bf16 weights once per step + KV of all sequences (SURVEY 8(d)); whole model step incl. host launch gaps"}}
+    if "generate" in legs:
+        def _gen():
+            gsec, pre, n_new = generate_leg(m, B, T, image, a.gen_len, timer, dev)
+            dphase = max(gsec - pre, 1e-9)
+            return {"tok_s_end_to_end": round(n_new * world / gsec, 1), "seconds": round(gsec, 4), "new_tokens": n_new, "prefill_seconds": round(pre, 4),
+                    "tok_s_after_prefill": round(n_new * world / dphase, 1),
+                    "note": f"MetaModel.generate(temperature=0): {B} prompts x {T} tokens + image, {a.gen_len} new tokens each; host tokenise / "
+                            "detokenise, one C call per model step and ONE a3v_generate_step launch per token (teacher forcing, stop match, "
+                            "stop_pos on the device), `live` polled every 4 steps"}
+        res["generate"] = guarded("generate", _gen)
+    if "fp8" in legs:
+        def _fp8():
+            out = {}
+            try:
+                m.quantize_decode_weights("fp8")
+                dsec8 = decode_leg(m, fwd, B, T, a.decode_steps, timer, dev)
+                f_bytes = bytes_decode_step(args, B, S + 2 + a.decode_steps // 2) - bytes_decoder_matrices(args)
+                out = {"tok_s": round(B * world / dsec8, 1), "ms_per_step": round(dsec8 * 1e3, 3), "hbm_frac": round(f_bytes / dsec8 / HBM_PEAK, 4),
+                       "bytes_per_step": f_bytes,
+                       "note": "weight-only OCP e4m3fn decoder matrices with per-row fp32 scales (embeddings, norms, LM head, KV cache bf16); no "
+                               "reference oracle exists for fp8 (SURVEY 8(a) row Q): parity vs the bf16 kernels on the dequantised weights"}
+                m.quantize_decode_weights("fp8", prefill=True)
+                psec = timer(fwd, a.steps, 2)
+                out["forward_w8a8"] = {"samples_s": round(B * world / psec, 2), "ms_per_step": round(psec * 1e3, 2), "tflops": round(fl["total"] * world / psec / 1e12, 1)}
+            finally:
+                m.quantize_decode_weights(None)
+            return out
+        res["decode_fp8"] = guarded("fp8", _fp8)
+    if "geometry_r" in legs:
+        res["geometry_R"] = guarded("geometry_r", lambda: geometry_r_leg(m, args, B, T, max(2, a.steps // 2), 1, timer, dev))
+    if "config5" in legs:
+        res["config5"] = guarded("config5", lambda: config5_leg(m, args, B, max(2, a.steps // 2), 1, timer, dev))
+    if "lora" in legs:
+        def _lora():
+            sec, tl, mem, ntr = lora_leg(m, args, B, T, image, tokens, a.steps, a.warmup, timer, dev)
+            return {"samples_s": round(B * world / sec, 2), "ms_per_step": round(sec * 1e3, 1), "loss": round(tl, 4), "hbm_gib": round(mem, 1),
+                    "trainable_params": ntr, "tflops": round(2 * fl["total"] * world / sec / 1e12, 1), "mfma_frac": round(2 * fl["total"] / sec / MFMA_PEAK_BF16, 4),
                     "config": f"configs[2]: LoRA r=16 on all 7 decoder linears + norms + projector trainable, base frozen bf16, bs={B}/GPU, dp{world}",
                     "flop_convention": "2 x forward FLOPs (forward + input-gradient GEMMs; no weight-gradient GEMMs for frozen matrices)"}
-        except Exception as e:
-            lora = {"samples_s": None, "error": repr(e)[:300]}
+        res["train_lora"] = guarded("lora", _lora)
     train = None
-    if not a.no_train and a.model != "13b":
-        try:
-            sec, tl, mem = train_leg(m, args, B, T, image, tokens, a.train_steps, dist, dev)
-            fl_t = flops_forward(args, B, T, W)
-            # 3x (fwd + dgrad + wgrad) of the trainable part + 1x recompute + frozen ViT forward once
-            vit = fl_t["total"] - (fl_t["gemm"] + fl_t["att"]) + 0.0
-            train = {"samples_s": round(B * world / sec, 2), "ms_per_step": round(sec * 1e3, 1), "loss": round(tl, 4),
-                     "hbm_gib": round(mem, 1), "tflops": round((3 * fl_t["total"]) * world / sec / 1e12, 1),
-                     "mfma_frac": round(3 * fl_t["total"] / sec / MFMA_PEAK_BF16, 4),
-                     "config": f"full fine-tune of decoder+projector (6.7 G trainable), bs={B}/GPU, {T}-token prompts + 579 image words, fp32 masters + "
-                               f"bf16 GEMMs, block activations kept in HBM (no recompute), global-norm clip 8 + AdamW (a3v_adamw_scaled), dp{world}"
-                               + (" with RCCL all-reduce of per-layer fp32 grad buckets overlapped with backward" if world > 1 else ""),
-                     "flop_convention": "3 x forward FLOPs of the step (SURVEY 8(d)); LM head on all text positions and the frozen ViT counted once are ignored"}
-        except Exception as e:
-            train = {"samples_s": None, "error": repr(e)[:300]}
-    out = None
+    if "train" in legs:
+        def _train():
+            sec, tl, mem, ntr, rec = train_leg(m, B, T, image, tokens, a.steps, a.warmup, timer)
+            return {"samples_s": round(B * world / sec, 3), "ms_per_step": round(sec * 1e3, 2), "seconds_per_step": sec, "loss": round(tl, 4),
+                    "hbm_gib": round(mem, 1), "trainable_params": ntr, "tflops": round(3 * fl["total"] * world / sec / 1e12, 1),
+                    "mfma_frac": round(3 * fl["total"] / sec / MFMA_PEAK_BF16, 4),
+                    "config": f"full fine-tune of decoder+projector, bs={B}/GPU, {T}-token prompts + {W} image words, fp32 masters + bf16 GEMMs, "
+                              + ("per-block recompute" if rec else "block activations kept in HBM (no recompute)")
+                              + f", global-norm clip 8 + AdamW (a3v_adamw_scaled), dp{world}"
+                              + (" with RCCL all-reduce (bf16 wire) of per-layer grad buckets overlapped with backward" if world > 1 else ""),
+                    "flop_convention": "3 x forward FLOPs of the step (SURVEY 8(d)); LM head on all text positions and the frozen ViT counted once are ignored"}
+        train = guarded("train", _train)
+        res["train"] = train
+    # ---- roofline of the headline step's dominant kernel family (rank 0)
+    roof = None
     if rank == 0:
-        fl = flops_forward(args, B, T, W)
-        gf, gt, table = time_gemm_shapes(m, args, B, T, W, dev)
+        def _roof():
+            fam, table = time_gemm_shapes(args, B, T, W, dev, train="train" in legs)
+            tot_f = sum(v[0] for v in fam.values())
+            tot_t = sum(v[1] for v in fam.values())
+            return {"kernel": "MFMA GEMM family of the step: gemm_nt_bf16_ring_kernel (256x256x64 ping-pong over a 160-KiB LDS ring; forward linears), "
+                              "gemm_tn_bf16_pp_kernel<A_ROWS> (NN input gradients / TN weight gradients), gemm_nt_bf16_kernel<128,128> on tail rows and small shapes",
+                    "bound": "mfma", "achieved": round(tot_f / tot_t / 1e12, 1), "peak": MFMA_PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                    "frac": round(tot_f / tot_t / MFMA_PEAK_BF16, 4), "traffic": pmc_traffic(),
+                    "families": {k: {"tflops": round(v[0] / v[1] / 1e12, 1), "frac": round(v[0] / v[1] / MFMA_PEAK_BF16, 4), "ms_per_step": round(v[1] * 1e3, 2)}
+                                 for k, v in fam.items() if v[1] > 0},
+                    "gemm_ms_per_step": round(tot_t * 1e3, 2), "gemm_calls_per_step": sum(r["count"] for r in table),
+                    "note": "achieved = algorithmic 2MNK of every GEMM call of one step / its HIP-event duration on the launch stream (FLOP-weighted "
+                            "over the step's shapes = total GEMM FLOP / total GEMM time); traffic = rocprofv3 PMC bytes per launch of the dominant "
+                            "w1|w3 forward shape (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction), newest summary under profiles/",
+                    "shapes": table}
+        del m
+        gc.collect(); torch.cuda.empty_cache()
+        roof = guarded("roofline", _roof)
+    else:
+        del m
+        gc.collect(); torch.cuda.empty_cache()
+    if "m13b" in legs:
+        res["m13b"] = guarded("m13b", lambda: m13b_leg(B, T, a.steps, a.warmup, timer, dev))
+    if rank == 0:
+        if train and train.get("seconds_per_step"):
+            head_s, what = train.pop("seconds_per_step"), "train"
+        else:
+            head_s, what = res.get("forward", {}).get("ms_per_step", float("nan")) * 1e-3, "forward"
         out = {
-            "metric": "image-text samples/sec (ViT-L/14 + Llama-2-7B multimodal forward, bf16, bs=8/GPU) + articulation-decode tok/s",
-            "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "metric": "image-text samples/sec (train) + articulation-decode tok/s" if what == "train"
+                      else "image-text samples/sec (inference forward; training legs skipped) + articulation-decode tok/s",
+            "value": round(B * world / head_s, 3), "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(head_s * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic (uint8-uniform 336x336 images, uniform token ids, N(0,0.02) weights)",
-            "config": {"workload": f"configs[1]: ViT-L/14@336 (577+2 image words) + Llama-2-{a.model.upper()} bf16 inference forward, "
-                                   f"bs={B} per GPU, {T}-token prompt, S={S}", "geometry": "S (single 336x336 crop)",
-                       "global_batch": B * world, "seq_len": S, "parallelism": f"dp{world} replicas (no data-path collective)"},
-            "forward_tflops": round(fl["total"] * world / (ms_step * 1e-3) / 1e12, 1),
-            "forward_mfma_frac": round(fl["total"] / (ms_step * 1e-3) / MFMA_PEAK_BF16, 4),
-            "roofline": {"kernel": "gemm_nt_bf16_pp_kernel (256x256x64 ping-pong; gemm_nt_bf16_kernel<128,128> on tail rows / small shapes)",
-                         "bound": "mfma", "achieved": round(gf / gt / 1e12, 1), "peak": MFMA_PEAK_BF16 / 1e12,
-                         "unit": "TFLOP/s", "frac": round(gf / gt / MFMA_PEAK_BF16, 4), "traffic": pmc_traffic(),
-                         "note": "algorithmic 2MNK per GEMM call / HIP-event duration on the launch stream, FLOP-weighted over the step's GEMM "
-                                 "shapes (= total GEMM FLOP / total GEMM time of one step); traffic = rocprofv3 PMC bytes per launch of the "
-                                 "dominant w1|w3 shape (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction), from profiles/",
-                         "gemm_ms_per_step": round(gt * 1e3, 2), "gemm_calls_per_step": sum(r["count"] for r in table),
-                         "avg_call_us": round(gt * 1e6 / max(1, sum(r["count"] for r in table)), 1), "shapes": table},
-            "decode_tok_s": round(dec_tok_s, 1), "decode_ms_per_step": round(dec_ms, 3), "decode_steps": a.decode_steps,
-            "decode_roofline": {"bound": "hbm", "achieved": round(dec_bytes / (dec_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                                "frac": round(dec_bytes / (dec_ms * 1e-3) / HBM_PEAK, 4), "bytes_per_step": dec_bytes,
-                                "note": "bf16 weights once per step + KV of all sequences (SURVEY 8(d)); whole step incl. host launch gaps"},
+            "config": {"workload": (f"configs[1] backbone (ViT-L/14@336, 577+2 image words, + Llama-2-{a.model.upper()}), "
+                                    + ("FULL FINE-TUNE step" if what == "train" else "inference forward step")
+                                    + f", bs={B} per GPU, {T}-token prompt, S={S}"),
+                       "geometry": "S (single 336x336 crop); geometry R (W=1455) in `geometry_R`",
+                       "global_batch": B * world, "seq_len": S,
+                       "parallelism": f"dp{world}" + (" (bucketed RCCL gradient all-reduce overlapped with backward)" if world > 1 else "")},
+            "decode_tok_s": res.get("decode", {}).get("tok_s"),
+            "generate_tok_s": (res.get("generate") or {}).get("tok_s_end_to_end"),
+            "roofline": roof,
         }
-        out["decode_fp8"] = fp8
-        out["train"] = train
-        out["train_lora"] = lora
-        if not a.no_cpu_baseline:
+        out.update(res)
+        if "cpu" in legs:
             try:
-                out["cpu_baseline"] = cpu_baseline(args, T, W, a.cpu_seconds)
+                out["cpu_baseline"] = cpu_baseline(args, T, W, a.cpu_seconds, dev)
             except Exception as e:  # the baseline must never hide the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
         print(json.dumps(out), flush=True)

@@ -215,6 +215,19 @@ int a3v_split_views(const void* img, void* out, int B, int crop, int in_dtype, i
 int a3v_vit_embed(const void* patch, const void* cls, const void* pos, void* x, int N, int T,
                   int width, int dtype, void* stream);
 
+/* Image preprocessing of the input contract on the device (data/transform.py:13-68: PadToSquare with the CLIP-mean fill ->
+ * Resize(bicubic) -> ToTensor -> Normalize): src = one decoded RGB image, uint8 [H][W][3]; it sits at (pad_x, pad_y) inside a
+ * side x side square filled with fill_rgb; the square is resized to out_size x out_size with Pillow's 8-bit two-pass resampling
+ * (the reference transform runs torchvision on PIL images, i.e. Pillow's ImagingResample): kx / ky = the fixed-point (2^22)
+ * coefficient rows of the horizontal / vertical pass, ksize_* ints per output sample, bx / by = (first input index, tap count)
+ * per output sample -- tables computed on the host from (side, out_size) exactly as Resample.c does (a3vlm_amd/data/transform.py).
+ * tmp: uint8 scratch [side][out_size][3].  dst: [3][out_size][out_size] in dst_dtype, ((v / 255) - mean[c]) / std[c] with fp32
+ * arithmetic.  Host-side scalars (fill_rgb, mean, std) are HOST pointers; everything else is device memory.  Bit-identical to
+ * the PIL path (tests/test_gpu_preprocess.py). */
+int a3v_preprocess_image(const uint8_t* src, int H, int W, int side, int pad_x, int pad_y, const int* fill_rgb,
+                         const int32_t* kx, const int32_t* bx, int ksize_x, const int32_t* ky, const int32_t* by, int ksize_y,
+                         int out_size, uint8_t* tmp, void* dst, int dst_dtype, const float* mean, const float* std, void* stream);
+
 /* One step of the token bookkeeping of MetaModel.generate (model/meta.py:456-477), one launch for the whole batch: greedy argmax of
  * logits [B, V] (fp32, row stride ld) -- or, when `sampled` is non-NULL, the externally sampled ids of the top-p branch (:457-459) --
  * then, per row: teacher forcing of prompt positions (text_mask[row, cur_pos], :463-465), tokens[row, cur_pos] = next,

@@ -145,21 +145,27 @@ def test_rope_scaling_fp32_matches_hf_pin(golden_dir):
     assert rel_err(lg, fx["hf_logits"][:, 15]) < REL
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (BF, 3e-2)])
-def test_vit_quick_gelu_matches_oracle(dtype, tol):
+@pytest.mark.parametrize("dtype,tol,std", [(torch.float32, 1e-3, 0.25), (BF, 5e-2, 0.05)])
+def test_vit_quick_gelu_matches_oracle(dtype, tol, std):
     """``vit_quick_gelu`` = the activation of open_clip's ``openai``-pretrained ViT-L/14 config (x * sigmoid(1.702 x)); the default
     build uses erf-GELU.  The flag switches the epilogue of the ViT's c_fc GEMM; ``clip_encode_image`` (LLM/llama_ens5.py:351-375)
-    is checked against the oracle's ViT with the same flag, on weights wide enough for the two activations to differ visibly."""
+    is checked against the oracle's ViT with the same flag.  fp32: on weights wide enough for the two activations to differ by
+    18x the tolerance, each build must match ITS oracle and not the other one; bf16: tolerance check at the usual weight scale."""
     kw = dict(dim=128, n_layers=1, n_heads=2, vocab_size=256, multiple_of=64, max_seq_len=1024)
-    vsd = ref_cpu.make_vision_weights(128, width=128, layers=2, patch=14, grid=24, seed=4, std=0.25)
+    vsd = ref_cpu.make_vision_weights(128, width=128, layers=2, patch=14, grid=24, seed=4, std=std)
     sd = ref_cpu.make_decoder_weights(ref_cpu.OracleArgs(**kw), seed=3, std=0.05)
     img = synth_image(2, size=336, seed=9)
     want = {q: ref_cpu.clip_encode_image(img, vsd, 2, 2, 14, quick_gelu=q) for q in (True, False)}
-    assert rel_err(want[True], want[False].numpy()) > 0.1, "the two activations must be distinguishable on this input"
+    gap = rel_err(want[True], want[False].numpy())
+    if dtype == torch.float32:
+        assert gap > 10 * tol, "the two activations must be distinguishable on this input"
     for q in (True, False):
         args = plugin.ModelArgs(**kw, vit_width=128, vit_layers=2, vit_heads=2, vit_crop=336, n_views=1, vit_quick_gelu=q)
         m = plugin.Transformer(args, with_visual=True)
         m.load_state_dict({**sd, **vsd})
         m.to(dtype).to(DEV)
         got = m.clip_encode_image(img.to(dtype).to(DEV)).view(2, 577, 128)
-        assert rel_err(got, want[q].numpy()) < tol, q
+        err, err_other = rel_err(got, want[q].numpy()), rel_err(got, want[not q].numpy())
+        assert err < tol, (q, err, err_other, gap)
+        if dtype == torch.float32:
+            assert err < 0.1 * err_other, (q, err, err_other, gap)

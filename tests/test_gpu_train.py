@@ -446,3 +446,50 @@ def test_clip_grad_norm_on_flat_buffer_matches_per_parameter_form():
     assert torch.allclose(flat, before * coef, rtol=1e-6, atol=0)
     for p, q in zip(ps, ref):
         assert torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-8)
+
+
+def test_train_step_with_hook_fed_encoder_streams_fp32():
+    """The reference llama_ens5 configuration trains visual_proj over the concat [CLIP | ConvNeXt | DINOv2] and qformer_proj over the
+    Q-Former tokens (LLM/llama_ens5.py:325-349, 436-458); the three extra encoders are frozen inputs.  One fp32 training step with
+    ``extra_feat_dim`` and ``qformer_tokens`` set (features injected as the provider hooks would) against oracle autograd:
+    loss and every trainable gradient, the two projectors' included."""
+    X1, X2, Q = 48, 32, 5
+    args = plugin.ModelArgs(**TK, vit_width=64, vit_layers=2, vit_heads=4, vit_crop=112, n_views=1, extra_feat_dim=X1 + X2, qformer_tokens=Q)
+    m = plugin.Transformer(args, with_visual=True)
+    sd = ref_cpu.make_decoder_weights(ref_cpu.OracleArgs(**TK), seed=0, std=0.08)
+    vsd = ref_cpu.make_vision_weights(64, width=64, layers=2, patch=14, grid=8, in_feat=64 + X1 + X2, with_qformer=True, seed=1, std=0.05)
+    m.load_state_dict({**sd, **vsd})
+    for n, p in m.named_parameters():
+        p.requires_grad = not n.startswith("clip.")
+    m.to(DEV)
+    promote_trainable_params_to_fp32(m)
+    assert m.image_words == (Q + 65 + 2)
+    g = torch.Generator().manual_seed(6)
+    B, T = 2, 11
+    ex = torch.randint(3, 192, (B, T), generator=g)
+    ex[:, 0] = 1
+    lab = ex.clone()
+    lab[:, :3] = 0
+    img = synth_image(B, size=112, seed=3)
+    qf = torch.randn(B, Q, 768, generator=g)
+    extra = [torch.randn(B, 65, X1, generator=g), torch.randn(B, 65, X2, generator=g)]
+    # oracle
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    vg = {k: v.clone().requires_grad_(k.startswith(("visual_proj", "qformer_proj", "start_img", "end_img"))) for k, v in vsd.items()}
+    dec = ref_cpu.OracleDecoder(ref_cpu.OracleArgs(**TK), sdg)
+    views = ref_cpu.encode_image(img, vg, vit_layers=2, vit_heads=4, n_views=1, qformer_feats=qf, extra_feats=extra)
+    want_loss = ref_cpu.meta_forward_loss(dec, ex, lab, ref_cpu.assemble_image_tokens(views, vg["start_img"], vg["end_img"]))
+    want_loss.backward()
+    want = {k: v.grad for k, v in sdg.items()}
+    want.update({k: v.grad for k, v in vg.items() if v.requires_grad})
+    eng = TrainEngine(m, torch.float32, recompute=False)
+    loss = eng.forward_loss(ex.to(DEV), lab.to(DEV), img.to(DEV), qformer_feats=qf.to(DEV), extra_feats=[e.to(DEV) for e in extra])
+    assert abs(float(loss) - float(want_loss)) < 1e-3 * abs(float(want_loss))
+    eng.backward(1.0)
+    names = set(m.get_trainable_params())
+    assert {"qformer_proj.0.weight", "qformer_proj.1.bias", "visual_proj.0.weight"} <= names
+    for name, p in m.get_trainable_params().items():
+        assert p.grad is not None, name
+        assert relerr(p.grad, want[name]) < 1e-3, (name, relerr(p.grad, want[name]))
+    with pytest.raises(ValueError):
+        eng.forward_loss(ex.to(DEV), lab.to(DEV), img.to(DEV))            # features missing and no provider hook attached
