@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_bf16_kernel(AttnArgs p) {
 // ------------------------------------------------------------------------------------
 // Decode (Sq == 1): grid (nsplit, H, B); block 256.  part[b][h][split] = {o[HD], m, l}
 // ------------------------------------------------------------------------------------
-template <int HD>
+template <int HD, bool NT = false>   // NT: non-temporal policy on the K / V^T stream (read once per step by one block)
 __global__ __launch_bounds__(256) void attn_decode_bf16_kernel(AttnArgs p, float* part, int nsplit, int chunk, int* counters) {
   constexpr int LPR = HD / 8;            // lanes per K row (16-B each)
   constexpr int RPW = 64 / LPR;          // K rows per wave-load
@@ -352,7 +352,8 @@ __global__ __launch_bounds__(256) void attn_decode_bf16_kernel(AttnArgs p, float
     for (int u = 0; u < U; ++u) {
       int r = r0 + u * RPW + lr;
       r = r < n ? r : n - 1;
-      kk[u] = *reinterpret_cast<const bf16x8*>(K + (int64_t)(kv_lo + r) * p.k_ss + lc);
+      const bf16x8* kp = reinterpret_cast<const bf16x8*>(K + (int64_t)(kv_lo + r) * p.k_ss + lc);
+      kk[u] = NT ? __builtin_nontemporal_load(kp) : *kp;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -401,7 +402,10 @@ __global__ __launch_bounds__(256) void attn_decode_bf16_kernel(AttnArgs p, float
     for (int c = lane * 8; c < n8; c += 64 * 8) {
       bf16x8 vv[DB];
 #pragma unroll
-      for (int j = 0; j < DB; ++j) vv[j] = *reinterpret_cast<const bf16x8*>(VT + (int64_t)(d0 + j) * p.v_sd + kv_lo + c);
+      for (int j = 0; j < DB; ++j) {
+        const bf16x8* vp = reinterpret_cast<const bf16x8*>(VT + (int64_t)(d0 + j) * p.v_sd + kv_lo + c);
+        vv[j] = NT ? __builtin_nontemporal_load(vp) : *vp;
+      }
       float pv[8];
       const int nvalid = p.Sk - (kv_lo + c);          // >= 8 except in the last chunk
 #pragma unroll
@@ -678,8 +682,15 @@ int a3v_attention_decode_fused(const void* q, const void* k, const void* vt, voi
   decode_plan(B, H, Sk, &ns, &ch);
   const size_t shm = (size_t)(ch + 8) * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
-  if (hd == 128) hipLaunchKernelGGL(attn_decode_bf16_kernel<128>, dim3(ns, H, B), dim3(256), shm, st, p, scratch, ns, ch, counters);
-  else hipLaunchKernelGGL(attn_decode_bf16_kernel<64>, dim3(ns, H, B), dim3(256), shm, st, p, scratch, ns, ch, counters);
+  const char* nte = getenv("A3V_ATTN_DECODE_NT");       // default: non-temporal KV stream (A3V_ATTN_DECODE_NT=0 for A/B runs)
+  const bool nt = !(nte && nte[0] == '0');
+  if (hd == 128) {
+    if (nt) hipLaunchKernelGGL((attn_decode_bf16_kernel<128, true>), dim3(ns, H, B), dim3(256), shm, st, p, scratch, ns, ch, counters);
+    else hipLaunchKernelGGL((attn_decode_bf16_kernel<128, false>), dim3(ns, H, B), dim3(256), shm, st, p, scratch, ns, ch, counters);
+  } else {
+    if (nt) hipLaunchKernelGGL((attn_decode_bf16_kernel<64, true>), dim3(ns, H, B), dim3(256), shm, st, p, scratch, ns, ch, counters);
+    else hipLaunchKernelGGL((attn_decode_bf16_kernel<64, false>), dim3(ns, H, B), dim3(256), shm, st, p, scratch, ns, ch, counters);
+  }
   A3V_LAUNCH_CHECK();
   return A3V_OK;
 }

@@ -38,7 +38,7 @@ def test_flop_and_byte_accounting_7b():
 
 
 def test_committed_bench_lines_follow_the_contract():
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01*_bench_7b.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_bench_7b.json")))
     assert files, "no committed bench line under profiles/"
     d = json.loads(open(files[-1]).read().strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
@@ -52,3 +52,14 @@ def test_committed_bench_lines_follow_the_contract():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["unit"] == "samples/s" and c["sample"]
     assert abs(d["value"] - 8 * 1000.0 / d["ms_per_step"]) / d["value"] < 0.01
+    if os.path.basename(files[-1]) >= "r02":
+        # round 2 on: the headline IS the BASELINE metric (train samples/s of the configs[1] backbone), the other configs are named legs
+        assert "(train)" in d["metric"] and "FULL FINE-TUNE" in d["config"]["workload"]
+        assert abs(d["train"]["samples_s"] - d["value"]) / d["value"] < 1e-3
+        for leg in ("forward", "decode", "generate", "decode_fp8", "geometry_R", "config5", "train_lora", "m13b"):
+            assert leg in d and "error" not in d[leg], leg
+        assert d["geometry_R"]["image_words"] == 1455 and d["config5"]["seq_len"] == 1024 + 2 * 579
+        assert d["m13b"]["train_replica"]["hbm_gib"] < 288 and d["m13b"]["train_replica"]["trainable_params"] > 13e9
+        assert set(r["families"]) == {"nt", "nn", "tn"} and r["traffic"]["file"].startswith("r02")
+        assert c["c1"]["ids_equal"] is True and c["decode_tok_s"] > 0
+        assert d["generate"]["tok_s_end_to_end"] > 0 and d["decode"]["roofline"]["bound"] == "hbm"

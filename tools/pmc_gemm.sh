@@ -21,8 +21,20 @@ for f in glob.glob("$out/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         if "gemm" in r["Kernel_Name"]:
             acc[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+import json, os
 for k, d in acc.items():
     print(k)
     for c, v in sorted(d.items()):
         print(f"   {c:34s} n={len(v)} mean={sum(v)/len(v):.4g}")
+    m = {c: sum(v) / len(v) for c, v in d.items()}
+    if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
+        M, N, K = $M, $N, $K
+        alg = 2 * (M * K + N * K + M * N)
+        hit = m.get("TCC_HIT_sum", 0) / max(1.0, m.get("TCC_HIT_sum", 0) + m.get("TCC_MISS_sum", 0))
+        out = {"kernel": k.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].strip(), "shape": [M, N, K], "fetch_size_kb": m["FETCH_SIZE"], "write_size_kb": m["WRITE_SIZE"],
+               "correction": "FETCH_SIZE x2 on gfx950 for 16-B/lane streaming reads (MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported",
+               "traffic_bytes_per_launch": int((2 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024), "algorithmic_bytes_per_launch": alg,
+               "l2_hit_rate": round(hit, 4), "mfma_busy_frac_of_gui_active": round(m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / 4 / 256 / max(1.0, m.get("GRBM_GUI_ACTIVE", 1) / 8), 4) if "GRBM_GUI_ACTIVE" in m else None,
+               "source": "tools/pmc_gemm.sh $tag $M $N $K $cfg (rocprofv3 --pmc, separate passes with --kernel-trace only, 3 launches averaged)"}
+        open(os.path.join("$out", "traffic.json"), "w").write(json.dumps(out, indent=1))
 PY
