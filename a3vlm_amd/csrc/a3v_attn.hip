@@ -37,7 +37,12 @@ __device__ __forceinline__ void buf_dma16(__amdgpu_buffer_rsrc_t rs, char* lds_d
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
 }
 
-template <int HD, bool CAUSAL>
+// PSWAP: the P^T operand is regrouped so that a lane half holds 8 CONSECUTIVE keys (two v_permlane32_swap per 16 keys exchange the
+// {4 hh .. 4 hh + 3} quarters between lanes l and l + 32), and the V^T fragment becomes ONE 16-B chunk per lane (ds_read_b128,
+// lanes 0-31 chunk c, lanes 32-63 chunk c + 1: the 16 lanes of a read group cover 16 distinct bank slots) instead of two 8-B
+// halves of two chunks (ds_read_b64 pairs where rows r and r + 16 of a lane half share their banks: 2-way on every read,
+// 1.18e7 conflict cycles per launch against 3.2e6 active LDS cycles in profiles/r01u_pmc_decode_lds.txt).
+template <int HD, bool CAUSAL, bool PSWAP = true>
 __global__ __launch_bounds__(256, 2) void attn_prefill_bf16_kernel(AttnArgs p) {
   constexpr int KVB = 64;
   constexpr int KROW = HD * 2;            // bytes per K row in LDS
@@ -259,6 +264,22 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_bf16_kernel(AttnArgs p) {
         pf[tb][r >> 3][r & 7] = f2bf(pv);
       }
     l_run = l_run * alpha + lsum;
+    if constexpr (PSWAP) {
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          u32x4 w;
+          __builtin_memcpy(&w, &pf[tb][c], 16);           // dwords: keys 16c + 4hh + {0,1 | 2,3} and 16c + 8 + 4hh + {0,1 | 2,3}
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(w[e], w[2 + e], false, false);
+            w[e] = sw[0];                                 // lanes < 32: own first quarter   | lanes >= 32: partner's third quarter
+            w[2 + e] = sw[1];                             // lanes < 32: partner's 2nd quarter | lanes >= 32: own fourth quarter
+          }
+          __builtin_memcpy(&pf[tb][c], &w, 16);           // lanes < 32: keys 16c + 0..7, lanes >= 32: keys 16c + 8..15
+        }
+    }
 #pragma unroll
     for (int d = 0; d < HD / 32; ++d)
 #pragma unroll
@@ -275,11 +296,15 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_bf16_kernel(AttnArgs p) {
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
           const int c16 = 4 * tb + 2 * c;      // 16-B chunk of kv columns {0..7}; lane half hh takes its 8-B half (k = 4hh..4hh+3)
-          const u32x2 a0 = *reinterpret_cast<const u32x2*>(vp + ((c16 ^ g) << 4));
-          const u32x2 a1 = *reinterpret_cast<const u32x2*>(vp + (((c16 + 1) ^ g) << 4));
-          const u32x4 av = {a0[0], a0[1], a1[0], a1[1]};
           bf16x8 vf;
-          __builtin_memcpy(&vf, &av, 16);
+          if constexpr (PSWAP) {               // lane half hh takes the WHOLE chunk c16 + hh (8 consecutive keys)
+            vf = *reinterpret_cast<const bf16x8*>(Vs + drow * 128 + (((c16 + hh) ^ g) << 4));
+          } else {
+            const u32x2 a0 = *reinterpret_cast<const u32x2*>(vp + ((c16 ^ g) << 4));
+            const u32x2 a1 = *reinterpret_cast<const u32x2*>(vp + (((c16 + 1) ^ g) << 4));
+            const u32x4 av = {a0[0], a0[1], a1[0], a1[1]};
+            __builtin_memcpy(&vf, &av, 16);
+          }
 #ifdef AP_NO_PV
           if (tb == 0 && c == 0)
 #endif
@@ -639,8 +664,15 @@ static int attention_impl(const void* q, const void* k, const void* vt, void* ou
   }
   dim3 grid(((Sq + 127) / 128) * H * B);
   if (hd == 128) {
-    if (causal) hipLaunchKernelGGL((attn_prefill_bf16_kernel<128, true>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((attn_prefill_bf16_kernel<128, false>), grid, dim3(256), 0, st, p);
+    const char* pe = getenv("A3V_ATTN_PSWAP");          // A3V_ATTN_PSWAP=0: the 8-B-half V^T reads (A/B runs)
+    const bool ps = !(pe && pe[0] == '0');
+    if (causal) {
+      if (ps) hipLaunchKernelGGL((attn_prefill_bf16_kernel<128, true, true>), grid, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((attn_prefill_bf16_kernel<128, true, false>), grid, dim3(256), 0, st, p);
+    } else {
+      if (ps) hipLaunchKernelGGL((attn_prefill_bf16_kernel<128, false, true>), grid, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((attn_prefill_bf16_kernel<128, false, false>), grid, dim3(256), 0, st, p);
+    }
   } else {
     if (causal) hipLaunchKernelGGL((attn_prefill_bf16_kernel<64, true>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((attn_prefill_bf16_kernel<64, false>), grid, dim3(256), 0, st, p);
