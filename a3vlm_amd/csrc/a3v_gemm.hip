@@ -52,6 +52,8 @@ struct GemmArgs {
   int M, N, K, epi;
   int tiles_m, tiles_n;
   int dbg;   // ablation switches for tuning runs (0 in production): 1 = no DMA in the k-loop, 2 = no ds_read in the k-loop
+  int skew;  // ring kernel: XCD x starts x * skew cycles late, so the eight XCDs' store bursts do not hit HBM together
+  int slow_epi;   // 1: interior tiles also take the general epilogue (A3V_GEMM_FAST_EPI=0; equality tests and A/B runs)
   int64_t c_split;   // split-K (128x128 kernel, gridDim.y slices): byte stride between the slices' output planes
   RopeKvArgs rk;     // GEMM_EPI_ROPEKV only
   const float* sa;   // GEMM_EPI_SCALE: per-row dequantisation scales of A [M] and W [N]
@@ -90,16 +92,244 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, int64_t
   }
 }
 
+// Compiler-level ordering point between the two halves of a wave-private LDS transpose (the hardware executes one wave's LDS
+// instructions in order; what has to be prevented is the compiler moving a read of one vector type across writes of another)
+#define LDS_ORDER() asm volatile("" ::: "memory")
+
+// Fast forms of the epilogue for wave tiles that lie INSIDE C (16 TM x 64 outputs, no ragged edge) and the output kinds of the
+// decoder's big linears: plain bf16, bf16 residual, fp32 residual stream, fp32 (raw or rounded, with or without accumulation),
+// SwiGLU.  Same arithmetic as the general form below, bit for bit; what differs is the cost.  The general form tests the
+// epilogue flags and both bounds per 16 x 16 tile and forms every address with a 64-bit multiply: its instruction stream for
+// one 256 x 256 tile measured 21-25 k cycles where the stores alone need 3.5 k (one CU) to 8 k (all CUs storing at once,
+// tools/ubench/stores.hip).  Here the kind is decided once per wave tile, addresses advance by a constant stride, residuals
+// are read in the layout they are stored in (whole 128 / 256-byte row segments), and every value passes through the wave's
+// private 4-KiB LDS patch so that it leaves as 16 bytes per lane.  Returns false when the tile is not eligible.
+template <int TM, int TN>
+__device__ __forceinline__ bool gemm_epilogue_fast(f32x4 (&acc)[TM][TN], const GemmArgs& p, int mbase, int nbase, int lane, char* stage) {
+  if constexpr (TN != 4 || (TM % 4) != 0) {
+    return false;
+  } else {
+    // opaque copies: everything below is recomputed per tile AFTER the k-loop instead of being hoisted out of the persistent tile
+    // loop and kept (or spilled) across the k-loop, whose 244 live VGPRs leave no room
+    int kind = p.epi & (0xffff | GEMM_EPI_RAW | GEMM_EPI_ROPEKV | GEMM_EPI_SCALE);
+    int64_t ldc_ = p.ldc, ldr_ = p.ldr;
+    uintptr_t c_ = reinterpret_cast<uintptr_t>(p.C), r_ = reinterpret_cast<uintptr_t>(p.res);
+    asm volatile("" : "+s"(kind), "+s"(ldc_), "+s"(ldr_), "+s"(c_), "+s"(r_));
+    if (!stage || p.slow_epi || mbase + TM * 16 > p.M || nbase + 64 > p.N || (c_ & 15)) return false;
+    const int mrow = lane & 15, g = lane >> 4;
+    const int pre = kind & (A3V_EPI_BIAS | A3V_EPI_GELU | A3V_EPI_QUICKGELU);     // applied in the accumulator layout, before staging
+    if (pre) kind &= ~pre;
+    if (kind == 0 || kind == A3V_EPI_RESIDUAL || kind == A3V_EPI_RES_F32) {
+      // bf16 staging: chunk = two 16-row tiles x 64 columns = 32 rows x 128 B; 8-byte slot s of row r at slot s ^ (r & 14),
+      // read back as 16-byte pairs: pair q of row r from physical pair q ^ ((r >> 1) & 7) (see the general form)
+      const bool f32 = kind == A3V_EPI_RES_F32;
+      if (f32 ? ((ldc_ & 3) || (ldr_ & 3) || (r_ & 15)) : (ldc_ & 7)) return false;       // (before anything touches the accumulators)
+      if (kind == A3V_EPI_RESIDUAL && ((ldr_ & 7) || (r_ & 15))) return false;
+      if ((pre & A3V_EPI_BIAS) && (reinterpret_cast<uintptr_t>(p.bias) & 7)) return false;
+      if (pre) {         // y = act(bf16(acc + bias)), each step rounded to bf16 as the general form does (the ViT's linears)
+        float bv[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          bf16x4 b4 = {};
+          if (pre & A3V_EPI_BIAS) b4 = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(p.bias) + nbase + j * 16 + g * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bv[j][e] = (pre & A3V_EPI_BIAS) ? bf2f(b4[e]) : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float v = rbf(acc[i][j][e] + bv[j][e]);
+              if (pre & A3V_EPI_GELU) v = rbf(gelu_erf_fast(v));
+              else if (pre & A3V_EPI_QUICKGELU) v = rbf(quick_gelu(v));
+              acc[i][j][e] = v;
+            }
+      }
+      const int l3 = lane >> 3, q = lane & 7;
+      char* const wr = stage + mrow * 128;
+      const int wx = mrow & 14;
+      const char* const rd = stage + l3 * 128;
+      const int rx = l3 >> 1;
+      auto put = [&](int ic) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = f2bf(acc[2 * ic + ii][j][e]);
+            *reinterpret_cast<bf16x4*>(wr + ii * 2048 + (((j * 4 + g) ^ wx) << 3)) = o;
+          }
+        LDS_ORDER();        // the reads below are of another vector type: keep the compiler from moving them across these writes
+      };
+      auto get = [&](int it) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(rd + it * 1024 + ((q ^ rx ^ ((it & 1) << 2)) << 4));
+        LDS_ORDER();        // ... and the next chunk's writes behind this read
+        return v;
+      };
+      if (!f32) {
+        bf16_t* cp = reinterpret_cast<bf16_t*>(c_) + (int64_t)(mbase + l3) * ldc_ + nbase + q * 8;
+        const int64_t cstep = 8 * ldc_;
+        if (kind == 0) {
+#pragma unroll
+          for (int ic = 0; ic < TM / 2; ++ic) {
+            put(ic);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) { *reinterpret_cast<bf16x8*>(cp) = get(it); cp += cstep; }
+          }
+        } else {
+          const bf16_t* rp = reinterpret_cast<const bf16_t*>(r_) + (int64_t)(mbase + l3) * ldr_ + nbase + q * 8;
+          const int64_t rstep = 8 * ldr_;
+#pragma unroll
+          for (int half = 0; half < TM / 4; ++half) {       // the loads of half a wave tile in flight at a time (32 VGPRs)
+            bf16x8 rr[2][4];
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+              for (int it = 0; it < 4; ++it) { rr[c][it] = *reinterpret_cast<const bf16x8*>(rp); rp += rstep; }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+              put(half * 2 + c);
+#pragma unroll
+              for (int it = 0; it < 4; ++it) {
+                const bf16x8 v = get(it);
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(rr[c][it][e]) + bf2f(v[e]));
+                *reinterpret_cast<bf16x8*>(cp) = o;
+                cp += cstep;
+              }
+            }
+          }
+        }
+      } else {
+        // fp32 residual stream: out = res + bf16(acc); a lane's 8 values of a row are 32 contiguous bytes of res / C
+        float* cp = reinterpret_cast<float*>(c_) + (int64_t)(mbase + l3) * ldc_ + nbase + q * 8;
+        const float* rp = reinterpret_cast<const float*>(r_) + (int64_t)(mbase + l3) * ldr_ + nbase + q * 8;
+        const int64_t cstep = 8 * ldc_, rstep = 8 * ldr_;
+#pragma unroll
+        for (int ic = 0; ic < TM / 2; ++ic) {               // one 32-row chunk's residual in flight at a time (32 VGPRs)
+          f32x4 rr[4][2];
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            rr[it][0] = *reinterpret_cast<const f32x4*>(rp);
+            rr[it][1] = *reinterpret_cast<const f32x4*>(rp + 4);
+            rp += rstep;
+          }
+          put(ic);
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const bf16x8 v = get(it);
+            f32x4 o0, o1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o0[e] = rr[it][0][e] + bf2f(v[e]); o1[e] = rr[it][1][e] + bf2f(v[4 + e]); }
+            *reinterpret_cast<f32x4*>(cp) = o0;
+            *reinterpret_cast<f32x4*>(cp + 4) = o1;
+            cp += cstep;
+          }
+        }
+      }
+      return true;
+    }
+    if (kind == (A3V_EPI_RES_F32 | GEMM_EPI_RAW) || kind == (A3V_EPI_OUT_F32 | GEMM_EPI_RAW) || kind == A3V_EPI_OUT_F32) {
+      // fp32 staging: chunk = one 16-row tile x 64 columns = 16 rows x 256 B, 16-byte slot s of row r at slot s ^ r
+      const bool accum = (kind & A3V_EPI_RES_F32) != 0, raw = (kind & GEMM_EPI_RAW) != 0;
+      if ((ldc_ & 3) || (accum && ((ldr_ & 3) || (r_ & 15)))) return false;
+      const int q = lane & 15;
+      char* const wr = stage + mrow * 256;
+      const char* const rd = stage + g * 256;
+      float* cp = reinterpret_cast<float*>(c_) + (int64_t)(mbase + g) * ldc_ + nbase + q * 4;
+      const float* rp = accum ? reinterpret_cast<const float*>(r_) + (int64_t)(mbase + g) * ldr_ + nbase + q * 4 : nullptr;
+      const int64_t cstep = 4 * ldc_, rstep = 4 * ldr_;
+#pragma unroll
+      for (int half = 0; half < TM / 2; ++half) {           // two 16-row tiles' worth of the accumulated-into rows in flight (32 VGPRs)
+        f32x4 rr[2][4];
+        if (accum) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int it = 0; it < 4; ++it) { rr[i][it] = *reinterpret_cast<const f32x4*>(rp); rp += rstep; }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            f32x4 v = acc[half * 2 + i][j];
+            if (!raw) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = rbf(v[e]);
+            }
+            *reinterpret_cast<f32x4*>(wr + (((j * 4 + g) ^ mrow) << 4)) = v;
+          }
+          LDS_ORDER();
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(rd + it * 1024 + ((q ^ (it * 4 + g)) << 4));
+            LDS_ORDER();
+            if (accum) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = rr[i][it][e] + v[e];
+            }
+            *reinterpret_cast<f32x4*>(cp) = v;
+            cp += cstep;
+          }
+        }
+      }
+      return true;
+    }
+    if (kind == A3V_EPI_SWIGLU) {
+      // 64 interleaved columns -> 32 output columns = 64 B per row.  chunk = four 16-row tiles = 64 rows x 64 B; 8-byte slot
+      // s = 4 jp + g of row r at slot s ^ (((r >> 2) & 3) << 1) (rows r, r+4, r+8, r+12 share banks: the XOR separates them and keeps
+      // 16-byte pairs together); read back as pairs, 16 rows x 64 B per store instruction
+      if (ldc_ & 7) return false;
+      const int rr_ = lane >> 2, qq = lane & 3;
+      char* const wr = stage + mrow * 64;
+      const int wx = ((mrow >> 2) & 3) << 1;
+      const char* const rd = stage + rr_ * 64 + ((qq ^ ((rr_ >> 2) & 3)) << 4);
+      bf16_t* cp = reinterpret_cast<bf16_t*>(c_) + (int64_t)(mbase + rr_) * ldc_ + (nbase >> 1) + qq * 8;
+      const int64_t cstep = 16 * ldc_;
+#pragma unroll
+      for (int ic = 0; ic < TM / 4; ++ic) {
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+          for (int jp = 0; jp < 2; ++jp) {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float gt = rbf(acc[4 * ic + ii][2 * jp][e]);
+              const float up = rbf(acc[4 * ic + ii][2 * jp + 1][e]);
+              o[e] = f2bf(rbf(silu(gt)) * up);
+            }
+            *reinterpret_cast<bf16x4*>(wr + ii * 1024 + (((jp * 4 + g) ^ wx) << 3)) = o;
+          }
+        LDS_ORDER();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const bf16x8 v = *reinterpret_cast<const bf16x8*>(rd + it * 1024);
+          LDS_ORDER();
+          *reinterpret_cast<bf16x8*>(cp) = v;
+          cp += cstep;
+        }
+      }
+      return true;
+    }
+    return false;
+  }
+}
+
 // Epilogue shared by the tile kernels.  The lane holds, for each (i, j) MFMA tile,
 // C[m = mbase + 16 i + (lane&15)][n = nbase + 16 j + 4 (lane>>4) + 0..3].
-// `stage`: optional wave-private 4-KiB LDS scratch (32 rows x 128 B).  With it, bf16 row-major outputs leave the wave as whole
-// 128-byte rows (16 B per lane, 8 rows per store instruction) instead of 8 B per lane scattered over 16 rows: the accumulator
-// layout gives every lane 4 consecutive n of ONE row, so the direct form writes each 128-B line of C in four separate
-// 32-B pieces from four instructions -- measured 31-33 k cycles per 256x256 tile (15 % of a K = 4096 tile, half of a K = 1024
-// one) against ~8 k through the LDS transpose.
+// `stage`: optional wave-private 4-KiB LDS scratch for gemm_epilogue_fast (tiles inside C, the common output kinds); everything
+// else takes the general form below, whose stores are 8 bytes per lane scattered over 16 rows.
 template <int TM, int TN, bool F8 = false>
 __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GemmArgs& p, int mbase, int nbase, int lane, char* stage = nullptr) {
   // ---- epilogue: lane holds C[m][n..n+3], m = .. + (lane&15), n = .. + (lane>>4)*4 ----
+  if constexpr (!F8) {
+    if (gemm_epilogue_fast<TM, TN>(acc, p, mbase, nbase, lane, stage)) return;
+  }
   const int epi = p.epi;
   const int mrow = lane & 15;
   const int ncol = (lane >> 4) * 4;
@@ -216,57 +446,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GemmAr
       }
     }
   }
-  // Phase 2 -- stores only
-  if (TN == 4 && TM % 2 == 0 && stage && !(epi & (GEMM_EPI_ROPEKV | A3V_EPI_RES_F32 | A3V_EPI_OUT_F32)) && !(p.ldc & 7) && !(p.N & 7) &&
-      !(reinterpret_cast<uintptr_t>(p.C) & 15)) {
-    // chunk = two 16-row tiles x 64 columns of bf16 = 32 rows x 128 B.  8-byte slot s of row r sits at slot s ^ (r & 14): the 16
-    // lanes of a ds_write_b64 group (16 rows, one slot) spread over the banks (2-way at worst), and the pair structure survives,
-    // so a lane reads back 16 contiguous bytes: pair q of row r from physical pair q ^ ((r >> 1) & 7) (conflict-free b128 reads).
-    bf16_t* const Cb = reinterpret_cast<bf16_t*>(p.C);
-#pragma unroll
-    for (int ic = 0; ic < TM / 2; ++ic) {
-#pragma unroll
-      for (int ii = 0; ii < 2; ++ii) {
-        const int r = ii * 16 + mrow;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          bf16x4 o;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) o[q] = f2bf(acc[2 * ic + ii][j][q]);
-          *reinterpret_cast<bf16x4*>(stage + r * 128 + (((j * 4 + (lane >> 4)) ^ (r & 14)) << 3)) = o;
-        }
-      }
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int r = it * 8 + (lane >> 3), q = lane & 7;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(stage + r * 128 + ((q ^ ((r >> 1) & 7)) << 4));
-        const int m = mbase + ic * 32 + r, n = nbase + q * 8;
-        if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(Cb + (int64_t)m * p.ldc + n) = v;
-      }
-    }
-    return;
-  }
-  if (TN == 4 && stage && (epi & (A3V_EPI_RES_F32 | A3V_EPI_OUT_F32)) && !(epi & GEMM_EPI_ROPEKV) && !(p.ldc & 3) && !(p.N & 3) &&
-      !(reinterpret_cast<uintptr_t>(p.C) & 15)) {
-    // fp32 outputs (weight gradients, fp32 residual stream): chunk = one 16-row tile x 64 columns = 16 rows x 256 B; the lane's
-    // 16-B slot s of row r sits at slot s ^ r (conflict-free for the 8-lane ds_write_b128 groups and for the row-contiguous reads);
-    // read back 4 rows x 256 B per instruction, stored as whole 256-B row segments.
-    float* const Cf = reinterpret_cast<float*>(p.C);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        *reinterpret_cast<f32x4*>(stage + mrow * 256 + (((j * 4 + (lane >> 4)) ^ mrow) << 4)) = acc[i][j];
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int r = it * 4 + (lane >> 4), q = lane & 15;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(stage + r * 256 + ((q ^ r) << 4));
-        const int m = mbase + i * 16 + r, n = nbase + q * 4;
-        if (m < p.M && n < p.N) *reinterpret_cast<f32x4*>(Cf + (int64_t)m * p.ldc + n) = v;
-      }
-    }
-    return;
-  }
+  // Phase 2 -- stores only (ragged tiles and the rarer output kinds: 8 bytes per lane straight from the accumulator layout)
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int m = mbase + i * 16 + mrow;
@@ -831,6 +1011,10 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
     }
   };
   prologue();
+  if (p.skew > 0 && (blockIdx.x & 7)) {                 // persistent blocks: blockIdx & 7 = XCD; the delay persists over the tile walk
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), d = (unsigned long long)(blockIdx.x & 7) * (unsigned)p.skew;
+    while (__builtin_amdgcn_s_memtime() - t0 < d) __builtin_amdgcn_s_sleep(16);
+  }
 
   // fragments.  16x16x32: lane -> row (lane&15), 16-B slots (lane>>4) and 4 + (lane>>4) of the 64-k row (two MFMAs per tile);
   // 32x32x16: lane -> row (lane&31), slots 2 kk + (lane>>5), kk = 0..3 (four MFMAs per tile).  24 ds_read_b128 either way.
@@ -904,9 +1088,15 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
         RG_READ_FRAGS(lds + ATOP + (t & 1) * AH, lds + WB + wcur * WT);
         A3V_WAIT_LGKM0();
         RG_STAMP(t, 1);
-        if (t + 2 < nk) RG_VMCNT(12);
-        else if (t + 2 == nk) RG_VMCNT(8);
-        else RG_VMCNT(0);
+        if constexpr (EARLY < 0) {                       // variant: W(t+1) is waited for HERE (one interval earlier), so nothing stands
+          if (t + 2 < nk) RG_VMCNT(8);                   // between this group's last MFMA and the barrier that releases the other group
+          else if (t + 2 == nk) RG_VMCNT(4);
+          else RG_VMCNT(0);
+        } else {
+          if (t + 2 < nk) RG_VMCNT(12);
+          else if (t + 2 == nk) RG_VMCNT(8);
+          else RG_VMCNT(0);
+        }
         RG_STAMP(t, 2);
         A3V_BARRIER();
         RG_STAMP(t, 3);
@@ -914,9 +1104,11 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
         RG_MFMA_PART(false);
         __builtin_amdgcn_s_setprio(0);                 // never wait (vmcnt / barrier) at raised priority: measured -20 %
         RG_STAMP(t, 4);
-        if (t + 2 < nk) RG_VMCNT(8);
-        else if (t + 2 == nk) RG_VMCNT(4);
-        else RG_VMCNT(0);
+        if constexpr (EARLY >= 0) {
+          if (t + 2 < nk) RG_VMCNT(8);
+          else if (t + 2 == nk) RG_VMCNT(4);
+          else RG_VMCNT(0);
+        }
         RG_STAMP(t, 5);
         if constexpr (EARLY > 0) __builtin_amdgcn_sched_barrier(0);   // keep the tail MFMAs behind the barrier, the others before it
         A3V_BARRIER();
@@ -2039,8 +2231,15 @@ static bool pp_ring() {       // the 160-KiB ring form of the ping-pong kernel (
   return !(e && e[0] == '0');
 }
 
+static int slow_epi_env() {    // A3V_GEMM_FAST_EPI=0: every tile through the general epilogue (read per launch)
+  const char* e = getenv("A3V_GEMM_FAST_EPI");
+  return (e && e[0] == '0') ? 1 : 0;
+}
+
 template <bool A_ROWS>
-static void launch_tn(dim3 grid, hipStream_t st, const GemmArgs& q) {
+static void launch_tn(dim3 grid, hipStream_t st, const GemmArgs& q0) {
+  GemmArgs q = q0;
+  q.slow_epi = slow_epi_env();
   hipLaunchKernelGGL(gemm_tn_bf16_pp_kernel<A_ROWS>, grid, dim3(512), 0, st, q);
 }
 
@@ -2067,7 +2266,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
   if (K % BK || lda % 8 || ldw % 8 || N % 4 || ldc % 4) return A3V_ERR_SHAPE;
   if ((epilogue & A3V_EPI_SWIGLU) && (N % 32)) return A3V_ERR_SHAPE;
   if ((epilogue & (A3V_EPI_RESIDUAL | A3V_EPI_RES_F32)) && (ldr % 4)) return A3V_ERR_SHAPE;
-  GemmArgs p;
+  GemmArgs p{};
   p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.C = C; p.bias = bias; p.res = residual;
   p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr;
   p.M = M; p.N = N; p.K = K; p.epi = epilogue & 0xffff;
@@ -2080,6 +2279,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
   // rows, and every problem the big tile would quantise badly, go to the 128x128 kernel (4 waves,
   // 2 blocks/CU).  A3V_EPI_TILE_* force one configuration for the whole problem (tuning / tests).
   auto launch = [&](int cfg, GemmArgs q) {
+    q.slow_epi = slow_epi_env();
     if (cfg == 128) {
       q.tiles_m = (q.M + 127) / 128; q.tiles_n = (q.N + 127) / 128;
       hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 128, 2, 2>), dim3(q.tiles_m * q.tiles_n), dim3(256), 0, st, q);
@@ -2094,10 +2294,13 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
     else {
       int dbg = q.dbg;
       if (dbg == 0 && pp_ring()) dbg = 5;
+      { const char* e = getenv("A3V_GEMM_SKEW"); q.skew = e ? atoi(e) : 0; }
       switch (dbg) {
         case 0: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<0, 0>), g, b, 0, st, q); break;
         case 5: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0>), g, b, 0, st, q); break;
         case 11: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0, false>), g, b, 0, st, q); break;   // ring, direct (unstaged) epilogue stores
+        case 12: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, -1>), g, b, 0, st, q); break;   // ring, group 0 waits for its W half at the end of L
+        case 13: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<4, false, -1>), g, b, 0, st, q); break;   // ... with cycle stamps
         case 7: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<0, 0>), g, b, 0, st, q); break;   // two-stage kernel, for A/B runs
         case 9: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, true, 0>), g, b, 0, st, q); break;   // ring, 32x32x16 MFMA
         case 10: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<4, true, 0>), g, b, 0, st, q); break;   // 32x32x16, stamps
@@ -2164,6 +2367,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
         t.epi = A3V_EPI_OUT_F32 | GEMM_EPI_RAW;
         t.tiles_m = (t.M + 127) / 128; t.tiles_n = (N + 127) / 128;
         t.c_split = (int64_t)t.M * N * 4;
+        t.slow_epi = slow_epi_env();
         hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 128, 2, 2>), dim3(t.tiles_m * t.tiles_n, S), dim3(256), 0, st, t);
         const int64_t n4 = (int64_t)r.M * (N / 4);
         const int rb = (int)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256);
@@ -2391,6 +2595,7 @@ extern "C" int a3v_gemm_nt_splitk(const void* A, int64_t lda, const void* W, int
     return A3V_OK;
   }
   p.tiles_m = (M + 127) / 128; p.tiles_n = (N + 127) / 128;
+  p.slow_epi = slow_epi_env();
   hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 128, 2, 2>), dim3(p.tiles_m * p.tiles_n, S), dim3(256), 0, (hipStream_t)stream, p);
   A3V_LAUNCH_CHECK();
   return A3V_OK;

@@ -677,3 +677,91 @@ def test_gemm_tn_split_tail(M, N, K, mode):
         out = torch.empty(M, N, dtype=BF, device=DEV)
         ops.gemm_tn(at, wt, out)
         assert float((out.float() - want).abs().max()) <= 2 ** -7 * scale
+
+
+# ------------------------------------------------------------------ epilogue forms
+def _with_general_epilogue(fn):
+    """fn() once with the interior-tile fast epilogues and once with A3V_GEMM_FAST_EPI=0 (every tile through the general form)."""
+    import os
+    outs = []
+    for flag in ("1", "0"):
+        os.environ["A3V_GEMM_FAST_EPI"] = flag
+        try:
+            outs.append(fn())
+        finally:
+            os.environ["A3V_GEMM_FAST_EPI"] = "1"
+    return outs
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 776, 256), (2048, 1024, 512), (300, 264, 128)])
+@pytest.mark.parametrize("tile", ["auto", "pp", "t128"])
+def test_gemm_fast_epilogue_forms_equal_general_form(M, N, K, tile):
+    """The LDS-staged epilogues of tiles inside C (plain / bias+activation / bf16 residual / fp32 residual stream / fp32 output /
+    SwiGLU) are bit-identical to the general per-lane epilogue, on shapes that mix interior and ragged tiles."""
+    from a3vlm_amd import lib
+    t = {"auto": 0, "pp": lib.EPI_TILE_256PP, "t128": lib.EPI_TILE_128}[tile]
+    a, w = gen(M, K, seed=70).to(BF).to(DEV), gen(N, K, seed=71, scale=0.05).to(BF).to(DEV)
+    bias, res, resf = gen(N, seed=72).to(BF).to(DEV), gen(M, N, seed=73).to(BF).to(DEV), gen(M, N, seed=74).to(DEV)
+
+    def run(kind):
+        def f():
+            if kind == "swiglu":
+                o = torch.full((M, N // 2), 3.0, dtype=BF, device=DEV)
+                return ops.gemm_nt(a, w, o, epilogue=t | ops.EPI_SWIGLU)
+            if kind in ("res_f32", "out_f32"):
+                o = resf.clone() if kind == "res_f32" else torch.full((M, N), 3.0, device=DEV)
+                return ops.gemm_nt(a, w, o, residual=o if kind == "res_f32" else None,
+                                   epilogue=t | (ops.EPI_RES_F32 if kind == "res_f32" else ops.EPI_OUT_F32))
+            o = res.clone() if "residual" in kind else torch.full((M, N), 3.0, dtype=BF, device=DEV)
+            return ops.gemm_nt(a, w, o, bias=bias if "bias" in kind else None, residual=o if "residual" in kind else None,
+                               epilogue=t | (ops.EPI_GELU if "gelu" in kind else 0) | (ops.EPI_QUICKGELU if "quick" in kind else 0))
+        return f
+    kinds = ["plain", "bias", "bias_gelu", "bias_quick", "residual", "bias_residual", "res_f32", "out_f32"] + (["swiglu"] if N % 32 == 0 else [])
+    for kind in kinds:
+        fast, general = _with_general_epilogue(run(kind))
+        assert torch.equal(fast, general), kind
+
+
+def test_gemm_ring_ragged_rows_over_several_tiles_per_block():
+    """Persistent ring kernel on a shape with more tiles than CUs AND a ragged last tile row (M = 8728 = 34 x 256 + 24): blocks
+    walk interior tiles (fast epilogue) and edge tiles (general epilogue, divergent lanes) in one launch.  An earlier build of the
+    staged epilogues spilled ~100 dwords per lane in this kernel and produced wrong tiles exactly here; the bench shapes never
+    showed it because the hybrid dispatch sends the ragged rows to the 128x128 kernel."""
+    from a3vlm_amd import lib
+    for (M, N, K) in [(8728, 4096, 1024), (8728, 3072, 256)]:
+        a, w = gen(M, K, seed=80).to(BF).to(DEV), gen(N, K, seed=81, scale=0.05).to(BF).to(DEV)
+        want = a.float() @ w.float().t()
+        for dbg in (0, 7):                                          # ring (default) and the two-stage kernel
+            o = torch.full((M, N), 3.0, dtype=BF, device=DEV)
+            ops.gemm_nt(a, w, o, epilogue=lib.EPI_TILE_256PP | (dbg << 24))
+            assert_close(o, want, rtol=2 ** -7, atol=1e-3 * math.sqrt(K) * 0.05, what=f"ring ragged {M}x{N}x{K} dbg {dbg}")
+        r = gen(M, N, seed=82).to(DEV)
+        o = r.clone()
+        ops.gemm_nt(a, w, o, residual=o, epilogue=lib.EPI_TILE_256PP | ops.EPI_RES_F32)
+        assert_close(o, r.cpu() + rt(want.cpu()), rtol=2 ** -7, atol=0.04, what="ring ragged res_f32")   # 1 bf16 ulp of the product at |y| < 8
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 768, 1000), (4352, 2048, 1024), (520, 264, 512)])
+def test_gemm_tn_nn_fast_epilogue_forms_equal_general_form(M, N, K):
+    at, wt = gen(K, M, seed=90).to(BF).to(DEV), gen(K, N, seed=91, scale=0.05).to(BF).to(DEV)
+    a = gen(M, K, seed=92).to(BF).to(DEV)
+    accf = gen(M, N, seed=93).to(DEV)
+
+    def tn(dtype, acc):
+        def f():
+            o = accf.clone() if acc else torch.zeros(M, N, dtype=dtype, device=DEV)
+            ops.gemm_tn(at, wt, o, residual=o if acc else None,
+                        epilogue=ops.EPI_RES_F32 if acc else (ops.EPI_OUT_F32 if dtype == torch.float32 else 0))
+            return o
+        return f
+
+    def nn(dtype):
+        def f():
+            o = torch.zeros(M, N, dtype=dtype, device=DEV)
+            ops.gemm_nn(a, wt, o, epilogue=ops.EPI_OUT_F32 if dtype == torch.float32 else 0)
+            return o
+        return f
+    cases = [tn(BF, False), tn(torch.float32, False), tn(torch.float32, True)] + ([nn(BF), nn(torch.float32)] if K % 64 == 0 else [])
+    for f in cases:
+        fast, general = _with_general_epilogue(f)
+        assert torch.equal(fast, general)

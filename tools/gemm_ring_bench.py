@@ -2,7 +2,8 @@
 """A/B of the two-stage ping-pong GEMM (dbg 7) against its 160-KiB ring forms: bit equality on ragged / short-K shapes,
 then interleaved timing rounds in ONE process on the bench step's shapes (guide rules 24, 25: random data).
   dbg 5  ring, epilogue stores staged through LDS (whole 128-B rows)      dbg 11  ring, direct 8-B-per-lane epilogue stores
-  dbg 9  ring on v_mfma_f32_32x32x16_bf16 (direct stores)"""
+  dbg 9  ring on v_mfma_f32_32x32x16_bf16 (direct stores)      dbg 12  ring, group 0 waits for its W half at the end of L
+A3V_GEMM_SKEW=<cycles> (env, read per launch): XCD x starts x * cycles late."""
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,7 +11,7 @@ from a3vlm_amd import ops, lib
 
 dev = "cuda"
 T = lib.EPI_TILE_256PP
-VARIANTS = {"pp": 7, "ring": 5, "ring_direct": 11, "ring32": 9}
+VARIANTS = {"pp": 7, "ring": 5, "ring_direct": 11, "ring32": 9, "ring_lw": 12}
 if len(sys.argv) > 1:
     VARIANTS = {k: v for k, v in VARIANTS.items() if k in sys.argv[1].split(",") or k == "pp"}
 flag = {k: T | (v << 24) for k, v in VARIANTS.items()}

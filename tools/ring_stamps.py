@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from a3vlm_amd import lib, ops
 DBG = int(sys.argv[1]) if len(sys.argv) > 1 else 6
-shapes = [(8192, 8192, 8192, 0), (8728, 22016, 4096, ops.EPI_SWIGLU), (8728, 22016, 4096, 0), (8728, 4096, 11008, 0), (4616, 4096, 1024, 0)]
+shapes = [(1024, 2048, 8192, 0), (1024, 2048, 4096, 0), (8192, 8192, 8192, 0), (8728, 22016, 4096, ops.EPI_SWIGLU), (8728, 22016, 4096, 0), (8728, 4096, 11008, 0), (4616, 4096, 1024, 0)]
 for (M, N, K, epi) in shapes:
     a = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
     w = torch.randn(N, K, device="cuda", dtype=torch.bfloat16) * 0.02
