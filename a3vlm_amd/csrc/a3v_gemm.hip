@@ -104,7 +104,12 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, int64_t
 // tools/ubench/stores.hip).  Here the kind is decided once per wave tile, addresses advance by a constant stride, residuals
 // are read in the layout they are stored in (whole 128 / 256-byte row segments), and every value passes through the wave's
 // private 4-KiB LDS patch so that it leaves as 16 bytes per lane.  Returns false when the tile is not eligible.
-template <int TM, int TN>
+// SET selects which forms an instantiation carries: EPI_SET_COMMON the kinds of the decoder's linears, EPI_SET_PRE additionally
+// bias / activation in front of them (the ViT), EPI_SET_ROPE the fused-qkv form alone.  The 256x256 kernels hold 128 accumulator
+// registers and ~110 more across the k-loop; compiled together, the forms' peak pushed the k-loop's invariants into scratch
+// (100 dwords per lane, 5-20 % of every kind's speed), so each big-tile kernel is instantiated per set and picked by the host.
+constexpr int EPI_SET_COMMON = 1, EPI_SET_PRE = 2, EPI_SET_ROPE = 4;
+template <int TM, int TN, int SET>
 __device__ __forceinline__ bool gemm_epilogue_fast(f32x4 (&acc)[TM][TN], const GemmArgs& p, int mbase, int nbase, int lane, char* stage) {
   if constexpr (TN != 4 || (TM % 4) != 0) {
     return false;
@@ -117,8 +122,9 @@ __device__ __forceinline__ bool gemm_epilogue_fast(f32x4 (&acc)[TM][TN], const G
     asm volatile("" : "+s"(kind), "+s"(ldc_), "+s"(ldr_), "+s"(c_), "+s"(r_));
     if (!stage || p.slow_epi || mbase + TM * 16 > p.M || nbase + 64 > p.N || (c_ & 15)) return false;
     const int mrow = lane & 15, g = lane >> 4;
-    const int pre = kind & (A3V_EPI_BIAS | A3V_EPI_GELU | A3V_EPI_QUICKGELU);     // applied in the accumulator layout, before staging
+    const int pre = (SET & EPI_SET_PRE) ? kind & (A3V_EPI_BIAS | A3V_EPI_GELU | A3V_EPI_QUICKGELU) : 0;   // applied in the accumulator layout
     if (pre) kind &= ~pre;
+    if constexpr ((SET & EPI_SET_COMMON) != 0) {
     if (kind == 0 || kind == A3V_EPI_RESIDUAL || kind == A3V_EPI_RES_F32) {
       // bf16 staging: chunk = two 16-row tiles x 64 columns = 32 rows x 128 B; 8-byte slot s of row r at slot s ^ (r & 14),
       // read back as 16-byte pairs: pair q of row r from physical pair q ^ ((r >> 1) & 7) (see the general form)
@@ -126,6 +132,7 @@ __device__ __forceinline__ bool gemm_epilogue_fast(f32x4 (&acc)[TM][TN], const G
       if (f32 ? ((ldc_ & 3) || (ldr_ & 3) || (r_ & 15)) : (ldc_ & 7)) return false;       // (before anything touches the accumulators)
       if (kind == A3V_EPI_RESIDUAL && ((ldr_ & 7) || (r_ & 15))) return false;
       if ((pre & A3V_EPI_BIAS) && (reinterpret_cast<uintptr_t>(p.bias) & 7)) return false;
+      if constexpr ((SET & EPI_SET_PRE) != 0)
       if (pre) {         // y = act(bf16(acc + bias)), each step rounded to bf16 as the general form does (the ViT's linears)
         float bv[4][4];
 #pragma unroll
@@ -316,6 +323,153 @@ __device__ __forceinline__ bool gemm_epilogue_fast(f32x4 (&acc)[TM][TN], const G
       }
       return true;
     }
+    }
+    if constexpr ((SET & EPI_SET_ROPE) != 0) {
+    if (kind == GEMM_EPI_ROPEKV && !pre) {
+      // Fused qkv epilogue.  The wave's 64 columns lie inside ONE head slot (hd >= 64), so the whole wave tile is q, k or v.
+      //   q, k : rotated in the accumulator layout (cos / sin rows read there), then through the bf16 transpose: q as whole
+      //          128-byte row segments of q_out, k as 128-byte segments of the token's K-cache row;
+      //   v    : token-major rows of v_rows (training) through the same transpose, and the V^T cache through a TRANSPOSING
+      //          stage ([64 d][32 tokens]): 16-byte stores of 8 consecutive tokens of one d (2-byte aligned: legal here,
+      //          tools/ubench/unaligned.hip) instead of one 2-byte store per element.
+      const RopeKvArgs& k = p.rk;
+      const int hd = 1 << k.hd_shift;
+      if (k.hd_shift < 6 || k.S < 32 || (k.ldq & 7) || (reinterpret_cast<uintptr_t>(k.q_out) & 15) || (reinterpret_cast<uintptr_t>(k.k_cache) & 15) ||
+          (k.v_rows && ((k.ldv & 7) || (reinterpret_cast<uintptr_t>(k.v_rows) & 15))))
+        return false;
+      int slot = nbase >> k.hd_shift, d0 = nbase & (hd - 1), mg0 = mbase + k.m_off, S_ = k.S;
+      asm volatile("" : "+s"(slot), "+s"(d0), "+s"(mg0), "+s"(S_));
+      const int l3 = lane >> 3, q = lane & 7;
+      if (slot < k.H + k.Hkv) {
+        int sq = (mg0 + mrow) % S_;                        // token position of this lane's row in tile i = 0; +16 per tile
+        const float* csb = k.cos_sin + ((d0 + g * 4) >> 1) * 2;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          asm volatile("" : "+v"(sq));                    // address chains stay next to their use (computed ahead, they spill)
+          const float* csr = csb + (((int64_t)(k.rope_pos0 + sq)) << k.hd_shift);      // (pos << (hd_shift - 1)) * 2 floats
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const f32x4 cs = *reinterpret_cast<const f32x4*>(csr + j * 16);
+            const float v0 = rbf(acc[i][j][0]), v1 = rbf(acc[i][j][1]), v2 = rbf(acc[i][j][2]), v3 = rbf(acc[i][j][3]);
+            acc[i][j][0] = v0 * cs[0] - v1 * cs[1];
+            acc[i][j][1] = v0 * cs[1] + v1 * cs[0];
+            acc[i][j][2] = v2 * cs[2] - v3 * cs[3];
+            acc[i][j][3] = v2 * cs[3] + v3 * cs[2];
+          }
+          sq += 16;
+          if (sq >= S_) sq -= S_;
+          __builtin_amdgcn_sched_barrier(0);         // one tile's cos / sin rows in flight at a time (the scheduler would hoist all 32 loads)
+        }
+      }
+      bf16x4 pk[TM][4];                                    // the tile as packed bf16: half the registers for the store phase
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pk[i][j][e] = f2bf(acc[i][j][e]);
+          asm volatile("" : "+v"(pk[i][j]));
+        }
+      char* const wr = stage + mrow * 128;
+      const int wx = mrow & 14;
+      const char* const rd = stage + l3 * 128;
+      const int rx = l3 >> 1;
+      auto put = [&](int ic) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) *reinterpret_cast<bf16x4*>(wr + ii * 2048 + (((j * 4 + g) ^ wx) << 3)) = pk[2 * ic + ii][j];
+        LDS_ORDER();
+      };
+      auto get = [&](int it) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(rd + it * 1024 + ((q ^ rx ^ ((it & 1) << 2)) << 4));
+        LDS_ORDER();
+        return v;
+      };
+      if (slot < k.H || (slot >= k.H + k.Hkv && k.v_rows)) {
+        const bool isq = slot < k.H;
+        const int64_t ld = isq ? k.ldq : k.ldv;
+        bf16_t* cp = (isq ? k.q_out + nbase : k.v_rows + (nbase - ((k.H + k.Hkv) << k.hd_shift))) + (int64_t)(mg0 + l3) * ld + q * 8;
+        const int64_t cstep = 8 * ld;
+#pragma unroll
+        for (int ic = 0; ic < TM / 2; ++ic) {
+          put(ic);
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            asm volatile("" : "+v"(cp));
+            *reinterpret_cast<bf16x8*>(cp) = get(it);
+            cp += cstep;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (isq) return true;
+      } else if (slot < k.H + k.Hkv) {
+        int b = (mg0 + l3) / S_, sq = (mg0 + l3) - b * S_;
+        bf16_t* const kb = k.k_cache + d0 + q * 8;
+        const int hk = slot - k.H;
+#pragma unroll
+        for (int ic = 0; ic < TM / 2; ++ic) {
+          put(ic);
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            asm volatile("" : "+v"(sq), "+v"(b));
+            *reinterpret_cast<bf16x8*>(kb + ((((int64_t)b * k.Hkv + hk) * k.Smax + k.start_pos + sq) << k.hd_shift)) = get(it);
+            sq += 8;
+            if (sq >= S_) { sq -= S_; ++b; }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        return true;
+      }
+      // V^T cache: [64 d][32 tokens] bf16 per chunk; the 16-byte token group c of row d sits at group c ^ ((d >> 2) & 3)
+      {
+        const int hv = slot - k.H - k.Hkv;
+        int b0 = mg0 / S_, sq0 = mg0 - b0 * S_;             // first token of the chunk (wave-uniform)
+        const int dr = lane >> 2, c = lane & 3;
+#pragma unroll
+        for (int ic = 0; ic < TM / 2; ++ic) {
+          asm volatile("" : "+s"(sq0), "+s"(b0));
+          if (sq0 + 32 <= S_) {
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  *reinterpret_cast<bf16_t*>(stage + (j * 16 + g * 4 + e) * 64 + (((ii * 2 + (mrow >> 3)) ^ g) << 4) + (mrow & 7) * 2) =
+                      pk[2 * ic + ii][j][e];
+            LDS_ORDER();
+            bf16_t* const vb = k.vt_cache + ((((int64_t)b0 * k.Hkv + hv) << k.hd_shift) + d0) * k.Smax + k.start_pos + sq0 + c * 8;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+              const int d = it * 16 + dr;
+              const bf16x8 v = *reinterpret_cast<const bf16x8*>(stage + d * 64 + ((c ^ ((d >> 2) & 3)) << 4));
+              LDS_ORDER();
+              bf16_t* const dst = vb + (int64_t)d * k.Smax;               // 2-byte-aligned 16-byte store: the compiler would split it
+              asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(v) : "memory");
+            }
+          } else {
+            // the chunk's 32 tokens straddle two batch elements: element-wise, as the general form does
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+              const int t = sq0 + ii * 16 + mrow;
+              const int bb = t >= S_ ? b0 + 1 : b0, ss = t >= S_ ? t - S_ : t;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                bf16_t* dst = k.vt_cache + ((((int64_t)bb * k.Hkv + hv) << k.hd_shift) + d0 + j * 16 + g * 4) * k.Smax + k.start_pos + ss;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dst[(int64_t)e * k.Smax] = pk[2 * ic + ii][j][e];
+              }
+            }
+          }
+          sq0 += 32;
+          if (sq0 >= S_) { sq0 -= S_; ++b0; }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      return true;
+    }
+    }
     return false;
   }
 }
@@ -324,11 +478,11 @@ __device__ __forceinline__ bool gemm_epilogue_fast(f32x4 (&acc)[TM][TN], const G
 // C[m = mbase + 16 i + (lane&15)][n = nbase + 16 j + 4 (lane>>4) + 0..3].
 // `stage`: optional wave-private 4-KiB LDS scratch for gemm_epilogue_fast (tiles inside C, the common output kinds); everything
 // else takes the general form below, whose stores are 8 bytes per lane scattered over 16 rows.
-template <int TM, int TN, bool F8 = false>
+template <int TM, int TN, bool F8 = false, int SET = EPI_SET_COMMON>
 __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GemmArgs& p, int mbase, int nbase, int lane, char* stage = nullptr) {
   // ---- epilogue: lane holds C[m][n..n+3], m = .. + (lane&15), n = .. + (lane>>4)*4 ----
   if constexpr (!F8) {
-    if (gemm_epilogue_fast<TM, TN>(acc, p, mbase, nbase, lane, stage)) return;
+    if (gemm_epilogue_fast<TM, TN, SET>(acc, p, mbase, nbase, lane, stage)) return;
   }
   const int epi = p.epi;
   const int mrow = lane & 15;
@@ -571,7 +725,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_bf16_kernel(Ge
   }
 
   // the loop's last __syncthreads() is behind every read of the stage buffers: a private 4 KiB per wave for whole-row stores
-  gemm_epilogue<TM, TN>(acc, p, m0 + wm * WTM, n0 + wn * WTN, lane, nk > 0 ? lds + wave * 4096 : nullptr);
+  gemm_epilogue<TM, TN, false, (TM > 4 ? EPI_SET_COMMON : EPI_SET_COMMON | EPI_SET_PRE)>(acc, p, m0 + wm * WTM, n0 + wn * WTN, lane, nk > 0 ? lds + wave * 4096 : nullptr);
 }
 
 // Epilogue for v_mfma_f32_32x32x16 accumulators (D = W_frag x A_frag): for tile (i, j) the lane holds
@@ -943,7 +1097,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_pp_kernel(GemmArgs p) {
 // EARLY: the barrier that ends an MFMA interval is executed EARLY tile-rows before the interval's last MFMA.  Nothing after it
 // needs the barrier (the tail MFMAs read registers only), and the partner wave on the SIMD -- released by the same barrier --
 // starts its own MFMA stream while this wave is still feeding the pipe: no matrix-pipe bubble at the hand-over.
-template <int DBG, bool M32, int EARLY, bool STAGED = true>   // M32: v_mfma_f32_32x32x16_bf16 (4x2 tiles per wave) instead of 16x16x32 (8x4)
+template <int DBG, bool M32, int EARLY, bool STAGED = true, int SET = EPI_SET_COMMON>   // SET: which fast epilogue forms (gemm_epilogue_fast); M32: v_mfma_f32_32x32x16_bf16 (4x2 tiles per wave) instead of 16x16x32 (8x4)
 __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
   constexpr int TBM = 256, TBN = 256, WTM = 128, WTN = 64, TM = M32 ? 4 : 8, TN = M32 ? 2 : 4;
   constexpr int AH = 128 * BK * 2;                      // 16 KiB: one group's half of an A K-tile
@@ -1170,7 +1324,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
       int lane_e = lane;
       asm volatile("" : "+v"(lane_e));
       if constexpr (M32) gemm_epilogue32<TM, TN>(acc, p, m0 + wr * WTM, n0 + wc * WTN, lane_e);
-      else gemm_epilogue<TM, TN>(acc, p, m0 + wr * WTM, n0 + wc * WTN, lane_e, STAGED ? lds + WB + 2 * WT + wave * 4096 : nullptr);
+      else gemm_epilogue<TM, TN, false, SET>(acc, p, m0 + wr * WTM, n0 + wc * WTN, lane_e, STAGED ? lds + WB + 2 * WT + wave * 4096 : nullptr);
     }
     RG_TSTAMP(3);
     ++tile_no;
@@ -2297,7 +2451,12 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
       { const char* e = getenv("A3V_GEMM_SKEW"); q.skew = e ? atoi(e) : 0; }
       switch (dbg) {
         case 0: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<0, 0>), g, b, 0, st, q); break;
-        case 5: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0>), g, b, 0, st, q); break;
+        case 5:
+          if (q.epi & GEMM_EPI_ROPEKV) hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0, true, EPI_SET_ROPE>), g, b, 0, st, q);
+          else if (q.epi & (A3V_EPI_BIAS | A3V_EPI_GELU | A3V_EPI_QUICKGELU))
+            hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0, true, EPI_SET_COMMON | EPI_SET_PRE>), g, b, 0, st, q);
+          else hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0>), g, b, 0, st, q);
+          break;
         case 11: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0, false>), g, b, 0, st, q); break;   // ring, direct (unstaged) epilogue stores
         case 12: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, -1>), g, b, 0, st, q); break;   // ring, group 0 waits for its W half at the end of L
         case 13: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<4, false, -1>), g, b, 0, st, q); break;   // ... with cycle stamps

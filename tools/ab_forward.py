@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """A/B on one box: bench forward (bs 8, 512-token prompt, 7B) with a Transformer attribute toggled.
-usage: ab_forward.py <attr> [reps]   e.g. ab_forward.py _fuse_qkv_rope"""
+usage: ab_forward.py <attr> [reps]   e.g. ab_forward.py _fuse_qkv_rope
+       ab_forward.py env:A3V_GEMM_FAST_EPI [reps]   toggles an environment switch the library reads per launch (1 / 0)"""
 import os
 import sys
 
@@ -35,6 +36,9 @@ def run(n):
 with torch.no_grad():
     for _ in range(reps):
         for val in (True, False):
-            setattr(m, attr, val)
+            if attr.startswith("env:"):
+                os.environ[attr[4:]] = "1" if val else "0"
+            else:
+                setattr(m, attr, val)
             run(2)
             print(f"{attr}={val}: {run(8):.2f} ms/step", flush=True)

@@ -94,6 +94,7 @@ print("EQUALITY", "OK" if ok else "FAILED", flush=True)
 T = 8728
 shapes = [("nt plain qkv-shape", "nt", T, 12288, 4096, 0), ("nt residual wo", "nt", T, 4096, 4096, "res"), ("nt swiglu w13", "nt", T, 22016, 4096, ops.EPI_SWIGLU),
           ("nt residual w2", "nt", T, 4096, 11008, "res"), ("nt res_f32 wo (train)", "nt", T, 4096, 4096, "resf"),
+          ("nt bias+gelu vit c_fc", "nt", 4616, 4096, 1024, "bias_gelu"), ("nt bias+residual vit c_proj", "nt", 4616, 1024, 4096, "bias_res"),
           ("nn dgrad w13", "nn", T, 4096, 22016, 0), ("nn dgrad qkv", "nn", T, 4096, 12288, 0),
           ("tn wgrad w13 accumulate", "tn", 22016, 4096, T, "resf"), ("tn wgrad wo accumulate", "tn", 4096, 4096, T, "resf")]
 for (name, fam, M, N, K, epi) in shapes:
@@ -107,6 +108,10 @@ for (name, fam, M, N, K, epi) in shapes:
         out = torch.zeros(M, N, device=dev, dtype=BF); kw = dict(residual=out, epilogue=0)
     elif epi == "resf":
         out = torch.zeros(M, N, device=dev, dtype=torch.float32); kw = dict(residual=out, epilogue=ops.EPI_RES_F32)
+    elif epi == "bias_gelu":
+        out = torch.zeros(M, N, device=dev, dtype=BF); kw = dict(bias=torch.randn(N, device=dev, dtype=BF), epilogue=ops.EPI_GELU)
+    elif epi == "bias_res":
+        out = torch.zeros(M, N, device=dev, dtype=BF); kw = dict(bias=torch.randn(N, device=dev, dtype=BF), residual=out, epilogue=0)
     elif epi == ops.EPI_SWIGLU:
         out = torch.zeros(M, N // 2, device=dev, dtype=BF); kw = dict(epilogue=epi)
     else:

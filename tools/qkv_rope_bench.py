@@ -1,26 +1,52 @@
-"""Cost of the fused RoPE / cache-write epilogue: a3v_gemm_qkv_rope vs plain a3v_gemm_nt (+ the separate a3v_rope_kvcache)."""
-import os
-import sys
-
+#!/usr/bin/env python3
+"""Cost of the fused qkv / RoPE / KV-cache epilogue: a3v_gemm_qkv_rope against the plain GEMM of the same shape (7B: 8 x 1091
+tokens, 4096 -> 12288), with and without the token-major v copy the training forward asks for."""
+import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch  # noqa: E402
+import torch
+from a3vlm_amd import ops
 
-from a3vlm_amd import ops  # noqa: E402
-from a3vlm_amd.model.LLM.llama_ens5 import precompute_cos_sin  # noqa: E402
-from tools.gemm_fp8_bench import t_us  # noqa: E402
-
-DEV = "cuda:0"
-B, S, H, Hkv, hd, K = 8, 1091, 32, 32, 128, 4096
-rows, N = B * S, (H + 2 * Hkv) * hd
+dev = "cuda"
+BF = torch.bfloat16
+B, S, H, hd, K = 8, 1091, 32, 128, 4096
 Smax = 2048
-x = (torch.randn(rows, K, device=DEV) * 0.5).bfloat16()
-w = (torch.randn(N, K, device=DEV) * 0.02).bfloat16()
-qkv = torch.empty(rows, N, device=DEV, dtype=torch.bfloat16)
-kc = torch.zeros(B, Hkv, Smax, hd, device=DEV, dtype=torch.bfloat16)
-vc = torch.zeros(B, Hkv, hd, Smax, device=DEV, dtype=torch.bfloat16)
-cs = precompute_cos_sin(hd, 2 * Smax, 10000.0, None).to(DEV)
-a = t_us(lambda: ops.gemm_nt(x, w, qkv))
-b = t_us(lambda: ops.rope_kvcache(qkv, qkv, kc, vc, cs, B, S, H, Hkv, hd, 0, 0))
-c = t_us(lambda: ops.gemm_qkv_rope(x, w, qkv, kc, vc, cs, B, S, H, Hkv, hd, 0, 0))
-d = t_us(lambda: ops.gemm_qkv_rope(x, w, qkv, kc, vc, cs, B, S, H, Hkv, hd, 0, 0, v_rows=qkv[:, (H + Hkv) * hd:]))
-print(f"gemm_nt {a:.1f} us + rope_kvcache {b:.1f} us = {a + b:.1f};  fused {c:.1f} us;  fused + v_rows {d:.1f} us")
+x = torch.randn(B * S, K, device=dev, dtype=BF)
+w = torch.randn(3 * H * hd, K, device=dev, dtype=BF) * 0.02
+qkv = torch.zeros(B * S, 3 * H * hd, device=dev, dtype=BF)
+kc = torch.zeros(B, H, Smax, hd, device=dev, dtype=BF)
+vt = torch.zeros(B, H, hd, Smax, device=dev, dtype=BF)
+vr = torch.zeros(B * S, H * hd, device=dev, dtype=BF)
+t = torch.arange(2 * Smax, device=dev, dtype=torch.float32)
+fr = 1.0 / (10000.0 ** (torch.arange(0, hd, 2, device=dev).float() / hd))
+ang = torch.outer(t, fr)
+cs = torch.stack([ang.cos(), ang.sin()], -1).contiguous()
+
+
+def timed(fn, reps=8, rounds=9):
+    ts = []
+    for _ in range(rounds):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / reps)
+    return sorted(ts)[len(ts) // 2]
+
+
+fl = 2.0 * B * S * 3 * H * hd * K
+import time
+t0 = time.time()
+while time.time() - t0 < 0.6:          # clock ramp: the first few hundred ms after an idle gap read ~15 % low
+    ops.gemm_nt(x, w, qkv)
+    torch.cuda.synchronize()
+res = {}
+for fast in ("1", "0"):
+    os.environ["A3V_GEMM_FAST_EPI"] = fast
+    res["plain_" + fast] = timed(lambda: ops.gemm_nt(x, w, qkv))
+    res["rope_" + fast] = timed(lambda: ops.gemm_qkv_rope(x, w, qkv, kc, vt, cs, B, S, H, H, hd, 0, 0))
+    res["rope_vrows_" + fast] = timed(lambda: ops.gemm_qkv_rope(x, w, qkv, kc, vt, cs, B, S, H, H, hd, 0, 0, v_rows=vr))
+os.environ["A3V_GEMM_FAST_EPI"] = "1"
+print(json.dumps({k: {"us": round(v * 1e3, 1), "tf": round(fl / v / 1e9, 1)} for k, v in res.items()}))
