@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const TA* __restrict__ 
     load8(p, g);
     load8(p + ustep, u);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = Cvt<TA>::rnd(g[e] / (1.f + __expf(-g[e]))) * u[e];
+    for (int e = 0; e < 8; ++e) o[e] = Cvt<TA>::rnd(g[e] * __builtin_amdgcn_rcpf(1.f + __expf(-g[e]))) * u[e];   // = silu() of the GEMM epilogue
     store8(act + (int64_t)r * lda + c, o);
   }
 }
