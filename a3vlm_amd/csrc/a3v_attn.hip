@@ -340,6 +340,66 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_bf16_kernel(AttnArgs p) {
   }
 }
 
+// Fused combine of the decode kernels (all threads of the block call it; `po` = this block's partial, already written with plain stores)
+template <int HD>
+__device__ __forceinline__ void decode_combine_tail(const AttnArgs& p, float* part, float* po, int nsplit, int* counters, int b, int h, int tid) {
+  // Fused combine (decode step): the block that arrives last at the (batch, head) counter merges the nsplit partials.
+  // The splits of a head may run on different XCDs (private L2s), so the hand-off uses agent-coherent accesses: this
+  // block re-writes its HD+2 partial values with sc0 sc1 stores (write-through), waits for the acknowledgement, bumps
+  // the counter; the last block reads all partials with sc0 sc1 loads.  (An agent-scope fence instead = L2 write-back
+  // + invalidate per wave: measured 5x slower on the GEMV that uses the same scheme.)
+  __shared__ int last_s;
+  __syncthreads();                                    // po[] of this block is complete (plain stores, same CU)
+  if (tid < HD + 2) st_agent(po + tid, po[tid]);      // L1 is write-through: the value read back is this block's own
+  agent_wait();
+  __syncthreads();
+  if (tid == 0) {
+    int* ctr = counters + b * p.H + h;
+    const int old = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last_s = old == nsplit - 1;
+    if (old == nsplit - 1) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!last_s || tid >= HD) return;
+  const float* pp = part + (int64_t)(b * p.H + h) * nsplit * (HD + 2);
+  float acc = 0.f, l = 0.f;
+  if (nsplit <= 8) {                                  // all loads in flight at once: one memory round trip
+    float mv[8], av[8], lv[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const float* q = pp + (s < nsplit ? s : nsplit - 1) * (HD + 2);
+      mv[s] = ld_agent_issue(q + HD);
+      av[s] = ld_agent_issue(q + tid);
+      lv[s] = ld_agent_issue(q + HD + 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(mv[0]), "+v"(mv[1]), "+v"(mv[2]), "+v"(mv[3]), "+v"(mv[4]), "+v"(mv[5]), "+v"(mv[6]), "+v"(mv[7])::"memory");
+    asm volatile("" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]), "+v"(av[4]), "+v"(av[5]), "+v"(av[6]), "+v"(av[7]));
+    asm volatile("" : "+v"(lv[0]), "+v"(lv[1]), "+v"(lv[2]), "+v"(lv[3]), "+v"(lv[4]), "+v"(lv[5]), "+v"(lv[6]), "+v"(lv[7]));
+    float m = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) if (s < nsplit) m = fmaxf(m, mv[s]);
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+      if (s < nsplit) {
+        const float w = (mv[s] == -INFINITY) ? 0.f : __expf(mv[s] - m);
+        acc += w * av[s];
+        l += w * lv[s];
+      }
+  } else {
+    float m = -INFINITY;
+    for (int s = 0; s < nsplit; ++s) m = fmaxf(m, ld_agent(pp + s * (HD + 2) + HD));
+    for (int s = 0; s < nsplit; ++s) {
+      const float ms = ld_agent(pp + s * (HD + 2) + HD);
+      const float a1 = ld_agent(pp + s * (HD + 2) + tid);
+      const float l1 = ld_agent(pp + s * (HD + 2) + HD + 1);
+      const float w = (ms == -INFINITY) ? 0.f : __expf(ms - m);
+      acc += w * a1;
+      l += w * l1;
+    }
+  }
+  ((bf16_t*)p.out)[b * p.o_sb + h * p.o_sh + tid] = f2bf(acc / l);
+}
+
 // ------------------------------------------------------------------------------------
 // Decode (Sq == 1): grid (nsplit, H, B); block 256.  part[b][h][split] = {o[HD], m, l}
 // ------------------------------------------------------------------------------------
@@ -449,61 +509,152 @@ __global__ __launch_bounds__(256) void attn_decode_bf16_kernel(AttnArgs p, float
   if (tid == 0) { po[HD] = mx; po[HD + 1] = ls; }
   }  // n > 0
   if (!counters) return;
-  // Fused combine (decode step): the block that arrives last at the (batch, head) counter merges the nsplit partials.
-  // The splits of a head may run on different XCDs (private L2s), so the hand-off uses agent-coherent accesses: this
-  // block re-writes its HD+2 partial values with sc0 sc1 stores (write-through), waits for the acknowledgement, bumps
-  // the counter; the last block reads all partials with sc0 sc1 loads.  (An agent-scope fence instead = L2 write-back
-  // + invalidate per wave: measured 5x slower on the GEMV that uses the same scheme.)
-  __shared__ int last_s;
-  __syncthreads();                                    // po[] of this block is complete (plain stores, same CU)
-  if (tid < HD + 2) st_agent(po + tid, po[tid]);      // L1 is write-through: the value read back is this block's own
-  agent_wait();
-  __syncthreads();
-  if (tid == 0) {
-    int* ctr = counters + b * p.H + h;
-    const int old = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    last_s = old == nsplit - 1;
-    if (old == nsplit - 1) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  if (!last_s || tid >= HD) return;
-  const float* pp = part + (int64_t)(b * p.H + h) * nsplit * (HD + 2);
-  float acc = 0.f, l = 0.f;
-  if (nsplit <= 8) {                                  // all loads in flight at once: one memory round trip
-    float mv[8], av[8], lv[8];
+  decode_combine_tail<HD>(p, part, po, nsplit, counters, b, h, tid);
+}
+
+// Sums over the 16 (8) lanes of a DPP row (half row) with four (three) v_add_f32_dpp: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror,
+// row_mirror.  (__shfl_xor compiles to ds_bpermute_b32: an LDS-pipe round trip per step.)
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_max(float v) {
+  return fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true)));
+}
+__device__ __forceinline__ float row8_sum(float v) { return dpp_add<0x141>(dpp_add<0x4E>(dpp_add<0xB1>(v))); }
+__device__ __forceinline__ float row16_sum(float v) { return dpp_add<0x140>(row8_sum(v)); }
+__device__ __forceinline__ float row8_max(float v) { return dpp_max<0x141>(dpp_max<0x4E>(dpp_max<0xB1>(v))); }
+
+// ------------------------------------------------------------------------------------
+// Decode, wave-streaming form (round 2): grid (nsplit, H, B), block 512 = 8 waves; nsplit = 1 when B*H alone fills the CUs.
+// The first form streams K, synchronises the block for the softmax, then streams V^T: every block of the chip changes phase
+// together and ~17 of its 37 us at context 1100 did not scale with the bytes (tools/attn_decode_bench.py).  Here each WAVE owns
+// every eighth 64-key tile: the tile's K rows (16 KB) AND its V^T columns (128 B of each of the HD rows, 16 KB) are in flight
+// together (32 x 16 B per lane), the next tile's K rows are requested before this tile's softmax, scores -> wave-private online softmax -> P.V
+// without leaving the wave; the eight waves merge (m, l, o) once through LDS.  No block-wide phase change, and with one block
+// per (batch, head) no cross-block hand-off either.
+// ------------------------------------------------------------------------------------
+template <int HD, bool NT>
+__global__ __launch_bounds__(512) void attn_decode_wave_kernel(AttnArgs p, float* part, int nsplit, int chunk, int* counters) {
+  constexpr int LPR = HD / 8;        // lanes per K row (16 B each)
+  constexpr int RPW = 64 / LPR;      // K rows per wave-wide load
+  constexpr int NKL = 64 / RPW;      // K loads per 64-key tile
+  constexpr int NVL = HD / 8;        // V^T loads per tile (8 d rows x 128 B per load)
+  __shared__ __attribute__((aligned(16))) float sc_s[8][64];
+  __shared__ float comb[8][HD + 2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sp = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int hk = h / (p.H / p.Hkv);
+  const int kv_lo = sp * chunk;
+  const int n = min(p.Sk, kv_lo + chunk) - kv_lo;
+  float* po = part + ((int64_t)(b * p.H + h) * nsplit + sp) * (HD + 2);
+  const bf16_t* Q = (const bf16_t*)p.q + b * p.q_sb + h * p.q_sh;
+  const bf16_t* K = (const bf16_t*)p.k + b * p.k_sb + hk * p.k_sh + (int64_t)kv_lo * p.k_ss;
+  const bf16_t* VT = (const bf16_t*)p.vt + b * p.v_sb + hk * p.v_sh + kv_lo;
+  // 64-key tiles of the block's n keys go round-robin to the eight waves: every V^T request is a whole, aligned 128-byte line
+  // (contiguous eighths of the keys start at multiples of 8 keys: Sk = 1110 put every wave 32 B into a line, 43 us against 30)
+  const int lo = wave * 64, hi = max(n, 0);
+  float m = -INFINITY, l = 0.f, acc[NVL];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const float* q = pp + (s < nsplit ? s : nsplit - 1) * (HD + 2);
-      mv[s] = ld_agent_issue(q + HD);
-      av[s] = ld_agent_issue(q + tid);
-      lv[s] = ld_agent_issue(q + HD + 1);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(mv[0]), "+v"(mv[1]), "+v"(mv[2]), "+v"(mv[3]), "+v"(mv[4]), "+v"(mv[5]), "+v"(mv[6]), "+v"(mv[7])::"memory");
-    asm volatile("" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]), "+v"(av[4]), "+v"(av[5]), "+v"(av[6]), "+v"(av[7]));
-    asm volatile("" : "+v"(lv[0]), "+v"(lv[1]), "+v"(lv[2]), "+v"(lv[3]), "+v"(lv[4]), "+v"(lv[5]), "+v"(lv[6]), "+v"(lv[7]));
-    float m = -INFINITY;
+  for (int j = 0; j < NVL; ++j) acc[j] = 0.f;
+  const int lr = lane / LPR, lc = (lane % LPR) * 8;
+  const int dr = lane >> 3, c8 = (lane & 7) * 8;
+  if (hi > lo) {
+    float qv[8];
+    load8(Q + lc, qv);
+    const int last_vec = (hi - 1) & ~7;
+    bf16x8 kk[NKL];
+    auto load_k = [&](int t0) {
 #pragma unroll
-    for (int s = 0; s < 8; ++s) if (s < nsplit) m = fmaxf(m, mv[s]);
-#pragma unroll
-    for (int s = 0; s < 8; ++s)
-      if (s < nsplit) {
-        const float w = (mv[s] == -INFINITY) ? 0.f : __expf(mv[s] - m);
-        acc += w * av[s];
-        l += w * lv[s];
+      for (int u = 0; u < NKL; ++u) {
+        const int r = min(t0 + u * RPW + lr, hi - 1);
+        const bf16x8* kp = reinterpret_cast<const bf16x8*>(K + (int64_t)r * p.k_ss + lc);
+        kk[u] = NT ? __builtin_nontemporal_load(kp) : *kp;
       }
-  } else {
-    float m = -INFINITY;
-    for (int s = 0; s < nsplit; ++s) m = fmaxf(m, ld_agent(pp + s * (HD + 2) + HD));
-    for (int s = 0; s < nsplit; ++s) {
-      const float ms = ld_agent(pp + s * (HD + 2) + HD);
-      const float a1 = ld_agent(pp + s * (HD + 2) + tid);
-      const float l1 = ld_agent(pp + s * (HD + 2) + HD + 1);
-      const float w = (ms == -INFINITY) ? 0.f : __expf(ms - m);
-      acc += w * a1;
-      l += w * l1;
+    };
+    load_k(lo);
+    // software pipeline: V^T(t) is requested before the scores of tile t are computed, K(t+1) before its softmax / P.V -- the
+    // memory system always has 16-32 KB per wave outstanding (without it every wave of the chip asks for its 32 KB at the same
+    // moment, computes while HBM idles, and asks again: 40 us instead of the 33 of the two-phase form)
+    for (int t0 = lo; t0 < hi; t0 += 512) {
+      bf16x8 vv[NVL];
+      const int kvc = min(t0 + c8, last_vec);              // vectors past the wave's range re-read its last one (masked below)
+#pragma unroll
+      for (int j = 0; j < NVL; ++j) {
+        const bf16x8* vp = reinterpret_cast<const bf16x8*>(VT + (int64_t)(j * 8 + dr) * p.v_sd + kvc);
+        vv[j] = NT ? __builtin_nontemporal_load(vp) : *vp;
+      }
+#pragma unroll
+      for (int u = 0; u < NKL; ++u) {
+        float a = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a = fmaf(qv[e], (float)kk[u][e], a);
+        a = LPR == 16 ? row16_sum(a) : row8_sum(a);
+        if ((lane % LPR) == 0) sc_s[wave][u * RPW + lr] = (t0 + u * RPW + lr < hi) ? a * p.scale : -INFINITY;
+      }
+      if (t0 + 512 < hi) load_k(t0 + 512);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // wave-private round trip through LDS: no barrier, in-order LDS
+      const f32x4 sa = *reinterpret_cast<const f32x4*>(&sc_s[wave][c8]);
+      const f32x4 sb = *reinterpret_cast<const f32x4*>(&sc_s[wave][c8 + 4]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      float s8[8] = {sa[0], sa[1], sa[2], sa[3], sb[0], sb[1], sb[2], sb[3]};
+      float mt = s8[0];
+#pragma unroll
+      for (int e = 1; e < 8; ++e) mt = fmaxf(mt, s8[e]);
+      mt = row8_max(mt);
+      const float mn = fmaxf(m, mt);                         // finite: the tile holds at least one key of the range
+      const float alpha = (m == -INFINITY) ? 0.f : __expf(m - mn);
+      float pe[8], ps = 0.f;
+      const int nvalid = hi - (t0 + c8);                     // <= 0 for the vectors past the range
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        pe[e] = e < nvalid ? __expf(s8[e] - mn) : 0.f;
+        ps += pe[e];
+      }
+      l = l * alpha + ps;
+#pragma unroll
+      for (int j = 0; j < NVL; ++j) {
+        float a = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a = fmaf(pe[e], e < nvalid ? (float)vv[j][e] : 0.f, a);   // the cache tail may hold anything
+        acc[j] = acc[j] * alpha + a;
+      }
+      m = mn;
     }
   }
-  ((bf16_t*)p.out)[b * p.o_sb + h * p.o_sh + tid] = f2bf(acc / l);
+#pragma unroll
+  for (int j = 0; j < NVL; ++j) {
+    acc[j] = row8_sum(acc[j]);
+  }
+  l = row8_sum(l);
+  if ((lane & 7) == 0) {
+#pragma unroll
+    for (int j = 0; j < NVL; ++j) comb[wave][j * 8 + dr] = acc[j];
+  }
+  if (lane == 0) { comb[wave][HD] = m; comb[wave][HD + 1] = l; }
+  __syncthreads();
+  if (tid < HD) {
+    float M = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) M = fmaxf(M, comb[w][HD]);
+    float o = 0.f, L = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+      const float mw = comb[w][HD];
+      const float sw = (mw == -INFINITY) ? 0.f : __expf(mw - M);
+      o += sw * comb[w][tid];
+      L += sw * comb[w][HD + 1];
+    }
+    if (nsplit == 1 && counters) {
+      ((bf16_t*)p.out)[b * p.o_sb + h * p.o_sh + tid] = f2bf(o / L);
+    } else {
+      po[tid] = o;
+      if (tid == 0) { po[HD] = M; po[HD + 1] = L; }
+    }
+  }
+  if (!counters || nsplit == 1) return;
+  decode_combine_tail<HD>(p, part, po, nsplit, counters, b, h, tid);
 }
 
 template <int HD>
@@ -650,6 +801,22 @@ static int attention_impl(const void* q, const void* k, const void* vt, void* ou
     int ns, ch;
     decode_plan(B, H, Sk, &ns, &ch);
     const size_t shm = (size_t)(ch + 8) * sizeof(float);
+    const char* we = getenv("A3V_ATTN_DECODE_WAVE_STANDALONE");     // tuning runs (tools/attn_decode_bench.py): the wave-streaming form here too
+    if (we && we[0] == '1' && dtype == A3V_BF16) {
+      int ns2 = (256 + B * H - 1) / (B * H);
+      if (ns2 > ns) ns2 = ns;
+      int ch2 = (((Sk + ns2 - 1) / ns2) + 63) & ~63;
+      ns2 = (Sk + ch2 - 1) / ch2;
+      if (hd == 128) {
+        hipLaunchKernelGGL((attn_decode_wave_kernel<128, true>), dim3(ns2, H, B), dim3(512), 0, st, p, scratch, ns2, ch2, (int*)nullptr);
+        hipLaunchKernelGGL(attn_decode_combine_kernel<128>, dim3(H, B), dim3(128), 0, st, scratch, out, p.o_sb, p.o_sh, H, ns2, dtype);
+      } else {
+        hipLaunchKernelGGL((attn_decode_wave_kernel<64, true>), dim3(ns2, H, B), dim3(512), 0, st, p, scratch, ns2, ch2, (int*)nullptr);
+        hipLaunchKernelGGL(attn_decode_combine_kernel<64>, dim3(H, B), dim3(64), 0, st, scratch, out, p.o_sb, p.o_sh, H, ns2, dtype);
+      }
+      A3V_LAUNCH_CHECK();
+      return A3V_OK;
+    }
     if (hd == 128) {
       hipLaunchKernelGGL(attn_decode_bf16_kernel<128>, dim3(ns, H, B), dim3(256), shm, st, p, scratch, ns, ch, (int*)nullptr);
       A3V_LAUNCH_CHECK();
@@ -716,6 +883,26 @@ int a3v_attention_decode_fused(const void* q, const void* k, const void* vt, voi
   hipStream_t st = (hipStream_t)stream;
   const char* nte = getenv("A3V_ATTN_DECODE_NT");       // default: non-temporal KV stream (A3V_ATTN_DECODE_NT=0 for A/B runs)
   const bool nt = !(nte && nte[0] == '0');
+  const char* v2e = getenv("A3V_ATTN_DECODE_WAVE");     // default: the wave-streaming form (A3V_ATTN_DECODE_WAVE=0: the two-phase form)
+  if (!(v2e && v2e[0] == '0')) {
+    // one block per (batch, head) when that alone covers the CUs, else the fewest splits that do (never more than the
+    // two-phase plan: the scratch buffer is sized for that one)
+    int ns2 = (256 + B * H - 1) / (B * H);
+    if (ns2 > ns) ns2 = ns;
+    int ch2 = (Sk + ns2 - 1) / ns2;
+    ch2 = (ch2 + 63) & ~63;
+    ns2 = (Sk + ch2 - 1) / ch2;
+    const dim3 grid(ns2, H, B);
+    if (hd == 128) {
+      if (nt) hipLaunchKernelGGL((attn_decode_wave_kernel<128, true>), grid, dim3(512), 0, st, p, scratch, ns2, ch2, counters);
+      else hipLaunchKernelGGL((attn_decode_wave_kernel<128, false>), grid, dim3(512), 0, st, p, scratch, ns2, ch2, counters);
+    } else {
+      if (nt) hipLaunchKernelGGL((attn_decode_wave_kernel<64, true>), grid, dim3(512), 0, st, p, scratch, ns2, ch2, counters);
+      else hipLaunchKernelGGL((attn_decode_wave_kernel<64, false>), grid, dim3(512), 0, st, p, scratch, ns2, ch2, counters);
+    }
+    A3V_LAUNCH_CHECK();
+    return A3V_OK;
+  }
   if (hd == 128) {
     if (nt) hipLaunchKernelGGL((attn_decode_bf16_kernel<128, true>), dim3(ns, H, B), dim3(256), shm, st, p, scratch, ns, ch, counters);
     else hipLaunchKernelGGL((attn_decode_bf16_kernel<128, false>), dim3(ns, H, B), dim3(256), shm, st, p, scratch, ns, ch, counters);

@@ -346,11 +346,34 @@ def test_attention_prefill_bf16_spike_rescale():
     assert_close(out, oracle_attn(q, k, v, True), rtol=2 ** -6, atol=1.5e-2, what="attn spike")
 
 
-@pytest.mark.parametrize("B,Sk,H,Hkv,hd", [(2, 6, 4, 2, 64), (8, 1091, 4, 4, 128), (1, 4000, 2, 1, 128), (3, 129, 2, 2, 128)])
-def test_attention_decode_bf16(B, Sk, H, Hkv, hd):
+@pytest.mark.parametrize("form", ["two_phase", "wave"])
+@pytest.mark.parametrize("B,Sk,H,Hkv,hd", [(2, 6, 4, 2, 64), (8, 1091, 4, 4, 128), (1, 4000, 2, 1, 128), (3, 129, 2, 2, 128), (40, 700, 8, 8, 128),
+                                           (2, 513, 2, 2, 64)])
+def test_attention_decode_bf16(B, Sk, H, Hkv, hd, form):
+    """Both decode-attention kernels (the wave-streaming form is the decode step's default; here it is reached through the
+    tuning switch of the stand-alone entry).  The V^T cache beyond Sk is NaN: a kernel that lets a masked column touch the sum fails."""
+    import os
     q, k, v = rt(gen(B, 1, H, hd, seed=39)), rt(gen(B, Sk, Hkv, hd, seed=40)), rt(gen(B, Sk, Hkv, hd, seed=41))
-    out = run_attn(q, k, v, False, BF, Smax=4096)
-    assert_close(out, oracle_attn(q, k, v, False), rtol=2 ** -7, atol=4e-3, what="attn decode bf16")
+    os.environ["A3V_ATTN_DECODE_WAVE_STANDALONE"] = "1" if form == "wave" else "0"
+    try:
+        out = run_attn(q, k, v, False, BF, Smax=4096)
+    finally:
+        os.environ["A3V_ATTN_DECODE_WAVE_STANDALONE"] = "0"
+    assert_close(out, oracle_attn(q, k, v, False), rtol=2 ** -7, atol=4e-3, what=f"attn decode bf16 ({form})")
+
+
+def test_attention_decode_wave_form_spike_rescale():
+    """Online softmax across a wave's tiles and across the eight waves: one late key dominates."""
+    import os
+    B, Sk, H, hd = 2, 1500, 2, 128
+    q, k, v = rt(gen(B, 1, H, hd, seed=43)), rt(gen(B, Sk, H, hd, seed=44)), rt(gen(B, Sk, H, hd, seed=45))
+    k[:, 1400] = q[:, 0] * 3.0
+    os.environ["A3V_ATTN_DECODE_WAVE_STANDALONE"] = "1"
+    try:
+        out = run_attn(q, k, v, False, BF, Smax=2048)
+    finally:
+        os.environ["A3V_ATTN_DECODE_WAVE_STANDALONE"] = "0"
+    assert_close(out, oracle_attn(q, k, v, False), rtol=2 ** -7, atol=4e-3, what="attn decode wave spike")
 
 
 def test_vt_pack():
