@@ -43,12 +43,14 @@ class GradReducer:
         self.enabled = True
         self.reduce_dtype = reduce_dtype          # None: reduce the fp32 buffer in place; bf16: halve the wire bytes
         self._pending: List = []
+        self._keys: List[Tuple[int, int]] = []
         self._stream = None
         self._wire: Dict[Tuple[int, int], torch.Tensor] = {}      # persistent low-precision buckets, keyed by flat range
         try:                                       # RCCL averages in the collective; gloo (CPU tests) only sums
             self._avg = dist.get_backend(group) == "nccl" and hasattr(dist.ReduceOp, "AVG")
         except Exception:
             self._avg = False
+        self.sumsq: Optional["GradSquareSums"] = None       # set by GradSquareSums(engine, reducer=self): sums over the REDUCED buckets
         engine.on_layer_grads_ready = self._on_ready
 
     def _side_stream(self, device):
@@ -72,6 +74,7 @@ class GradReducer:
 
     def _launch(self, seg: torch.Tensor, key: Tuple[int, int]) -> None:
         dist = self.dist
+        self._keys.append(key)
         if self.reduce_dtype is not None and self.reduce_dtype != seg.dtype:
             low = self._wire.get(key)
             if low is None or low.device != seg.device:
@@ -99,7 +102,17 @@ class GradReducer:
                 work.wait()
                 if seg is not None:
                     seg.copy_(low)
+        if self.sumsq is not None and self._pending:
+            eng_flat = self.eng.flat_grads()
+            for key in self._keys:
+                seg = eng_flat[key[0]:key[1]]
+                if seg.is_cuda:
+                    with torch.cuda.stream(self._stream):
+                        self.sumsq.add(seg, key)
+                else:
+                    self.sumsq.add(seg, key)
         self._pending.clear()
+        self._keys.clear()
         if self._stream is not None:
             torch.cuda.current_stream().wait_stream(self._stream)
 
@@ -113,21 +126,97 @@ class GradReducer:
         self.finish()
 
 
-def clip_grad_norm(parameters, max_norm: float, flat: Optional[torch.Tensor] = None, defer: bool = False):
+class GradSquareSums:
+    """Sum of squares of the flat gradient buffer, bucket by bucket, for the global-norm clip (reference ``util/clip_grad.py:59-210``).
+
+    Without it the clip reads the whole buffer (27 GB at 7B) after the backward, serially, before the optimizer can start.  Here
+    every bucket's partial sums are taken the moment the bucket is final -- on a side stream while the MFMA-bound backward of the
+    earlier layers still runs (one rank), or right behind the bucket's all-reduce on the reducer's stream (DP: the norm is over the
+    REDUCED gradients, identical on every rank, so clipping needs no collective).  Buckets that were not announced in a step (no
+    image in the batch, ...) are summed at ``norm()`` time.  ``enabled`` follows the reducer's convention: False on the micro-steps
+    of an accumulation window that do not end it."""
+
+    def __init__(self, engine, reducer: Optional[GradReducer] = None):
+        self.eng, self.enabled = engine, True
+        self.ranges, self.slot, self.part = None, None, None      # laid out at the first bucket (the engine allocates its buffer lazily)
+        self.seen = set()
+        self._stream = None
+        if reducer is not None and reducer.world > 1:
+            reducer.sumsq = self
+        else:
+            self._chained = engine.on_layer_grads_ready
+            engine.on_layer_grads_ready = self._on_ready
+
+    def _layout(self):
+        if self.part is None:
+            from . import ops
+            flat = self.eng.flat_grads()
+            self.ranges = [(st, en) for _, st, en in self.eng.grad_ranges() if en > st]
+            self.slot = {key: i for i, key in enumerate(self.ranges)}
+            self.part = torch.zeros(len(self.ranges), ops.SUMSQ_SLOTS if flat.is_cuda else 1, dtype=torch.float32, device=flat.device)
+
+    def add(self, seg: torch.Tensor, key: Tuple[int, int]) -> None:
+        """Partial sums of one bucket on the CURRENT stream."""
+        self._layout()
+        i = self.slot.get(key)
+        if i is None:
+            return
+        if seg.is_cuda:
+            from . import ops
+            ops.sumsq_partials(seg, self.part[i])
+        else:
+            self.part[i, 0] = (seg.double() ** 2).sum().float()
+        self.seen.add(key)
+
+    def _on_ready(self, name: str, start: int, end: int) -> None:
+        if self._chained is not None:
+            self._chained(name, start, end)
+        if not self.enabled or end <= start:
+            return
+        seg = self.eng.flat_grads()[start:end]
+        if seg.is_cuda:
+            if self._stream is None:
+                self._stream = torch.cuda.Stream(device=seg.device)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(seg.device))
+            self._stream.wait_event(ev)
+            with torch.cuda.stream(self._stream):
+                self.add(seg, (start, end))
+        else:
+            self.add(seg, (start, end))
+
+    def norm(self) -> torch.Tensor:
+        """sqrt(sum over all buckets) as a device scalar on the current stream; resets the per-step bookkeeping."""
+        self._layout()
+        flat = self.eng.flat_grads()
+        if self._stream is not None:
+            torch.cuda.current_stream(flat.device).wait_stream(self._stream)
+        for key in self.ranges:
+            if key not in self.seen:
+                self.add(flat[key[0]:key[1]], key)
+        self.seen.clear()
+        return self.part.sum(dtype=torch.float32).sqrt()
+
+
+def clip_grad_norm(parameters, max_norm: float, flat: Optional[torch.Tensor] = None, defer: bool = False,
+                   sumsq: Optional[GradSquareSums] = None):
     """util/clip_grad.py:59-210 for pure DP: fp32 global L2 norm, coef = max_norm/(norm+1e-6) clamped to 1, every gradient
     multiplied by coef.  Returns the norm.
 
     ``flat``: the training engine's flat gradient buffer (``TrainEngine.flat_grads()``); when every gradient is a view into
     it the norm is ONE reduction over the buffer instead of one per parameter (its padding is zero).  ``defer=True`` returns
     ``(norm, coef)`` and leaves the gradients untouched: the caller hands ``coef`` (a device scalar) to
-    ``FusedAdamW.step(grad_scale=coef)``, which multiplies as it reads -- no separate read + write of every gradient."""
+    ``FusedAdamW.step(grad_scale=coef)``, which multiplies as it reads -- no separate read + write of every gradient.
+    ``sumsq``: a ``GradSquareSums`` fed during the backward; the norm is then the square root of its partial sums."""
     grads = [p.grad for p in parameters if p.grad is not None]
     if not grads:
         z = torch.zeros(())
         return (z, torch.ones(())) if defer else z
     in_flat = flat is not None and flat.dtype == torch.float32 and all(
         g.dtype == torch.float32 and g.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() for g in grads)
-    if in_flat:
+    if in_flat and sumsq is not None:
+        norm = sumsq.norm()                    # per-bucket partial sums taken while the backward ran (GradSquareSums)
+    elif in_flat:
         norm = torch.linalg.vector_norm(flat)
     else:
         norm = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(g.float()) for g in grads]))

@@ -26,7 +26,7 @@ from typing import Callable, Dict, Optional
 
 import torch
 
-from .dp import GradReducer, clip_grad_norm
+from .dp import GradReducer, GradSquareSums, clip_grad_norm
 from .util import adjust_learning_rate_epoch
 
 
@@ -66,6 +66,12 @@ def train_one_epoch(model, data_loader, optimizer, epoch: int, start_iter: int, 
     engine = model.train_engine() if hasattr(model, "train_engine") and dev.type == "cuda" and params else None
     if engine is not None:
         engine.static_grad_scale = 1.0 / accum_iter
+    # the clip's sums of squares ride the backward (side stream / behind each bucket's all-reduce) instead of one 27-GB pass after it
+    sumsq = None
+    if engine is not None and clip > 0 and takes_scale and optimizer.engine is engine:
+        sumsq = getattr(engine, "_grad_square_sums", None)
+        if sumsq is None:
+            sumsq = engine._grad_square_sums = GradSquareSums(engine, reducer)
     for step, batch in enumerate(data_loader, start=start_iter):
         examples, labels, imgs, depth = _unpack(batch)
         if trim is not None and not examples.is_cuda:
@@ -76,6 +82,8 @@ def train_one_epoch(model, data_loader, optimizer, epoch: int, start_iter: int, 
         update_grad = (step + 1) % accum_iter == 0
         if reducer is not None:
             reducer.enabled = update_grad
+        if sumsq is not None:
+            sumsq.enabled = update_grad
         examples, labels = examples.to(dev, non_blocking=True), labels.to(dev, non_blocking=True)
         imgs = imgs.to(dev, non_blocking=True) if imgs is not None else None
         if trim is not None:
@@ -96,7 +104,8 @@ def train_one_epoch(model, data_loader, optimizer, epoch: int, start_iter: int, 
                     # one norm over the engine's flat gradient buffer; the coefficient stays on the device and is applied by the
                     # optimizer kernel as it reads the gradients (a3v_adamw_scaled): no grad.mul_ pass, no host sync
                     eng = optimizer.engine
-                    stats["grad_norm"], coef = clip_grad_norm(params, clip, flat=eng.flat_grads() if eng is not None else None, defer=True)
+                    stats["grad_norm"], coef = clip_grad_norm(params, clip, flat=eng.flat_grads() if eng is not None else None, defer=True,
+                                                              sumsq=sumsq if eng is engine else None)
                 else:
                     stats["grad_norm"] = clip_grad_norm(params, clip)
                 bad |= ~torch.isfinite(torch.as_tensor(stats["grad_norm"]).to(dev))

@@ -33,6 +33,7 @@ SIGNATURES = {
     "a3v_adamw": (I, [P, P, P, P, L, F, F, F, F, F, L, P, P]),
     "a3v_adamw_scaled": (I, [P, P, P, P, L, F, F, F, F, F, L, P, P, P]),
     "a3v_scale_cast": (I, [P, I, P, I, L, F, P]),
+    "a3v_sumsq_partials": (I, [P, L, P, P]),
     "a3v_gemm_nn": (I, [P, L, P, L, P, L, I, I, I, P, L, I, P]),
     "a3v_gemm_tn": (I, [P, L, P, L, P, L, I, I, I, P, L, I, P]),
     "a3v_gemm_set_workspace": (I, [P, L]),

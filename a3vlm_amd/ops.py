@@ -380,6 +380,18 @@ def scale_cast(src, dst, scale: float = 1.0):
     return dst
 
 
+SUMSQ_SLOTS = 1024
+
+
+def sumsq_partials(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """out[0 .. SUMSQ_SLOTS) = partial sums of squares of the fp32 vector x (deterministic; the clip's norm = sqrt of their sum)."""
+    _dev(x, out)
+    assert x.dtype == torch.float32 and out.dtype == torch.float32 and out.numel() >= SUMSQ_SLOTS and x.is_contiguous() and out.is_contiguous()
+    rc = _l.load().a3v_sumsq_partials(_p(x), x.numel(), _p(out), _stream())
+    _l.check(rc, "a3v_sumsq_partials")
+    return out
+
+
 def add2d(dst, src):
     """dst += src (2-D blocks of one dtype, arbitrary row strides)."""
     _dev(dst, src)

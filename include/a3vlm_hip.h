@@ -385,6 +385,12 @@ int a3v_adamw_scaled(float* param, const float* grad, float* exp_avg, float* exp
  * (main_finetune.py:251-255) without separate scale / cast / copy passes over the gradient buffer. */
 int a3v_scale_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, float scale, void* stream);
 
+/* Partial sums of squares of an fp32 range: out[0 .. A3V_SUMSQ_SLOTS) (every slot written).  The global-norm gradient clip
+ * (reference util/clip_grad.py:59-210) = sqrt(sum of the partials of all gradient buckets); called per bucket on a side stream
+ * while the backward still runs.  x 16-byte aligned. */
+#define A3V_SUMSQ_SLOTS 1024
+int a3v_sumsq_partials(const float* x, int64_t n, float* out, void* stream);
+
 /* Re-write one adapter's rows / columns of a fused LoRA group's bf16 images from its fp32 parameters (model/peft.py:40-64
  * lora_a [r, in], lora_b [nj, r]): A[col0+i, :] and At[:, col0+i] from lora_a, B[row0+n, col0+i] and Bt[col0+i, row0+n] from lora_b. */
 int a3v_lora_refresh(const float* lora_a, const float* lora_b, int r, int in_f, int nj, void* A, int64_t lda, void* At, int64_t ldat,

@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from a3vlm_amd.dp import FinetuneDistSampler, GradReducer, clip_grad_norm
+from a3vlm_amd.dp import FinetuneDistSampler, GradReducer, GradSquareSums, clip_grad_norm
 from a3vlm_amd.util import add_weight_decay, adjust_learning_rate_epoch
 
 
@@ -81,6 +81,54 @@ def test_clip_grad_norm_matches_reference_coefficient():
         p.grad = torch.full_like(p, 0.1)
     clip_grad_norm(ps, max_norm=8.0)
     assert torch.allclose(ps[0].grad, torch.full((10,), 0.1)), "coefficient is clamped to 1"
+
+
+def test_grad_square_sums_single_rank_follow_the_bucket_hooks():
+    """Per-bucket sums of squares collected through the engine's bucket hook = the norm of the flat buffer; buckets that were not
+    announced in a step are summed at norm() time; micro-steps that do not end an accumulation window are ignored."""
+    eng = FakeEngine([1000, 64, 5000, 0])
+    sq = GradSquareSums(eng)
+    g = torch.Generator().manual_seed(3)
+    params = [torch.nn.Parameter(torch.zeros(e - s)) for _, s, e in eng.grad_ranges() if e > s]
+    for step in range(2):
+        eng.flat_grads().copy_(torch.randn(eng.flat_grads().numel(), generator=g))
+        for p, (_, s, e) in zip(params, [r for r in eng.grad_ranges() if r[2] > r[1]]):
+            p.grad = eng.flat_grads()[s:e]
+        sq.enabled = False                                   # a non-boundary micro-step: its (partial) gradients must not count
+        eng.on_layer_grads_ready("layer2", 1064, 6064)
+        eng.flat_grads()[1064:6064].mul_(2.0)
+        sq.enabled = True
+        for n, s, e in list(reversed(eng.grad_ranges()))[:-1 if step == 0 else None]:     # step 0: layer0 never announced
+            eng.on_layer_grads_ready(n, s, e)
+        norm, coef = clip_grad_norm(params, 8.0, flat=eng.flat_grads(), defer=True, sumsq=sq)
+        want = torch.linalg.vector_norm(eng.flat_grads())
+        assert torch.allclose(norm, want, rtol=1e-5), (step, float(norm), float(want))
+        assert torch.allclose(coef, torch.clamp(8.0 / (want + 1e-6), max=1.0), rtol=1e-5)
+
+
+def _sumsq_worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        eng = FakeEngine([1000, 64, 5000])
+        red = GradReducer(eng, dist, reduce_dtype=torch.bfloat16)
+        sq = GradSquareSums(eng, red)
+        eng.flat_grads().copy_(torch.randn(6064, generator=torch.Generator().manual_seed(200 + rank)))
+        for n, s, e in reversed(eng.grad_ranges()):
+            eng.on_layer_grads_ready(n, s, e)
+        red.finish()
+        torch.save((sq.norm(), torch.linalg.vector_norm(eng.flat_grads())), os.path.join(outdir, f"n{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_square_sums_world2_are_over_the_reduced_gradients(tmp_path):
+    world, port = 2, 29750 + (os.getpid() % 200)
+    mp.spawn(_sumsq_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(str(tmp_path), f"n{r}.pt")) for r in range(world)]
+    for got, want in res:
+        assert torch.allclose(got, want, rtol=1e-5)
+    assert torch.equal(res[0][0], res[1][0]), "every rank must clip with the same norm"
 
 
 @pytest.fixture(scope="module")

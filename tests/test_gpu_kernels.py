@@ -788,3 +788,18 @@ def test_gemm_tn_nn_fast_epilogue_forms_equal_general_form(M, N, K):
     for f in cases:
         fast, general = _with_general_epilogue(f)
         assert torch.equal(fast, general)
+
+
+@pytest.mark.parametrize("n", [4, 1003, 4096 * 4096 + 12, 200_000_001])
+def test_sumsq_partials(n):
+    """Partial sums of squares of a gradient bucket (the clip's norm = sqrt of the sum of all partials): against a float64 sum, and
+    bit-identical across launches."""
+    x = torch.randn(n, device=DEV, generator=torch.Generator(device=DEV).manual_seed(n % 97))
+    out = torch.full((ops.SUMSQ_SLOTS,), float("nan"), device=DEV)
+    ops.sumsq_partials(x, out)
+    got = out.double().sum()
+    want = (x.double() ** 2).sum()
+    assert abs(float(got - want)) <= 1e-6 * float(want)
+    out2 = torch.empty_like(out)
+    ops.sumsq_partials(x, out2)
+    assert torch.equal(out, out2)
