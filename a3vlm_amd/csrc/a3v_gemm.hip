@@ -2494,13 +2494,16 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
     // that fill whole rounds + small kernel on the remaining rows.
     const long tn256 = (N + 255) / 256, tn128 = (N + 127) / 128;
     const bool eligible = desc_ok && M >= 512 && N >= 512;
-    auto small_cost = [&](long rows) { return rows <= 0 ? 0.0 : 0.65 * std::max(1.0, (double)((rows + 127) / 128) * tn128 / 512.0); };
+    // (round 2 recalibration, tools/hybrid_vs_ring.py: with the ring kernel at 1.35-1.45 PF and the small kernel at ~0.6 PF a round
+    // of 512 small tiles costs ~1.15 T256, and a split-K tail adds its reduce pass: the 7B qkv shape (6.56 rounds) went to the
+    // hybrid under the old 0.65 and lost 11 % to the all-ring launch)
+    auto small_cost = [&](long rows) { return rows <= 0 ? 0.0 : 1.15 * std::max(0.5, (double)((rows + 127) / 128) * tn128 / 512.0); };
     const double c_small = small_cost(M);
     const double c_big = eligible ? (double)((((long)(M + 255) / 256) * tn256 + 255) / 256) : 1e30;
     long mt_h = ((long)(M / 256) * tn256 / 256) * 256 / tn256;          // M-tile rows that make whole rounds
     double c_hyb = 1e30;
     if (eligible && mt_h >= 1 && mt_h * 256 < M)
-      c_hyb = (double)((mt_h * tn256 + 255) / 256) + small_cost(M - mt_h * 256) + 0.1;
+      c_hyb = (double)((mt_h * tn256 + 255) / 256) + small_cost(M - mt_h * 256) + 0.25;
     if (c_big <= c_small && c_big <= c_hyb) {
       launch(257, p);
     } else if (c_hyb < c_small) {
