@@ -35,8 +35,9 @@ def _scale_cast(src: torch.Tensor, dst: torch.Tensor, scale: float) -> None:
 
 
 class GradReducer:
-    def __init__(self, engine, dist, reduce_dtype: Optional[torch.dtype] = None, group=None):
+    def __init__(self, engine, dist, reduce_dtype: Optional[torch.dtype] = None, group=None, reduce_single_rank: bool = False):
         self.eng = engine
+        self.reduce_single_rank = reduce_single_rank      # tests: run the whole bucket path on a one-rank group
         self.dist = dist
         self.group = group
         self.world = dist.get_world_size(group) if group is not None else dist.get_world_size()
@@ -59,7 +60,7 @@ class GradReducer:
         return self._stream
 
     def _on_ready(self, name: str, start: int, end: int) -> None:
-        if not self.enabled or self.world == 1 or end <= start:      # (a bucket is empty when all its parameters are frozen)
+        if not self.enabled or (self.world == 1 and not self.reduce_single_rank) or end <= start:      # (empty: all its parameters frozen)
             return
         seg = self.eng.flat_grads()[start:end]
         if seg.is_cuda:
@@ -82,35 +83,39 @@ class GradReducer:
             _scale_cast(seg, low, 1.0 if self._avg else 1.0 / self.world)
             op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
             work = dist.all_reduce(low, op=op, group=self.group, async_op=True)
-            self._pending.append((work, seg, low))
         elif self._avg:
+            low = None
             work = dist.all_reduce(seg, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
-            self._pending.append((work, None, None))
         else:
+            low = None
             seg.mul_(1.0 / self.world)
             work = dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            self._pending.append((work, None, None))
+        if seg.is_cuda:
+            # on a device stream Work.wait() only makes THIS (side) stream wait for the collective: the widening pass and the
+            # clip's sums of squares are queued behind it right away and overlap the backward like the collective itself
+            work.wait()
+            if low is not None:
+                _scale_cast(low, seg, 1.0)
+            if self.sumsq is not None:
+                self.sumsq.add(seg, key)
+            self._pending.append((None, None, None))
+        else:
+            self._pending.append((work, seg if low is not None else None, low))
 
     def finish(self) -> None:
         """Join every outstanding bucket (call before clipping / optimizer.step)."""
+        host_side = False
         for work, seg, low in self._pending:
-            if seg is not None and seg.is_cuda:
-                with torch.cuda.stream(self._stream):     # the widening runs on the side stream: THAT stream must wait for the collective
-                    work.wait()
-                    _scale_cast(low, seg, 1.0)
-            else:
-                work.wait()
-                if seg is not None:
-                    seg.copy_(low)
-        if self.sumsq is not None and self._pending:
+            if work is None:                       # device bucket: everything is already queued on the side stream
+                continue
+            host_side = True
+            work.wait()
+            if seg is not None:
+                seg.copy_(low)
+        if self.sumsq is not None and host_side:
             eng_flat = self.eng.flat_grads()
             for key in self._keys:
-                seg = eng_flat[key[0]:key[1]]
-                if seg.is_cuda:
-                    with torch.cuda.stream(self._stream):
-                        self.sumsq.add(seg, key)
-                else:
-                    self.sumsq.add(seg, key)
+                self.sumsq.add(eng_flat[key[0]:key[1]], key)
         self._pending.clear()
         self._keys.clear()
         if self._stream is not None:
@@ -141,7 +146,7 @@ class GradSquareSums:
         self.ranges, self.slot, self.part = None, None, None      # laid out at the first bucket (the engine allocates its buffer lazily)
         self.seen = set()
         self._stream = None
-        if reducer is not None and reducer.world > 1:
+        if reducer is not None and (reducer.world > 1 or reducer.reduce_single_rank):
             reducer.sumsq = self
         else:
             self._chained = engine.on_layer_grads_ready
