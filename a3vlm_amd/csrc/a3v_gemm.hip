@@ -1099,7 +1099,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_pp_kernel(GemmArgs p) {
 // EARLY: the barrier that ends an MFMA interval is executed EARLY tile-rows before the interval's last MFMA.  Nothing after it
 // needs the barrier (the tail MFMAs read registers only), and the partner wave on the SIMD -- released by the same barrier --
 // starts its own MFMA stream while this wave is still feeding the pipe: no matrix-pipe bubble at the hand-over.
-template <int DBG, bool M32, int EARLY, bool STAGED = true, int SET = EPI_SET_COMMON>   // SET: which fast epilogue forms (gemm_epilogue_fast); M32: v_mfma_f32_32x32x16_bf16 (4x2 tiles per wave) instead of 16x16x32 (8x4)
+template <int DBG, bool M32, int EARLY, bool STAGED = true, int SET = EPI_SET_COMMON, bool LW = false>   // SET: which fast epilogue forms (gemm_epilogue_fast); M32: v_mfma_f32_32x32x16_bf16 (4x2 tiles per wave) instead of 16x16x32 (8x4)
 __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
   constexpr int TBM = 256, TBN = 256, WTM = 128, WTN = 64, TM = M32 ? 4 : 8, TN = M32 ? 2 : 4;
   constexpr int AH = 128 * BK * 2;                      // 16 KiB: one group's half of an A K-tile
@@ -1244,7 +1244,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
         RG_READ_FRAGS(lds + ATOP + (t & 1) * AH, lds + WB + wcur * WT);
         A3V_WAIT_LGKM0();
         RG_STAMP(t, 1);
-        if constexpr (EARLY < 0) {                       // variant: W(t+1) is waited for HERE (one interval earlier), so nothing stands
+        if constexpr (LW) {                              // variant: W(t+1) is waited for HERE (one interval earlier), so nothing stands
           if (t + 2 < nk) RG_VMCNT(8);                   // between this group's last MFMA and the barrier that releases the other group
           else if (t + 2 == nk) RG_VMCNT(4);
           else RG_VMCNT(0);
@@ -1260,7 +1260,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
         RG_MFMA_PART(false);
         __builtin_amdgcn_s_setprio(0);                 // never wait (vmcnt / barrier) at raised priority: measured -20 %
         RG_STAMP(t, 4);
-        if constexpr (EARLY >= 0) {
+        if constexpr (!LW) {
           if (t + 2 < nk) RG_VMCNT(8);
           else if (t + 2 == nk) RG_VMCNT(4);
           else RG_VMCNT(0);
@@ -2460,8 +2460,11 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
           else hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0>), g, b, 0, st, q);
           break;
         case 11: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0, false>), g, b, 0, st, q); break;   // ring, direct (unstaged) epilogue stores
-        case 12: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, -1>), g, b, 0, st, q); break;   // ring, group 0 waits for its W half at the end of L
-        case 13: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<4, false, -1>), g, b, 0, st, q); break;   // ... with cycle stamps
+        case 12: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0, true, EPI_SET_COMMON, true>), g, b, 0, st, q); break;   // ring, group 0 waits for its W half at the end of L
+        case 13: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<4, false, 0, true, EPI_SET_COMMON, true>), g, b, 0, st, q); break;   // ... with cycle stamps
+        case 14: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 1, true, EPI_SET_COMMON, true>), g, b, 0, st, q); break;   // ... + barrier 1 tile row before the last MFMA
+        case 15: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 2, true, EPI_SET_COMMON, true>), g, b, 0, st, q); break;   // ... 2 tile rows
+        case 8: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 4, true, EPI_SET_COMMON, true>), g, b, 0, st, q); break;    // ... 4 tile rows
         case 7: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<0, 0>), g, b, 0, st, q); break;   // two-stage kernel, for A/B runs
         case 9: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, true, 0>), g, b, 0, st, q); break;   // ring, 32x32x16 MFMA
         case 10: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<4, true, 0>), g, b, 0, st, q); break;   // 32x32x16, stamps
@@ -2471,8 +2474,6 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
         case 2: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<2, 0>), g, b, 0, st, q); break;
         case 3: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<3, 0>), g, b, 0, st, q); break;
         case 4: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<4, 0>), g, b, 0, st, q); break;
-        case 8: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<0, 1>), g, b, 0, st, q); break;
-        case 12: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<4, 1>), g, b, 0, st, q); break;
 #endif
         default: break;
       }

@@ -11,7 +11,7 @@ from a3vlm_amd import ops, lib
 
 dev = "cuda"
 T = lib.EPI_TILE_256PP
-VARIANTS = {"pp": 7, "ring": 5, "ring_direct": 11, "ring32": 9, "ring_lw": 12}
+VARIANTS = {"pp": 7, "ring": 5, "ring_direct": 11, "ring32": 9, "ring_lw": 12, "lw_e1": 14, "lw_e2": 15, "lw_e4": 8}
 if len(sys.argv) > 1:
     VARIANTS = {k: v for k, v in VARIANTS.items() if k in sys.argv[1].split(",") or k == "pp"}
 flag = {k: T | (v << 24) for k, v in VARIANTS.items()}
