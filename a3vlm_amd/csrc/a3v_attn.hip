@@ -30,6 +30,7 @@ struct AttnArgs {
   float scale_log2;             // log2(e) / sqrt(hd)
   float scale;
   float* lse;                   // optional [B,H,Sq] log-sum-exp of the scaled scores (training backward)
+  int head_group;               // causal prefill: heads per tile-rank-major group of the block order (1 = head-major)
 };
 
 // one 16-B-per-lane LDS-DMA through a buffer descriptor: per-lane byte offset + wave-uniform byte offset (an SGPR)
@@ -63,8 +64,18 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_bf16_kernel(AttnArgs p) {
     const int xcd = id & 7, q = total >> 3, r = total & 7;
     vb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
   }
-  const int head_slot = vb / nqt;
-  const int qt = nqt - 1 - (vb - head_slot * nqt);
+  int head_slot = vb / nqt;
+  int qt = nqt - 1 - (vb - head_slot * nqt);
+  if (CAUSAL && p.head_group > 1) {
+    // causal tiles cost 2, 4, ..., 2 nqt KV tiles: with "heavy first" per head the long blocks of the XCD's last heads start late
+    // and run alone (a list-scheduling simulation of the 7B prefill: 129 us against 103 for perfect packing).  Groups of
+    // `head_group` heads are walked tile-rank-major instead (every head's heaviest tile, then every head's second, ...): the
+    // group's K / V (head_group x 0.56 MB at S = 1091) still sits in the XCD's L2 while its tiles run.
+    const int G = p.head_group, per = G * nqt;
+    const int grp = vb / per, r = vb - grp * per;
+    head_slot = grp * G + r % G;
+    qt = nqt - 1 - r / G;
+  }
   const int b = head_slot / p.H, h = head_slot - b * p.H;
   const int hk = h / (p.H / p.Hkv);
   const int q0 = qt * 128 + wave * 32;
@@ -779,6 +790,7 @@ static int attention_impl(const void* q, const void* k, const void* vt, void* ou
   p.scale = 1.0f / sqrtf((float)hd);
   p.scale_log2 = p.scale * 1.4426950408889634f;
   p.lse = lse;
+  p.head_group = 1;
   if (lse && Sq == 1 && dtype == A3V_BF16 && (hd == 64 || hd == 128)) return A3V_ERR_ARG;  // decode kernel has no LSE output
   if (dtype == A3V_F32) {
     if (hd > 256) return A3V_ERR_SHAPE;
@@ -830,6 +842,17 @@ static int attention_impl(const void* q, const void* k, const void* vt, void* ou
     return A3V_OK;
   }
   dim3 grid(((Sq + 127) / 128) * H * B);
+  if (causal && (grid.x & 7) == 0 && ((B * H) & 7) == 0) {
+    // default: the largest power of two (<= 16) whose K + V^T fit ~9 MB (measured best: 16 heads at S = 1091, 8 at S ~ 2000 --
+    // twice the 4-MB L2, the Infinity Cache absorbs the rest; tools/ab_attn_order.py): 160.8 -> 142.3 us at S = 1091
+    const char* ge = getenv("A3V_ATTN_HEAD_GROUP");      // read per launch (A/B runs)
+    int want = 16;
+    while (want > 1 && (int64_t)want * Sk * hd * 4 > (9 << 20)) want >>= 1;
+    if (ge) want = atoi(ge);
+    int G = want < 1 ? 1 : want;
+    while (G > 1 && ((B * H) / 8) % G) G >>= 1;            // groups must not straddle an XCD's range of heads
+    p.head_group = G;
+  }
   if (hd == 128) {
     const char* pe = getenv("A3V_ATTN_PSWAP");          // A3V_ATTN_PSWAP=0: the 8-B-half V^T reads (A/B runs)
     const bool ps = !(pe && pe[0] == '0');
@@ -877,6 +900,7 @@ int a3v_attention_decode_fused(const void* q, const void* k, const void* vt, voi
   p.scale = 1.0f / sqrtf((float)hd);
   p.scale_log2 = p.scale * 1.4426950408889634f;
   p.lse = nullptr;
+  p.head_group = 1;
   int ns, ch;
   decode_plan(B, H, Sk, &ns, &ch);
   const size_t shm = (size_t)(ch + 8) * sizeof(float);
