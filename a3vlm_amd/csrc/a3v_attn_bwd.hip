@@ -28,6 +28,7 @@ struct BwdArgs {
   int64_t k_sb, k_sh, v_sb, v_ss, v_sh;
   int B, S, Sp, H, Hkv, causal;
   float scale;
+  int group_q, group_kv;     // causal: heads per tile-rank-major group of the block order (dQ kernel / dK, dV kernels); 1 = head-major
 };
 
 // 16-B chunk swizzle of a row tile: logical chunk c of row r sits at physical chunk c ^ tile_swz(r).  Two access patterns must
@@ -149,10 +150,18 @@ __device__ __forceinline__ void store_grad_rows(const BwdArgs& p, f32x16 (&acc)[
 // ------------------------------------------------------------------ dQ
 // 1-D grid -> (tile, head slot) with the XCD-aware order of attn_prefill_bf16_kernel: workgroup id & 7 is the XCD, and each XCD
 // takes a contiguous range of (head, tile) pairs so the K / V / Q / dO tiles a head's blocks share stay in one L2.
-__device__ __forceinline__ void xcd_head_tile(int nt, int& head_slot, int& t) {
+// G > 1 (causal): groups of G heads are walked tile-rank-major -- every head's heaviest tile, then every head's second, ... -- so
+// that the long blocks of an XCD's last heads do not start late and run alone (see attn_prefill_bf16_kernel).
+__device__ __forceinline__ void xcd_head_tile(int nt, int& head_slot, int& t, int G = 1) {
   const int total = gridDim.x, id = blockIdx.x;
   const int xcd = id & 7, q = total >> 3, r = total & 7;
   const int vb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  if (G > 1) {
+    const int per = G * nt, grp = vb / per, rr = vb - grp * per;
+    head_slot = grp * G + rr % G;
+    t = rr / G;
+    return;
+  }
   head_slot = vb / nt;
   t = vb - head_slot * nt;
 }
@@ -166,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nqt = (p.S + 127) / 128;
   int head_slot, ti;
-  xcd_head_tile(nqt, head_slot, ti);
+  xcd_head_tile(nqt, head_slot, ti, p.group_q);
   const int qt = nqt - 1 - ti, b = head_slot / p.H, h = head_slot - b * p.H;     // heavy causal tiles first within a head
   const int hk = h / (p.H / p.Hkv);
   const int ql = lane & 31, hh = lane >> 5;
@@ -267,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs p) {
   __shared__ __attribute__((aligned(1024))) char lds[4 * TILE + 1024];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int head_slot, kt_;
-  xcd_head_tile((p.S + 127) / 128, head_slot, kt_);
+  xcd_head_tile((p.S + 127) / 128, head_slot, kt_, p.group_kv);
   const int b = head_slot / p.Hkv, hk = head_slot - b * p.Hkv;
   const int nrep = p.H / p.Hkv;
   const int kl = lane & 31, hh = lane >> 5;
@@ -449,6 +458,18 @@ static int attention_bwd_mfma_impl(const void* q, const void* k, int64_t k_sb, i
   p.B = B; p.S = S; p.Sp = Sp; p.H = H; p.Hkv = Hkv; p.causal = causal;
   p.scale = 1.0f / sqrtf((float)hd);
   dim3 gq(((S + 127) / 128) * H * B), gk(((S + 127) / 128) * Hkv * B);
+  auto group_of = [&](int heads, unsigned blocks) {         // as in the forward (a3v_attn.hip), with Q + dO + K + V per head: 8 heads at S = 1091 (592.8 -> 550.2 us for the three kernels)
+    if (!causal || (blocks & 7) || (heads & 7)) return 1;
+    const char* ge = getenv("A3V_ATTN_HEAD_GROUP");
+    int want = 16;
+    while (want > 1 && (int64_t)want * S * hd * 4 > (9 << 19)) want >>= 1;
+    if (ge) want = atoi(ge);
+    int G = want < 1 ? 1 : want;
+    while (G > 1 && (heads / 8) % G) G >>= 1;
+    return G;
+  };
+  p.group_q = group_of(B * H, gq.x);
+  p.group_kv = group_of(B * Hkv, gk.x);
 #define A3V_BWD_LAUNCH(HDV, PK)                                                                  \
   do {                                                                                           \
     hipLaunchKernelGGL((attn_bwd_dq_kernel<HDV, PK>), gq, dim3(256), 0, st, p);                  \
