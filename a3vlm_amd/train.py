@@ -608,7 +608,7 @@ class TrainEngine:
         vis = None
         if image is not None:
             vis = self._encode_image_train(h, image, B, S, qformer_feats, extra_feats)
-        hs = self._buf("h_saved", (m.n_layers, rows, dim), torch.float32)
+        hs = self._buf("h_saved", (m.n_layers + 1, rows, dim), torch.float32)
         if self.recompute is None:
             F_, Hq = m.ffn, (m.n_heads + 2 * m.n_kv_heads) * m.head_dim
             esz = 2 if self.act == torch.bfloat16 else 4
@@ -616,12 +616,17 @@ class TrainEngine:
             free, _ = torch.cuda.mem_get_info(m._device)
             self.recompute = need > 0.5 * free
         kept = []
-        for i in range(m.n_layers):
-            hs[i].copy_(h)                       # the block input (checkpoint, main_finetune.py:268-276)
-            if self.recompute:
+        if self.recompute:
+            for i in range(m.n_layers):
+                hs[i].copy_(h)                   # the block input (checkpoint, main_finetune.py:268-276)
                 self._block_forward(i, h, B, S, keep=False)
-            else:
-                kept.append(self._block_forward(i, hs[i], B, S, keep=True, tag=f".L{i}", h_out=h))
+        else:
+            # stored activations: block i reads hs[i] and writes hs[i + 1] (its w2 GEMM's residual epilogue stores there), so the
+            # checkpoints cost no copy (was one 143-MB read + write per layer)
+            hs[0].copy_(h)
+            for i in range(m.n_layers):
+                kept.append(self._block_forward(i, hs[i], B, S, keep=True, tag=f".L{i}", h_out=hs[i + 1]))
+            h = hs[m.n_layers]
         xt = self._buf("xn_text", (B * T, dim))
         hv = h.view(B, S, dim)
         for b in range(B):
