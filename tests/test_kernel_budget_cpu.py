@@ -1,0 +1,47 @@
+"""CPU: register / scratch budget of the big-tile GEMM kernels, read from hipcc's resource remarks (cross-compiles without a GPU).
+
+The 256x256 kernels keep 128 accumulator VGPRs plus ~110 more across their k-loop.  Twice in round 2 an innocent-looking epilogue
+change pushed the k-loop's invariants into scratch: 5-20 % off every GEMM, and one such build computed wrong tiles after a ragged
+tile (tests/test_gpu_kernels.py::test_gemm_ring_ragged_rows_over_several_tiles_per_block).  This test fails the build instead."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+BUDGET = [   # (substring of the mangled kernel name, max scratch bytes per lane)
+    ("gemm_nt_bf16_ring_kernelILi0ELb0ELi0ELb1ELi1ELb0E", 64),     # ring, common epilogue forms: the decoder's linears
+    ("gemm_tn_bf16_pp_kernelILb0E", 0),                            # weight gradients
+    ("gemm_tn_bf16_pp_kernelILb1E", 0),                            # input gradients
+    ("gemm_nt_bf16_pp_kernelILi0ELi0E", 64),                       # two-stage NT (A/B reference)
+    ("gemm_nt_bf16_ring_kernelILi0ELb0ELi0ELb1ELi4ELb0E", 320),    # fused-qkv form (its own instantiation: DESIGN.md section 4)
+    ("gemm_nt_fp8_pp_kernel", 0),
+    ("gemm_nt_bf16_kernelILi128ELi128ELi2ELi2E", 0),
+]
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_gemm_kernels_stay_inside_their_register_budget(tmp_path):
+    src = os.path.join(ROOT, "a3vlm_amd", "csrc", "a3v_gemm.hip")
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "--cuda-device-only",
+                        "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", str(tmp_path / "g.o")],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    scratch, name = {}, None
+    for line in r.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+        if m and name:
+            scratch[name] = int(m.group(1))
+    assert scratch, "no resource remarks in the compiler output"
+    for key, limit in BUDGET:
+        hits = {n: v for n, v in scratch.items() if key in n}
+        assert hits, f"kernel {key} not found (renamed? update the budget table)"
+        for n, v in hits.items():
+            assert v <= limit, f"{n}: {v} B of scratch per lane (budget {limit})"
