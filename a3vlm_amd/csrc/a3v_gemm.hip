@@ -334,7 +334,9 @@ __device__ __forceinline__ bool gemm_epilogue_fast(f32x4 (&acc)[TM][TN], const G
       //   v    : token-major rows of v_rows (training) through the same transpose, and the V^T cache through a TRANSPOSING
       //          stage ([64 d][32 tokens]): 16-byte stores of 8 consecutive tokens of one d (2-byte aligned: legal here,
       //          tools/ubench/unaligned.hip) instead of one 2-byte store per element.
-      const RopeKvArgs& k = p.rk;
+      RopeKvArgs k = p.rk;                                   // opaque per-tile copy: none of it is hoisted out of the tile loop
+      asm volatile("" : "+s"(k.q_out), "+s"(k.k_cache), "+s"(k.vt_cache), "+s"(k.cos_sin), "+s"(k.v_rows), "+s"(k.ldq), "+s"(k.ldv));
+      asm volatile("" : "+s"(k.S), "+s"(k.H), "+s"(k.Hkv), "+s"(k.hd_shift), "+s"(k.Smax), "+s"(k.start_pos), "+s"(k.rope_pos0), "+s"(k.m_off));
       const int hd = 1 << k.hd_shift;
       if (k.hd_shift < 6 || k.S < 32 || (k.ldq & 7) || (reinterpret_cast<uintptr_t>(k.q_out) & 15) || (reinterpret_cast<uintptr_t>(k.k_cache) & 15) ||
           (k.v_rows && ((k.ldv & 7) || (reinterpret_cast<uintptr_t>(k.v_rows) & 15))))
@@ -346,21 +348,29 @@ __device__ __forceinline__ bool gemm_epilogue_fast(f32x4 (&acc)[TM][TN], const G
         int sq = (mg0 + mrow) % S_;                        // token position of this lane's row in tile i = 0; +16 per tile
         const float* csb = k.cos_sin + ((d0 + g * 4) >> 1) * 2;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          asm volatile("" : "+v"(sq));                    // address chains stay next to their use (computed ahead, they spill)
-          const float* csr = csb + (((int64_t)(k.rope_pos0 + sq)) << k.hd_shift);      // (pos << (hd_shift - 1)) * 2 floats
+        for (int i0 = 0; i0 < TM; i0 += 4) {                // the cos / sin rows of FOUR tiles in flight (64 VGPRs): two memory round
+          f32x4 cs[4][4];                                   // trips per wave tile; one tile at a time was eight, all of them hoisted spilled
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const f32x4 cs = *reinterpret_cast<const f32x4*>(csr + j * 16);
-            const float v0 = rbf(acc[i][j][0]), v1 = rbf(acc[i][j][1]), v2 = rbf(acc[i][j][2]), v3 = rbf(acc[i][j][3]);
-            acc[i][j][0] = v0 * cs[0] - v1 * cs[1];
-            acc[i][j][1] = v0 * cs[1] + v1 * cs[0];
-            acc[i][j][2] = v2 * cs[2] - v3 * cs[3];
-            acc[i][j][3] = v2 * cs[3] + v3 * cs[2];
+          for (int ii = 0; ii < 4; ++ii) {
+            asm volatile("" : "+v"(sq));
+            const float* csr = csb + (((int64_t)(k.rope_pos0 + sq)) << k.hd_shift);      // (pos << (hd_shift - 1)) * 2 floats
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cs[ii][j] = *reinterpret_cast<const f32x4*>(csr + j * 16);
+            sq += 16;
+            if (sq >= S_) sq -= S_;
           }
-          sq += 16;
-          if (sq >= S_) sq -= S_;
-          __builtin_amdgcn_sched_barrier(0);         // one tile's cos / sin rows in flight at a time (the scheduler would hoist all 32 loads)
+#pragma unroll
+          for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int i = i0 + ii;
+              const float v0 = rbf(acc[i][j][0]), v1 = rbf(acc[i][j][1]), v2 = rbf(acc[i][j][2]), v3 = rbf(acc[i][j][3]);
+              acc[i][j][0] = v0 * cs[ii][j][0] - v1 * cs[ii][j][1];
+              acc[i][j][1] = v0 * cs[ii][j][1] + v1 * cs[ii][j][0];
+              acc[i][j][2] = v2 * cs[ii][j][2] - v3 * cs[ii][j][3];
+              acc[i][j][3] = v2 * cs[ii][j][3] + v3 * cs[ii][j][2];
+            }
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
       bf16x4 pk[TM][4];                                    // the tile as packed bf16: half the registers for the store phase
@@ -489,6 +499,11 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GemmAr
   const int epi = p.epi;
   const int mrow = lane & 15;
   const int ncol = (lane >> 4) * 4;
+  RopeKvArgs rk_ = p.rk;                                   // opaque per-tile copy (see gemm_epilogue_fast): not hoisted out of a persistent tile loop
+  if (epi & GEMM_EPI_ROPEKV) {
+    asm volatile("" : "+s"(rk_.q_out), "+s"(rk_.k_cache), "+s"(rk_.vt_cache), "+s"(rk_.cos_sin), "+s"(rk_.v_rows), "+s"(rk_.ldq), "+s"(rk_.ldv));
+    asm volatile("" : "+s"(rk_.S), "+s"(rk_.H), "+s"(rk_.Hkv), "+s"(rk_.hd_shift), "+s"(rk_.Smax), "+s"(rk_.start_pos), "+s"(rk_.rope_pos0), "+s"(rk_.m_off));
+  }
   if constexpr (F8) {
     // fp8 operands: the accumulator holds sum_k qa[m][k] qw[n][k]; the value of the product is that times sa[m] sw[n].
     // All scale loads are issued before the first store of the tile: a load behind a store would wait for the store to drain.
@@ -563,7 +578,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GemmAr
         if (epi & GEMM_EPI_ROPEKV) {
           // v[] = the bf16 qkv values of token (b, s), columns n..n+3 of head slot n >> hd_shift: rotate the two (even, odd)
           // pairs of q / k by the token's position (LLM/llama_ens5.py:123-135 apply_rotary_emb); v passes through
-          const RopeKvArgs& k = p.rk;
+          const RopeKvArgs& k = rk_;
           if (epi & A3V_EPI_RESIDUAL) {      // an additive term of the projection (the LoRA branch, model/peft.py:89-95): the
             // reference adds it to the bf16 linear output and rounds, before the rotation
             const bf16x4 rr = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(p.res) + (int64_t)m * p.ldr + n);
@@ -613,7 +628,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GemmAr
       if (n >= p.N) continue;
       if (epi & GEMM_EPI_ROPEKV) {
         // q in place of the qkv row, k into the K cache, v transposed into the V^T cache (and token-major into v_rows)
-        const RopeKvArgs& k = p.rk;
+        const RopeKvArgs& k = rk_;
         const int mg = m + k.m_off;
         const int b = mg / k.S, sq = mg - b * k.S;
         const int slot = n >> k.hd_shift, d = n & ((1 << k.hd_shift) - 1);
