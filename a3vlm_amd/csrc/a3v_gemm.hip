@@ -1144,6 +1144,16 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
   typedef typename std::conditional<M32, f32x16, f32x4>::type acc_t;
   acc_t acc[TM][TN];
 
+  // split-K (gridDim.y slices; the tail rows of the hybrid dispatch): slice z takes the k-tiles [z nk/S, (z+1) nk/S) and writes
+  // its own raw fp32 plane (summed, rounded and finished by splitk_epilogue_kernel)
+  if (gridDim.y > 1) {
+    const int nk_all = p.K / BK, z = blockIdx.y, S = gridDim.y;
+    const int t0 = (int)(((int64_t)z * nk_all) / S), t1 = (int)(((int64_t)(z + 1) * nk_all) / S);
+    p.A += (int64_t)t0 * BK;
+    p.W += (int64_t)t0 * BK;
+    p.K = (t1 - t0) * BK;
+    p.C = reinterpret_cast<char*>(p.C) + (int64_t)z * p.c_split;
+  }
   const int nk = p.K / BK;
   const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)(((int64_t)(p.M - 1) * p.lda + p.K) * 2), 0x00020000);
   const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)(((int64_t)(p.N - 1) * p.ldw + p.K) * 2), 0x00020000);
@@ -2518,8 +2528,16 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
     const double c_big = eligible ? (double)((((long)(M + 255) / 256) * tn256 + 255) / 256) : 1e30;
     long mt_h = ((long)(M / 256) * tn256 / 256) * 256 / tn256;          // M-tile rows that make whole rounds
     double c_hyb = 1e30;
-    if (eligible && mt_h >= 1 && mt_h * 256 < M)
-      c_hyb = (double)((mt_h * tn256 + 255) / 256) + small_cost(M - mt_h * 256) + 0.25;
+    if (eligible && mt_h >= 1 && mt_h * 256 < M) {
+      // tail rows: on the ring kernel split over K when that fills the CUs (1/S of a tile time + the reduce pass), else small tiles
+      const long tail_rows = M - mt_h * 256, tail_tiles = ((tail_rows + 255) / 256) * tn256;
+      int S2 = tail_tiles > 0 ? (int)(cu_count() / tail_tiles) : 0;
+      if (S2 > 8) S2 = 8;
+      while (S2 > 1 && K / 64 < 8 * S2) --S2;
+      const bool simple_epi = !(p.epi & ~(A3V_EPI_RESIDUAL | A3V_EPI_RES_F32 | A3V_EPI_OUT_F32)) && g_gemm_ws && N % 4 == 0;
+      const double tail = (S2 >= 3 && simple_epi && pp_ring() && pp_persistent()) ? 1.0 / S2 + 0.2 : small_cost(tail_rows) + 0.25;
+      c_hyb = (double)((mt_h * tn256 + 255) / 256) + tail;
+    }
     if (c_big <= c_small && c_big <= c_hyb) {
       launch(257, p);
     } else if (c_hyb < c_small) {
@@ -2541,7 +2559,26 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
       int S = 1;
       const int tblocks = ((r.M + 127) / 128) * ((N + 127) / 128);
       while (tblocks * S < 512 && S < 8 && K / 64 >= 16 * S) S *= 2;
-      if (S > 1 && !(p.epi & ~simple) && g_gemm_ws && (int64_t)S * r.M * N * 4 <= g_gemm_ws_bytes && N % 4 == 0) {
+      // (round 2) the same tail on the ring kernel: its ceil(rows / 256) x tn256 big tiles split S ways over K so that they fill the
+      // CUs once -- a fraction 1/S of a tile time instead of ~0.6 on the small kernel (wo: 257 -> ~235 us)
+      const int big_tiles = (int)(((r.M + 255) / 256) * tn256);
+      int S2 = big_tiles > 0 ? cu_count() / big_tiles : 0;
+      if (S2 > 8) S2 = 8;
+      while (S2 > 1 && K / 64 < 8 * S2) --S2;
+      static const bool ring_tail = [] { const char* e = getenv("A3V_GEMM_RING_TAIL"); return !(e && e[0] == '0'); }();
+      if (ring_tail && pp_ring() && pp_persistent() && S2 >= 3 && !(p.epi & ~simple) && g_gemm_ws && (int64_t)S2 * r.M * N * 4 <= g_gemm_ws_bytes && N % 4 == 0) {
+        GemmArgs t = r;
+        t.C = g_gemm_ws; t.ldc = N; t.res = nullptr; t.bias = nullptr;
+        t.epi = A3V_EPI_OUT_F32 | GEMM_EPI_RAW;
+        t.tiles_m = (t.M + 255) / 256; t.tiles_n = (int)tn256;
+        t.c_split = (int64_t)t.M * N * 4;
+        t.slow_epi = slow_epi_env();
+        t.skew = 0;
+        hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0>), dim3(big_tiles, S2), dim3(512), 0, st, t);
+        const int64_t n4 = (int64_t)r.M * (N / 4);
+        const int rb = (int)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256);
+        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(rb), dim3(256), 0, st, g_gemm_ws, S2, (int64_t)r.M * N, r.M, N, r.C, r.ldc, r.res, r.ldr, p.epi);
+      } else if (S > 1 && !(p.epi & ~simple) && g_gemm_ws && (int64_t)S * r.M * N * 4 <= g_gemm_ws_bytes && N % 4 == 0) {
         GemmArgs t = r;
         t.C = g_gemm_ws; t.ldc = N; t.res = nullptr; t.bias = nullptr;
         t.epi = A3V_EPI_OUT_F32 | GEMM_EPI_RAW;
