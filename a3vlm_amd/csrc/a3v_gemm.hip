@@ -2356,7 +2356,8 @@ extern "C" int a3v_gemm_set_workspace(void* ptr, int64_t bytes) {
 namespace {
 // sum of S raw fp32 planes [M][N] -> rounded once to bf16 ("the value F.linear returns") -> residual / output forms of gemm_epilogue
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __restrict__ part, int S, int64_t plane, int M, int N, void* __restrict__ C,
-                                                              int64_t ldc, const void* __restrict__ res, int64_t ldr, int epi) {
+                                                              int64_t ldc, const void* __restrict__ res, int64_t ldr, int epi,
+                                                              const bf16_t* __restrict__ bias = nullptr) {
   const int64_t n4 = (int64_t)M * (N / 4);
   for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
     const int r = (int)(i / (N / 4)), c = (int)(i % (N / 4)) * 4;
@@ -2365,6 +2366,11 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
       const f32x4 x = *reinterpret_cast<const f32x4*>(part + (int64_t)s * plane + (int64_t)r * N + c);
 #pragma unroll
       for (int e = 0; e < 4; ++e) a[e] += x[e];
+    }
+    if (bias) {
+      const bf16x4 b4 = *reinterpret_cast<const bf16x4*>(bias + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] += bf2f(b4[e]);
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) a[e] = rbf(a[e]);
@@ -2538,7 +2544,33 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
       const double tail = (S2 >= 3 && simple_epi && pp_ring() && pp_persistent()) ? 1.0 / S2 + 0.2 : small_cost(tail_rows) + 0.25;
       c_hyb = (double)((mt_h * tn256 + 255) / 256) + tail;
     }
-    if (c_big <= c_small && c_big <= c_hyb) {
+    // few big tiles (small N or M: the ViT's output projections, 76 tiles): the whole problem on the ring kernel split over K
+    double c_spl = 1e30;
+    int S3 = 0;
+    {
+      const long tiles_all = ((long)(M + 255) / 256) * tn256;
+      S3 = tiles_all > 0 ? (int)(cu_count() / tiles_all) : 0;
+      if (S3 > 8) S3 = 8;
+      while (S3 > 1 && K / 64 < 8 * S3) --S3;
+      const int okbits = A3V_EPI_BIAS | A3V_EPI_RESIDUAL | A3V_EPI_RES_F32 | A3V_EPI_OUT_F32;
+      static const bool on = [] { const char* e = getenv("A3V_GEMM_RING_SPLIT"); return !(e && e[0] == '0'); }();
+      if (on && eligible && S3 >= 3 && !(p.epi & ~okbits) && pp_ring() && pp_persistent() && g_gemm_ws && N % 4 == 0 &&
+          (int64_t)S3 * M * N * 4 <= g_gemm_ws_bytes && (!(p.epi & A3V_EPI_BIAS) || !(reinterpret_cast<uintptr_t>(bias) & 7)))
+        c_spl = 1.0 / S3 + 0.2;
+    }
+    if (c_spl < c_small && c_spl < c_big && c_spl < c_hyb) {
+      GemmArgs t = p;
+      t.C = g_gemm_ws; t.ldc = N; t.res = nullptr; t.bias = nullptr;
+      t.epi = A3V_EPI_OUT_F32 | GEMM_EPI_RAW;
+      t.tiles_m = (M + 255) / 256; t.tiles_n = (int)tn256;
+      t.c_split = (int64_t)M * N * 4;
+      t.slow_epi = slow_epi_env();
+      hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0>), dim3(t.tiles_m * t.tiles_n, S3), dim3(512), 0, st, t);
+      const int64_t n4 = (int64_t)M * (N / 4);
+      const int rb = (int)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256);
+      hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(rb), dim3(256), 0, st, g_gemm_ws, S3, (int64_t)M * N, M, N, p.C, p.ldc, p.res, p.ldr,
+                         p.epi & ~A3V_EPI_BIAS, (p.epi & A3V_EPI_BIAS) ? (const bf16_t*)p.bias : nullptr);
+    } else if (c_big <= c_small && c_big <= c_hyb) {
       launch(257, p);
     } else if (c_hyb < c_small) {
       const int m_big = (int)(mt_h * 256);

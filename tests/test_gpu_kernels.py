@@ -803,3 +803,28 @@ def test_sumsq_partials(n):
     out2 = torch.empty_like(out)
     ops.sumsq_partials(x, out2)
     assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("M,N,K", [(4616, 1024, 4096), (1024, 768, 2048), (600, 1024, 4096)])
+def test_gemm_few_big_tiles_go_split_k_on_the_ring_kernel(M, N, K):
+    """Small-N problems (the ViT's output projections: 76 big tiles for 256 CUs) run on the ring kernel split over K with the
+    epilogue (bias, bf16 rounding, residual) applied by the reduce pass: against an fp32 reference, against the small-tile
+    kernel (another summation order: 1 bf16 ulp of the product), and deterministic across launches."""
+    from a3vlm_amd import lib
+    a, w = rt(gen(M, K, seed=95)), rt(gen(N, K, seed=96, scale=0.03))
+    bias, res = rt(gen(N, seed=97)), rt(gen(M, N, seed=98))
+    ad, wd, bd = a.to(BF).to(DEV), w.to(BF).to(DEV), bias.to(BF).to(DEV)
+    want = rt(res + rt(a @ w.t() + bias))
+    outs = []
+    for rep in range(2):
+        h = res.to(BF).to(DEV).clone()
+        ops.gemm_nt(ad, wd, h, bias=bd, residual=h)                      # auto dispatch
+        outs.append(h)
+    assert torch.equal(outs[0], outs[1])
+    assert_close(outs[0], want, rtol=2 ** -6, atol=0.05, what="ring split-K, bias + residual")
+    h128 = res.to(BF).to(DEV).clone()
+    ops.gemm_nt(ad, wd, h128, bias=bd, residual=h128, epilogue=lib.EPI_TILE_128)
+    assert_close(outs[0], h128.float().cpu(), rtol=2 ** -6, atol=0.05, what="vs the small-tile kernel")
+    o32 = torch.empty(M, N, device=DEV)
+    ops.gemm_nt(ad, wd, o32, epilogue=ops.EPI_OUT_F32)
+    assert_close(o32, rt(a @ w.t()), rtol=2 ** -7, atol=0.02, what="ring split-K, fp32 out")
