@@ -133,29 +133,30 @@ __device__ __forceinline__ bool gemm_epilogue_fast(f32x4 (&acc)[TM][TN], const G
       const bool f32 = kind == A3V_EPI_RES_F32;
       if (f32 ? ((ldc_ & 3) || (ldr_ & 3) || (r_ & 15)) : (ldc_ & 7)) return false;       // (before anything touches the accumulators)
       if (kind == A3V_EPI_RESIDUAL && ((ldr_ & 7) || (r_ & 15))) return false;
-      if ((pre & A3V_EPI_BIAS) && (reinterpret_cast<uintptr_t>(p.bias) & 7)) return false;
-      if constexpr ((SET & EPI_SET_PRE) != 0)
-      if (pre) {         // y = act(bf16(acc + bias)), each step rounded to bf16 as the general form does (the ViT's linears)
-        float bv[4][4];
+      uintptr_t b_ = reinterpret_cast<uintptr_t>(p.bias);
+      asm volatile("" : "+s"(b_));
+      if ((pre & A3V_EPI_BIAS) && (b_ & 7)) return false;
+      // bias / activation in front (the ViT's linears): y = act(bf16(acc + bias)), each step rounded to bf16 as the general form
+      // does; applied as the values are staged (a separate pass over the 128 accumulators kept the k-loop's state in scratch)
+      float bv[4][4];
+      if constexpr ((SET & EPI_SET_PRE) != 0) {
+        if (pre) {
+          if (f32) return false;                               // (fp32 stream with bias: not a shape of the path; general form)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          bf16x4 b4 = {};
-          if (pre & A3V_EPI_BIAS) b4 = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(p.bias) + nbase + j * 16 + g * 4);
+          for (int j = 0; j < 4; ++j) {
+            bf16x4 b4 = {};
+            if (pre & A3V_EPI_BIAS) b4 = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(b_) + nbase + j * 16 + g * 4);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) bv[j][e] = (pre & A3V_EPI_BIAS) ? bf2f(b4[e]) : 0.f;
+            for (int e = 0; e < 4; ++e) bv[j][e] = (pre & A3V_EPI_BIAS) ? bf2f(b4[e]) : 0.f;
+          }
         }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              float v = rbf(acc[i][j][e] + bv[j][e]);
-              if (pre & A3V_EPI_GELU) v = rbf(gelu_erf_fast(v));
-              else if (pre & A3V_EPI_QUICKGELU) v = rbf(quick_gelu(v));
-              acc[i][j][e] = v;
-            }
       }
+      auto pre_value = [&](float v, int j, int e) {
+        v = rbf(v + bv[j][e]);
+        if (pre & A3V_EPI_GELU) v = rbf(gelu_erf_fast(v));
+        else if (pre & A3V_EPI_QUICKGELU) v = rbf(quick_gelu(v));
+        return v;
+      };
       const int l3 = lane >> 3, q = lane & 7;
       char* const wr = stage + mrow * 128;
       const int wx = mrow & 14;
@@ -168,7 +169,11 @@ __device__ __forceinline__ bool gemm_epilogue_fast(f32x4 (&acc)[TM][TN], const G
           for (int j = 0; j < 4; ++j) {
             bf16x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = f2bf(acc[2 * ic + ii][j][e]);
+            for (int e = 0; e < 4; ++e) {
+              float v = acc[2 * ic + ii][j][e];
+              if constexpr ((SET & EPI_SET_PRE) != 0) { if (pre) v = pre_value(v, j, e); }
+              o[e] = f2bf(v);
+            }
             *reinterpret_cast<bf16x4*>(wr + ii * 2048 + (((j * 4 + g) ^ wx) << 3)) = o;
           }
         LDS_ORDER();        // the reads below are of another vector type: keep the compiler from moving them across these writes
