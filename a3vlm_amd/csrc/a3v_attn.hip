@@ -31,6 +31,7 @@ struct AttnArgs {
   float scale;
   float* lse;                   // optional [B,H,Sq] log-sum-exp of the scaled scores (training backward)
   int head_group;               // causal prefill: heads per tile-rank-major group of the block order (1 = head-major)
+  int staged_o;                 // prefill: O leaves through an LDS patch as whole rows (A3V_ATTN_STAGED_O=0: per-lane row stores)
 };
 
 // one 16-B-per-lane LDS-DMA through a buffer descriptor: per-lane byte offset + wave-uniform byte offset (an SGPR)
@@ -337,6 +338,36 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_bf16_kernel(AttnArgs p) {
   if (false)
 #endif
     p.lse[((int64_t)b * p.H + h) * p.Sq + qrow] = m_run * p.scale + __logf(l_tot);
+  if (p.staged_o && !(p.o_ss & 7) && !(p.o_sh & 7) && !(p.o_sb & 7) && !(reinterpret_cast<uintptr_t>(p.out) & 15)) {
+    // The lane owns one query row: stored directly, an instruction writes 16 bytes into each of 32 rows (partial lines, ~6 B/clk/CU:
+    // tools/ubench/stores.hip).  The wave's 32 x HD tile goes through a private LDS patch (the K / V^T buffers are free after one
+    // more barrier) and leaves as whole rows, 16 bytes per lane.  8-byte slot s of row r sits at slot s ^ ((r & (HD/8 - 1)) << 1).
+    constexpr int ROWB = HD * 2, NPAIR = HD / 8, RPI = 64 / NPAIR;          // row bytes, 16-byte pairs per row, rows per store instruction
+    __syncthreads();
+    char* patch = lds + wave * (32 * ROWB);
+    char* wrow = patch + ql * ROWB;
+    const int wx = (ql & (NPAIR - 1)) << 1;
+#pragma unroll
+    for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        bf16x4 ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ov[e] = f2bf(o[d][g4 * 4 + e] * inv);
+        *reinterpret_cast<bf16x4*>(wrow + (((d * 8 + g4 * 2 + hh) ^ wx) << 3)) = ov;
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int pr = lane % NPAIR, rr = lane / NPAIR;
+    bf16_t* Ob = (bf16_t*)p.out + b * p.o_sb + h * p.o_sh + pr * 8;
+    const int qw = qt * 128 + wave * 32;
+#pragma unroll
+    for (int it = 0; it < 32 / RPI; ++it) {
+      const int r = it * RPI + rr;
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(patch + r * ROWB + ((pr ^ (r & (NPAIR - 1))) << 4));
+      if (qw + r < p.Sq) *reinterpret_cast<bf16x8*>(Ob + (int64_t)(qw + r) * p.o_ss) = v;
+    }
+    return;
+  }
   if (qrow < p.Sq) {
     bf16_t* O = (bf16_t*)p.out + b * p.o_sb + (int64_t)qrow * p.o_ss + h * p.o_sh;
 #pragma unroll
@@ -791,6 +822,7 @@ static int attention_impl(const void* q, const void* k, const void* vt, void* ou
   p.scale_log2 = p.scale * 1.4426950408889634f;
   p.lse = lse;
   p.head_group = 1;
+  { const char* e = getenv("A3V_ATTN_STAGED_O"); p.staged_o = !(e && e[0] == '0'); }
   if (lse && Sq == 1 && dtype == A3V_BF16 && (hd == 64 || hd == 128)) return A3V_ERR_ARG;  // decode kernel has no LSE output
   if (dtype == A3V_F32) {
     if (hd > 256) return A3V_ERR_SHAPE;
@@ -901,6 +933,7 @@ int a3v_attention_decode_fused(const void* q, const void* k, const void* vt, voi
   p.scale_log2 = p.scale * 1.4426950408889634f;
   p.lse = nullptr;
   p.head_group = 1;
+  p.staged_o = 0;
   int ns, ch;
   decode_plan(B, H, Sk, &ns, &ch);
   const size_t shm = (size_t)(ch + 8) * sizeof(float);
