@@ -349,68 +349,94 @@ __device__ __forceinline__ bool gemm_epilogue_fast(f32x4 (&acc)[TM][TN], const G
       int slot = nbase >> k.hd_shift, d0 = nbase & (hd - 1), mg0 = mbase + k.m_off, S_ = k.S;
       asm volatile("" : "+s"(slot), "+s"(d0), "+s"(mg0), "+s"(S_));
       const int l3 = lane >> 3, q = lane & 7;
-      if (slot < k.H + k.Hkv) {
-        int sq = (mg0 + mrow) % S_;                        // token position of this lane's row in tile i = 0; +16 per tile
-        const float* csb = k.cos_sin + ((d0 + g * 4) >> 1) * 2;
-#pragma unroll
-        for (int i0 = 0; i0 < TM; i0 += 4) {                // the cos / sin rows of FOUR tiles in flight (64 VGPRs): two memory round
-          f32x4 cs[4][4];                                   // trips per wave tile; one tile at a time was eight, all of them hoisted spilled
-#pragma unroll
-          for (int ii = 0; ii < 4; ++ii) {
-            asm volatile("" : "+v"(sq));
-            const float* csr = csb + (((int64_t)(k.rope_pos0 + sq)) << k.hd_shift);      // (pos << (hd_shift - 1)) * 2 floats
-#pragma unroll
-            for (int j = 0; j < 4; ++j) cs[ii][j] = *reinterpret_cast<const f32x4*>(csr + j * 16);
-            sq += 16;
-            if (sq >= S_) sq -= S_;
-          }
-#pragma unroll
-          for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int i = i0 + ii;
-              const float v0 = rbf(acc[i][j][0]), v1 = rbf(acc[i][j][1]), v2 = rbf(acc[i][j][2]), v3 = rbf(acc[i][j][3]);
-              acc[i][j][0] = v0 * cs[ii][j][0] - v1 * cs[ii][j][1];
-              acc[i][j][1] = v0 * cs[ii][j][1] + v1 * cs[ii][j][0];
-              acc[i][j][2] = v2 * cs[ii][j][2] - v3 * cs[ii][j][3];
-              acc[i][j][3] = v2 * cs[ii][j][3] + v3 * cs[ii][j][2];
-            }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      bf16x4 pk[TM][4];                                    // the tile as packed bf16: half the registers for the store phase
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) pk[i][j][e] = f2bf(acc[i][j][e]);
-          asm volatile("" : "+v"(pk[i][j]));
-        }
       char* const wr = stage + mrow * 128;
       const int wx = mrow & 14;
       const char* const rd = stage + l3 * 128;
       const int rx = l3 >> 1;
-      auto put = [&](int ic) {
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) *reinterpret_cast<bf16x4*>(wr + ii * 2048 + (((j * 4 + g) ^ wx) << 3)) = pk[2 * ic + ii][j];
-        LDS_ORDER();
-      };
       auto get = [&](int it) {
         const bf16x8 v = *reinterpret_cast<const bf16x8*>(rd + it * 1024 + ((q ^ rx ^ ((it & 1) << 2)) << 4));
         LDS_ORDER();
         return v;
       };
-      if (slot < k.H || (slot >= k.H + k.Hkv && k.v_rows)) {
+      auto put_plain = [&](int ic) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = f2bf(acc[2 * ic + ii][j][e]);
+            *reinterpret_cast<bf16x4*>(wr + ii * 2048 + (((j * 4 + g) ^ wx) << 3)) = o;
+          }
+        LDS_ORDER();
+      };
+      if (slot < k.H + k.Hkv) {
+        // q / k: rotated as the chunk is staged.  The cos / sin rows of a 32-row chunk (8 x 16 B per lane) are requested one chunk
+        // ahead -- before the previous chunk's stores, so the loads never queue behind them -- and nothing of the tile is copied.
+        int sqr = (mg0 + mrow) % S_;                        // token position of this lane's row in tile i; +16 per tile
+        const float* csb = k.cos_sin + ((d0 + g * 4) >> 1) * 2;
+        f32x4 csA[2][4], csB[2][4];
+        auto load_cs = [&](f32x4 (&cs)[2][4]) {
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii) {
+            asm volatile("" : "+v"(sqr));
+            const float* csr = csb + (((int64_t)(k.rope_pos0 + sqr)) << k.hd_shift);      // (pos << (hd_shift - 1)) * 2 floats
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cs[ii][j] = *reinterpret_cast<const f32x4*>(csr + j * 16);
+            sqr += 16;
+            if (sqr >= S_) sqr -= S_;
+          }
+        };
+        auto put_rot = [&](int ic, const f32x4 (&cs)[2][4]) {
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int i = 2 * ic + ii;
+              const float v0 = rbf(acc[i][j][0]), v1 = rbf(acc[i][j][1]), v2 = rbf(acc[i][j][2]), v3 = rbf(acc[i][j][3]);
+              bf16x4 o;
+              o[0] = f2bf(v0 * cs[ii][j][0] - v1 * cs[ii][j][1]);
+              o[1] = f2bf(v0 * cs[ii][j][1] + v1 * cs[ii][j][0]);
+              o[2] = f2bf(v2 * cs[ii][j][2] - v3 * cs[ii][j][3]);
+              o[3] = f2bf(v2 * cs[ii][j][3] + v3 * cs[ii][j][2]);
+              *reinterpret_cast<bf16x4*>(wr + ii * 2048 + (((j * 4 + g) ^ wx) << 3)) = o;
+            }
+          LDS_ORDER();
+        };
         const bool isq = slot < k.H;
-        const int64_t ld = isq ? k.ldq : k.ldv;
-        bf16_t* cp = (isq ? k.q_out + nbase : k.v_rows + (nbase - ((k.H + k.Hkv) << k.hd_shift))) + (int64_t)(mg0 + l3) * ld + q * 8;
-        const int64_t cstep = 8 * ld;
+        bf16_t* cp = k.q_out + nbase + (int64_t)(mg0 + l3) * k.ldq + q * 8;
+        const int64_t cstep = 8 * k.ldq;
+        int b = (mg0 + l3) / S_, sq = (mg0 + l3) - b * S_;
+        bf16_t* const kb = k.k_cache + d0 + q * 8;
+        const int hk = slot - k.H;
+        load_cs(csA);
 #pragma unroll
         for (int ic = 0; ic < TM / 2; ++ic) {
-          put(ic);
+          if (ic + 1 < TM / 2) { if (ic & 1) load_cs(csA); else load_cs(csB); }
+          if (ic & 1) put_rot(ic, csB); else put_rot(ic, csA);
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            if (isq) {
+              asm volatile("" : "+v"(cp));
+              *reinterpret_cast<bf16x8*>(cp) = get(it);
+              cp += cstep;
+            } else {
+              asm volatile("" : "+v"(sq), "+v"(b));
+              *reinterpret_cast<bf16x8*>(kb + ((((int64_t)b * k.Hkv + hk) * k.Smax + k.start_pos + sq) << k.hd_shift)) = get(it);
+              sq += 8;
+              if (sq >= S_) { sq -= S_; ++b; }
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        return true;
+      }
+      if (k.v_rows) {
+        bf16_t* cp = k.v_rows + (nbase - ((k.H + k.Hkv) << k.hd_shift)) + (int64_t)(mg0 + l3) * k.ldv + q * 8;
+        const int64_t cstep = 8 * k.ldv;
+#pragma unroll
+        for (int ic = 0; ic < TM / 2; ++ic) {
+          put_plain(ic);
 #pragma unroll
           for (int it = 0; it < 4; ++it) {
             asm volatile("" : "+v"(cp));
@@ -419,24 +445,6 @@ __device__ __forceinline__ bool gemm_epilogue_fast(f32x4 (&acc)[TM][TN], const G
           }
           __builtin_amdgcn_sched_barrier(0);
         }
-        if (isq) return true;
-      } else if (slot < k.H + k.Hkv) {
-        int b = (mg0 + l3) / S_, sq = (mg0 + l3) - b * S_;
-        bf16_t* const kb = k.k_cache + d0 + q * 8;
-        const int hk = slot - k.H;
-#pragma unroll
-        for (int ic = 0; ic < TM / 2; ++ic) {
-          put(ic);
-#pragma unroll
-          for (int it = 0; it < 4; ++it) {
-            asm volatile("" : "+v"(sq), "+v"(b));
-            *reinterpret_cast<bf16x8*>(kb + ((((int64_t)b * k.Hkv + hk) * k.Smax + k.start_pos + sq) << k.hd_shift)) = get(it);
-            sq += 8;
-            if (sq >= S_) { sq -= S_; ++b; }
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        return true;
       }
       // V^T cache: [64 d][32 tokens] bf16 per chunk; the 16-byte token group c of row d sits at group c ^ ((d >> 2) & 3)
       {
@@ -454,7 +462,7 @@ __device__ __forceinline__ bool gemm_epilogue_fast(f32x4 (&acc)[TM][TN], const G
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                   *reinterpret_cast<bf16_t*>(stage + (j * 16 + g * 4 + e) * 64 + (((ii * 2 + (mrow >> 3)) ^ g) << 4) + (mrow & 7) * 2) =
-                      pk[2 * ic + ii][j][e];
+                      f2bf(acc[2 * ic + ii][j][e]);
             LDS_ORDER();
             bf16_t* const vb = k.vt_cache + ((((int64_t)b0 * k.Hkv + hv) << k.hd_shift) + d0) * k.Smax + k.start_pos + sq0 + c * 8;
 #pragma unroll
@@ -475,7 +483,7 @@ __device__ __forceinline__ bool gemm_epilogue_fast(f32x4 (&acc)[TM][TN], const G
               for (int j = 0; j < 4; ++j) {
                 bf16_t* dst = k.vt_cache + ((((int64_t)bb * k.Hkv + hv) << k.hd_shift) + d0 + j * 16 + g * 4) * k.Smax + k.start_pos + ss;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) dst[(int64_t)e * k.Smax] = pk[2 * ic + ii][j][e];
+                for (int e = 0; e < 4; ++e) dst[(int64_t)e * k.Smax] = f2bf(acc[2 * ic + ii][j][e]);
               }
             }
           }

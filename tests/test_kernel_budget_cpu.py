@@ -19,7 +19,7 @@ BUDGET = [   # (substring of the mangled kernel name, max scratch bytes per lane
     ("gemm_tn_bf16_pp_kernelILb0E", 0),                            # weight gradients
     ("gemm_tn_bf16_pp_kernelILb1E", 0),                            # input gradients
     ("gemm_nt_bf16_pp_kernelILi0ELi0E", 64),                       # two-stage NT (A/B reference)
-    ("gemm_nt_bf16_ring_kernelILi0ELb0ELi0ELb1ELi4ELb0E", 320),    # fused-qkv form (its own instantiation: DESIGN.md section 4)
+    ("gemm_nt_bf16_ring_kernelILi0ELb0ELi0ELb1ELi4ELb0E", 64),     # fused-qkv form (its own instantiation: DESIGN.md section 4)
     ("gemm_nt_fp8_pp_kernel", 0),
     ("gemm_nt_bf16_kernelILi128ELi128ELi2ELi2E", 0),
 ]
