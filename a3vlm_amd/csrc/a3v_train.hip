@@ -133,7 +133,8 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
 template <typename TA, int RPB, int MAXV, bool PART>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_vec_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ w,
                                                               const TA* __restrict__ dy, int64_t lddy, float* __restrict__ dh,
-                                                              int64_t lddh, float* __restrict__ dw, int rows, int dim, float eps) {
+                                                              int64_t lddh, float* __restrict__ dw, int rows, int dim, float eps,
+                                                              bf16_t* __restrict__ dh_bf = nullptr, int64_t ld_bf = 0) {
   __shared__ float red[2][8];
   const int tid = threadIdx.x;
   const int nv = dim >> 2;
@@ -194,6 +195,12 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_vec_kernel(const float* __res
           dwp[i][e] += gv[i][e] * xv[i][e] * r;
         }
         dhr[c] = o;
+        if (dh_bf) {            // the bf16 copy the next weight / input gradient GEMMs read (was a cast pass of its own)
+          bf16x4 ob;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ob[e] = f2bf(o[e]);
+          *reinterpret_cast<bf16x4*>(dh_bf + (int64_t)row * ld_bf + 4 * c) = ob;
+        }
       }
     }
   }
@@ -679,8 +686,9 @@ int a3v_transpose_2level(const bf16_t* src, int64_t ld_src, int64_t bs_in, int64
 
 extern "C" int64_t a3v_rmsnorm_bwd_scratch_floats(int rows, int dim) { return (int64_t)((rows + 7) / 8) * dim; }
 
-extern "C" int a3v_rmsnorm_bwd(const float* x, int64_t ldx, const float* w, const void* dy, int64_t lddy, float* dh, int64_t lddh,
-                               float* dw, float* dw_scratch, int rows, int dim, float eps, int act_dtype, void* stream) {
+static int rmsnorm_bwd_impl(const float* x, int64_t ldx, const float* w, const void* dy, int64_t lddy, float* dh, int64_t lddh,
+                            float* dw, float* dw_scratch, int rows, int dim, float eps, int act_dtype, void* stream, bf16_t* dh_bf,
+                            int64_t ld_bf) {
   if (!x || !w || !dy || !dh || rows <= 0) return A3V_ERR_ARG;
   if (dim > 8192) return A3V_ERR_SHAPE;
   if (dim % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && lddh % 4 == 0 && (act_dtype == A3V_BF16 || act_dtype == A3V_F32) &&
@@ -691,7 +699,7 @@ extern "C" int a3v_rmsnorm_bwd(const float* x, int64_t ldx, const float* w, cons
     dim3 gv(nb);
     const bool part = dw && dw_scratch && (reinterpret_cast<uintptr_t>(dw_scratch) & 15) == 0;
     float* dwo = part ? dw_scratch : dw;
-#define A3V_RB(TT, MV, PP) hipLaunchKernelGGL((rmsnorm_bwd_vec_kernel<TT, RV, MV, PP>), gv, dim3(256), 0, ST, x, ldx, w, (const TT*)dy, lddy, dh, lddh, dwo, rows, dim, eps)
+#define A3V_RB(TT, MV, PP) hipLaunchKernelGGL((rmsnorm_bwd_vec_kernel<TT, RV, MV, PP>), gv, dim3(256), 0, ST, x, ldx, w, (const TT*)dy, lddy, dh, lddh, dwo, rows, dim, eps, dh_bf, ld_bf)
     if (dim <= 4096) {
       if (act_dtype == A3V_BF16) { if (part) A3V_RB(bf16_t, 4, true); else A3V_RB(bf16_t, 4, false); }
       else { if (part) A3V_RB(float, 4, true); else A3V_RB(float, 4, false); }
@@ -713,7 +721,20 @@ extern "C" int a3v_rmsnorm_bwd(const float* x, int64_t ldx, const float* w, cons
   else if (act_dtype == A3V_F32) hipLaunchKernelGGL((rmsnorm_bwd_kernel<float, RPB>), g, dim3(256), 0, ST, x, ldx, w, (const float*)dy, lddy, dh, lddh, dw, rows, dim, eps);
   else return A3V_ERR_DTYPE;
   A3V_LAUNCH_CHECK();
+  if (dh_bf) return a3v_cast(dh, lddh, A3V_F32, dh_bf, ld_bf, A3V_BF16, rows, dim, stream);     // (scalar form of the kernel: the copy as a pass)
   return A3V_OK;
+}
+
+extern "C" int a3v_rmsnorm_bwd(const float* x, int64_t ldx, const float* w, const void* dy, int64_t lddy, float* dh, int64_t lddh,
+                               float* dw, float* dw_scratch, int rows, int dim, float eps, int act_dtype, void* stream) {
+  return rmsnorm_bwd_impl(x, ldx, w, dy, lddy, dh, lddh, dw, dw_scratch, rows, dim, eps, act_dtype, stream, nullptr, 0);
+}
+
+extern "C" int a3v_rmsnorm_bwd_cast(const float* x, int64_t ldx, const float* w, const void* dy, int64_t lddy, float* dh, int64_t lddh,
+                                    float* dw, float* dw_scratch, int rows, int dim, float eps, int act_dtype, void* dh_bf16,
+                                    int64_t ld_bf16, void* stream) {
+  if (!dh_bf16 || (ld_bf16 & 3) || (reinterpret_cast<uintptr_t>(dh_bf16) & 7)) return A3V_ERR_ARG;
+  return rmsnorm_bwd_impl(x, ldx, w, dy, lddy, dh, lddh, dw, dw_scratch, rows, dim, eps, act_dtype, stream, (bf16_t*)dh_bf16, ld_bf16);
 }
 
 extern "C" int a3v_layernorm_bwd(const void* x, int64_t ldx, const float* w, const float* dy, int64_t lddy, const int32_t* row_map,

@@ -405,8 +405,9 @@ def add2d(dst, src):
 _rb_scratch = {}
 
 
-def rmsnorm_bwd(x, w, dy, dh, dw, eps):
-    _dev(x, w, dy, dh, dw)
+def rmsnorm_bwd(x, w, dy, dh, dw, eps, dh_lowp=None):
+    """dh += d(rmsnorm)/dx . dy (fp32 stream), dw += ...; ``dh_lowp``: the updated dh also as bf16 (the next GEMMs' operand)."""
+    _dev(x, w, dy, dh, dw, dh_lowp)
     assert x.dtype == torch.float32 and w.dtype == torch.float32 and dh.dtype == torch.float32
     rows, dim = x.shape
     scratch = None
@@ -416,6 +417,12 @@ def rmsnorm_bwd(x, w, dy, dh, dw, eps):
         if scratch is None or scratch.numel() < need:
             scratch = torch.empty(need, dtype=torch.float32, device=x.device)
             _rb_scratch[x.device] = scratch
+    if dh_lowp is not None:
+        assert dh_lowp.dtype == torch.bfloat16 and dh_lowp.shape == dh.shape
+        rc = _l.load().a3v_rmsnorm_bwd_cast(_p(x), x.stride(0), _p(w), _p(dy), dy.stride(0), _p(dh), dh.stride(0), _p(dw), _p(scratch), rows,
+                                            dim, eps, dt(dy), _p(dh_lowp), dh_lowp.stride(0), _stream())
+        _l.check(rc, "a3v_rmsnorm_bwd_cast")
+        return
     rc = _l.load().a3v_rmsnorm_bwd(_p(x), x.stride(0), _p(w), _p(dy), dy.stride(0), _p(dh), dh.stride(0), _p(dw), _p(scratch), rows, dim,
                                    eps, dt(dy), _stream())
     _l.check(rc, "a3v_rmsnorm_bwd")

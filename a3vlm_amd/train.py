@@ -520,7 +520,10 @@ class TrainEngine:
             dha_full, dha = ybuf("dh_act.x", dim, f"w2.{i}")
         else:
             dha = self._buf("dh_act", (rows, dim))
-        ops.cast(dh, dha)
+        fuse_cast = self.act == torch.bfloat16       # the norm backward that produced dh also wrote its bf16 copy (a3v_rmsnorm_bwd_cast)
+        if not (fuse_cast and getattr(self, "_dha_ready", False)):
+            ops.cast(dh, dha)
+        self._dha_ready = False
         if self._has(pre + "feed_forward.w2.weight"):
             self._wgrad(dha, k["act"], self._views[pre + "feed_forward.w2.weight"], "w2", (pre + "feed_forward.w2.weight",))
         dact = self._buf("dact", (rows, F))
@@ -543,9 +546,11 @@ class TrainEngine:
             self._dgrad_w(dgu, f"w13.{i}", dxn)
             if self.lora:
                 self._lora_bwd(i, f"w13.{i}", dgu, k["xn2"], lt["w13"], dxn)
-        ops.rmsnorm_bwd(k["h_mid"], l.ffn_norm.weight, dxn, dh, self._views.get(pre + "ffn_norm.weight"), a.norm_eps)
+        ops.rmsnorm_bwd(k["h_mid"], l.ffn_norm.weight, dxn, dh, self._views.get(pre + "ffn_norm.weight"), a.norm_eps,
+                        dh_lowp=dha if fuse_cast else None)
         # ---- attention: h_mid = h_in + wo(attn(rope(qkv(norm(h_in)))))
-        ops.cast(dh, dha)
+        if not fuse_cast:
+            ops.cast(dh, dha)
         if self._has(pre + "attention.wo.weight"):
             self._wgrad(dha, k["att"], self._views[pre + "attention.wo.weight"], "wo", (pre + "attention.wo.weight",))
         datt = self._buf("datt", (rows, H * hd))
@@ -588,7 +593,9 @@ class TrainEngine:
             self._dgrad_w(dqkv, f"qkv.{i}", dxn)
             if self.lora:
                 self._lora_bwd(i, f"qkv.{i}", dqkv, k["xn"], lt["qkv"], dxn)
-        ops.rmsnorm_bwd(h_in, l.attention_norm.weight, dxn, dh, self._views.get(pre + "attention_norm.weight"), a.norm_eps)
+        ops.rmsnorm_bwd(h_in, l.attention_norm.weight, dxn, dh, self._views.get(pre + "attention_norm.weight"), a.norm_eps,
+                        dh_lowp=dha if fuse_cast else None)
+        self._dha_ready = fuse_cast                        # the next block's backward finds its bf16 operand in place
 
     # ------------------------------------------------------------------ forward (loss) and backward
     @torch.no_grad()
@@ -649,6 +656,7 @@ class TrainEngine:
     @torch.no_grad()
     def backward(self, grad_scale: float = 1.0) -> None:
         s = self._saved
+        self._dha_ready = False
         assert s is not None, "backward() without forward_loss()"
         m, a = self.m, self.m.args
         im = self._images()

@@ -303,6 +303,11 @@ int64_t a3v_rmsnorm_bwd_scratch_floats(int rows, int dim);
 int a3v_rmsnorm_bwd(const float* x, int64_t ldx, const float* w, const void* dy, int64_t lddy,
                     float* dh, int64_t lddh, float* dw, float* dw_scratch, int rows, int dim, float eps,
                     int act_dtype, void* stream);
+/* The same, and the updated dh also as bf16 (dh_bf16 [rows][ld_bf16]): the operand of the weight / input gradient GEMMs that
+ * follow (autograd casts the fp32 stream gradient for the autocast linears, engine_finetune.py:49) without a pass of its own. */
+int a3v_rmsnorm_bwd_cast(const float* x, int64_t ldx, const float* w, const void* dy, int64_t lddy,
+                         float* dh, int64_t lddh, float* dw, float* dw_scratch, int rows, int dim, float eps,
+                         int act_dtype, void* dh_bf16, int64_t ld_bf16, void* stream);
 
 /* backward of a3v_layernorm (x in act_dtype, fp32 w; dy fp32 rows gathered through row_map):
  * dx (act_dtype), dw += , db += . */

@@ -67,6 +67,14 @@ def test_rmsnorm_bwd(act, rows, dim):
     ops.rmsnorm_bwd(x.detach().to(DEV), w.detach().to(DEV), dy.to(DEV), dh, dw, 1e-5)
     assert relerr(dh.cpu() - dh0, x.grad) < 1e-4
     assert relerr(dw, w.grad) < 1e-4
+    if dim % 4 == 0:
+        # the form that also emits the bf16 copy of the updated stream gradient (the next GEMMs' operand): same dh, same dw, and
+        # the copy is exactly the bf16 rounding of it -- into a wider buffer (row stride != dim), as the adapter path has it
+        dh2, dw2 = dh0.to(DEV).clone(), torch.zeros(dim, device=DEV)
+        wide = torch.full((rows, dim + 64), 7.0, dtype=BF, device=DEV)
+        ops.rmsnorm_bwd(x.detach().to(DEV), w.detach().to(DEV), dy.to(DEV), dh2, dw2, 1e-5, dh_lowp=wide[:, :dim])
+        assert torch.equal(dh2, dh) and torch.allclose(dw2, dw, rtol=1e-5, atol=1e-5)      # (dw: partial sums added in no fixed order)
+        assert torch.equal(wide[:, :dim], dh.to(BF)) and bool((wide[:, dim:] == 7.0).all())
 
 
 @pytest.mark.parametrize("act", [torch.float32, BF])
