@@ -2899,7 +2899,11 @@ extern "C" int a3v_gemm_tn(const void* At, int64_t lda, const void* Wt, int64_t 
   const long mt_h = (total / ncu) * ncu / p.tiles_n;
   const long rem_tiles = total - mt_h * p.tiles_n;
   int S = 1;
-  while (rem_tiles * S * 2 <= ncu && S < 8 && ((K + 63) / 64) >= 16 * S) S *= 2;
+  // as many K-slices as fill the CUs once (round 2: was the largest power of two with 2 S rem_tiles <= CUs, i.e. 96 blocks for the 48
+  // tail tiles of a [8728, 4096] output; 5 slices = 240 blocks finish the tail in 1/5 of a tile time instead of 1/2)
+  S = rem_tiles > 0 ? (int)std::min<long>(8, ncu / rem_tiles) : 1;
+  while (S > 1 && ((K + 63) / 64) < 16 * S) --S;
+  if (S < 1) S = 1;
   const int m_big = (int)(mt_h * 256);
   static const bool tail_on = [] { const char* e = getenv("A3V_TN_TAIL"); return !(e && e[0] == '0'); }();
   if (tail_on && mt_h >= 1 && m_big < M && S > 1 && rem_tiles * 4 < 3 * ncu && g_gemm_ws && (int64_t)S * (M - m_big) * N * 4 <= g_gemm_ws_bytes) {
@@ -3052,7 +3056,9 @@ extern "C" int a3v_gemm_nn(const void* A, int64_t lda, const void* Wt, int64_t l
   const long mt_h = (total / ncu) * ncu / p.tiles_n;
   const long rem_tiles = total - mt_h * p.tiles_n;
   int S = 1;
-  while (rem_tiles * S * 2 <= ncu && S < 8 && (K / 64) >= 16 * S) S *= 2;
+  S = rem_tiles > 0 ? (int)std::min<long>(8, ncu / rem_tiles) : 1;      // as many K-slices as fill the CUs once (see a3v_gemm_tn)
+  while (S > 1 && (K / 64) < 16 * S) --S;
+  if (S < 1) S = 1;
   const int m_big = (int)(mt_h * 256);
   if (mt_h >= 1 && m_big < M && S > 1 && rem_tiles * 4 < 3 * ncu && g_gemm_ws && (int64_t)S * (M - m_big) * N * 4 <= g_gemm_ws_bytes) {
     GemmArgs q = p;
