@@ -107,6 +107,22 @@ __device__ __forceinline__ bf16x8 frag_rows_tr(const char* lds, int db, int tb, 
   return f;
 }
 
+// Read back a wave's 32 x HD bf16 tile from its LDS patch (8-byte slot s of row r at slot s ^ ((r & (HD/8 - 1)) << 1), written by the
+// lane that owns row r) and store it as whole rows, 16 bytes per lane: rows row0 .. row0 + 31 of a matrix with `ld` elements per
+// row, rows >= nrows skipped.  (Per-lane row stores put 16 bytes into each of 32 rows per instruction: tools/ubench/stores.hip.)
+template <int HD>
+__device__ __forceinline__ void store_patch_rows(const char* patch, bf16_t* base, int64_t ld, int row0, int nrows, int lane) {
+  constexpr int ROWB = HD * 2, NPAIR = HD / 8, RPI = 64 / NPAIR;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const int pr = lane % NPAIR, rr = lane / NPAIR;
+#pragma unroll
+  for (int it = 0; it < 32 / RPI; ++it) {
+    const int r = it * RPI + rr;
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(patch + r * ROWB + ((pr ^ (r & (NPAIR - 1))) << 4));
+    if (row0 + r < nrows) *reinterpret_cast<bf16x8*>(base + (int64_t)(row0 + r) * ld + pr * 8) = v;
+  }
+}
+
 // Store one [32 x HD] accumulator set (lane: one row, 4 consecutive d at 32 db + 8 g4 + 4 hh): as a plain [.., HD] row at `plain`,
 // or (packed mode) into the fused-qkv gradient row `prow` at column slot * HD, with the inverse rotary rotation of position pos
 // when `rotate`.  The mode is a template parameter of the kernels: with a run-time test (or per-store pointer selects) the dK
@@ -260,8 +276,32 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs p) {
   }
   int q_e = qrow, hh_e = hh;                 // opaque copies: keeps the store's address arithmetic out of the key loop (see dK below)
   asm volatile("" : "+v"(q_e), "+v"(hh_e));
-  if (q_e < p.S)
-    store_grad_rows<HD, PACKED>(p, acc, p.dq + (((int64_t)b * p.S + q_e) * p.H + h) * HD, (int64_t)b * p.S + q_e, h, p.rope_pos0 + q_e, true, hh_e);
+  if constexpr (PACKED) {
+    // the wave's 32 x HD tile of dq, rotated back, through a private LDS patch (the K / V tiles are free after one more barrier)
+    // into whole rows of the fused-qkv gradient (see store_patch_rows)
+    __syncthreads();
+    int ql_e = q_e - (qt * 128 + wave * 32);
+    char* patch = lds + wave * (32 * HD * 2);
+    char* wrow = patch + ql_e * (HD * 2);
+    const int wx = (ql_e & (HD / 8 - 1)) << 1;
+    const float* CS = p.cos_sin + (int64_t)(p.rope_pos0 + (q_e < p.S ? q_e : p.S - 1)) * HD;
+#pragma unroll
+    for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int dc = d * 32 + g4 * 8 + hh_e * 4;
+        const f32x4 cs = *reinterpret_cast<const f32x4*>(CS + dc);
+        const float v0 = acc[d][g4 * 4 + 0], v1 = acc[d][g4 * 4 + 1], v2 = acc[d][g4 * 4 + 2], v3 = acc[d][g4 * 4 + 3];
+        bf16x4 ov;
+        ov[0] = f2bf(v0 * cs[0] + v1 * cs[1]); ov[1] = f2bf(-v0 * cs[1] + v1 * cs[0]);
+        ov[2] = f2bf(v2 * cs[2] + v3 * cs[3]); ov[3] = f2bf(-v2 * cs[3] + v3 * cs[2]);
+        *reinterpret_cast<bf16x4*>(wrow + (((d * 8 + g4 * 2 + hh_e) ^ wx) << 3)) = ov;
+      }
+    store_patch_rows<HD>(patch, p.dqkv + (int64_t)b * p.S * p.ld_qkv + (int64_t)h * HD, p.ld_qkv, qt * 128 + wave * 32, p.S, lane);
+  } else {
+    if (q_e < p.S)
+      store_grad_rows<HD, PACKED>(p, acc, p.dq + (((int64_t)b * p.S + q_e) * p.H + h) * HD, (int64_t)b * p.S + q_e, h, p.rope_pos0 + q_e, true, hh_e);
+  }
 }
 
 // ------------------------------------------------------------------ dK, dV
@@ -402,26 +442,34 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs p) {
           for (int e = 0; e < 4; ++e) a[e] = f2bf(acc[d][g4 * 4 + e]);
           *reinterpret_cast<bf16x4*>(O + d * 32 + g4 * 8 + hh * 4) = a;
         }
-    } else {
-      bf16_t* O = p.dqkv + ((int64_t)b * p.S + kvrow) * p.ld_qkv + (int64_t)(WHICH == 0 ? p.H + p.Hkv + hk : p.H + hk) * HD;
-      const float* CS = p.cos_sin + (int64_t)(p.rope_pos0 + kvrow) * HD;      // [pos][HD / 2][cos, sin]
-#pragma unroll
-      for (int d = 0; d < HD / 32; ++d)
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          const int dc = d * 32 + g4 * 8 + hh * 4;
-          float v0 = acc[d][g4 * 4 + 0], v1 = acc[d][g4 * 4 + 1], v2 = acc[d][g4 * 4 + 2], v3 = acc[d][g4 * 4 + 3];
-          if (WHICH == 1) {      // dK: rotate back, dx = R(-theta) dy on the (even, odd) pairs (LLM/llama_ens5.py:123-135 backward)
-            const f32x4 cs = *reinterpret_cast<const f32x4*>(CS + dc);
-            const float a0 = v0 * cs[0] + v1 * cs[1], a1 = -v0 * cs[1] + v1 * cs[0];
-            const float a2 = v2 * cs[2] + v3 * cs[3], a3 = -v2 * cs[3] + v3 * cs[2];
-            v0 = a0; v1 = a1; v2 = a2; v3 = a3;
-          }
-          bf16x4 ov;
-          ov[0] = f2bf(v0); ov[1] = f2bf(v1); ov[2] = f2bf(v2); ov[3] = f2bf(v3);
-          *reinterpret_cast<bf16x4*>(O + dc) = ov;
-        }
     }
+  }
+  if constexpr (PACKED) {
+    // packed mode: the wave's 32 x HD tile goes through a private LDS patch (the row tiles are free after one more barrier) and
+    // leaves as whole rows of the fused-qkv gradient
+    __syncthreads();
+    char* patch = lds + wave * (32 * HD * 2);
+    char* wrow = patch + kl * (HD * 2);
+    const int wx = (kl & (HD / 8 - 1)) << 1;
+    const float* CS = p.cos_sin + (int64_t)(p.rope_pos0 + kc) * HD;          // [pos][HD / 2][cos, sin] (kc: the clamped row)
+#pragma unroll
+    for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int dc = d * 32 + g4 * 8 + hh * 4;
+        float v0 = acc[d][g4 * 4 + 0], v1 = acc[d][g4 * 4 + 1], v2 = acc[d][g4 * 4 + 2], v3 = acc[d][g4 * 4 + 3];
+        if (WHICH == 1) {      // dK: rotate back, dx = R(-theta) dy on the (even, odd) pairs (LLM/llama_ens5.py:123-135 backward)
+          const f32x4 cs = *reinterpret_cast<const f32x4*>(CS + dc);
+          const float a0 = v0 * cs[0] + v1 * cs[1], a1 = -v0 * cs[1] + v1 * cs[0];
+          const float a2 = v2 * cs[2] + v3 * cs[3], a3 = -v2 * cs[3] + v3 * cs[2];
+          v0 = a0; v1 = a1; v2 = a2; v3 = a3;
+        }
+        bf16x4 ov;
+        ov[0] = f2bf(v0); ov[1] = f2bf(v1); ov[2] = f2bf(v2); ov[3] = f2bf(v3);
+        *reinterpret_cast<bf16x4*>(wrow + (((d * 8 + g4 * 2 + hh) ^ wx) << 3)) = ov;
+      }
+    store_patch_rows<HD>(patch, p.dqkv + (int64_t)b * p.S * p.ld_qkv + (int64_t)(WHICH == 0 ? p.H + p.Hkv + hk : p.H + hk) * HD, p.ld_qkv,
+                         kt_ * 128 + wave * 32, p.S, lane);
   }
 }
 
