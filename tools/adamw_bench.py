@@ -1,23 +1,33 @@
-"""AdamW step on 7B-sized fp32 state: torch.optim.AdamW(fused=True) vs a3vlm_amd.optim.FusedAdamW (with / without bf16 image)."""
-import os
-import sys
-
+#!/usr/bin/env python3
+"""AdamW kernel (a3v_adamw_scaled with the bf16 image) on 7B-sized tensors, cache policy variants (A3V_ADAMW_NT: bit 0 = non-temporal
+loads, bit 1 = non-temporal stores; read per launch).  Tensors rotate through > 256 MB so that nothing stays in the Infinity Cache."""
+import sys, os, json, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch  # noqa: E402
-
-from a3vlm_amd.optim import FusedAdamW  # noqa: E402
-from tools.gemm_fp8_bench import t_us  # noqa: E402
-
-DEV = "cuda:0"
-shapes = [(4096, 4096)] * 8 + [(11008, 4096)] * 6 + [(4096, 11008)] * 3 + [(4096,)] * 8      # ~0.5 G parameters
-ps = [torch.randn(*s, device=DEV).requires_grad_(True) for s in shapes]
-for p in ps:
-    p.grad = torch.randn_like(p) * 0.01
-n = sum(p.numel() for p in ps)
-o1 = torch.optim.AdamW(ps, lr=2e-5, betas=(0.9, 0.95), weight_decay=0.0, fused=True)
-o2 = FusedAdamW(ps, lr=2e-5, betas=(0.9, 0.95), weight_decay=0.0)
-imgs = {id(p): torch.empty(p.shape, dtype=torch.bfloat16, device=DEV) for p in ps}
-o3 = FusedAdamW(ps, lr=2e-5, betas=(0.9, 0.95), weight_decay=0.0, image_of=lambda p: imgs[id(p)])
-for name, o, b in (("torch fused", o1, 28), ("a3v_adamw", o2, 28), ("a3v_adamw + bf16 image", o3, 30)):
-    t = t_us(o.step, n=5)
-    print(f"{name:24s}: {t / 1e3:7.2f} ms for {n / 1e9:.2f} G params = {n * b / t / 1e6:5.2f} TB/s  (7B: {t / 1e3 * 6.74e9 / n:6.1f} ms)", flush=True)
+import torch
+from a3vlm_amd import lib
+dev = "cuda"
+n = 11008 * 4096
+sets = []
+for i in range(3):
+    sets.append([torch.randn(n, device=dev) for _ in range(4)] + [torch.empty(n, device=dev, dtype=torch.bfloat16)])
+coef = torch.ones(1, device=dev)
+L = lib.load()
+def f(i):
+    p, g, m, v, img = sets[i % 3]
+    v.abs_() if i < 0 else None
+    rc = L.a3v_adamw_scaled(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-5, 0.9, 0.95, 1e-8, 0.02, 10, img.data_ptr(), coef.data_ptr(),
+                            torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+for s_ in sets:
+    s_[3].abs_()
+res = {}
+for r in range(4):
+    for nt in ("0", "1", "2", "3"):
+        os.environ["A3V_ADAMW_NT"] = nt
+        for i in range(3): f(i)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(9): f(i)
+        e1.record(); torch.cuda.synchronize()
+        res.setdefault(nt, []).append(e0.elapsed_time(e1) / 9 * 1e3)
+print(json.dumps({f"nt{k}": {"us": round(sorted(v)[1], 1), "tbs": round(30.0 * n / sorted(v)[1] / 1e6, 2)} for k, v in res.items()}))
