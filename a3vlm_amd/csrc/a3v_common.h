@@ -44,6 +44,35 @@ __device__ __forceinline__ void load8(const float* p, float* o) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) { o[i] = a[i]; o[4 + i] = b[i]; }
 }
+// non-temporal forms for streams that are touched once (NT is a compile-time flag of the calling kernel)
+template <bool NT>
+__device__ __forceinline__ void load8_s(const bf16_t* p, float* o) {
+  const bf16x8 v = NT ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p)) : *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
+}
+template <bool NT>
+__device__ __forceinline__ void load8_s(const float* p, float* o) {
+  const f32x4 a = NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)) : *reinterpret_cast<const f32x4*>(p);
+  const f32x4 b = NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + 4)) : *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { o[i] = a[i]; o[4 + i] = b[i]; }
+}
+template <bool NT>
+__device__ __forceinline__ void store8_s(bf16_t* p, const float* v) {
+  bf16x8 o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = (bf16_t)v[i];
+  if (NT) __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(p)); else *reinterpret_cast<bf16x8*>(p) = o;
+}
+template <bool NT>
+__device__ __forceinline__ void store8_s(float* p, const float* v) {
+  f32x4 a, b;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { a[i] = v[i]; b[i] = v[4 + i]; }
+  if (NT) { __builtin_nontemporal_store(a, reinterpret_cast<f32x4*>(p)); __builtin_nontemporal_store(b, reinterpret_cast<f32x4*>(p + 4)); }
+  else { *reinterpret_cast<f32x4*>(p) = a; *reinterpret_cast<f32x4*>(p + 4) = b; }
+}
 __device__ __forceinline__ void store8(bf16_t* p, const float* v) {
   bf16x8 o;
 #pragma unroll

@@ -54,6 +54,7 @@ struct GemmArgs {
   int dbg;   // ablation switches for tuning runs (0 in production): 1 = no DMA in the k-loop, 2 = no ds_read in the k-loop
   int skew;  // ring kernel: XCD x starts x * skew cycles late, so the eight XCDs' store bursts do not hit HBM together
   int slow_epi;   // 1: interior tiles also take the general epilogue (A3V_GEMM_FAST_EPI=0; equality tests and A/B runs)
+  int nt_store;   // fast epilogue forms: non-temporal stores of the output tile (A3V_GEMM_NT_STORE, read per launch)
   int64_t c_split;   // split-K (128x128 kernel, gridDim.y slices): byte stride between the slices' output planes
   RopeKvArgs rk;     // GEMM_EPI_ROPEKV only
   const float* sa;   // GEMM_EPI_SCALE: per-row dequantisation scales of A [M] and W [N]
@@ -124,6 +125,8 @@ __device__ __forceinline__ bool gemm_epilogue_fast(f32x4 (&acc)[TM][TN], const G
     asm volatile("" : "+s"(kind), "+s"(ldc_), "+s"(ldr_), "+s"(c_), "+s"(r_));
     if (!stage || p.slow_epi || mbase + TM * 16 > p.M || nbase + 64 > p.N || (c_ & 15)) return false;
     const int mrow = lane & 15, g = lane >> 4;
+    const bool nts = p.nt_store != 0;                      // output tiles are written once and read by a later kernel: streaming stores
+    auto st_c = [&](auto* ptr, auto val) { if (nts) __builtin_nontemporal_store(val, ptr); else *ptr = val; };
     const int pre = (SET & EPI_SET_PRE) ? kind & (A3V_EPI_BIAS | A3V_EPI_GELU | A3V_EPI_QUICKGELU) : 0;   // applied in the accumulator layout
     if (pre) kind &= ~pre;
     if constexpr ((SET & EPI_SET_COMMON) != 0) {
@@ -191,7 +194,7 @@ __device__ __forceinline__ bool gemm_epilogue_fast(f32x4 (&acc)[TM][TN], const G
           for (int ic = 0; ic < TM / 2; ++ic) {
             put(ic);
 #pragma unroll
-            for (int it = 0; it < 4; ++it) { *reinterpret_cast<bf16x8*>(cp) = get(it); cp += cstep; }
+            for (int it = 0; it < 4; ++it) { st_c(reinterpret_cast<bf16x8*>(cp), get(it)); cp += cstep; }
           }
         } else {
           const bf16_t* rp = reinterpret_cast<const bf16_t*>(r_) + (int64_t)(mbase + l3) * ldr_ + nbase + q * 8;
@@ -212,7 +215,7 @@ __device__ __forceinline__ bool gemm_epilogue_fast(f32x4 (&acc)[TM][TN], const G
                 bf16x8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(rr[c][it][e]) + bf2f(v[e]));
-                *reinterpret_cast<bf16x8*>(cp) = o;
+                st_c(reinterpret_cast<bf16x8*>(cp), o);
                 cp += cstep;
               }
             }
@@ -239,8 +242,8 @@ __device__ __forceinline__ bool gemm_epilogue_fast(f32x4 (&acc)[TM][TN], const G
             f32x4 o0, o1;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { o0[e] = rr[it][0][e] + bf2f(v[e]); o1[e] = rr[it][1][e] + bf2f(v[4 + e]); }
-            *reinterpret_cast<f32x4*>(cp) = o0;
-            *reinterpret_cast<f32x4*>(cp + 4) = o1;
+            st_c(reinterpret_cast<f32x4*>(cp), o0);
+            st_c(reinterpret_cast<f32x4*>(cp + 4), o1);
             cp += cstep;
           }
         }
@@ -286,7 +289,7 @@ __device__ __forceinline__ bool gemm_epilogue_fast(f32x4 (&acc)[TM][TN], const G
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = rr[i][it][e] + v[e];
             }
-            *reinterpret_cast<f32x4*>(cp) = v;
+            st_c(reinterpret_cast<f32x4*>(cp), v);
             cp += cstep;
           }
         }
@@ -324,7 +327,7 @@ __device__ __forceinline__ bool gemm_epilogue_fast(f32x4 (&acc)[TM][TN], const G
         for (int it = 0; it < 4; ++it) {
           const bf16x8 v = *reinterpret_cast<const bf16x8*>(rd + it * 1024);
           LDS_ORDER();
-          *reinterpret_cast<bf16x8*>(cp) = v;
+          st_c(reinterpret_cast<bf16x8*>(cp), v);
           cp += cstep;
         }
       }
@@ -418,7 +421,7 @@ __device__ __forceinline__ bool gemm_epilogue_fast(f32x4 (&acc)[TM][TN], const G
           for (int it = 0; it < 4; ++it) {
             if (isq) {
               asm volatile("" : "+v"(cp));
-              *reinterpret_cast<bf16x8*>(cp) = get(it);
+              st_c(reinterpret_cast<bf16x8*>(cp), get(it));
               cp += cstep;
             } else {
               asm volatile("" : "+v"(sq), "+v"(b));
@@ -440,7 +443,7 @@ __device__ __forceinline__ bool gemm_epilogue_fast(f32x4 (&acc)[TM][TN], const G
 #pragma unroll
           for (int it = 0; it < 4; ++it) {
             asm volatile("" : "+v"(cp));
-            *reinterpret_cast<bf16x8*>(cp) = get(it);
+            st_c(reinterpret_cast<bf16x8*>(cp), get(it));
             cp += cstep;
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -2431,6 +2434,11 @@ static bool pp_ring() {       // the 160-KiB ring form of the ping-pong kernel (
   return !(e && e[0] == '0');
 }
 
+static int nt_store_env() {
+  const char* e = getenv("A3V_GEMM_NT_STORE");
+  return e ? atoi(e) : 0;
+}
+
 static int slow_epi_env() {    // A3V_GEMM_FAST_EPI=0: every tile through the general epilogue (read per launch)
   const char* e = getenv("A3V_GEMM_FAST_EPI");
   return (e && e[0] == '0') ? 1 : 0;
@@ -2439,7 +2447,7 @@ static int slow_epi_env() {    // A3V_GEMM_FAST_EPI=0: every tile through the ge
 template <bool A_ROWS>
 static void launch_tn(dim3 grid, hipStream_t st, const GemmArgs& q0) {
   GemmArgs q = q0;
-  q.slow_epi = slow_epi_env();
+  q.slow_epi = slow_epi_env(); q.nt_store = nt_store_env();
   hipLaunchKernelGGL(gemm_tn_bf16_pp_kernel<A_ROWS>, grid, dim3(512), 0, st, q);
 }
 
@@ -2479,7 +2487,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
   // rows, and every problem the big tile would quantise badly, go to the 128x128 kernel (4 waves,
   // 2 blocks/CU).  A3V_EPI_TILE_* force one configuration for the whole problem (tuning / tests).
   auto launch = [&](int cfg, GemmArgs q) {
-    q.slow_epi = slow_epi_env();
+    q.slow_epi = slow_epi_env(); q.nt_store = nt_store_env();
     if (cfg == 128) {
       q.tiles_m = (q.M + 127) / 128; q.tiles_n = (q.N + 127) / 128;
       hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 128, 2, 2>), dim3(q.tiles_m * q.tiles_n), dim3(256), 0, st, q);
@@ -2577,7 +2585,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
       t.epi = A3V_EPI_OUT_F32 | GEMM_EPI_RAW;
       t.tiles_m = (M + 255) / 256; t.tiles_n = (int)tn256;
       t.c_split = (int64_t)M * N * 4;
-      t.slow_epi = slow_epi_env();
+      t.slow_epi = slow_epi_env(); t.nt_store = nt_store_env();
       hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0>), dim3(t.tiles_m * t.tiles_n, S3), dim3(512), 0, st, t);
       const int64_t n4 = (int64_t)M * (N / 4);
       const int rb = (int)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256);
@@ -2617,7 +2625,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
         t.epi = A3V_EPI_OUT_F32 | GEMM_EPI_RAW;
         t.tiles_m = (t.M + 255) / 256; t.tiles_n = (int)tn256;
         t.c_split = (int64_t)t.M * N * 4;
-        t.slow_epi = slow_epi_env();
+        t.slow_epi = slow_epi_env(); t.nt_store = nt_store_env();
         t.skew = 0;
         hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0>), dim3(big_tiles, S2), dim3(512), 0, st, t);
         const int64_t n4 = (int64_t)r.M * (N / 4);
@@ -2629,7 +2637,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
         t.epi = A3V_EPI_OUT_F32 | GEMM_EPI_RAW;
         t.tiles_m = (t.M + 127) / 128; t.tiles_n = (N + 127) / 128;
         t.c_split = (int64_t)t.M * N * 4;
-        t.slow_epi = slow_epi_env();
+        t.slow_epi = slow_epi_env(); t.nt_store = nt_store_env();
         hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 128, 2, 2>), dim3(t.tiles_m * t.tiles_n, S), dim3(256), 0, st, t);
         const int64_t n4 = (int64_t)r.M * (N / 4);
         const int rb = (int)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256);
@@ -2857,7 +2865,7 @@ extern "C" int a3v_gemm_nt_splitk(const void* A, int64_t lda, const void* W, int
     return A3V_OK;
   }
   p.tiles_m = (M + 127) / 128; p.tiles_n = (N + 127) / 128;
-  p.slow_epi = slow_epi_env();
+  p.slow_epi = slow_epi_env(); p.nt_store = nt_store_env();
   hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 128, 2, 2>), dim3(p.tiles_m * p.tiles_n, S), dim3(256), 0, (hipStream_t)stream, p);
   A3V_LAUNCH_CHECK();
   return A3V_OK;

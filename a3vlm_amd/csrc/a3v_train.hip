@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TA* __restrict
 // ------------------------------------------------------------------ SwiGLU on the interleaved layout
 // gu[r, 32 j + t] = gate col 16 j + t (t<16), gu[r, 32 j + 16 + t] = up col 16 j + t
 // 8 consecutive columns per thread (16-B bf16 accesses); F % 16 == 0 so a vector never straddles a 16-column block.
-template <typename TA>
+template <typename TA, int NT = 0>   // NT: bit 0 non-temporal loads, bit 1 non-temporal stores
 __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const TA* __restrict__ gu, int64_t ldg, TA* __restrict__ act, int64_t lda, int rows, int F, int inter) {
   const int F8 = F >> 3;
   const int64_t n = (int64_t)rows * F8;
@@ -315,14 +315,14 @@ __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const TA* __restrict__ 
     const int r = (int)(i / F8), c = (int)(i - (int64_t)r * F8) * 8;
     const TA* p = gu + (int64_t)r * ldg + (inter ? (c >> 4) * 32 + (c & 15) : c);
     float g[8], u[8], o[8];
-    load8(p, g);
-    load8(p + ustep, u);
+    load8_s<(NT & 1) != 0>(p, g);
+    load8_s<(NT & 1) != 0>(p + ustep, u);
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = Cvt<TA>::rnd(g[e] * __builtin_amdgcn_rcpf(1.f + __expf(-g[e]))) * u[e];   // = silu() of the GEMM epilogue
-    store8(act + (int64_t)r * lda + c, o);
+    store8_s<(NT & 2) != 0>(act + (int64_t)r * lda + c, o);
   }
 }
-template <typename TA>
+template <typename TA, int NT = 0>   // NT: bit 0 non-temporal loads, bit 1 non-temporal stores
 __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const TA* __restrict__ gu, int64_t ldg, const TA* __restrict__ dact, int64_t lda,
                                                          TA* __restrict__ dgu, int64_t lddg, int rows, int F, int inter) {
   const int F8 = F >> 3;
@@ -332,17 +332,17 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const TA* __restrict__ 
     const int r = (int)(i / F8), c = (int)(i - (int64_t)r * F8) * 8;
     const int64_t o = inter ? (int64_t)(c >> 4) * 32 + (c & 15) : c;
     float g[8], u[8], da[8], dg[8], du[8];
-    load8(gu + (int64_t)r * ldg + o, g);
-    load8(gu + (int64_t)r * ldg + o + ustep, u);
-    load8(dact + (int64_t)r * lda + c, da);
+    load8_s<(NT & 1) != 0>(gu + (int64_t)r * ldg + o, g);
+    load8_s<(NT & 1) != 0>(gu + (int64_t)r * ldg + o + ustep, u);
+    load8_s<(NT & 1) != 0>(dact + (int64_t)r * lda + c, da);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float sig = 1.f / (1.f + __expf(-g[e]));
       dg[e] = da[e] * u[e] * (sig * (1.f + g[e] * (1.f - sig)));
       du[e] = da[e] * (g[e] * sig);
     }
-    store8(dgu + (int64_t)r * lddg + o, dg);
-    store8(dgu + (int64_t)r * lddg + o + ustep, du);
+    store8_s<(NT & 2) != 0>(dgu + (int64_t)r * lddg + o, dg);
+    store8_s<(NT & 2) != 0>(dgu + (int64_t)r * lddg + o + ustep, du);
   }
 }
 
@@ -750,13 +750,22 @@ extern "C" int a3v_layernorm_bwd(const void* x, int64_t ldx, const float* w, con
   return A3V_OK;
 }
 
+// cache policy of the streaming training kernels (A3V_STREAM_NT: bit 0 non-temporal loads, bit 1 stores; read per launch)
+static int stream_nt() {
+  const char* e = getenv("A3V_STREAM_NT");
+  return e ? (atoi(e) & 3) : 3;      // default: both (SwiGLU forward 102 -> 91 us, backward 174 -> 154 us at 7B size, tools/stream_nt_bench.py)
+}
+
 extern "C" int a3v_swiglu_fwd(const void* gu, int64_t ldg, void* act, int64_t lda, int rows, int F, int interleaved, int dtype, void* stream) {
   const int inter = interleaved;
   if (!gu || !act || rows <= 0 || F <= 0 || (F % 16)) return A3V_ERR_ARG;
   if ((ldg % 8) || (lda % 8)) return A3V_ERR_SHAPE;
   int64_t n = (int64_t)rows * (F / 8);
   int blocks = (int)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256);
-  if (dtype == A3V_BF16) hipLaunchKernelGGL(swiglu_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, ST, (const bf16_t*)gu, ldg, (bf16_t*)act, lda, rows, F, inter);
+  const int nt = stream_nt();
+  if (dtype == A3V_BF16 && nt == 3) hipLaunchKernelGGL((swiglu_fwd_kernel<bf16_t, 3>), dim3(blocks), dim3(256), 0, ST, (const bf16_t*)gu, ldg, (bf16_t*)act, lda, rows, F, inter);
+  else if (dtype == A3V_BF16 && nt == 1) hipLaunchKernelGGL((swiglu_fwd_kernel<bf16_t, 1>), dim3(blocks), dim3(256), 0, ST, (const bf16_t*)gu, ldg, (bf16_t*)act, lda, rows, F, inter);
+  else if (dtype == A3V_BF16) hipLaunchKernelGGL(swiglu_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, ST, (const bf16_t*)gu, ldg, (bf16_t*)act, lda, rows, F, inter);
   else if (dtype == A3V_F32) hipLaunchKernelGGL(swiglu_fwd_kernel<float>, dim3(blocks), dim3(256), 0, ST, (const float*)gu, ldg, (float*)act, lda, rows, F, inter);
   else return A3V_ERR_DTYPE;
   A3V_LAUNCH_CHECK();
@@ -770,7 +779,10 @@ extern "C" int a3v_swiglu_bwd(const void* gu, int64_t ldg, const void* dact, int
   if ((ldg % 8) || (lda % 8) || (lddg % 8)) return A3V_ERR_SHAPE;
   int64_t n = (int64_t)rows * (F / 8);
   int blocks = (int)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256);
-  if (dtype == A3V_BF16) hipLaunchKernelGGL(swiglu_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, ST, (const bf16_t*)gu, ldg, (const bf16_t*)dact, lda, (bf16_t*)dgu, lddg, rows, F, inter);
+  const int nt = stream_nt();
+  if (dtype == A3V_BF16 && nt == 3) hipLaunchKernelGGL((swiglu_bwd_kernel<bf16_t, 3>), dim3(blocks), dim3(256), 0, ST, (const bf16_t*)gu, ldg, (const bf16_t*)dact, lda, (bf16_t*)dgu, lddg, rows, F, inter);
+  else if (dtype == A3V_BF16 && nt == 1) hipLaunchKernelGGL((swiglu_bwd_kernel<bf16_t, 1>), dim3(blocks), dim3(256), 0, ST, (const bf16_t*)gu, ldg, (const bf16_t*)dact, lda, (bf16_t*)dgu, lddg, rows, F, inter);
+  else if (dtype == A3V_BF16) hipLaunchKernelGGL(swiglu_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, ST, (const bf16_t*)gu, ldg, (const bf16_t*)dact, lda, (bf16_t*)dgu, lddg, rows, F, inter);
   else if (dtype == A3V_F32) hipLaunchKernelGGL(swiglu_bwd_kernel<float>, dim3(blocks), dim3(256), 0, ST, (const float*)gu, ldg, (const float*)dact, lda, (float*)dgu, lddg, rows, F, inter);
   else return A3V_ERR_DTYPE;
   A3V_LAUNCH_CHECK();
