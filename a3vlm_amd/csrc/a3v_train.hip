@@ -590,10 +590,10 @@ __global__ __launch_bounds__(256) void scale_cast_kernel(const TS* __restrict__ 
   const int64_t n8 = n / 8, stride = (int64_t)gridDim.x * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += stride) {
     float v[8];
-    load8(src + i * 8, v);
+    load8_s<true>(src + i * 8, v);                   // gradient buckets are touched once per pass: streaming loads and stores
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] *= scale;
-    store8(dst + i * 8, v);
+    store8_s<true>(dst + i * 8, v);
   }
   if (blockIdx.x == 0 && threadIdx.x < (int)(n - n8 * 8)) {
     const int64_t i = n8 * 8 + threadIdx.x;
