@@ -55,6 +55,7 @@ struct GemmArgs {
   int skew;  // ring kernel: XCD x starts x * skew cycles late, so the eight XCDs' store bursts do not hit HBM together
   int slow_epi;   // 1: interior tiles also take the general epilogue (A3V_GEMM_FAST_EPI=0; equality tests and A/B runs)
   int nt_store;   // fast epilogue forms: non-temporal stores of the output tile (A3V_GEMM_NT_STORE, read per launch)
+  float* sumsq;   // fp32 outputs (weight gradients): slot (tile * 8 + wave) <- sum of squares of the values this wave stored (NULL: off)
   int64_t c_split;   // split-K (128x128 kernel, gridDim.y slices): byte stride between the slices' output planes
   RopeKvArgs rk;     // GEMM_EPI_ROPEKV only
   const float* sa;   // GEMM_EPI_SCALE: per-row dequantisation scales of A [M] and W [N]
@@ -95,6 +96,15 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, int64_t
   }
 }
 
+// Weight-gradient GEMMs can hand the global-norm clip its sum of squares for free: every wave adds up the squares of the fp32
+// values it stores and writes ONE partial to slot (tile_m * tiles_n + tile_n) * 8 + (wave's position in the tile) -- a layout that
+// depends only on the output coordinates, not on the block order (the caller zeroes the slots once per step and sums them).
+__device__ __forceinline__ void sumsq_flush(const GemmArgs& p, float ss, int mbase, int nbase, int lane) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+  if (lane == 0) p.sumsq[(((int64_t)(mbase >> 8) * p.tiles_n + (nbase >> 8)) << 3) + (((mbase >> 7) & 1) << 2) + ((nbase >> 6) & 3)] = ss;
+}
+
 // Compiler-level ordering point between the two halves of a wave-private LDS transpose (the hardware executes one wave's LDS
 // instructions in order; what has to be prevented is the compiler moving a read of one vector type across writes of another)
 #define LDS_ORDER() asm volatile("" ::: "memory")
@@ -125,6 +135,7 @@ __device__ __forceinline__ bool gemm_epilogue_fast(f32x4 (&acc)[TM][TN], const G
     asm volatile("" : "+s"(kind), "+s"(ldc_), "+s"(ldr_), "+s"(c_), "+s"(r_));
     if (!stage || p.slow_epi || mbase + TM * 16 > p.M || nbase + 64 > p.N || (c_ & 15)) return false;
     const int mrow = lane & 15, g = lane >> 4;
+    float ss = 0.f;                                      // p.sumsq: squares of the fp32 values this wave stores
     const bool nts = p.nt_store != 0;                      // output tiles are written once and read by a later kernel: streaming stores
     auto st_c = [&](auto* ptr, auto val) { if (nts) __builtin_nontemporal_store(val, ptr); else *ptr = val; };
     const int pre = (SET & EPI_SET_PRE) ? kind & (A3V_EPI_BIAS | A3V_EPI_GELU | A3V_EPI_QUICKGELU) : 0;   // applied in the accumulator layout
@@ -242,11 +253,16 @@ __device__ __forceinline__ bool gemm_epilogue_fast(f32x4 (&acc)[TM][TN], const G
             f32x4 o0, o1;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { o0[e] = rr[it][0][e] + bf2f(v[e]); o1[e] = rr[it][1][e] + bf2f(v[4 + e]); }
+            if (p.sumsq) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) ss = fmaf(o0[e], o0[e], fmaf(o1[e], o1[e], ss));
+            }
             st_c(reinterpret_cast<f32x4*>(cp), o0);
             st_c(reinterpret_cast<f32x4*>(cp + 4), o1);
             cp += cstep;
           }
         }
+        if (p.sumsq) sumsq_flush(p, ss, mbase, nbase, lane);
       }
       return true;
     }
@@ -289,11 +305,16 @@ __device__ __forceinline__ bool gemm_epilogue_fast(f32x4 (&acc)[TM][TN], const G
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = rr[i][it][e] + v[e];
             }
+            if (p.sumsq) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) ss = fmaf(v[e], v[e], ss);
+            }
             st_c(reinterpret_cast<f32x4*>(cp), v);
             cp += cstep;
           }
         }
       }
+      if (p.sumsq) sumsq_flush(p, ss, mbase, nbase, lane);
       return true;
     }
     if (kind == A3V_EPI_SWIGLU) {
@@ -634,6 +655,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GemmAr
     }
   }
   // Phase 2 -- stores only (ragged tiles and the rarer output kinds: 8 bytes per lane straight from the accumulator layout)
+  float gss = 0.f;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int m = mbase + i * 16 + mrow;
@@ -665,6 +687,10 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GemmAr
       }
       if (epi & (A3V_EPI_RES_F32 | A3V_EPI_OUT_F32)) {
         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n) = acc[i][j];
+        if (p.sumsq) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) gss = fmaf(acc[i][j][r], acc[i][j][r], gss);
+        }
       } else {
         bf16x4 o;
 #pragma unroll
@@ -673,6 +699,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GemmAr
       }
     }
   }
+  if (p.sumsq) sumsq_flush(p, gss, mbase, nbase, lane);
 }
 
 // TBM x TBN block tile, WAVES_M x WAVES_N waves, each wave (TBM/WAVES_M) x (TBN/WAVES_N).
@@ -2373,8 +2400,9 @@ namespace {
 // sum of S raw fp32 planes [M][N] -> rounded once to bf16 ("the value F.linear returns") -> residual / output forms of gemm_epilogue
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __restrict__ part, int S, int64_t plane, int M, int N, void* __restrict__ C,
                                                               int64_t ldc, const void* __restrict__ res, int64_t ldr, int epi,
-                                                              const bf16_t* __restrict__ bias = nullptr) {
+                                                              const bf16_t* __restrict__ bias = nullptr, float* __restrict__ sumsq = nullptr) {
   const int64_t n4 = (int64_t)M * (N / 4);
+  float ss = 0.f;                                        // sumsq: squares of the fp32 values this block stores -> slot blockIdx.x
   for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
     const int r = (int)(i / (N / 4)), c = (int)(i % (N / 4)) * 4;
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
@@ -2395,6 +2423,8 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
 #pragma unroll
       for (int e = 0; e < 4; ++e) a[e] += rr[e];
       *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(C) + (int64_t)r * ldc + c) = a;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ss = fmaf(a[e], a[e], ss);
       continue;
     }
     if (epi & A3V_EPI_RESIDUAL) {
@@ -2404,12 +2434,22 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
     }
     if (epi & A3V_EPI_OUT_F32) {
       *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(C) + (int64_t)r * ldc + c) = a;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ss = fmaf(a[e], a[e], ss);
     } else {
       bf16x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = f2bf(a[e]);
       *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(C) + (int64_t)r * ldc + c) = o;
     }
+  }
+  if (sumsq) {
+    __shared__ float red[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) sumsq[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
   }
 }
 }  // namespace
@@ -2886,9 +2926,14 @@ extern "C" int a3v_splitk_reduce(const float* partial, int S, int M, int N, void
 // C[M,N] = epilogue(At^T . Wt): At [K, M] (row stride lda), Wt [K, N] (row stride ldw), both bf16 with the CONTRACTED index
 // as the row index -- dW = dY^T . X straight from the token-major activations (no a3v_transpose of either operand).
 // 256x256 tiles only (M, N >= 256 recommended); plain / residual / fp32 epilogues as a3v_gemm_nt; any K >= 1.
-extern "C" int a3v_gemm_tn(const void* At, int64_t lda, const void* Wt, int64_t ldw, void* C, int64_t ldc, int M, int N, int K,
-                           const void* residual, int64_t ldr, int epilogue, void* stream) {
+extern "C" int64_t a3v_gemm_tn_sumsq_slots(int M, int N) {
+  return (int64_t)((M + 255) / 256) * ((N + 255) / 256) * 8 + 2048;      // 8 waves per 256 x 256 tile + the split-K reduce pass' blocks
+}
+
+static int gemm_tn_impl(const void* At, int64_t lda, const void* Wt, int64_t ldw, void* C, int64_t ldc, int M, int N, int K,
+                        const void* residual, int64_t ldr, int epilogue, void* stream, float* sumsq, int64_t sumsq_cap) {
   if (!At || !Wt || !C || M <= 0 || N <= 0 || K <= 0) return A3V_ERR_ARG;
+  if (sumsq && (!(epilogue & (A3V_EPI_OUT_F32 | A3V_EPI_RES_F32)) || sumsq_cap < a3v_gemm_tn_sumsq_slots(M, N))) return A3V_ERR_ARG;
   if (lda % 8 || ldw % 8 || N % 4 || ldc % 4 || M % 8) return A3V_ERR_SHAPE;
   if (epilogue & ~(A3V_EPI_RESIDUAL | A3V_EPI_RES_F32 | A3V_EPI_OUT_F32)) return A3V_ERR_ARG;
   if ((epilogue & (A3V_EPI_RESIDUAL | A3V_EPI_RES_F32)) && !residual) return A3V_ERR_ARG;
@@ -2898,6 +2943,7 @@ extern "C" int a3v_gemm_tn(const void* At, int64_t lda, const void* Wt, int64_t 
   p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr;
   p.M = M; p.N = N; p.K = K; p.epi = epilogue; p.dbg = 0;
   p.tiles_n = (N + 255) / 256;
+  p.sumsq = sumsq;
   hipStream_t st = (hipStream_t)stream;
   // rows of C beyond whole tile rounds (e.g. dW of w1|w3: 86 x 16 tiles = 5.4 rounds): split over the contracted index into fp32
   // planes + the reduce epilogue, as in a3v_gemm_nn / a3v_gemm_nt (needs the registered workspace; otherwise one plain launch)
@@ -2921,7 +2967,7 @@ extern "C" int a3v_gemm_tn(const void* At, int64_t lda, const void* Wt, int64_t 
     GemmArgs t = p;
     t.M = M - m_big;
     t.A = p.A + m_big;                      // At is [K][lda] with the C-row index contiguous: the tail rows of C are columns m_big.. of At
-    t.C = g_gemm_ws; t.ldc = N; t.res = nullptr;
+    t.C = g_gemm_ws; t.ldc = N; t.res = nullptr; t.sumsq = nullptr;      // (raw planes: the reduce pass below adds up the final values)
     t.epi = A3V_EPI_OUT_F32 | GEMM_EPI_RAW;
     t.tiles_m = (t.M + 255) / 256;
     t.c_split = (int64_t)t.M * N * 4;
@@ -2931,7 +2977,8 @@ extern "C" int a3v_gemm_tn(const void* At, int64_t lda, const void* Wt, int64_t 
     const void* Rt = residual ? (const char*)residual + (int64_t)m_big * ldr * ((epilogue & A3V_EPI_RES_F32) ? 4 : 2) : nullptr;
     const int64_t n4 = (int64_t)t.M * (N / 4);
     const int rb = (int)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256);
-    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(rb), dim3(256), 0, st, g_gemm_ws, S, (int64_t)t.M * N, t.M, N, Ct, ldc, Rt, ldr, epilogue);
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(rb), dim3(256), 0, st, g_gemm_ws, S, (int64_t)t.M * N, t.M, N, Ct, ldc, Rt, ldr, epilogue,
+                       (const bf16_t*)nullptr, sumsq ? sumsq + (int64_t)tm_all * p.tiles_n * 8 : nullptr);
     A3V_LAUNCH_CHECK();
     return A3V_OK;
   }
@@ -2939,6 +2986,19 @@ extern "C" int a3v_gemm_tn(const void* At, int64_t lda, const void* Wt, int64_t 
   launch_tn<false>(dim3(p.tiles_m * p.tiles_n), st, p);
   A3V_LAUNCH_CHECK();
   return A3V_OK;
+}
+
+extern "C" int a3v_gemm_tn(const void* At, int64_t lda, const void* Wt, int64_t ldw, void* C, int64_t ldc, int M, int N, int K,
+                           const void* residual, int64_t ldr, int epilogue, void* stream) {
+  return gemm_tn_impl(At, lda, Wt, ldw, C, ldc, M, N, K, residual, ldr, epilogue, stream, nullptr, 0);
+}
+
+// a3v_gemm_tn with fp32 output that also leaves the sum of squares of what it stored, as a3v_gemm_tn_sumsq_slots(M, N) partial
+// sums in `sumsq` (every slot it owns is written or was zeroed by the caller; slots of tiles outside C stay untouched = 0).
+extern "C" int a3v_gemm_tn_sumsq(const void* At, int64_t lda, const void* Wt, int64_t ldw, void* C, int64_t ldc, int M, int N, int K,
+                                 const void* residual, int64_t ldr, int epilogue, float* sumsq, int64_t sumsq_cap, void* stream) {
+  if (!sumsq) return A3V_ERR_ARG;
+  return gemm_tn_impl(At, lda, Wt, ldw, C, ldc, M, N, K, residual, ldr, epilogue, stream, sumsq, sumsq_cap);
 }
 
 // split-K form of a3v_gemm_tn for adapter-sized outputs (M or N of a few dozen, long K: the LoRA weight gradients

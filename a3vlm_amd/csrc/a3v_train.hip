@@ -623,27 +623,35 @@ extern "C" int a3v_scale_cast(const void* src, int src_dtype, void* dst, int dst
 // inside a block): the global-norm clip (util/clip_grad.py:59-210 of the reference) takes sqrt(sum of all partials).  Launched per
 // gradient bucket on a side stream as soon as the bucket is final, so the 27 GB read of the clip overlaps the rest of the backward.
 namespace {
+// (slot s always sums the same vectors -- s, s + SLOTS, ... -- whatever the launch width: a narrow grid, which disturbs the GEMMs it
+//  runs beside less, gives bit-identical sums)
 __global__ __launch_bounds__(256) void sumsq_partials_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
-  __shared__ float red[4];
-  const int64_t n4 = n / 4, stride = (int64_t)gridDim.x * 256;
-  float a = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(x) + i);
-    a = fmaf(v[0], v[0], a); a = fmaf(v[1], v[1], a); a = fmaf(v[2], v[2], a); a = fmaf(v[3], v[3], a);
-  }
-  if (blockIdx.x == 0 && threadIdx.x < (int)(n - n4 * 4)) { const float t = x[n4 * 4 + threadIdx.x]; a = fmaf(t, t, a); }
+  __shared__ float red[2][4];
+  const int64_t n4 = n / 4, stride = (int64_t)A3V_SUMSQ_SLOTS * 256;
+  int par = 0;
+  for (int vb = blockIdx.x; vb < A3V_SUMSQ_SLOTS; vb += gridDim.x, par ^= 1) {
+    float a = 0.f;
+    for (int64_t i = (int64_t)vb * 256 + threadIdx.x; i < n4; i += stride) {
+      const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(x) + i);
+      a = fmaf(v[0], v[0], a); a = fmaf(v[1], v[1], a); a = fmaf(v[2], v[2], a); a = fmaf(v[3], v[3], a);
+    }
+    if (vb == 0 && threadIdx.x < (int)(n - n4 * 4)) { const float t = x[n4 * 4 + threadIdx.x]; a = fmaf(t, t, a); }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
-  __syncthreads();
-  if (threadIdx.x == 0) out[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if ((threadIdx.x & 63) == 0) red[par][threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) out[vb] = (red[par][0] + red[par][1]) + (red[par][2] + red[par][3]);
+  }
 }
 }  // namespace
 
 extern "C" int a3v_sumsq_partials(const float* x, int64_t n, float* out, void* stream) {
   if (!x || !out || n <= 0) return A3V_ERR_ARG;
   if ((uintptr_t)x & 15) return A3V_ERR_SHAPE;
-  hipLaunchKernelGGL(sumsq_partials_kernel, dim3(A3V_SUMSQ_SLOTS), dim3(256), 0, ST, x, n, out);
+  const char* e = getenv("A3V_SUMSQ_BLOCKS");                 // launch width (read per launch): default 1024 = one block per slot
+  int nb = e ? atoi(e) : A3V_SUMSQ_SLOTS;
+  if (nb < 1 || nb > A3V_SUMSQ_SLOTS) nb = A3V_SUMSQ_SLOTS;
+  hipLaunchKernelGGL(sumsq_partials_kernel, dim3(nb), dim3(256), 0, ST, x, n, out);
   A3V_LAUNCH_CHECK();
   return A3V_OK;
 }

@@ -141,16 +141,24 @@ class GradSquareSums:
     image in the batch, ...) are summed at ``norm()`` time.  ``enabled`` follows the reducer's convention: False on the micro-steps
     of an accumulation window that do not end it."""
 
-    def __init__(self, engine, reducer: Optional[GradReducer] = None):
+    def __init__(self, engine, reducer: Optional[GradReducer] = None, fused: bool = True):
         self.eng, self.enabled = engine, True
         self.ranges, self.slot, self.part = None, None, None      # laid out at the first bucket (the engine allocates its buffer lazily)
         self.seen = set()
         self._stream = None
+        # one rank: the big weight-gradient GEMMs add up the squares of what they store in their own epilogue (a3v_gemm_tn_sumsq), so
+        # only the small rest of a bucket (norm weights, ...) is read again; under DP the sums must be over the REDUCED gradients
+        self._fused_buf: Dict[int, torch.Tensor] = {}             # grad data_ptr -> its slots (views of _fused_all)
+        self._fused_all: Optional[torch.Tensor] = None
+        self._fused_used = 0
+        self._covered: List[Tuple[int, int]] = []                 # flat ranges whose sums came out of a GEMM this step
         if reducer is not None and (reducer.world > 1 or reducer.reduce_single_rank):
             reducer.sumsq = self
         else:
             self._chained = engine.on_layer_grads_ready
             engine.on_layer_grads_ready = self._on_ready
+            if fused and hasattr(engine, "sumsq_sink"):
+                engine.sumsq_sink = self
 
     def _layout(self):
         if self.part is None:
@@ -160,6 +168,40 @@ class GradSquareSums:
             self.slot = {key: i for i, key in enumerate(self.ranges)}
             self.part = torch.zeros(len(self.ranges), ops.SUMSQ_SLOTS if flat.is_cuda else 1, dtype=torch.float32, device=flat.device)
 
+    def wgrad_slots(self, grad: torch.Tensor, M: int, N: int) -> Optional[torch.Tensor]:
+        """Called by the engine for a weight-gradient GEMM that writes ``grad`` [M, N] (a view of the flat buffer): the slots its
+        epilogue fills, or None when sums are not wanted for this micro-step."""
+        if not self.enabled or not grad.is_cuda:
+            return None
+        from . import ops
+        flat = self.eng.flat_grads()
+        off = (grad.data_ptr() - flat.data_ptr()) // 4
+        if off < 0 or off + grad.numel() > flat.numel():
+            return None
+        buf = self._fused_buf.get(grad.data_ptr())
+        if buf is None:
+            n = ops.gemm_tn_sumsq_slots(M, N)
+            if self._fused_all is None:
+                self._fused_all = torch.zeros(4 << 20, dtype=torch.float32, device=grad.device)       # 16 MB: ~10x the 7B need
+            if self._fused_used + n > self._fused_all.numel():
+                return None
+            buf = self._fused_all[self._fused_used:self._fused_used + n]
+            self._fused_used += n
+            self._fused_buf[grad.data_ptr()] = buf
+        self._covered.append((off, off + grad.numel()))
+        return buf
+
+    def _uncovered(self, start: int, end: int) -> List[Tuple[int, int]]:
+        """[start, end) minus the ranges whose sums a GEMM produced this step."""
+        out, cur = [], start
+        for a, b in sorted(r for r in self._covered if r[1] > start and r[0] < end):
+            if a > cur:
+                out.append((cur, min(a, end)))
+            cur = max(cur, b)
+        if cur < end:
+            out.append((cur, end))
+        return out
+
     def add(self, seg: torch.Tensor, key: Tuple[int, int]) -> None:
         """Partial sums of one bucket on the CURRENT stream."""
         self._layout()
@@ -168,10 +210,30 @@ class GradSquareSums:
             return
         if seg.is_cuda:
             from . import ops
-            ops.sumsq_partials(seg, self.part[i])
+            rest = self._uncovered(key[0], key[1]) if self._covered else [key]
+            if rest == [key]:
+                ops.sumsq_partials(seg, self.part[i])
+            else:
+                # the bucket's big matrices were summed by their GEMMs: read only what is left (16-byte aligned pieces; a bucket has a
+                # handful of them), accumulated into the bucket's first slot row through a scratch row
+                self.part[i].zero_()
+                flat = self.eng.flat_grads()
+                for a_, b_ in rest:
+                    if b_ > a_:
+                        piece = flat[a_:b_]
+                        if piece.data_ptr() % 16 == 0:
+                            ops.sumsq_partials(piece, self._scratch_row())
+                            self.part[i] += self._scratch
+                        else:
+                            self.part[i, 0] += (piece.double() ** 2).sum().float()
         else:
             self.part[i, 0] = (seg.double() ** 2).sum().float()
         self.seen.add(key)
+
+    def _scratch_row(self) -> torch.Tensor:
+        if getattr(self, "_scratch", None) is None:
+            self._scratch = torch.zeros_like(self.part[0])
+        return self._scratch
 
     def _on_ready(self, name: str, start: int, end: int) -> None:
         if self._chained is not None:
@@ -200,7 +262,12 @@ class GradSquareSums:
             if key not in self.seen:
                 self.add(flat[key[0]:key[1]], key)
         self.seen.clear()
-        return self.part.sum(dtype=torch.float32).sqrt()
+        total = self.part.sum(dtype=torch.float32)
+        if self._covered:
+            total = total + self._fused_all[:self._fused_used].sum(dtype=torch.float32)
+            self._fused_all[:self._fused_used].zero_()          # the next step's GEMMs write (only) the slots of tiles inside their output
+            self._covered.clear()
+        return total.sqrt()
 
 
 def clip_grad_norm(parameters, max_norm: float, flat: Optional[torch.Tensor] = None, defer: bool = False,

@@ -36,6 +36,8 @@ SIGNATURES = {
     "a3v_sumsq_partials": (I, [P, L, P, P]),
     "a3v_gemm_nn": (I, [P, L, P, L, P, L, I, I, I, P, L, I, P]),
     "a3v_gemm_tn": (I, [P, L, P, L, P, L, I, I, I, P, L, I, P]),
+    "a3v_gemm_tn_sumsq": (I, [P, L, P, L, P, L, I, I, I, P, L, I, P, L, P]),
+    "a3v_gemm_tn_sumsq_slots": (L, [I, I]),
     "a3v_gemm_set_workspace": (I, [P, L]),
     "a3v_gemm_nt_splitk": (I, [P, L, P, L, P, I, I, I, I, P]),
     "a3v_splitk_reduce": (I, [P, I, I, I, P, L, I, I, P]),

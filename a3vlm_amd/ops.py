@@ -69,9 +69,15 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, r
     return out
 
 
-def gemm_tn(at, wt, out, *, residual=None, epilogue: int = 0):
-    """out[M, N] = epilogue(at[K, M]^T @ wt[K, N]) -- both operands with the contracted index as rows (no transposes)."""
-    _dev(at, wt, out, residual)
+def gemm_tn_sumsq_slots(M: int, N: int) -> int:
+    return int(_l.load().a3v_gemm_tn_sumsq_slots(M, N))
+
+
+def gemm_tn(at, wt, out, *, residual=None, epilogue: int = 0, sumsq=None):
+    """out[M, N] = epilogue(at[K, M]^T @ wt[K, N]) -- both operands with the contracted index as rows (no transposes).
+    ``sumsq`` (fp32 outputs only): a zeroed float32 buffer of >= gemm_tn_sumsq_slots(M, N) elements that receives partial sums of
+    squares of the stored values (the clip's norm without a pass over the gradient)."""
+    _dev(at, wt, out, residual, sumsq)
     K, M = at.shape
     N = wt.shape[1]
     assert wt.shape[0] == K and at.stride(1) == 1 and wt.stride(1) == 1 and out.stride(1) == 1
@@ -79,6 +85,12 @@ def gemm_tn(at, wt, out, *, residual=None, epilogue: int = 0):
     ep = epilogue
     if residual is not None and not (ep & EPI_RES_F32):
         ep |= EPI_RESIDUAL
+    if sumsq is not None:
+        assert sumsq.dtype == torch.float32 and sumsq.is_contiguous()
+        rc = _l.load().a3v_gemm_tn_sumsq(_p(at), at.stride(0), _p(wt), wt.stride(0), _p(out), out.stride(0), M, N, K,
+                                         _p(residual), residual.stride(0) if residual is not None else 0, ep, _p(sumsq), sumsq.numel(), _stream())
+        _l.check(rc, f"a3v_gemm_tn_sumsq(M={M},N={N},K={K},epi={ep})")
+        return out
     rc = _l.load().a3v_gemm_tn(_p(at), at.stride(0), _p(wt), wt.stride(0), _p(out), out.stride(0), M, N, K,
                                _p(residual), residual.stride(0) if residual is not None else 0, ep, _stream())
     _l.check(rc, f"a3v_gemm_tn(M={M},N={N},K={K},epi={ep})")

@@ -52,6 +52,7 @@ class TrainEngine:
         self._fresh: set = set()                            # grads attached this step whose storage is still undefined
         self._gemm_written: set = set()                     # names whose gradient comes from exactly one wgrad GEMM per micro-step
         self.on_layer_grads_ready: Optional[Callable[[str, int, int], None]] = None
+        self.sumsq_sink = None               # see _wgrad
         self.static_grad_scale: Optional[float] = None      # set by a trainer that knows d(total)/d(loss) (1 / accum_iter)
         self._saved = None
 
@@ -214,7 +215,9 @@ class TrainEngine:
         if tn_ok and min(N, K) >= 256:
             # both operands as they are (token-major): the TN kernel transposes fragments on the LDS read
             self._fresh.difference_update(names if fresh else ())
-            ops.gemm_tn(dy, x, grad, residual=None if fresh else grad, epilogue=ops.EPI_OUT_F32 if fresh else ops.EPI_RES_F32)
+            sink = self.sumsq_sink            # dp.GradSquareSums (one rank): the clip's sum of squares comes out of this GEMM's epilogue
+            sq = sink.wgrad_slots(grad, N, K) if sink is not None and grad.is_contiguous() else None
+            ops.gemm_tn(dy, x, grad, residual=None if fresh else grad, epilogue=ops.EPI_OUT_F32 if fresh else ops.EPI_RES_F32, sumsq=sq)
             return
         if tn_ok and min(N, K) <= 64 and max(N, K) >= 256:
             # adapter gradients: a strip of 256 x 256 tiles, split over the tokens so the whole chip streams dy / x once

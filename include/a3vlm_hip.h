@@ -105,6 +105,14 @@ int a3v_quantize_rows_fp8(const void* x, int64_t ldx, const void* norm_w, float 
 int a3v_gemm_tn(const void* At, int64_t lda, const void* Wt, int64_t ldw, void* C, int64_t ldc, int M, int N,
                 int K, const void* residual, int64_t ldr, int epilogue, void* stream);
 
+/* a3v_gemm_tn with an fp32 output kind (A3V_EPI_OUT_F32 / A3V_EPI_RES_F32: the weight gradients) that also leaves the sum of
+ * squares of the values it stored, as a3v_gemm_tn_sumsq_slots(M, N) partial sums in `sumsq` (the caller zeroes the buffer once per
+ * step; slots of tiles outside C are not written).  The global-norm clip (reference util/clip_grad.py:59-210) then needs no pass
+ * over these gradients at all. */
+int64_t a3v_gemm_tn_sumsq_slots(int M, int N);
+int a3v_gemm_tn_sumsq(const void* At, int64_t lda, const void* Wt, int64_t ldw, void* C, int64_t ldc, int M, int N, int K,
+                      const void* residual, int64_t ldr, int epilogue, float* sumsq, int64_t sumsq_cap, void* stream);
+
 /* "NN" GEMM: C[M,N] = epilogue(A . Wt), A [M, K] and Wt [K, N] both row-major (the contracted index is Wt's ROW index): the
  * input gradient dX = dY . W of F.linear (autograd of LLM/llama_ens5.py:112,169,214-217) on the weight image the forward pass
  * uses -- no transposed copy of W.  K % 64 == 0, N % 8 == 0; epilogues NONE / RESIDUAL / RES_F32 / OUT_F32. */

@@ -501,3 +501,37 @@ def test_train_step_with_hook_fed_encoder_streams_fp32():
         assert relerr(p.grad, want[name]) < 1e-3, (name, relerr(p.grad, want[name]))
     with pytest.raises(ValueError):
         eng.forward_loss(ex.to(DEV), lab.to(DEV), img.to(DEV))            # features missing and no provider hook attached
+
+
+@pytest.mark.parametrize("accum", [1, 2])
+def test_grad_square_sums_from_the_weight_gradient_epilogues(accum):
+    """One rank: the clip's norm is assembled from (a) the partial sums the big weight-gradient GEMMs leave (a3v_gemm_tn_sumsq:
+    fast epilogue tiles, ragged tiles, split-K reduce pass) and (b) a3v_sumsq_partials over what is left of each bucket -- equal to
+    the norm of the flat buffer, over two steps (slots are re-zeroed), with a non-boundary accumulation micro-step ignored."""
+    from a3vlm_amd.dp import GradSquareSums, clip_grad_norm
+    big = dict(dim=512, n_layers=2, n_heads=4, n_kv_heads=4, vocab_size=1024, multiple_of=256, max_seq_len=512)
+    oargs = ref_cpu.OracleArgs(**big)
+    sd = ref_cpu.make_decoder_weights(oargs, seed=3, std=0.05)
+    m = plugin.Transformer(plugin.ModelArgs(**big), with_visual=False)
+    m.load_state_dict(sd)
+    m.to(BF).to(DEV)
+    promote_trainable_params_to_fp32(m)
+    eng = TrainEngine(m, BF)
+    sq = GradSquareSums(eng)
+    assert eng.sumsq_sink is sq
+    g = torch.Generator().manual_seed(9)
+    B, T = 4, 301                                           # 1204 rows: whole tiles, ragged tiles and a split tail in the TN GEMMs
+    params = [p for p in m.parameters() if p.requires_grad]
+    for step in range(2):
+        for micro in range(accum):
+            ex = torch.randint(3, 1024, (B, T), generator=g)
+            ex[:, 0] = 1
+            sq.enabled = micro == accum - 1
+            eng.forward_loss(ex.to(DEV), ex.to(DEV), None)
+            eng.backward(1.0 / accum)
+        assert sq._covered, "no weight-gradient GEMM handed over its sums"
+        norm, coef = clip_grad_norm(params, 8.0, flat=eng.flat_grads(), defer=True, sumsq=sq)
+        ref = torch.linalg.vector_norm(eng.flat_grads().double()).float()
+        assert torch.allclose(norm, ref, rtol=2e-5), (step, float(norm), float(ref))
+        for p in params:
+            p.grad = None
