@@ -121,7 +121,7 @@ __device__ __forceinline__ void sumsq_flush(const GemmArgs& p, float ss, int mba
 // bias / activation in front of them (the ViT), EPI_SET_ROPE the fused-qkv form alone.  The 256x256 kernels hold 128 accumulator
 // registers and ~110 more across the k-loop; compiled together, the forms' peak pushed the k-loop's invariants into scratch
 // (100 dwords per lane, 5-20 % of every kind's speed), so each big-tile kernel is instantiated per set and picked by the host.
-constexpr int EPI_SET_COMMON = 1, EPI_SET_PRE = 2, EPI_SET_ROPE = 4;
+constexpr int EPI_SET_COMMON = 1, EPI_SET_PRE = 2, EPI_SET_ROPE = 4, EPI_SET_SUMSQ = 8;   // SUMSQ: GemmArgs::sumsq honoured (weight-gradient kernels only)
 template <int TM, int TN, int SET>
 __device__ __forceinline__ bool gemm_epilogue_fast(f32x4 (&acc)[TM][TN], const GemmArgs& p, int mbase, int nbase, int lane, char* stage) {
   if constexpr (TN != 4 || (TM % 4) != 0) {
@@ -253,16 +253,18 @@ __device__ __forceinline__ bool gemm_epilogue_fast(f32x4 (&acc)[TM][TN], const G
             f32x4 o0, o1;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { o0[e] = rr[it][0][e] + bf2f(v[e]); o1[e] = rr[it][1][e] + bf2f(v[4 + e]); }
-            if (p.sumsq) {
+            if constexpr ((SET & EPI_SET_SUMSQ) != 0) {
+              if (p.sumsq) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) ss = fmaf(o0[e], o0[e], fmaf(o1[e], o1[e], ss));
+                for (int e = 0; e < 4; ++e) ss = fmaf(o0[e], o0[e], fmaf(o1[e], o1[e], ss));
+              }
             }
             st_c(reinterpret_cast<f32x4*>(cp), o0);
             st_c(reinterpret_cast<f32x4*>(cp + 4), o1);
             cp += cstep;
           }
         }
-        if (p.sumsq) sumsq_flush(p, ss, mbase, nbase, lane);
+        if constexpr ((SET & EPI_SET_SUMSQ) != 0) { if (p.sumsq) sumsq_flush(p, ss, mbase, nbase, lane); }
       }
       return true;
     }
@@ -305,16 +307,18 @@ __device__ __forceinline__ bool gemm_epilogue_fast(f32x4 (&acc)[TM][TN], const G
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = rr[i][it][e] + v[e];
             }
-            if (p.sumsq) {
+            if constexpr ((SET & EPI_SET_SUMSQ) != 0) {
+              if (p.sumsq) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) ss = fmaf(v[e], v[e], ss);
+                for (int e = 0; e < 4; ++e) ss = fmaf(v[e], v[e], ss);
+              }
             }
             st_c(reinterpret_cast<f32x4*>(cp), v);
             cp += cstep;
           }
         }
       }
-      if (p.sumsq) sumsq_flush(p, ss, mbase, nbase, lane);
+      if constexpr ((SET & EPI_SET_SUMSQ) != 0) { if (p.sumsq) sumsq_flush(p, ss, mbase, nbase, lane); }
       return true;
     }
     if (kind == A3V_EPI_SWIGLU) {
@@ -687,9 +691,11 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GemmAr
       }
       if (epi & (A3V_EPI_RES_F32 | A3V_EPI_OUT_F32)) {
         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n) = acc[i][j];
-        if (p.sumsq) {
+        if constexpr ((SET & EPI_SET_SUMSQ) != 0) {
+          if (p.sumsq) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) gss = fmaf(acc[i][j][r], acc[i][j][r], gss);
+            for (int r = 0; r < 4; ++r) gss = fmaf(acc[i][j][r], acc[i][j][r], gss);
+          }
         }
       } else {
         bf16x4 o;
@@ -699,7 +705,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GemmAr
       }
     }
   }
-  if (p.sumsq) sumsq_flush(p, gss, mbase, nbase, lane);
+  if constexpr ((SET & EPI_SET_SUMSQ) != 0) { if (p.sumsq) sumsq_flush(p, gss, mbase, nbase, lane); }
 }
 
 // TBM x TBN block tile, WAVES_M x WAVES_N waves, each wave (TBM/WAVES_M) x (TBN/WAVES_N).
@@ -1700,7 +1706,8 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_pp_kernel(GemmArgs p) {
 #undef TN_READ_FRAGS
 #undef TN_MFMA_ALL
   // every read of the stage buffers is behind the last barrier: each wave takes a private 4 KiB of them for the row-contiguous stores
-  if (active) gemm_epilogue<TM, TN>(acc, p, m0 + wr * WTM, n0 + wc * WTN, lane, lds + wave * 4096);
+  // (sums of squares only in the TN form: the NN form computes input gradients)
+  if (active) gemm_epilogue<TM, TN, false, (A_ROWS ? EPI_SET_COMMON : EPI_SET_COMMON | EPI_SET_SUMSQ)>(acc, p, m0 + wr * WTM, n0 + wc * WTN, lane, lds + wave * 4096);
 }
 
 // A ring form of this kernel (A_top / A_bot / W rings over all 160 KiB as in gemm_nt_bf16_ring_kernel; for TN the A halves as

@@ -16,7 +16,7 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 BUDGET = [   # (substring of the mangled kernel name, max scratch bytes per lane)
     ("gemm_nt_bf16_ring_kernelILi0ELb0ELi0ELb1ELi1ELb0E", 64),     # ring, common epilogue forms: the decoder's linears
     ("gemm_nt_bf16_ring_kernelILi0ELb0ELi0ELb1ELi3ELb0E", 64),     # ring, bias / activation in front (the ViT)
-    ("gemm_tn_bf16_pp_kernelILb0E", 0),                            # weight gradients
+    ("gemm_tn_bf16_pp_kernelILb0E", 128),                          # weight gradients (+ sums of squares: epilogue-only spills, none in the k-loop)
     ("gemm_tn_bf16_pp_kernelILb1E", 0),                            # input gradients
     ("gemm_nt_bf16_pp_kernelILi0ELi0E", 64),                       # two-stage NT (A/B reference)
     ("gemm_nt_bf16_ring_kernelILi0ELb0ELi0ELb1ELi4ELb0E", 64),     # fused-qkv form (its own instantiation: DESIGN.md section 4)
