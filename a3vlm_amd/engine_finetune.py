@@ -20,6 +20,7 @@ Changed:
 from __future__ import annotations
 
 import inspect
+import os
 import math
 import sys
 from typing import Callable, Dict, Optional
@@ -72,6 +73,8 @@ def train_one_epoch(model, data_loader, optimizer, epoch: int, start_iter: int, 
         sumsq = getattr(engine, "_grad_square_sums", None)
         if sumsq is None:
             sumsq = engine._grad_square_sums = GradSquareSums(engine, reducer)
+    overlap = takes_scale and engine is not None and getattr(optimizer, "engine", None) is engine \
+        and os.environ.get("A3V_ADAMW_OVERLAP", "1") != "0"
     for step, batch in enumerate(data_loader, start=start_iter):
         examples, labels, imgs, depth = _unpack(batch)
         if trim is not None and not examples.is_cuda:
@@ -111,7 +114,8 @@ def train_one_epoch(model, data_loader, optimizer, epoch: int, start_iter: int, 
                 bad |= ~torch.isfinite(torch.as_tensor(stats["grad_norm"]).to(dev))
             if takes_scale:
                 one = coef if coef is not None else torch.ones((), dtype=torch.float32, device=dev)
-                optimizer.step(grad_scale=torch.where(bad, -one.new_ones(()), one).reshape(1))
+                # overlap: the update of layer i+1.. runs on the optimizer's stream under the next forward's layers ..i (optim.py)
+                optimizer.step(grad_scale=torch.where(bad, -one.new_ones(()), one).reshape(1), overlap=overlap)
             else:
                 stop_if_bad(step)                  # a stock optimizer cannot skip on a device flag: pay the host read
                 optimizer.step()
@@ -131,8 +135,11 @@ def train_one_epoch(model, data_loader, optimizer, epoch: int, start_iter: int, 
         if on_save is not None and update_grad and getattr(args, "save_iteration_interval", 0):
             if boundary_idx % max(args.save_iteration_interval // accum_iter, 1) == 0:
                 stop_if_bad(step)                  # never checkpoint past a bad step
+                if engine is not None:
+                    engine.sync_optimizer()        # the checkpoint reads parameters and optimizer state on this stream
                 on_save(step)
     if engine is not None:
         engine.static_grad_scale = None
+        engine.sync_optimizer()                    # whatever runs next (checkpoint, evaluation) sees the last update
     stop_if_bad(n_iter - 1)                        # the caller writes the epoch-end checkpoint next
     return {"closs": stats["closs"] / max(stats["n"], 1), "lr": stats["lr"]}

@@ -6,9 +6,17 @@ accumulation cycle (engine_finetune.py:63).
 
 One launch per parameter tensor streams p, g, m, v once (28 B per parameter).  ``image_of`` (optional) maps a parameter to a
 bf16 tensor of the same shape that receives the rounded updated values in the same pass (the compute-dtype operand of the next
-step's GEMMs)."""
+step's GEMMs).
+
+``step(overlap=True)`` (with ``engine``): the launches go to the optimizer's own stream in the order the forward first touches the
+parameters (``TrainEngine.forward_order``), one event per gradient bucket; ``TrainEngine.forward_loss`` of the next step waits
+bucket by bucket, so the 28-B/parameter HBM stream of the update runs under the MFMA-bound GEMMs of the next forward instead of
+in front of it.  Same arithmetic, same order per parameter.  The caller's contract: between ``step(overlap=True)`` and the next
+``forward_loss`` / ``backward`` only the host and ``zero_grad(set_to_none=True)`` touch parameters or gradients; anything else
+(checkpoints, evaluation through the model, a stock ``zero_grad(set_to_none=False)``) calls ``engine.sync_optimizer()`` first."""
 from __future__ import annotations
 
+import os
 from typing import Callable, Optional
 
 import torch
@@ -28,46 +36,85 @@ class FusedAdamW(torch.optim.Optimizer):
         # current -- the next step does not re-cast 6.7 G fp32 parameters (cat + cast = 14 B per parameter) to rebuild them
         self.engine = engine
         self.image_of = image_of if engine is None else engine.image_sink
+        self._stream: Optional[torch.cuda.Stream] = None
+
+    def state_dict(self):
+        if self.engine is not None:
+            self.engine.sync_optimizer()
+        return super().state_dict()
+
+    def _ordered(self):
+        """[(bucket or None, group, parameter)] in forward order (parameters the engine does not know first)."""
+        rank, name = {}, {}
+        for r, (bucket, plist) in enumerate(self.engine.forward_order()):
+            for _, q in plist:
+                rank[id(q)], name[id(q)] = r, bucket
+        items = [(rank.get(id(p), -1), name.get(id(p)), g, p) for g in self.param_groups for p in g["params"]]
+        items.sort(key=lambda it: it[0])
+        return [(b, g, p) for _, b, g, p in items]
 
     @torch.no_grad()
-    def step(self, closure=None, grad_scale: Optional[torch.Tensor] = None):
+    def step(self, closure=None, grad_scale: Optional[torch.Tensor] = None, overlap: bool = False):
         """``grad_scale``: optional fp32 device scalar every gradient is multiplied by as it is read (the clip coefficient of
-        ``dp.clip_grad_norm(..., defer=True)``): same update as ``grad.mul_(coef)`` + ``step()``; ``p.grad`` is left unscaled."""
+        ``dp.clip_grad_norm(..., defer=True)``): same update as ``grad.mul_(coef)`` + ``step()``; ``p.grad`` is left unscaled.
+        ``overlap``: see the module docstring."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
         lib = _l.load()
-        stream = torch.cuda.current_stream().cuda_stream
+        overlap = bool(overlap) and self.engine is not None
         if grad_scale is not None and (not grad_scale.is_cuda or grad_scale.dtype != torch.float32 or grad_scale.numel() != 1):
             raise RuntimeError("grad_scale must be a one-element fp32 device tensor")
         gs_ptr = grad_scale.data_ptr() if grad_scale is not None else None
+        order = self._ordered() if overlap else [(None, g, p) for g in self.param_groups for p in g["params"]]
+        for _, _, p in order:                  # states first: their zero fills are ordered before the hand-over to the other stream
+            if p.grad is None:
+                continue
+            if not p.is_cuda or p.dtype != torch.float32 or p.grad.dtype != torch.float32 or not p.is_contiguous() \
+                    or not p.grad.is_contiguous():
+                raise RuntimeError("FusedAdamW takes contiguous fp32 device parameters and gradients (no CPU fallback)")
+            st = self.state[p]
+            if len(st) == 0:
+                st["step"] = torch.tensor(0.0, dtype=torch.float32)          # torch.optim.AdamW's (non-capturable) layout
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        cur = torch.cuda.current_stream()
+        if overlap:
+            if self._stream is None:
+                self._stream = torch.cuda.Stream(priority=int(os.environ.get("A3V_ADAMW_STREAM_PRIO", "-1")))
+            self.engine.sync_optimizer()                       # a previous overlapped step nobody consumed
+            self._stream.wait_stream(cur)                      # gradients, states and the clip coefficient are ready
+            if grad_scale is not None:
+                grad_scale.record_stream(self._stream)
+            stream = self._stream.cuda_stream
+        else:
+            stream = cur.cuda_stream
         written = set()
-        for group in self.param_groups:
+        last = None
+        for bucket, group, p in order:
+            if overlap and bucket != last:
+                if last is not None:
+                    self.engine._weights_ready[last] = self._stream.record_event()
+                last = bucket
+            if p.grad is None:
+                continue
             b1, b2 = group["betas"]
-            for p in group["params"]:
-                if p.grad is None:
-                    continue
-                if not p.is_cuda or p.dtype != torch.float32 or p.grad.dtype != torch.float32 or not p.is_contiguous() \
-                        or not p.grad.is_contiguous():
-                    raise RuntimeError("FusedAdamW takes contiguous fp32 device parameters and gradients (no CPU fallback)")
-                st = self.state[p]
-                if len(st) == 0:
-                    st["step"] = torch.tensor(0.0, dtype=torch.float32)          # torch.optim.AdamW's (non-capturable) layout
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] += 1
-                img = self.image_of(p) if self.image_of is not None else None
-                if img is not None and (img.dtype != torch.bfloat16 or img.shape != p.shape or not img.is_contiguous()):
-                    raise RuntimeError("image_of must return a contiguous bf16 tensor of the parameter's shape")
-                rc = lib.a3v_adamw_scaled(p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(),
-                                          float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
-                                          int(st["step"].item()), img.data_ptr() if img is not None else None, gs_ptr, stream)
-                _l.check(rc, "a3v_adamw_scaled")
-                # the kernel wrote through raw pointers: tell autograd / version-keyed caches (the engine's bf16 weight images)
-                torch.autograd.graph.increment_version(p)
-                if img is not None:
-                    written.add(id(p))
+            st = self.state[p]
+            st["step"] += 1
+            img = self.image_of(p) if self.image_of is not None else None
+            if img is not None and (img.dtype != torch.bfloat16 or img.shape != p.shape or not img.is_contiguous()):
+                raise RuntimeError("image_of must return a contiguous bf16 tensor of the parameter's shape")
+            rc = lib.a3v_adamw_scaled(p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(),
+                                      float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
+                                      int(st["step"].item()), img.data_ptr() if img is not None else None, gs_ptr, stream)
+            _l.check(rc, "a3v_adamw_scaled")
+            # the kernel wrote through raw pointers: tell autograd / version-keyed caches (the engine's bf16 weight images)
+            torch.autograd.graph.increment_version(p)
+            if img is not None:
+                written.add(id(p))
+        if overlap:
+            self.engine._weights_ready[last if last is not None else "head"] = self._stream.record_event()
         if self.engine is not None:
             self.engine.images_adopted(written)
         return loss

@@ -55,6 +55,7 @@ class TrainEngine:
         self.sumsq_sink = None               # see _wgrad
         self.static_grad_scale: Optional[float] = None      # set by a trainer that knows d(total)/d(loss) (1 / accum_iter)
         self._saved = None
+        self._weights_ready: Dict[str, torch.cuda.Event] = {}   # bucket -> event of FusedAdamW.step(overlap=True), see await_weights
 
     # ------------------------------------------------------------------ buffers
     def _buf(self, name, shape, dtype=None, zero=False):
@@ -75,6 +76,28 @@ class TrainEngine:
 
     def images_adopted(self, written_ids) -> None:
         self._images().adopted(written_ids)
+
+    def forward_order(self):
+        """Gradient buckets in the order the forward first touches their parameters: ``FusedAdamW.step(overlap=True)`` updates
+        them in this order on its own stream, and the next forward waits per bucket (``await_weights``) -- the HBM-bound update
+        of layer i+1.. runs under the MFMA-bound GEMMs of layers ..i of the next step."""
+        lay = self._layout()
+        rank = {"embed": 0, "vision_proj": 1, "head": 3}
+        return sorted(lay, key=lambda it: rank.get(it[0], 2))          # stable: the layers keep their order
+
+    def await_weights(self, bucket: str) -> None:
+        """The current stream waits until the optimizer has written this bucket's parameters (no-op without an overlapped step)."""
+        ev = self._weights_ready.pop(bucket, None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
+    def sync_optimizer(self) -> None:
+        """The current stream waits for every update still in flight: before anything but ``forward_loss`` reads parameters or
+        writes gradients (backward, checkpoints, evaluation through the model)."""
+        if self._weights_ready:
+            for ev in self._weights_ready.values():
+                torch.cuda.current_stream().wait_event(ev)
+            self._weights_ready.clear()
 
     def _kext_cols(self, key: str) -> int:
         """Width of the adapter block appended to the image / input of decoder GEMM ``key`` (0: adapters not folded in)."""
@@ -614,9 +637,13 @@ class TrainEngine:
         rows = B * S
         dim, V = a.dim, a.vocab_size
         h = self._buf("h", (rows, dim), torch.float32)
+        if self.lora or self.act != torch.bfloat16:
+            self.sync_optimizer()          # adapter / fp32 images are rebuilt from all parameters at once
+        self.await_weights("embed")
         ops.embed_assemble(examples.contiguous(), m.tok_embeddings.weight, h, B, T, W, dim)
         vis = None
         if image is not None:
+            self.await_weights("vision_proj")
             vis = self._encode_image_train(h, image, B, S, qformer_feats, extra_feats)
         hs = self._buf("h_saved", (m.n_layers + 1, rows, dim), torch.float32)
         if self.recompute is None:
@@ -629,14 +656,17 @@ class TrainEngine:
         if self.recompute:
             for i in range(m.n_layers):
                 hs[i].copy_(h)                   # the block input (checkpoint, main_finetune.py:268-276)
+                self.await_weights(f"layer{i}")
                 self._block_forward(i, h, B, S, keep=False)
         else:
             # stored activations: block i reads hs[i] and writes hs[i + 1] (its w2 GEMM's residual epilogue stores there), so the
             # checkpoints cost no copy (was one 143-MB read + write per layer)
             hs[0].copy_(h)
             for i in range(m.n_layers):
+                self.await_weights(f"layer{i}")
                 kept.append(self._block_forward(i, hs[i], B, S, keep=True, tag=f".L{i}", h_out=hs[i + 1]))
             h = hs[m.n_layers]
+        self.sync_optimizer()                    # "head" is last in forward_order: everything has landed from here on
         xt = self._buf("xn_text", (B * T, dim))
         hv = h.view(B, S, dim)
         for b in range(B):
@@ -662,6 +692,7 @@ class TrainEngine:
         self._dha_ready = False
         assert s is not None, "backward() without forward_loss()"
         m, a = self.m, self.m.args
+        self.sync_optimizer()                    # the update reads the gradients this backward overwrites
         im = self._images()
         self.ensure_grads()
         B, T, W, S = s["B"], s["T"], s["W"], s["S"]

@@ -287,6 +287,8 @@ def time_gemm_shapes(args, B, T, W, dev, train=True):
 def _train_step_fn(eng, opt, red, params, tokens, labels, image):
     from a3vlm_amd.dp import clip_grad_norm, GradSquareSums
     sq = GradSquareSums(eng, red) if os.environ.get("A3V_CLIP_SUMSQ", "1") != "0" else None   # =0: one norm pass after the backward (A/B)
+    # the update runs on the optimizer's stream under the next step's forward, bucket by bucket (optim.py); =0: in line (A/B)
+    overlap = os.environ.get("A3V_ADAMW_OVERLAP", "1") != "0"
 
     def one():
         loss = eng.forward_loss(tokens, labels, image)
@@ -296,7 +298,7 @@ def _train_step_fn(eng, opt, red, params, tokens, labels, image):
         # global-norm clip of the reference recipe (--clip_grad 8, a3vlm_train.sh:47-55; util/misc.py:302-315): per-bucket sums of
         # squares taken on a side stream while the backward runs, coefficient applied inside the optimizer kernel
         _, coef = clip_grad_norm(params, 8.0, flat=eng.flat_grads(), defer=True, sumsq=sq)
-        opt.step(grad_scale=coef)
+        opt.step(grad_scale=coef, overlap=overlap)
         opt.zero_grad(set_to_none=True)
         one.loss = loss
     return one

@@ -535,3 +535,54 @@ def test_grad_square_sums_from_the_weight_gradient_epilogues(accum):
         assert torch.allclose(norm, ref, rtol=2e-5), (step, float(norm), float(ref))
         for p in params:
             p.grad = None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_visual", [False, True])
+def test_overlapped_optimizer_step_equals_in_line_step(with_visual):
+    """FusedAdamW.step(overlap=True) runs the update on its own stream in forward order and the next forward waits bucket by
+    bucket.  Two identical models, one stepped in line and one overlapped, fed the SAME gradients (the backward's atomics are not
+    bit-reproducible, and Adam amplifies that): parameters, optimizer state, weight images and the next forward's loss stay
+    bit-equal over three steps."""
+    from a3vlm_amd.dp import clip_grad_norm
+    from a3vlm_amd.optim import FusedAdamW
+    big = dict(dim=512, n_layers=3, n_heads=4, n_kv_heads=4, vocab_size=1024, multiple_of=256, max_seq_len=512)
+    g = torch.Generator().manual_seed(21)
+    B, T = 2, 130
+    exs = [torch.randint(3, 192 if with_visual else 1024, (B, T), generator=g) for _ in range(3)]
+    img = torch.randn(B, 3, 112, 112, generator=g).to(DEV).to(BF) if with_visual else None
+    side = []
+    for overlap in (False, True):
+        if with_visual:
+            m, _, _ = build(True, BF)
+        else:
+            m = plugin.Transformer(plugin.ModelArgs(**big), with_visual=False)
+            m.load_state_dict(ref_cpu.make_decoder_weights(ref_cpu.OracleArgs(**big), seed=3, std=0.05))
+            m.to(BF).to(DEV)
+        promote_trainable_params_to_fp32(m)
+        eng = TrainEngine(m, BF)
+        params = [p for p in m.parameters() if p.requires_grad]
+        side.append((m, eng, params, FusedAdamW(params, lr=1e-2, betas=(0.9, 0.95), weight_decay=0.1, engine=eng)))
+    (_, ea, pa, oa), (_, eb, pb, ob) = side
+    for ex in exs:
+        ex = ex.to(DEV)
+        ex[:, 0] = 1
+        la = ea.forward_loss(ex, ex, img).clone()
+        lb = eb.forward_loss(ex, ex, img).clone()          # waits, bucket by bucket, for the update still running on ob's stream
+        assert not eb._weights_ready
+        assert float(la) == float(lb), (float(la), float(lb))
+        ea.backward(1.0)
+        eb.backward(1.0)
+        eb.flat_grads().copy_(ea.flat_grads())
+        _, coef = clip_grad_norm(pa, 0.5, flat=ea.flat_grads(), defer=True)
+        oa.step(grad_scale=coef)
+        ob.step(grad_scale=coef, overlap=True)
+        assert eb._weights_ready, "the overlapped step left no events for the next forward"
+        oa.zero_grad(set_to_none=True)
+        ob.zero_grad(set_to_none=True)
+    eb.sync_optimizer()
+    torch.cuda.synchronize()
+    for a, b in zip(pa, pb):
+        assert torch.equal(a, b)
+        assert torch.equal(oa.state[a]["exp_avg_sq"], ob.state[b]["exp_avg_sq"]) and float(oa.state[a]["step"]) == float(ob.state[b]["step"]) == 3
+    assert torch.equal(ea._images()["qkv.1"], eb._images()["qkv.1"])
