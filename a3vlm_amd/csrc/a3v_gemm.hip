@@ -1415,6 +1415,195 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------
+// One-wave-per-SIMD form: 256 threads = 4 waves (2 x 2), each wave owns a 128 x 128 quarter of the 256 x 256 tile (256 fp32
+// accumulators in the accumulation registers + two fragment buffers of 64 VGPRs: the 512-register budget of a wave that has its
+// SIMD to itself).  No second wave to hand the matrix pipe to: the fragment reads of sub-stage s+1 are issued between the MFMAs
+// of sub-stage s by the same wave, and the only synchronisation is one workgroup barrier per 32-k sub-stage.
+//   LDS: ring of 5 sub-stages x 32 KiB; a sub-stage = 32 k of the A tile (256 rows x 64 B) + 32 k of the W tile (256 x 64 B);
+//        the 16-byte slot q of row r sits at q ^ ((r >> 2) & 3): conflict-free ds_read_b128 of 16 rows x one slot.
+//   DMA: each wave issues 8 one-KiB pieces (16 rows x 64 B) per sub-stage, four sub-stages (two K-tile periods) ahead.
+//   iteration s:  vmcnt(own pieces of s+1 landed) ; barrier  (=> stage s+1 visible, stage s read by everyone)
+//                 per MFMA row (8 MFMAs): two ds_read_b128 of stage s+1 into the other buffer and one DMA piece of stage s+4
+//                 -> slot (s+4) % 5 (stage s-1's slot).  All eight pieces in one burst from four waves at once cost 520
+//                 cycles per sub-stage: the CU's address unit takes ~16 cycles per piece and the issuing wave stalls
+//   LDS read traffic per K-tile and CU: 128 KiB (8-wave kernels: 192 KiB).
+// ------------------------------------------------------------------------------------
+template <int DBG, int SET = EPI_SET_COMMON>   // DBG 4: cycle stamps; 8: no DMA in the k-loop, 9: no DMA and no fragment reads, 10: every k-loop piece out of bounds = issued but fetching nothing (timing experiments, wrong results)
+__global__ __launch_bounds__(256) void gemm_nt_bf16_w4_kernel(GemmArgs p) {
+  constexpr int TBM = 256, TBN = 256, KS = 32, NST = 5;
+  constexpr int HALF = 256 * KS * 2;                    // 16 KiB: the A (or W) part of a sub-stage
+  constexpr int STG = 2 * HALF;                         // 32 KiB
+  __shared__ __attribute__((aligned(1024))) char lds[NST * STG];   // 163840 B
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+
+  const int ntiles = p.tiles_m * p.tiles_n;
+  auto tile_of = [&](int vb, int& tm0, int& tn0) {
+    const int xcd = vb & 7, q = ntiles >> 3, r = ntiles & 7;
+    const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
+    const int per_group = GROUP_M * p.tiles_n;
+    const int group = bid / per_group;
+    const int first_m = group * GROUP_M;
+    const int gsz = min(p.tiles_m - first_m, GROUP_M);
+    const int in_g = bid - group * per_group;
+    tm0 = (first_m + in_g % gsz) * TBM;
+    tn0 = (in_g / gsz) * TBN;
+  };
+  int m0, n0, sm0, sn0;
+  tile_of(blockIdx.x, m0, n0);
+  sm0 = m0; sn0 = n0;
+  if (gridDim.y > 1) {                                  // split-K slices as in the ring kernel
+    const int nk_all = p.K / BK, z = blockIdx.y, S = gridDim.y;
+    const int t0 = (int)(((int64_t)z * nk_all) / S), t1 = (int)(((int64_t)(z + 1) * nk_all) / S);
+    p.A += (int64_t)t0 * BK;
+    p.W += (int64_t)t0 * BK;
+    p.K = (t1 - t0) * BK;
+    p.C = reinterpret_cast<char*>(p.C) + (int64_t)z * p.c_split;
+  }
+  const int ns = p.K / KS;                              // even (K % 64 == 0)
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)(((int64_t)(p.M - 1) * p.lda + p.K) * 2), 0x00020000);
+  const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)(((int64_t)(p.N - 1) * p.ldw + p.K) * 2), 0x00020000);
+  // DMA lane -> (row lane/4 of the 16-row piece, physical slot lane%4) <- logical slot (lane%4) ^ ((row >> 2) & 3)
+  const unsigned lsl = (lane & 3) ^ ((lane >> 4) & 3);
+  const unsigned voA = (unsigned)(((lane >> 2) * p.lda + lsl * 8) * 2);
+  const unsigned voW = (unsigned)(((lane >> 2) * p.ldw + lsl * 8) * 2);
+  // piece c (0..3: A rows, 4..7: W rows) of this wave's 8 one-KiB pieces of sub-stage s of tile (sm0, sn0)
+  // `kill` = 0x80000000 pushes the offset past the buffer's bound: the piece fetches nothing (zeros land in a free slot) but still
+  // counts in vmcnt, so the k-loop needs no branches and one constant wait count
+  auto piece = [&](int s, int c, unsigned kill) {
+    char* const dst = lds + (s % NST) * STG;
+    const int ch = wave * 4 + (c & 3);
+    if (c < 4) {
+      const unsigned so = (unsigned)(((int64_t)(sm0 + ch * 16) * p.lda + s * KS) * 2) | kill;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(dst + ch * 1024), 16, voA + so, 0, 0, 0);
+    } else {
+      const unsigned so = (unsigned)(((int64_t)(sn0 + ch * 16) * p.ldw + s * KS) * 2) | kill;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(dst + HALF + ch * 1024), 16, voW + so, 0, 0, 0);
+    }
+  };
+  auto stage = [&](int s) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) piece(s, c, 0u);
+  };
+  auto prologue = [&]() {                               // stages 0..3, the two halves of a line back to back (ns is even)
+#pragma unroll
+    for (int s = 0; s < 4; s += 2)
+      if (s < ns) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { piece(s, c, 0u); piece(s + 1, c, 0u); }
+      }
+  };
+  prologue();
+
+  // fragments of one sub-stage: A row tile i -> row wr*128 + 16 i + (lane & 15), logical slot lane >> 4; W likewise with wc
+  const int fl = lane & 15;
+  const int fq = ((lane >> 4) ^ ((fl >> 2) & 3)) << 4;
+  const int a_off = (wr * 128 + fl) * 64 + fq;
+  const int w_off = HALF + (wc * 128 + fl) * 64 + fq;
+  bf16x8 af[2][8], wf[2][8];
+  f32x4 accl[8][4], accr[8][4];                         // columns 0..63 / 64..127 of the wave's quarter (two epilogue calls)
+
+  unsigned long long* stamps = (DBG == 4 && blockIdx.x == 0 && lane == 0) ? (unsigned long long*)p.bias + wave * 64 * 8 : nullptr;
+#define W4_STAMP(s, k) do { if (DBG == 4 && stamps && (s) < 64) stamps[(s) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define W4_TSTAMP(k) do { if (DBG == 4 && stamps && tile_no < 12) stamps[tile_no * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+  int tile_no = 0;
+#define W4_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+  // The k-loop is written instruction by instruction (volatile asm keeps the order): accumulators pinned to the accumulation
+  // registers ("+a", in place), fragment reads as explicit ds_read_b128 placed between the MFMA rows.  The compiler's own
+  // scheduling of the builtin form moved half of the accumulators into VGPRs and shuffled them through v_accvgpr moves.
+#define W4_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define W4_MFMA(c, w, a) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(w), "v"(a))
+  // MFMA j of row g; after it, this wave's slot j of the row: wave PH reads its two fragments behind MFMAs 2 PH and 2 PH + 1
+  // (row 7: both behind MFMA PH, so the last reads have >= 4 MFMAs to return in) and issues its DMA piece behind MFMA
+  // (2 PH + 4) % 8.  The four waves run in lock step (one barrier per sub-stage): without the stagger they hit the LDS and the
+  // address unit in the same cycle and each piece stalls its wave ~50 cycles (40 % of the kernel).
+#define W4_SLOT(cur, nxt, s, PH, g, j, EVEN)                                                                  \
+  do {                                                                                                        \
+    if ((j) < 4) W4_MFMA(accl[g][(j) & 3], wf[cur][j], af[cur][g]);                                           \
+    else W4_MFMA(accr[g][(j) & 3], wf[cur][j], af[cur][g]);                                                   \
+    if (DBG != 9 && (j) == ((g) < 7 ? 2 * (PH) : (PH))) W4_READ(af[nxt][g], ra_, (g) * 1024);                 \
+    if (DBG != 9 && (j) == ((g) < 7 ? 2 * (PH) + 1 : (PH))) W4_READ(wf[nxt][g], rw_, (g) * 1024);             \
+    if (DBG < 8 && (EVEN) && (j) == ((2 * (PH) + 4) & 7)) piece((s) + 4, g, kill_);                           \
+    if (DBG < 8 && (EVEN) && (j) == ((2 * (PH) + 5) & 7)) piece((s) + 5, g, kill2_);                          \
+  } while (0)
+  // one sub-stage: MFMAs of stage s from buffer `cur`, the fragments of stage s+1 into buffer `nxt`; EVEN sub-stages issue the
+  // pieces of stages s+4 and s+5 pairwise -- the two 64-byte halves of the same 128-byte lines back to back, so the second
+  // request finds the line in (or on its way into) the vector L1 instead of fetching it from L2 a second time one sub-stage later
+#define W4_ITER(cur, nxt, s, PH, EVEN)                                                                        \
+  do {                                                                                                        \
+    W4_STAMP(s, 0);                                                                                           \
+    if (DBG < 8) W4_VMCNT(16);                          /* everything but the newest pair of stages has landed */ \
+    W4_STAMP(s, 1);                                                                                           \
+    A3V_BARRIER();                                                                                            \
+    W4_STAMP(s, 2);                                                                                           \
+    const unsigned nb_ = (unsigned)((((s) + 1) % NST) * STG);                                                 \
+    const unsigned ra_ = nb_ + (unsigned)a_off, rw_ = nb_ + (unsigned)w_off;                                  \
+    const unsigned kill_ = ((s) + 4 < ns && DBG != 10) ? 0u : 0x80000000u, kill2_ = ((s) + 5 < ns && DBG != 10) ? 0u : 0x80000000u; \
+    _Pragma("unroll") for (int g = 0; g < 8; ++g) {                                                           \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) W4_SLOT(cur, nxt, s, PH, g, j, EVEN);                     \
+    }                                                                                                         \
+    W4_STAMP(s, 3);                                                                                           \
+    A3V_WAIT_LGKM0();                                                                                         \
+    W4_STAMP(s, 4);                                                                                           \
+  } while (0)
+#define W4_KLOOP(PH)                                                                                          \
+  for (int s = 0; s < ns; s += 2) {                     /* (the last sub-stage reads one stage past the end: in-ring, never used) */ \
+    W4_ITER(0, 1, s, PH, true);                                                                               \
+    W4_ITER(1, 0, s + 1, PH, false);                                                                          \
+  }
+
+  // clock probe (DBG >= 4 with a buffer in `bias`): shader-clock and 100-MHz real-time counters at kernel entry / exit of block 0
+  unsigned long long* const probe = (DBG >= 4 && p.bias && blockIdx.x == 0 && tid == 0) ? (unsigned long long*)p.bias + 4 * 64 * 8 : nullptr;
+  if (probe) { probe[0] = __builtin_amdgcn_s_memtime(); probe[1] = __builtin_amdgcn_s_memrealtime(); }
+  for (int vb = blockIdx.x;;) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { accl[i][j] = f32x4{}; accr[i][j] = f32x4{}; }
+    W4_TSTAMP(5);
+    A3V_WAIT_VM0();
+    A3V_BARRIER();
+    W4_TSTAMP(6);
+#pragma unroll
+    for (int g = 0; g < 8; ++g) { W4_READ(af[0][g], (unsigned)a_off, g * 1024); W4_READ(wf[0][g], (unsigned)w_off, g * 1024); }
+    A3V_WAIT_LGKM0();
+    if (wave == 0) { W4_KLOOP(0) }
+    else if (wave == 1) { W4_KLOOP(1) }
+    else if (wave == 2) { W4_KLOOP(2) }
+    else { W4_KLOOP(3) }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");    // the last MFMAs retire before the epilogue's v_accvgpr_read (no interlock)
+    W4_TSTAMP(7);
+    A3V_BARRIER();                                       // the last reads of the ring are done: the next tile may land
+    const int nb = vb + (int)gridDim.x;
+    if (nb < ntiles) {
+      tile_of(nb, sm0, sn0);
+      prologue();
+    }
+    {
+      int lane_e = lane;
+      asm volatile("" : "+v"(lane_e));
+      char* const patch = lds + 4 * STG + wave * 4096;   // slot 4: the prologue fills slots 0..3
+      gemm_epilogue<8, 4, false, SET>(accl, p, m0 + wr * 128, n0 + wc * 128, lane_e, patch);
+      gemm_epilogue<8, 4, false, SET>(accr, p, m0 + wr * 128, n0 + wc * 128 + 64, lane_e, patch);
+    }
+    ++tile_no;
+    if (nb >= ntiles) break;
+    vb = nb; m0 = sm0; n0 = sn0;
+  }
+  if (probe) { probe[2] = __builtin_amdgcn_s_memtime(); probe[3] = __builtin_amdgcn_s_memrealtime(); }
+#undef W4_TSTAMP
+#undef W4_KLOOP
+#undef W4_ITER
+#undef W4_SLOT
+#undef W4_READ
+#undef W4_MFMA
+#undef W4_VMCNT
+#undef W4_STAMP
+}
+
+// ------------------------------------------------------------------------------------
 // fp8 (OCP e4m3fn) form of the 256x256 ping-pong kernel: A [M][K] and W [N][K] are fp8 bytes, one k-tile is 128 elements =
 // the same 128-byte LDS rows, DMA pieces and swizzle as the bf16 kernel's 64-element tile, and the two 16-byte fragment reads
 // of a lane (16-B chunks g and 4 + g of its row) feed ONE v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales) instead of
@@ -2481,6 +2670,11 @@ static bool pp_ring() {       // the 160-KiB ring form of the ping-pong kernel (
   return !(e && e[0] == '0');
 }
 
+static int w4_env() {          // A3V_GEMM_W4=1: the one-wave-per-SIMD kernel instead of the ring (2: with cycle stamps); read per launch
+  const char* e = getenv("A3V_GEMM_W4");
+  return e ? atoi(e) : 0;
+}
+
 static int nt_store_env() {
   const char* e = getenv("A3V_GEMM_NT_STORE");
   return e ? atoi(e) : 0;
@@ -2556,6 +2750,11 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
           if (q.epi & GEMM_EPI_ROPEKV) hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0, true, EPI_SET_ROPE>), g, b, 0, st, q);
           else if (q.epi & (A3V_EPI_BIAS | A3V_EPI_GELU | A3V_EPI_QUICKGELU))
             hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0, true, EPI_SET_COMMON | EPI_SET_PRE>), g, b, 0, st, q);
+          else if (w4_env() == 1) hipLaunchKernelGGL((gemm_nt_bf16_w4_kernel<0>), g, dim3(256), 0, st, q);
+          else if (w4_env() == 2) hipLaunchKernelGGL((gemm_nt_bf16_w4_kernel<4>), g, dim3(256), 0, st, q);   // cycle stamps into `bias`
+          else if (w4_env() == 8) hipLaunchKernelGGL((gemm_nt_bf16_w4_kernel<8>), g, dim3(256), 0, st, q);
+          else if (w4_env() == 9) hipLaunchKernelGGL((gemm_nt_bf16_w4_kernel<9>), g, dim3(256), 0, st, q);
+          else if (w4_env() == 10) hipLaunchKernelGGL((gemm_nt_bf16_w4_kernel<10>), g, dim3(256), 0, st, q);   // every k-loop piece out of bounds
           else hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0>), g, b, 0, st, q);
           break;
         case 11: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0, false>), g, b, 0, st, q); break;   // ring, direct (unstaged) epilogue stores

@@ -764,6 +764,43 @@ def test_gemm_ring_ragged_rows_over_several_tiles_per_block():
         assert_close(o, r.cpu() + rt(want.cpu()), rtol=2 ** -7, atol=0.04, what="ring ragged res_f32")   # 1 bf16 ulp of the product at |y| < 8
 
 
+def test_gemm_one_wave_per_simd_kernel_equals_ring_kernel():
+    """The opt-in 4-wave (one wave per SIMD, 128 x 128 per wave, 5 x 32-KiB sub-stage ring) form of the NT kernel
+    (A3V_GEMM_W4=1; DESIGN.md section 4: measured, slower than the ring kernel, kept for the record) accumulates in the same
+    order through the same epilogues: bit-equal results on interior + ragged tiles, several tiles per block and the fp32 /
+    residual / SwiGLU output kinds."""
+    import os
+    from a3vlm_amd import lib
+    for (M, N, K) in [(8728, 3072, 256), (2048, 1024, 512), (520, 264, 128)]:
+        a, w = gen(M, K, seed=83).to(BF).to(DEV), gen(N, K, seed=84, scale=0.05).to(BF).to(DEV)
+        resf = gen(M, N, seed=85).to(DEV)
+
+        def run(kind):
+            if kind == "swiglu":
+                o = torch.full((M, N // 2), 3.0, dtype=BF, device=DEV)
+                return ops.gemm_nt(a, w, o, epilogue=lib.EPI_TILE_256PP | ops.EPI_SWIGLU)
+            if kind == "res_f32":
+                o = resf.clone()
+                return ops.gemm_nt(a, w, o, residual=o, epilogue=lib.EPI_TILE_256PP | ops.EPI_RES_F32)
+            o = torch.full((M, N), 3.0, dtype=torch.float32 if kind == "out_f32" else BF, device=DEV)
+            return ops.gemm_nt(a, w, o, epilogue=lib.EPI_TILE_256PP | (ops.EPI_OUT_F32 if kind == "out_f32" else 0))
+        for kind in ["plain", "res_f32", "out_f32"] + (["swiglu"] if N % 32 == 0 else []):
+            outs = []
+            for flag in ("0", "1"):
+                os.environ["A3V_GEMM_W4"] = flag
+                try:
+                    outs.append(run(kind).clone())
+                finally:
+                    os.environ["A3V_GEMM_W4"] = "0"
+            assert torch.equal(outs[0], outs[1]), (M, N, K, kind)
+        os.environ["A3V_GEMM_W4"] = "1"
+        try:
+            o = run("plain")
+        finally:
+            os.environ["A3V_GEMM_W4"] = "0"
+        assert_close(o, a.float() @ w.float().t(), rtol=2 ** -7, atol=1e-3 * math.sqrt(K) * 0.05, what=f"w4 {M}x{N}x{K} vs fp32")
+
+
 @pytest.mark.parametrize("M,N,K", [(1024, 768, 1000), (4352, 2048, 1024), (520, 264, 512)])
 def test_gemm_tn_nn_fast_epilogue_forms_equal_general_form(M, N, K):
     at, wt = gen(K, M, seed=90).to(BF).to(DEV), gen(K, N, seed=91, scale=0.05).to(BF).to(DEV)
