@@ -1604,6 +1604,171 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_w4_kernel(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------
+// "Overlapped" form: the 8 waves and 128 x 64 wave tiles of the ring kernel on the 32-k sub-stage ring of the kernel above, but
+// no L / M phases: every wave runs ONE stream in which its own fragment reads (12 per sub-stage) and DMA pieces sit in the
+// shadows of its MFMAs (32 per sub-stage), hand-ordered (volatile asm), accumulators pinned to AGPRs.  The two waves of a SIMD
+// issue into the matrix pipe whenever they can; when one stalls on a load issue the other one's MFMAs go out -- nobody hands
+// the pipe over.  One barrier per sub-stage; the two groups meet it half a sub-stage apart (group 0 at the top of its
+// iteration, group 1 after its 16th MFMA), so while one wave of a SIMD waits, its partner still has MFMAs to issue.
+//   group 0, iteration s:  vmcnt ; barrier(s) ; rows 0..7: 4 MFMAs + reads of stage s+1 (+ pieces on even s) ; lgkmcnt(0)
+//   group 1, iteration s:  rows 0..3: 4 MFMAs (+ pieces on even s) ; vmcnt ; barrier(s) ; rows 4..7: 4 MFMAs + reads ; lgkmcnt(0)
+//   pieces: 16 rows x 64 B; even sub-stages issue stages s+4 and s+5 pairwise (both halves of a 128-B line back to back).
+// ------------------------------------------------------------------------------------
+template <int DBG, int SET = EPI_SET_COMMON>
+__global__ __launch_bounds__(512) void gemm_nt_bf16_ov_kernel(GemmArgs p) {
+  constexpr int TBM = 256, TBN = 256, KS = 32, NST = 5;
+  constexpr int HALF = 256 * KS * 2;                    // 16 KiB: the A (or W) part of a sub-stage
+  constexpr int STG = 2 * HALF;                         // 32 KiB
+  __shared__ __attribute__((aligned(1024))) char lds[NST * STG];   // 163840 B
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;             // wr = group: waves 0..3 and 4..7 share the four SIMDs pairwise
+
+  const int ntiles = p.tiles_m * p.tiles_n;
+  auto tile_of = [&](int vb, int& tm0, int& tn0) {
+    const int xcd = vb & 7, q = ntiles >> 3, r = ntiles & 7;
+    const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
+    const int per_group = GROUP_M * p.tiles_n;
+    const int group = bid / per_group;
+    const int first_m = group * GROUP_M;
+    const int gsz = min(p.tiles_m - first_m, GROUP_M);
+    const int in_g = bid - group * per_group;
+    tm0 = (first_m + in_g % gsz) * TBM;
+    tn0 = (in_g / gsz) * TBN;
+  };
+  int m0, n0, sm0, sn0;
+  tile_of(blockIdx.x, m0, n0);
+  sm0 = m0; sn0 = n0;
+  if (gridDim.y > 1) {                                  // split-K slices as in the ring kernel
+    const int nk_all = p.K / BK, z = blockIdx.y, S = gridDim.y;
+    const int t0 = (int)(((int64_t)z * nk_all) / S), t1 = (int)(((int64_t)(z + 1) * nk_all) / S);
+    p.A += (int64_t)t0 * BK;
+    p.W += (int64_t)t0 * BK;
+    p.K = (t1 - t0) * BK;
+    p.C = reinterpret_cast<char*>(p.C) + (int64_t)z * p.c_split;
+  }
+  const int ns = p.K / KS;                              // even (K % 64 == 0)
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)(((int64_t)(p.M - 1) * p.lda + p.K) * 2), 0x00020000);
+  const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)(((int64_t)(p.N - 1) * p.ldw + p.K) * 2), 0x00020000);
+  const unsigned lsl = (lane & 3) ^ ((lane >> 4) & 3);
+  const unsigned voA = (unsigned)(((lane >> 2) * p.lda + lsl * 8) * 2);
+  const unsigned voW = (unsigned)(((lane >> 2) * p.ldw + lsl * 8) * 2);
+  // piece c (0, 1: A rows, 2, 3: W rows) of this wave's 4 one-KiB pieces of sub-stage s; `kill`: see the kernel above
+  auto piece = [&](int s, int c, unsigned kill) {
+    char* const dst = lds + (s % NST) * STG;
+    const int ch = wave * 2 + (c & 1);
+    if (c < 2) {
+      const unsigned so = (unsigned)(((int64_t)(sm0 + ch * 16) * p.lda + (DBG == 11 ? (s & 3) : DBG == 12 ? (s & 7) : DBG == 13 ? (s & 31) : s) * KS) * 2) | kill;   // DBG 11 / 12 / 13: the same 4 / 8 / 32 sub-stages over and over (L1 / L2 hits)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(dst + ch * 1024), 16, voA + so, 0, 0, 0);
+    } else {
+      const unsigned so = (unsigned)(((int64_t)(sn0 + ch * 16) * p.ldw + (DBG == 11 ? (s & 3) : DBG == 12 ? (s & 7) : DBG == 13 ? (s & 31) : s) * KS) * 2) | kill;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(dst + HALF + ch * 1024), 16, voW + so, 0, 0, 0);
+    }
+  };
+  auto prologue = [&]() {                               // stages 0..3, the two halves of a line back to back (ns is even)
+#pragma unroll
+    for (int s = 0; s < 4; s += 2)
+      if (s < ns) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { piece(s, c, 0u); piece(s + 1, c, 0u); }
+      }
+  };
+  prologue();
+
+  const int fl = lane & 15;
+  const int fq = ((lane >> 4) ^ ((fl >> 2) & 3)) << 4;
+  const int a_off = (wr * 128 + fl) * 64 + fq;
+  const int w_off = HALF + (wc * 64 + fl) * 64 + fq;
+  bf16x8 af[2][8], wf[2][4];
+  f32x4 acc[8][4];
+
+#define OV_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define OV_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define OV_MFMA(c, w, a) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(w), "v"(a))
+  // the 12 reads of stage s+1 in read slots 0..15 (slot = 4 * row-in-window + MFMA index): A_0..A_7 in slots 0..7, W_0..W_3 in 8..11
+#define OV_RSLOT(nxt, q)                                                                                      \
+  do {                                                                                                        \
+    if (DBG != 9 && (q) < 8) OV_READ(af[nxt][(q) & 7], ra_, ((q) & 7) * 1024);                                \
+    if (DBG != 9 && (q) >= 8 && (q) < 12) OV_READ(wf[nxt][(q) & 3], rw_, ((q) & 3) * 1024);                   \
+  } while (0)
+  // row g of the MFMA stream.  RB = first row of the read window (group 0: rows 0..7 two MFMAs apart, group 1: rows 4..7 every MFMA)
+#define OV_ROW(cur, nxt, s, g, GRP, EVEN)                                                                     \
+  do {                                                                                                        \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                           \
+      OV_MFMA(acc[g][j], wf[cur][j], af[cur][g]);                                                             \
+      if ((GRP) == 0) { if (((j) & 1) == 0) OV_RSLOT(nxt, (g) * 2 + ((j) >> 1)); }                            \
+      else { if ((g) >= 4) OV_RSLOT(nxt, ((g) - 4) * 4 + (j)); }                                              \
+      if (DBG < 8 && (EVEN) && (j) == 1 && ((GRP) == 0 || (g) < 4)) {                                         \
+        if ((GRP) == 0) piece((s) + 4 + ((g) & 1), (g) >> 1, ((g) & 1) ? kill2_ : kill_);                     \
+        else { piece((s) + 4, g, kill_); }                                                                    \
+      }                                                                                                       \
+      if (DBG < 8 && (EVEN) && (j) == 3 && (GRP) == 1 && (g) < 4) piece((s) + 5, g, kill2_);                  \
+    }                                                                                                         \
+  } while (0)
+#define OV_ITER(cur, nxt, s, GRP, EVEN)                                                                       \
+  do {                                                                                                        \
+    const unsigned nb_ = (unsigned)((((s) + 1) % NST) * STG);                                                 \
+    const unsigned ra_ = nb_ + (unsigned)a_off, rw_ = nb_ + (unsigned)w_off;                                  \
+    const unsigned kill_ = ((s) + 4 < ns && DBG != 10) ? 0u : 0x80000000u, kill2_ = ((s) + 5 < ns && DBG != 10) ? 0u : 0x80000000u; \
+    if ((GRP) == 0) {                                                                                         \
+      if (DBG < 8) OV_VMCNT(8);                         /* all but the newest pair of stages (4 pieces each) */ \
+      A3V_BARRIER();                                                                                          \
+      _Pragma("unroll") for (int g = 0; g < 8; ++g) OV_ROW(cur, nxt, s, g, GRP, EVEN);                        \
+    } else {                                                                                                  \
+      _Pragma("unroll") for (int g = 0; g < 4; ++g) OV_ROW(cur, nxt, s, g, GRP, EVEN);                        \
+      if (DBG < 8) { if (EVEN) OV_VMCNT(16); else OV_VMCNT(8); }   /* EVEN: this iteration's pair is already out */ \
+      A3V_BARRIER();                                                                                          \
+      _Pragma("unroll") for (int g = 4; g < 8; ++g) OV_ROW(cur, nxt, s, g, GRP, EVEN);                        \
+    }                                                                                                         \
+    A3V_WAIT_LGKM0();                                                                                         \
+  } while (0)
+#define OV_KLOOP(GRP)                                                                                         \
+  for (int s = 0; s < ns; s += 2) {                     /* (the last sub-stage reads one stage past the end: in-ring, never used) */ \
+    OV_ITER(0, 1, s, GRP, true);                                                                              \
+    OV_ITER(1, 0, s + 1, GRP, false);                                                                         \
+  }
+
+  for (int vb = blockIdx.x;;) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{};
+    A3V_WAIT_VM0();
+    A3V_BARRIER();
+#pragma unroll
+    for (int g = 0; g < 8; ++g) OV_READ(af[0][g], (unsigned)a_off, g * 1024);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) OV_READ(wf[0][g], (unsigned)w_off, g * 1024);
+    A3V_WAIT_LGKM0();
+    if (wr == 0) { OV_KLOOP(0) }
+    else { OV_KLOOP(1) }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");    // the last MFMAs retire before the epilogue's v_accvgpr_read (no interlock)
+    A3V_BARRIER();                                       // the last reads of the ring are done: the next tile may land
+    const int nb = vb + (int)gridDim.x;
+    if (nb < ntiles) {
+      tile_of(nb, sm0, sn0);
+      prologue();
+    }
+    {
+      int lane_e = lane;
+      asm volatile("" : "+v"(lane_e));
+      char* const patch = lds + 4 * STG + wave * 4096;   // slot 4: the prologue fills slots 0..3
+      gemm_epilogue<8, 4, false, SET>(acc, p, m0 + wr * 128, n0 + wc * 64, lane_e, patch);
+    }
+    if (nb >= ntiles) break;
+    vb = nb; m0 = sm0; n0 = sn0;
+  }
+#undef OV_KLOOP
+#undef OV_ITER
+#undef OV_ROW
+#undef OV_RSLOT
+#undef OV_MFMA
+#undef OV_READ
+#undef OV_VMCNT
+}
+
+// ------------------------------------------------------------------------------------
 // fp8 (OCP e4m3fn) form of the 256x256 ping-pong kernel: A [M][K] and W [N][K] are fp8 bytes, one k-tile is 128 elements =
 // the same 128-byte LDS rows, DMA pieces and swizzle as the bf16 kernel's 64-element tile, and the two 16-byte fragment reads
 // of a lane (16-B chunks g and 4 + g of its row) feed ONE v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales) instead of
@@ -2755,6 +2920,13 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
           else if (w4_env() == 8) hipLaunchKernelGGL((gemm_nt_bf16_w4_kernel<8>), g, dim3(256), 0, st, q);
           else if (w4_env() == 9) hipLaunchKernelGGL((gemm_nt_bf16_w4_kernel<9>), g, dim3(256), 0, st, q);
           else if (w4_env() == 10) hipLaunchKernelGGL((gemm_nt_bf16_w4_kernel<10>), g, dim3(256), 0, st, q);   // every k-loop piece out of bounds
+          else if (w4_env() == 20) hipLaunchKernelGGL((gemm_nt_bf16_ov_kernel<0>), g, b, 0, st, q);            // overlapped 8-wave form
+          else if (w4_env() == 28) hipLaunchKernelGGL((gemm_nt_bf16_ov_kernel<8>), g, b, 0, st, q);
+          else if (w4_env() == 29) hipLaunchKernelGGL((gemm_nt_bf16_ov_kernel<9>), g, b, 0, st, q);
+          else if (w4_env() == 30) hipLaunchKernelGGL((gemm_nt_bf16_ov_kernel<10>), g, b, 0, st, q);
+          else if (w4_env() == 31) hipLaunchKernelGGL((gemm_nt_bf16_ov_kernel<11>), g, b, 0, st, q);
+          else if (w4_env() == 32) hipLaunchKernelGGL((gemm_nt_bf16_ov_kernel<12>), g, b, 0, st, q);
+          else if (w4_env() == 33) hipLaunchKernelGGL((gemm_nt_bf16_ov_kernel<13>), g, b, 0, st, q);
           else hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0>), g, b, 0, st, q);
           break;
         case 11: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0, false>), g, b, 0, st, q); break;   // ring, direct (unstaged) epilogue stores

@@ -765,7 +765,7 @@ def test_gemm_ring_ragged_rows_over_several_tiles_per_block():
 
 
 def test_gemm_one_wave_per_simd_kernel_equals_ring_kernel():
-    """The opt-in 4-wave (one wave per SIMD, 128 x 128 per wave, 5 x 32-KiB sub-stage ring) form of the NT kernel
+    """(Also the overlapped 8-wave form, A3V_GEMM_W4=20.)  The opt-in 4-wave (one wave per SIMD, 128 x 128 per wave, 5 x 32-KiB sub-stage ring) form of the NT kernel
     (A3V_GEMM_W4=1; DESIGN.md section 4: measured, slower than the ring kernel, kept for the record) accumulates in the same
     order through the same epilogues: bit-equal results on interior + ragged tiles, several tiles per block and the fp32 /
     residual / SwiGLU output kinds."""
@@ -786,13 +786,13 @@ def test_gemm_one_wave_per_simd_kernel_equals_ring_kernel():
             return ops.gemm_nt(a, w, o, epilogue=lib.EPI_TILE_256PP | (ops.EPI_OUT_F32 if kind == "out_f32" else 0))
         for kind in ["plain", "res_f32", "out_f32"] + (["swiglu"] if N % 32 == 0 else []):
             outs = []
-            for flag in ("0", "1"):
+            for flag in ("0", "1", "20"):                                # ring, one wave per SIMD, overlapped 8-wave form
                 os.environ["A3V_GEMM_W4"] = flag
                 try:
                     outs.append(run(kind).clone())
                 finally:
                     os.environ["A3V_GEMM_W4"] = "0"
-            assert torch.equal(outs[0], outs[1]), (M, N, K, kind)
+            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (M, N, K, kind)
         os.environ["A3V_GEMM_W4"] = "1"
         try:
             o = run("plain")
