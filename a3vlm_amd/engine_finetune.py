@@ -74,7 +74,7 @@ def train_one_epoch(model, data_loader, optimizer, epoch: int, start_iter: int, 
         if sumsq is None:
             sumsq = engine._grad_square_sums = GradSquareSums(engine, reducer)
     overlap = takes_scale and engine is not None and getattr(optimizer, "engine", None) is engine \
-        and os.environ.get("A3V_ADAMW_OVERLAP", "1") != "0"
+        and os.environ.get("A3V_ADAMW_OVERLAP", "0") == "1"
     for step, batch in enumerate(data_loader, start=start_iter):
         examples, labels, imgs, depth = _unpack(batch)
         if trim is not None and not examples.is_cuda:
@@ -114,7 +114,8 @@ def train_one_epoch(model, data_loader, optimizer, epoch: int, start_iter: int, 
                 bad |= ~torch.isfinite(torch.as_tensor(stats["grad_norm"]).to(dev))
             if takes_scale:
                 one = coef if coef is not None else torch.ones((), dtype=torch.float32, device=dev)
-                # overlap: the update of layer i+1.. runs on the optimizer's stream under the next forward's layers ..i (optim.py)
+                # overlap (A3V_ADAMW_OVERLAP=1, off by default): the update of layer i+1.. runs on the optimizer's stream under the
+                # next forward's layers ..i (optim.py)
                 optimizer.step(grad_scale=torch.where(bad, -one.new_ones(()), one).reshape(1), overlap=overlap)
             else:
                 stop_if_bad(step)                  # a stock optimizer cannot skip on a device flag: pay the host read

@@ -287,8 +287,10 @@ def time_gemm_shapes(args, B, T, W, dev, train=True):
 def _train_step_fn(eng, opt, red, params, tokens, labels, image):
     from a3vlm_amd.dp import clip_grad_norm, GradSquareSums
     sq = GradSquareSums(eng, red) if os.environ.get("A3V_CLIP_SUMSQ", "1") != "0" else None   # =0: one norm pass after the backward (A/B)
-    # the update runs on the optimizer's stream under the next step's forward, bucket by bucket (optim.py); =0: in line (A/B)
-    overlap = os.environ.get("A3V_ADAMW_OVERLAP", "1") != "0"
+    # =1: the update runs on the optimizer's stream under the next step's forward, bucket by bucket (optim.py).  Off by default:
+    # +2 ms at best (the GEMMs leave it no registers to co-reside with), and -40 ms when the runtime maps the two streams onto one
+    # hardware queue (seen when another engine's optimizer stream existed earlier in the process)
+    overlap = os.environ.get("A3V_ADAMW_OVERLAP", "0") == "1"
 
     def one():
         loss = eng.forward_loss(tokens, labels, image)
