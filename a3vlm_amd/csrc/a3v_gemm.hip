@@ -60,6 +60,7 @@ struct GemmArgs {
   RopeKvArgs rk;     // GEMM_EPI_ROPEKV only
   const float* sa;   // GEMM_EPI_SCALE: per-row dequantisation scales of A [M] and W [N]
   const float* sw;
+  unsigned* xsync;   // ring kernel, A3V_GEMM_LOCKSTEP=1: eight zeroed counters; the blocks of an XCD start each tile round together
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
@@ -1299,6 +1300,19 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) acc[i][j] = acc_t{};
+    if (p.xsync && gridDim.y == 1 && tid == 0) {
+      // the XCD's blocks (blockIdx & 7) start their n-th tile together: tiles that share operand panels then stream them through
+      // the XCD's L2 in step instead of drifting apart over the rounds.  Bounded spin: a block that cannot see its peers goes on alone.
+      const int x = blockIdx.x & 7, G = (int)gridDim.x, nbx = (G - x + 7) >> 3;
+      unsigned target = 0;
+      for (int r = 0; r <= tile_no; ++r) {
+        const int rem = ntiles - G * r - x;
+        target += (unsigned)min(max((rem + 7) >> 3, 0), nbx);
+      }
+      __hip_atomic_fetch_add(p.xsync + x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int it = 0; it < 400 && __hip_atomic_load(p.xsync + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; ++it)
+        __builtin_amdgcn_s_sleep(4);
+    }
     A3V_WAIT_VM0();
     A3V_BARRIER();
     int wcur = 0;                                        // W ring slot of K-tile t
@@ -2835,6 +2849,16 @@ static bool pp_ring() {       // the 160-KiB ring form of the ping-pong kernel (
   return !(e && e[0] == '0');
 }
 
+static unsigned* xsync_buffer(hipStream_t st) {   // A3V_GEMM_LOCKSTEP=1: eight counters, zeroed on the launch stream before every launch
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("A3V_GEMM_LOCKSTEP"); on = (e && e[0] == '1') ? 1 : 0; }
+  if (!on) return nullptr;
+  static unsigned* buf = nullptr;
+  if (!buf && hipMalloc(&buf, 64) != hipSuccess) { buf = nullptr; return nullptr; }
+  if (hipMemsetAsync(buf, 0, 64, st) != hipSuccess) return nullptr;
+  return buf;
+}
+
 static int w4_env() {          // A3V_GEMM_W4=1: the one-wave-per-SIMD kernel instead of the ring (2: with cycle stamps); read per launch
   const char* e = getenv("A3V_GEMM_W4");
   return e ? atoi(e) : 0;
@@ -2909,6 +2933,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
       int dbg = q.dbg;
       if (dbg == 0 && pp_ring()) dbg = 5;
       { const char* e = getenv("A3V_GEMM_SKEW"); q.skew = e ? atoi(e) : 0; }
+      q.xsync = (dbg == 5 && g.y == 1) ? xsync_buffer(st) : nullptr;
       switch (dbg) {
         case 0: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<0, 0>), g, b, 0, st, q); break;
         case 5:
