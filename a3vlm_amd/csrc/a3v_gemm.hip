@@ -60,6 +60,7 @@ struct GemmArgs {
   RopeKvArgs rk;     // GEMM_EPI_ROPEKV only
   const float* sa;   // GEMM_EPI_SCALE: per-row dequantisation scales of A [M] and W [N]
   const float* sw;
+  int xmap;          // ring kernel: 1 = every round of gridDim.x tiles is cut into eight runs, one per XCD (see tile_of)
   unsigned* xsync;   // ring kernel, A3V_GEMM_LOCKSTEP=1: eight zeroed counters; the blocks of an XCD start each tile round together
 };
 
@@ -1178,8 +1179,18 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
 
   const int ntiles = p.tiles_m * p.tiles_n;
   auto tile_of = [&](int vb, int& tm0, int& tn0) {
-    const int xcd = vb & 7, q = ntiles >> 3, r = ntiles & 7;
-    const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
+    int bid;
+    const int G = (int)gridDim.x, full = ntiles / G, rnd = vb / G;
+    if (p.xmap && rnd < full) {
+      // round-major: the eight XCDs work on the SAME run of G consecutive tiles (8 tile rows x G/8 columns), XCD x on columns
+      // [x G/64, (x+1) G/64) of it -- the A panels of the row group are shared by all XCDs through the Infinity Cache instead of
+      // every XCD streaming its own eight panels from HBM
+      bid = rnd * G + (vb & 7) * (G >> 3) + ((vb - rnd * G) >> 3);
+    } else {
+      const int base = p.xmap ? full * G : 0, R = ntiles - base, v = vb - base;
+      const int xcd = v & 7, q = R >> 3, r = R & 7;
+      bid = base + (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
+    }
     const int per_group = GROUP_M * p.tiles_n;
     const int group = bid / per_group;
     const int first_m = group * GROUP_M;
@@ -1933,9 +1944,14 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_pp_kernel(GemmArgs p) {
 
   const int nwg = gridDim.x;
   int bid = blockIdx.x;
-  {
-    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  if (p.xmap && bid < (nwg & ~255)) {
+    // blocks are dispatched in index order, 256 (one per CU) at a time: within each such round XCD x takes the x-th run of 32
+    // consecutive tiles, so all eight XCDs share the round's row-group panels through the Infinity Cache (see the ring kernel)
+    bid = (bid & ~255) + (bid & 7) * 32 + ((bid & 255) >> 3);
+  } else {
+    const int base = p.xmap ? (nwg & ~255) : 0, R = nwg - base, v = bid - base;
+    const int xcd = v & 7, q = R >> 3, r = R & 7;
+    bid = base + (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
   }
   const int per_group = GROUP_M * p.tiles_n;
   const int group = bid / per_group;
@@ -2878,6 +2894,7 @@ template <bool A_ROWS>
 static void launch_tn(dim3 grid, hipStream_t st, const GemmArgs& q0) {
   GemmArgs q = q0;
   q.slow_epi = slow_epi_env(); q.nt_store = nt_store_env();
+  { const char* e = getenv("A3V_GEMM_XMAP_TN"); q.xmap = (e && e[0] == '0') ? 0 : 1; }   // =0: one contiguous run of tiles per XCD (A/B)
   hipLaunchKernelGGL(gemm_tn_bf16_pp_kernel<A_ROWS>, grid, dim3(512), 0, st, q);
 }
 
@@ -2934,6 +2951,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
       if (dbg == 0 && pp_ring()) dbg = 5;
       { const char* e = getenv("A3V_GEMM_SKEW"); q.skew = e ? atoi(e) : 0; }
       q.xsync = (dbg == 5 && g.y == 1) ? xsync_buffer(st) : nullptr;
+      { const char* e = getenv("A3V_GEMM_XMAP"); q.xmap = (!(e && e[0] == '0') && (g.x & 63) == 0) ? 1 : 0; }   // =0: one contiguous run of tiles per XCD (A/B)
       switch (dbg) {
         case 0: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<0, 0>), g, b, 0, st, q); break;
         case 5:
