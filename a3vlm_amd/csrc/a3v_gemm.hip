@@ -1197,7 +1197,10 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
     const int gsz = min(p.tiles_m - first_m, GROUP_M);
     const int in_g = bid - group * per_group;
     tm0 = (first_m + in_g % gsz) * TBM;
-    tn0 = (in_g / gsz) * TBN;
+    const int tn = in_g / gsz;
+    // xmap & 2: odd row groups walk the columns backwards, so a new group starts on the W panels the last one ended on (still in the
+    // Infinity Cache) instead of on the ones evicted longest ago
+    tn0 = (((p.xmap & 2) && (group & 1)) ? p.tiles_n - 1 - tn : tn) * TBN;
   };
   int m0, n0, sm0, sn0;     // tile being computed / tile being staged
   tile_of(blockIdx.x, m0, n0);
@@ -1959,7 +1962,7 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_pp_kernel(GemmArgs p) {
   const int gsz = min(p.tiles_m - first_m, GROUP_M);
   const int in_g = bid - group * per_group;
   const int tm = first_m + in_g % gsz;
-  const int tn = in_g / gsz;
+  const int tn = ((p.xmap & 2) && (group & 1)) ? p.tiles_n - 1 - in_g / gsz : in_g / gsz;   // serpentine over the row groups (see the ring kernel)
   const int m0 = tm * TBM, n0 = tn * TBN;
 
   f32x4 acc[TM][TN];
@@ -2894,7 +2897,7 @@ template <bool A_ROWS>
 static void launch_tn(dim3 grid, hipStream_t st, const GemmArgs& q0) {
   GemmArgs q = q0;
   q.slow_epi = slow_epi_env(); q.nt_store = nt_store_env();
-  { const char* e = getenv("A3V_GEMM_XMAP_TN"); q.xmap = (e && e[0] == '0') ? 0 : 1; }   // =0: one contiguous run of tiles per XCD (A/B)
+  { const char* e = getenv("A3V_GEMM_XMAP_TN"); q.xmap = e ? atoi(e) : 1; }   // =0: one contiguous run of tiles per XCD (A/B); 3: + serpentine
   hipLaunchKernelGGL(gemm_tn_bf16_pp_kernel<A_ROWS>, grid, dim3(512), 0, st, q);
 }
 
@@ -2951,7 +2954,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
       if (dbg == 0 && pp_ring()) dbg = 5;
       { const char* e = getenv("A3V_GEMM_SKEW"); q.skew = e ? atoi(e) : 0; }
       q.xsync = (dbg == 5 && g.y == 1) ? xsync_buffer(st) : nullptr;
-      { const char* e = getenv("A3V_GEMM_XMAP"); q.xmap = (!(e && e[0] == '0') && (g.x & 63) == 0) ? 1 : 0; }   // =0: one contiguous run of tiles per XCD (A/B)
+      { const char* e = getenv("A3V_GEMM_XMAP"); q.xmap = (g.x & 63) ? 0 : e ? atoi(e) : 1; }   // =0: one contiguous run of tiles per XCD (A/B)
       switch (dbg) {
         case 0: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<0, 0>), g, b, 0, st, q); break;
         case 5:
