@@ -1181,6 +1181,14 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
   auto tile_of = [&](int vb, int& tm0, int& tn0) {
     int bid;
     const int G = (int)gridDim.x, full = ntiles / G, rnd = vb / G;
+    if (p.xmap & 4) {
+      // super-tile walk (host sets it when G == 256 and both tile counts are multiples of 16): a round is ONE 16 x 16 block of tiles
+      // (32 operand panels from HBM instead of the 40 of an 8 x 32 strip), XCD x takes its 8 x 4 sub-block (still 12 panels per L2)
+      const int x = vb & 7, i = (vb & 255) >> 3, nsc = p.tiles_n >> 4;
+      tm0 = ((rnd / nsc) * 16 + (x >> 2) * 8 + (i & 7)) * TBM;
+      tn0 = ((rnd % nsc) * 16 + (x & 3) * 4 + (i >> 3)) * TBN;
+      return;
+    }
     if (p.xmap && rnd < full) {
       // round-major: the eight XCDs work on the SAME run of G consecutive tiles (8 tile rows x G/8 columns), XCD x on columns
       // [x G/64, (x+1) G/64) of it -- the A panels of the row group are shared by all XCDs through the Infinity Cache instead of
@@ -1961,8 +1969,13 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_pp_kernel(GemmArgs p) {
   const int first_m = group * GROUP_M;
   const int gsz = min(p.tiles_m - first_m, GROUP_M);
   const int in_g = bid - group * per_group;
-  const int tm = first_m + in_g % gsz;
-  const int tn = ((p.xmap & 2) && (group & 1)) ? p.tiles_n - 1 - in_g / gsz : in_g / gsz;   // serpentine over the row groups (see the ring kernel)
+  int tm = first_m + in_g % gsz;
+  int tn = ((p.xmap & 2) && (group & 1)) ? p.tiles_n - 1 - in_g / gsz : in_g / gsz;   // serpentine over the row groups (see the ring kernel)
+  if (p.xmap & 4) {                          // super-tile walk (see the ring kernel): 256 consecutive blocks = one 16 x 16 block of tiles
+    const int b = blockIdx.x, rnd = b >> 8, x = b & 7, i = (b & 255) >> 3, nsc = p.tiles_n >> 4;
+    tm = (rnd / nsc) * 16 + (x >> 2) * 8 + (i & 7);
+    tn = (rnd % nsc) * 16 + (x & 3) * 4 + (i >> 3);
+  }
   const int m0 = tm * TBM, n0 = tn * TBN;
 
   f32x4 acc[TM][TN];
@@ -2897,7 +2910,8 @@ template <bool A_ROWS>
 static void launch_tn(dim3 grid, hipStream_t st, const GemmArgs& q0) {
   GemmArgs q = q0;
   q.slow_epi = slow_epi_env(); q.nt_store = nt_store_env();
-  { const char* e = getenv("A3V_GEMM_XMAP_TN"); q.xmap = e ? atoi(e) : 1; }   // =0: one contiguous run of tiles per XCD (A/B); 3: + serpentine
+  { const char* e = getenv("A3V_GEMM_XMAP_TN"); q.xmap = e ? atoi(e) : 1; }   // =0: one contiguous run of tiles per XCD (A/B); 1: round-major; +2: serpentine; +4: 16 x 16 super-tiles where they fit
+  if (!((q.xmap & 4) && (q.tiles_m & 15) == 0 && (q.tiles_n & 15) == 0)) q.xmap &= ~4;
   hipLaunchKernelGGL(gemm_tn_bf16_pp_kernel<A_ROWS>, grid, dim3(512), 0, st, q);
 }
 
@@ -2954,7 +2968,8 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
       if (dbg == 0 && pp_ring()) dbg = 5;
       { const char* e = getenv("A3V_GEMM_SKEW"); q.skew = e ? atoi(e) : 0; }
       q.xsync = (dbg == 5 && g.y == 1) ? xsync_buffer(st) : nullptr;
-      { const char* e = getenv("A3V_GEMM_XMAP"); q.xmap = (g.x & 63) ? 0 : e ? atoi(e) : 1; }   // =0: one contiguous run of tiles per XCD (A/B)
+      { const char* e = getenv("A3V_GEMM_XMAP"); q.xmap = (g.x & 63) ? 0 : e ? atoi(e) : 1;
+        if (!((q.xmap & 4) && g.x == 256 && (q.tiles_m & 15) == 0 && (q.tiles_n & 15) == 0)) q.xmap &= ~4; }   // =0: one contiguous run of tiles per XCD (A/B)
       switch (dbg) {
         case 0: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<0, 0>), g, b, 0, st, q); break;
         case 5:
