@@ -63,3 +63,70 @@ def test_bucket_path_on_the_device(rccl_single_rank, wire):
         ref = torch.linalg.vector_norm(eng.flat_grads().double()).float()
         assert torch.allclose(norm, ref, rtol=1e-5), (float(norm), float(ref))
         assert torch.allclose(coef, torch.clamp(8.0 / (ref + 1e-6), max=1.0), rtol=1e-5)
+
+
+# ------------------------------------------------------------------ two ranks == one rank with the double batch (real engine)
+_EQ = dict(dim=128, n_layers=2, n_heads=4, n_kv_heads=4, vocab_size=256, multiple_of=64, max_seq_len=256)
+
+
+def _eq_model(dev):
+    from a3vlm_amd.model.LLM import llama_ens5 as plugin
+    from a3vlm_amd.util import promote_trainable_params_to_fp32
+    from oracle import ref_cpu
+    m = plugin.Transformer(plugin.ModelArgs(**_EQ), with_visual=False)
+    m.load_state_dict(ref_cpu.make_decoder_weights(ref_cpu.OracleArgs(**_EQ), seed=11, std=0.05))
+    m.to(torch.float32).to(dev)
+    promote_trainable_params_to_fp32(m)
+    return m
+
+
+def _eq_data():
+    g = torch.Generator().manual_seed(77)
+    ex = torch.randint(3, 256, (2, 4, 40), generator=g)      # [micro-step][sample of the global batch][token]; every label valid
+    ex[:, :, 0] = 1
+    return ex
+
+
+def _eq_worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from a3vlm_amd.train import TrainEngine
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        eng = TrainEngine(_eq_model(dev), torch.float32)
+        red = GradReducer(eng, dist, reduce_dtype=None)
+        ex = _eq_data()
+        for micro in range(2):                                 # accum_iter = 2: the first micro-step is a no_sync step
+            red.enabled = micro == 1
+            mine = ex[micro, rank::world].to(dev)              # the sampler's strided shard of the global batch
+            eng.forward_loss(mine, mine, None)
+            eng.backward(0.5)
+        red.finish()
+        torch.cuda.synchronize()
+        torch.save(eng.flat_grads().cpu(), os.path.join(outdir, f"grads{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_equal_one_rank_with_the_double_batch(tmp_path):
+    """The DP step on the real engine: two ranks (both on cuda:0, gloo), accum_iter 2, per-layer buckets all-reduced on the side
+    stream during the boundary micro-step's backward -- the averaged gradients equal those of ONE rank that sees both ranks'
+    samples in each micro-step (equal token counts per sample, fp32 kernels: the only difference is the summation order)."""
+    import torch.multiprocessing as mp
+    from a3vlm_amd.train import TrainEngine
+    world, port = 2, 29900 + os.getpid() % 90
+    mp.get_context("spawn")
+    mp.spawn(_eq_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    g0, g1 = (torch.load(os.path.join(str(tmp_path), f"grads{r}.pt")) for r in range(world))
+    assert torch.equal(g0, g1), "replicas must hold identical gradients after the all-reduce"
+    dev = torch.device("cuda", 0)
+    eng = TrainEngine(_eq_model(dev), torch.float32)
+    ex = _eq_data()
+    for micro in range(2):
+        both = ex[micro].to(dev)
+        eng.forward_loss(both, both, None)
+        eng.backward(0.5)
+    want = eng.flat_grads().cpu()
+    assert float(want.abs().max()) > 1e-4
+    assert torch.allclose(g0, want, rtol=2e-4, atol=2e-6 * float(want.abs().max()) + 1e-7), float((g0 - want).abs().max())
