@@ -630,6 +630,11 @@ __global__ __launch_bounds__(256) void sumsq_partials_kernel(const float* __rest
   const int64_t n4 = n / 4, stride = (int64_t)A3V_SUMSQ_SLOTS * 256;
   int par = 0;
   for (int vb = blockIdx.x; vb < A3V_SUMSQ_SLOTS; vb += gridDim.x, par ^= 1) {
+    if (vb != 0 && (int64_t)vb * 256 >= n4) {             // a slot with no vector of this (short) range: block-uniform, no barrier
+      if (threadIdx.x == 0) out[vb] = 0.f;
+      par ^= 1;
+      continue;
+    }
     float a = 0.f;
     for (int64_t i = (int64_t)vb * 256 + threadIdx.x; i < n4; i += stride) {
       const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(x) + i);
@@ -651,6 +656,10 @@ extern "C" int a3v_sumsq_partials(const float* x, int64_t n, float* out, void* s
   const char* e = getenv("A3V_SUMSQ_BLOCKS");                 // launch width (read per launch): default 1024 = one block per slot
   int nb = e ? atoi(e) : A3V_SUMSQ_SLOTS;
   if (nb < 1 || nb > A3V_SUMSQ_SLOTS) nb = A3V_SUMSQ_SLOTS;
+  // short ranges (the norm weights left over next to the GEMM-summed matrices): one block per slot that has data -- 1024 blocks for
+  // 8 K floats only queue behind the GEMM the call runs beside (same sums: slot s always adds the same vectors)
+  const int64_t useful = (n / 4 + 255) / 256;
+  if (useful < nb) nb = useful < 1 ? 1 : (int)useful;
   hipLaunchKernelGGL(sumsq_partials_kernel, dim3(nb), dim3(256), 0, ST, x, n, out);
   A3V_LAUNCH_CHECK();
   return A3V_OK;
