@@ -32,6 +32,7 @@ struct AttnArgs {
   float* lse;                   // optional [B,H,Sq] log-sum-exp of the scaled scores (training backward)
   int head_group;               // causal prefill: heads per tile-rank-major group of the block order (1 = head-major)
   int staged_o;                 // prefill: O leaves through an LDS patch as whole rows (A3V_ATTN_STAGED_O=0: per-lane row stores)
+  int lazy_rescale;             // prefill: the softmax reference only moves when a row's exponent would exceed 2^8 (A3V_ATTN_LAZY=0: every tile)
 };
 
 // one 16-B-per-lane LDS-DMA through a buffer descriptor: per-lane byte offset + wave-uniform byte offset (an SGPR)
@@ -254,12 +255,20 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_bf16_kernel(AttnArgs p) {
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[tb][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
+    // Lazy rescale: m_run is the REFERENCE the exponentials are taken against, not necessarily the running maximum.  It only moves
+    // when some row of the wave would otherwise see exp2 arguments above +LAZY (2^8: P <= 256 in bf16, the sums in fp32) -- after the
+    // first tiles of a row that is rare, and the 64 multiplies of the O rescale + the l update (a quarter of the tile's VALU work,
+    // which is what bounds this kernel) are skipped by a wave-uniform branch.  O / l and the LSE are unchanged in exact arithmetic.
+    const bool grow = p.lazy_rescale ? ((m_new - m_run) * p.scale_log2 > 8.f || m_run == -INFINITY) : true;
+    const bool resc = __builtin_amdgcn_ballot_w64(grow && m_new != m_run) != 0;
     // rows past Sq (clamped duplicates) and fully-masked tiles keep m finite once any tile was seen
-    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-    // raw v_exp_f32 (the arguments are <= 0 and results below the denormal range flush to 0, which is what a probability
+    const float m_tgt = resc ? m_new : m_run;
+    const float m_use = (m_tgt == -INFINITY) ? 0.f : m_tgt;
+    // raw v_exp_f32 (the arguments are <= 0 [<= LAZY] and results below the denormal range flush to 0, which is what a probability
     // that small should do; exp2f() wraps every call in a range fix-up: +4 VALU per element)
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * p.scale_log2);
-    m_run = m_new;
+    float alpha = 1.f;
+    if (resc) alpha = __builtin_amdgcn_exp2f((m_run - m_use) * p.scale_log2);
+    m_run = m_tgt;
     float lsum = 0.f;
     const float mb = m_use * p.scale_log2;
     bf16x8 pf[2][2];
@@ -275,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_bf16_kernel(AttnArgs p) {
         lsum += pv;
         pf[tb][r >> 3][r & 7] = f2bf(pv);
       }
-    l_run = l_run * alpha + lsum;
+    l_run = resc ? l_run * alpha + lsum : l_run + lsum;
     if constexpr (PSWAP) {
 #pragma unroll
       for (int tb = 0; tb < 2; ++tb)
@@ -292,10 +301,12 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_bf16_kernel(AttnArgs p) {
           __builtin_memcpy(&pf[tb][c], &w, 16);           // lanes < 32: keys 16c + 0..7, lanes >= 32: keys 16c + 8..15
         }
     }
+    if (resc) {
 #pragma unroll
-    for (int d = 0; d < HD / 32; ++d)
+      for (int d = 0; d < HD / 32; ++d)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+    }
     AP_ST(t, 3);
     // ---- O^T += V^T . P^T ----
 #pragma unroll
@@ -823,6 +834,7 @@ static int attention_impl(const void* q, const void* k, const void* vt, void* ou
   p.lse = lse;
   p.head_group = 1;
   { const char* e = getenv("A3V_ATTN_STAGED_O"); p.staged_o = !(e && e[0] == '0'); }
+  { const char* e = getenv("A3V_ATTN_LAZY"); p.lazy_rescale = !(e && e[0] == '0'); }
   if (lse && Sq == 1 && dtype == A3V_BF16 && (hd == 64 || hd == 128)) return A3V_ERR_ARG;  // decode kernel has no LSE output
   if (dtype == A3V_F32) {
     if (hd > 256) return A3V_ERR_SHAPE;

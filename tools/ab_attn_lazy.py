@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Lazy softmax rescale of the prefill attention (default) against the rescale on every KV tile (A3V_ATTN_LAZY=0, read per
+launch): interleaved rounds; outputs compared against an fp32 reference of the same bf16 inputs (the two forms round P at
+different scales, so they are not bit-equal)."""
+import sys, os, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from a3vlm_amd import ops
+dev = "cuda"
+for (B, S, H, hd, causal, amp) in [(8, 1091, 32, 128, True, 1.0), (8, 1091, 32, 128, True, 4.0), (8, 2182, 32, 128, True, 1.0), (40, 577, 16, 64, False, 1.0)]:
+    sp = (S + 63) // 64 * 64
+    q = torch.randn(B, S, H, hd, device=dev, dtype=torch.bfloat16) * amp
+    k = torch.randn(B, H, sp, hd, device=dev, dtype=torch.bfloat16)
+    vt = torch.randn(B, H, hd, sp, device=dev, dtype=torch.bfloat16)
+    st = (S*H*hd, H*hd, hd, H*sp*hd, sp*hd, hd, H*hd*sp, hd*sp, sp, S*H*hd, H*hd, hd)
+    o = torch.empty_like(q); lse = torch.empty(B, H, S, device=dev)
+    # fp32 reference on two (batch, head) pairs
+    errs = {}
+    times = {"1": [], "0": []}
+    for r in range(5):
+        for v in ("1", "0"):
+            os.environ["A3V_ATTN_LAZY"] = v
+            f = lambda: ops.attention_lse(q, k, vt, o, lse, B, S, S, H, H, hd, st, causal)
+            o.zero_(); f()
+            if v not in errs:
+                worst, worst_l = 0.0, 0.0
+                for (b, h) in ((0, 0), (B - 1, H - 1)):
+                    qq, kk, vv = q[b, :, h].float(), k[b, h, :S].float(), vt[b, h, :, :S].float().t()
+                    sc = qq @ kk.t() / hd ** 0.5
+                    if causal:
+                        sc = sc.masked_fill(torch.ones(S, S, device=dev, dtype=torch.bool).triu(1), float("-inf"))
+                    want = torch.softmax(sc, -1) @ vv
+                    worst = max(worst, float((o[b, :, h].float() - want).abs().max() / want.abs().max()))
+                    worst_l = max(worst_l, float((lse[b, h] - torch.logsumexp(sc, -1)).abs().max()))
+                errs[v] = (round(worst, 5), round(worst_l, 5))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5): f()
+            e1.record(); torch.cuda.synchronize()
+            times[v].append(e0.elapsed_time(e1) / 5 * 1e3)
+    print(json.dumps(dict(B=B, S=S, H=H, hd=hd, q_scale=amp, lazy_us=round(sorted(times["1"])[2], 1), every_tile_us=round(sorted(times["0"])[2], 1),
+                          relerr_lse_lazy=errs["1"], relerr_lse_every=errs["0"])), flush=True)
+os.environ.pop("A3V_ATTN_LAZY", None)
