@@ -337,13 +337,29 @@ def test_attention_prefill_bf16(B, Sq, Sk, H, Hkv, hd, causal):
     assert torch.isfinite(out.float()).all()
 
 
-def test_attention_prefill_bf16_spike_rescale():
-    """Forces the online-softmax rescale: one key row dominates late in the sequence."""
-    B, S, H, hd = 1, 256, 1, 128
+@pytest.mark.parametrize("lazy", ["1", "0"])
+@pytest.mark.parametrize("shape", ["spike", "ramp"])
+def test_attention_prefill_bf16_spike_rescale(shape, lazy):
+    """Forces the online-softmax rescale, with the lazy reference (moves only when an exponent would pass 2^8) and with the rescale
+    on every tile (A3V_ATTN_LAZY=0).  spike: one key row dominates late in the sequence (one big jump).  ramp: the scores grow a
+    little with every KV tile, so the lazy form keeps a stale reference for a few tiles (P up to 2^8) and then moves it."""
+    import os
+    B, S, H, hd = 1, 512, 1, 128
     q, k, v = rt(gen(B, S, H, hd, seed=36)), rt(gen(B, S, H, hd, seed=37)), rt(gen(B, S, H, hd, seed=38))
-    k[0, 200, 0] = q[0, 220, 0] * 4.0     # query 220+ see a huge score at key 200 (tile 3)
-    out = run_attn(q, k, v, True, BF)
-    assert_close(out, oracle_attn(q, k, v, True), rtol=2 ** -6, atol=1.5e-2, what="attn spike")
+    if shape == "spike":
+        k[0, 200, 0] = q[0, 220, 0] * 4.0     # query 220+ see a huge score at key 200 (tile 3)
+    else:
+        u = torch.nn.functional.normalize(gen(hd, seed=39), dim=0)
+        q[0, :, 0] += 6.0 * u                 # every query has a component along u ...
+        k[0, :, 0] += rt(torch.arange(S)[:, None] / 64.0 * 0.8 * u[None, :])      # ... and the keys' grows by 0.8 per tile: +~3 in log2 per tile
+        q, k = rt(q), rt(k)
+    os.environ["A3V_ATTN_LAZY"] = lazy
+    try:
+        out = run_attn(q, k, v, True, BF)
+    finally:
+        os.environ.pop("A3V_ATTN_LAZY", None)
+    assert torch.isfinite(out.float()).all()
+    assert_close(out, oracle_attn(q, k, v, True), rtol=2 ** -6, atol=1.5e-2, what=f"attn {shape} lazy={lazy}")
 
 
 @pytest.mark.parametrize("form", ["two_phase", "wave"])
