@@ -1240,11 +1240,11 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
   }
   // one 1-KiB piece = 8 rows x 128 B; `row` = first row inside the A (W) tile, `par` = its chunk index & 1 (swizzle key)
   auto piece_a = [&](int row, int t, int par, char* dst) {
-    const unsigned so = (unsigned)(((int64_t)(sm0 + row) * p.lda + t * BK) * 2);
+    const unsigned so = (unsigned)(((int64_t)(sm0 + row) * p.lda + (DBG == 7 ? (t & 3) : t) * BK) * 2);   // DBG 7 (timing experiment): the same four K-tiles over and over = cache-resident operands
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)dst, 16, voA[par] + so, 0, 0, 0);
   };
   auto piece_w = [&](int row, int t, int par, char* dst) {
-    const unsigned so = (unsigned)(((int64_t)(sn0 + row) * p.ldw + t * BK) * 2);
+    const unsigned so = (unsigned)(((int64_t)(sn0 + row) * p.ldw + (DBG == 7 ? (t & 3) : t) * BK) * 2);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)dst, 16, voW[par] + so, 0, 0, 0);
   };
   // tile prologue (all 8 waves, 14 pieces each): K-tile 0 whole, A_top and W of K-tile 1
@@ -2981,6 +2981,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
           else if (w4_env() == 8) hipLaunchKernelGGL((gemm_nt_bf16_w4_kernel<8>), g, dim3(256), 0, st, q);
           else if (w4_env() == 9) hipLaunchKernelGGL((gemm_nt_bf16_w4_kernel<9>), g, dim3(256), 0, st, q);
           else if (w4_env() == 10) hipLaunchKernelGGL((gemm_nt_bf16_w4_kernel<10>), g, dim3(256), 0, st, q);   // every k-loop piece out of bounds
+          else if (w4_env() == 7) hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<7, false, 0>), g, b, 0, st, q);   // ring kernel, cache-resident operands (timing experiment, wrong results)
           else if (w4_env() == 20) hipLaunchKernelGGL((gemm_nt_bf16_ov_kernel<0>), g, b, 0, st, q);            // overlapped 8-wave form
           else if (w4_env() == 28) hipLaunchKernelGGL((gemm_nt_bf16_ov_kernel<8>), g, b, 0, st, q);
           else if (w4_env() == 29) hipLaunchKernelGGL((gemm_nt_bf16_ov_kernel<9>), g, b, 0, st, q);
