@@ -34,6 +34,22 @@ def _scale_cast(src: torch.Tensor, dst: torch.Tensor, scale: float) -> None:
         torch.mul(src, scale, out=dst) if dst.dtype == src.dtype else dst.copy_(src * scale)
 
 
+class _DoneWork:
+    def wait(self):
+        return True
+
+
+class _NoCollective:
+    """``GradReducer.stub_collective``: the process group's interface with ``all_reduce`` doing nothing (bench.py's
+    exposed-all-reduce measurement; never used by the trainer)."""
+
+    def __init__(self, dist):
+        self.ReduceOp = dist.ReduceOp
+
+    def all_reduce(self, *a, **k):
+        return _DoneWork()
+
+
 class GradReducer:
     def __init__(self, engine, dist, reduce_dtype: Optional[torch.dtype] = None, group=None, reduce_single_rank: bool = False):
         self.eng = engine
@@ -52,6 +68,9 @@ class GradReducer:
         except Exception:
             self._avg = False
         self.sumsq: Optional["GradSquareSums"] = None       # set by GradSquareSums(engine, reducer=self): sums over the REDUCED buckets
+        self.stub_collective = False               # bench: everything but the collective itself (exposed all-reduce time = the difference)
+        self.wire_bytes_last_step = 0              # bytes handed to the collective since the last finish()
+        self._wire_bytes = 0
         engine.on_layer_grads_ready = self._on_ready
 
     def _side_stream(self, device):
@@ -76,18 +95,23 @@ class GradReducer:
     def _launch(self, seg: torch.Tensor, key: Tuple[int, int]) -> None:
         dist = self.dist
         self._keys.append(key)
+        if self.stub_collective:
+            dist = _NoCollective(dist)
         if self.reduce_dtype is not None and self.reduce_dtype != seg.dtype:
             low = self._wire.get(key)
             if low is None or low.device != seg.device:
                 low = self._wire[key] = torch.empty(seg.numel(), dtype=self.reduce_dtype, device=seg.device)
             _scale_cast(seg, low, 1.0 if self._avg else 1.0 / self.world)
+            self._wire_bytes += low.numel() * low.element_size()
             op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
             work = dist.all_reduce(low, op=op, group=self.group, async_op=True)
         elif self._avg:
             low = None
+            self._wire_bytes += seg.numel() * seg.element_size()
             work = dist.all_reduce(seg, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
         else:
             low = None
+            self._wire_bytes += seg.numel() * seg.element_size()
             seg.mul_(1.0 / self.world)
             work = dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         if seg.is_cuda:
@@ -118,6 +142,7 @@ class GradReducer:
                 self.sumsq.add(eng_flat[key[0]:key[1]], key)
         self._pending.clear()
         self._keys.clear()
+        self.wire_bytes_last_step, self._wire_bytes = self._wire_bytes, 0
         if self._stream is not None:
             torch.cuda.current_stream().wait_stream(self._stream)
 

@@ -953,3 +953,35 @@ class _StepLoss(torch.autograd.Function):
 
 def step_loss(engine: TrainEngine, anchor: torch.Tensor, examples, labels, image=None) -> torch.Tensor:
     return _StepLoss.apply(anchor, engine, examples, labels, image)
+
+
+def hbm_budget(dim: int, n_layers: int, n_heads: int, ffn: int, vocab: int, batch: int, seq: int, text: int, n_kv_heads: Optional[int] = None,
+               vit_params: int = 304_000_000, proj_in: int = 1024, world: int = 1, wire_bytes: int = 2, recompute: bool = False) -> Dict[str, int]:
+    """Bytes of one pure-DP replica of the FULL fine-tune (every rank of a DP job holds exactly this; SURVEY 7 "13B full fine-tune
+    memory", main_finetune.py:241-276): what ``TrainEngine`` + ``FusedAdamW`` + ``dp.GradReducer`` allocate, from their own layouts.
+    fp32 masters / flat gradient buffer / two AdamW moments of every trainable parameter, the bf16 GEMM images of the decoder and
+    head matrices, the frozen bf16 ViT, the reducer's persistent wire buckets (``wire_bytes`` per gradient element when world > 1
+    and the wire dtype is not fp32), the fp32 residual-stream checkpoints [L+1, rows, dim], the block intermediates (per layer when
+    activations are stored, once when blocks are recomputed), and the CE buffers.  Checked against the measured peaks of the bench
+    (tests/test_dp_cpu.py::test_dp_replica_fits_288_gib)."""
+    hkv = n_kv_heads or n_heads
+    hd = dim // n_heads
+    qkv = (n_heads + 2 * hkv) * hd
+    p_layer = dim * qkv + dim * dim + 3 * dim * ffn
+    p_mat = n_layers * p_layer + dim * vocab                      # matrices that get a bf16 GEMM image
+    p_train = p_mat + dim * vocab + (2 * n_layers + 1) * dim + proj_in * dim + 4 * dim     # + embeddings, norms, projector, tags
+    rows = batch * seq
+    spad = (seq + 63) // 64 * 64
+    block = rows * (2 * dim * 2 + qkv * 2 + 2 * n_heads * hd * 2 + 3 * ffn * 2 + dim * 4) + batch * hkv * spad * hd * 2 + batch * n_heads * seq * 4
+    bwd_ws = rows * (dim * 2 + ffn * 2 + 2 * ffn * 2 + dim * 2 + n_heads * hd * 2 + qkv * 2 + dim * 4) + batch * hkv * hd * spad * 2
+    out = {
+        "masters_fp32": 4 * p_train, "grads_fp32": 4 * p_train, "adamw_moments_fp32": 8 * p_train, "images_bf16": 2 * p_mat,
+        "vit_bf16": 2 * vit_params,
+        "wire_buckets": wire_bytes * p_train if world > 1 and wire_bytes != 4 else 0,
+        "stream_checkpoints_fp32": (n_layers + 1) * rows * dim * 4 + rows * dim * 4,
+        "block_activations": block * (1 if recompute else n_layers),
+        "backward_workspace": bwd_ws,
+        "ce_buffers": batch * text * vocab * 2 * 2 + batch * text * dim * 2 * 2,
+    }
+    out["total"] = sum(out.values())
+    return out

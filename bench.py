@@ -2,20 +2,24 @@
 """bench.py -- the A3VLM hot path on MI355X through liba3vlm_hip.so.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+    N > 1 without a launcher: this file re-executes itself under ``python -m torch.distributed.run --nproc-per-node N`` (one rank per
+    GPU, RCCL); under a launcher (WORLD_SIZE set, the driver's own torchrun line) it is that launcher's rank.  Rank 0 prints ONE line.
 
-Headline (`metric` / `value`, BASELINE.json: "image-text samples/sec (train) + articulation-decode tok/s"): ONE step = one FULL
-FINE-TUNING step of the configs[1] backbone (ViT-L/14 @ 336x336 single crop, 577 + 2 image words, + Llama-2-7B; bf16 GEMMs,
-fp32 masters) on this rank's micro-batch of 8 image + 512-token samples: multimodal forward (frozen ViT, projector, 32 decoder
-blocks over 8 x 1091 positions, LM head, CE), backward through the HIP kernels, DP all-reduce of the gradient buckets (N > 1;
-RCCL, overlapped with the backward), global-norm clip, fused AdamW.  W warm-up steps, then EXACTLY K timed steps between
-barrier + synchronize pairs, max over ranks; `value` = samples of ALL ranks per second.  Synthetic data, N(0, 0.02) weights.
+Headline (`metric` / `value`, BASELINE.json: "image-text samples/sec (train) + articulation-decode tok/s"): ONE step = one LoRA
+FINE-TUNING step of BASELINE configs[2] (ViT-L/14 @ 336x336 single crop, 577 + 2 image words, + Llama-2-7B, rank-16 adapters on the
+seven decoder linears of every block, norms + projector trainable, base matrices frozen in bf16; global batch 64 = 8 per GPU x DP 8)
+on this rank's micro-batch of 8 image + 512-token samples: multimodal forward (frozen ViT, projector, 32 decoder blocks over
+8 x 1091 positions, LM head, CE), backward through the HIP kernels, DP all-reduce of the gradient buckets (N > 1; RCCL, overlapped
+with the backward), global-norm clip, fused AdamW.  W warm-up steps, then EXACTLY K timed steps between barrier + synchronize
+pairs, max over ranks; `value` = samples of ALL ranks per second.  Synthetic data, N(0, 0.02) weights.  At N > 1 the line also
+carries `exposed_allreduce_ms` (the step timed again with the collective stubbed) and `rccl_ranks`.
 
 Named legs on the same JSON line (same inputs, each with its own warm-up and barrier-bracketed timing):
   forward        configs[1]: the inference forward (prefill) step, samples/s and fraction of the MFMA peak
   decode         greedy decode model step (tok/s, HBM roofline); generate = MetaModel.generate() END TO END (tokenise ... stop match)
   decode_fp8     configs[4] semantics on the base plugin: weight-only fp8 decode, W8A8 prefill
-  train_lora     configs[2]: LoRA r = 16 step
+  train_lora     configs[2]: LoRA r = 16 step (the headline)
+  train          full fine-tune step of the same backbone (fp32 masters, AdamW over 6.7 G parameters)
   geometry_R     the reference-faithful geometry (448x448 -> 5 x 224 crops, 1455 image words, S = 1967) next to the headline's S
   m13b           configs[3] shapes: 13B forward + decode, and ONE DP replica of the 13B full fine-tune (288 GB sizing)
   config5        configs[4]: RGB + depth, 1024-token prompt, fp8 weights (and its bf16 twin)
@@ -59,7 +63,29 @@ def parse():
     ap.add_argument("--no-train", action="store_true", help="skip the fine-tuning legs (profiling runs); the headline is then the forward step")
     ap.add_argument("--train-steps", type=int, default=None, help="(deprecated) the training legs use --steps / --warmup")
     ap.add_argument("--cpu-seconds", type=float, default=30.0)
+    ap.add_argument("--no-roofline", action="store_true", help="skip the per-shape GEMM timing loop (kernel-table runs of the step alone)")
     return ap.parse_args()
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(a):
+    """``python bench.py --gpus N`` with N > 1 and no rank environment: re-exec this file under ``torch.distributed.run`` with one
+    rank per GPU (RCCL over xGMI) and pass its output and exit code through.  Under a launcher (WORLD_SIZE set) this is a no-op, so
+    both the driver's ``python -m torch.distributed.run ... bench.py --gpus N`` and a bare ``python bench.py --gpus N`` end in the
+    same N-rank run (reference: one process per GPU, main_finetune.py:241-263 / util/misc.py:138-147)."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 GEOM = {
@@ -306,6 +332,21 @@ def _train_step_fn(eng, opt, red, params, tokens, labels, image):
     return one
 
 
+def _exposed_allreduce(one, red, sec, steps, timer):  # noqa: D401
+    """SURVEY 8(d) "exposed (non-overlapped) all-reduce time": the same step timed again with the collective itself stubbed out
+    (the bucket hand-over, wire casts and side-stream events still run), the difference is what the all-reduce adds to the step
+    beyond what the backward hides.  None on one rank."""
+    if red is None:
+        return None
+    red.stub_collective = True
+    try:
+        stub = timer(one, max(2, steps // 2), 1)
+    finally:
+        red.stub_collective = False
+    return {"exposed_allreduce_ms": round((sec - stub) * 1e3, 3), "ms_per_step_without_collective": round(stub * 1e3, 3),
+            "bucket_bytes_on_wire": int(red.wire_bytes_last_step)}
+
+
 def train_leg(m, B, T, image, tokens, steps, warmup, timer, recompute=None):
     """Full fine-tune step on this rank's micro-batch: fp32 masters for the trainables (decoder + projector), frozen bf16 ViT,
     bf16 GEMMs, AdamW(0.9, 0.95), clip 8; with N > 1 the per-layer gradient buckets are averaged over RCCL (bf16 on the wire =
@@ -330,7 +371,11 @@ def train_leg(m, B, T, image, tokens, steps, warmup, timer, recompute=None):
     labels[:, :T // 2] = 0
     one = _train_step_fn(eng, opt, red, params, tokens, labels, image)
     sec = timer(one, steps, max(1, warmup))
+    train_leg.exposed = _exposed_allreduce(one, red, sec, steps, timer)
     return sec, float(one.loss), torch.cuda.max_memory_allocated() / 2 ** 30, sum(p.numel() for p in params), bool(eng.recompute)
+
+
+train_leg.exposed = None
 
 
 def lora_leg(m, args, B, T, image, tokens, steps, warmup, timer, dev, rank=16):
@@ -357,6 +402,7 @@ def lora_leg(m, args, B, T, image, tokens, steps, warmup, timer, dev, rank=16):
     labels[:, :T // 2] = 0
     one = _train_step_fn(eng, opt, red, params, tokens, labels, image)
     sec = timer(one, steps, max(1, warmup))
+    lora_leg.exposed = _exposed_allreduce(one, red, sec, steps, timer)
     mem = torch.cuda.max_memory_allocated() / 2 ** 30
     loss = float(one.loss)
     for n, p in m.named_parameters():      # restore the shared parameters' state for the legs that follow
@@ -365,6 +411,9 @@ def lora_leg(m, args, B, T, image, tokens, steps, warmup, timer, dev, rank=16):
     gc.collect()                           # the engine holds lazy weight-image objects that point back at it: a cycle, not a leak
     torch.cuda.empty_cache()
     return sec, loss, mem, n_train
+
+
+lora_leg.exposed = None
 
 
 # ---------------------------------------------------------------------------------------------------------------- inference legs
@@ -668,11 +717,35 @@ def pmc_traffic():
         return None
 
 
+def launch_only(a, rank, world):
+    """A3V_BENCH_LAUNCH_ONLY=1 (CPU test of the launch contract, no GPU work): every rank joins a gloo group, one all-reduce
+    counts them, rank 0 prints the line's launch fields."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        seen = int(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        seen = 1
+    if rank == 0:
+        print(json.dumps({"launch_only": True, "n_gpus": world, "rccl_ranks": seen, "gpus_arg": a.gpus}), flush=True)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(a.gpus, 1) and rank == 0:
+        print(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks; reporting n_gpus={world}", file=sys.stderr)
+    if os.environ.get("A3V_BENCH_LAUNCH_ONLY") == "1":
+        return launch_only(a, rank, world)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -763,7 +836,8 @@ def main():
     if "lora" in legs:
         def _lora():
             sec, tl, mem, ntr = lora_leg(m, args, B, T, image, tokens, a.steps, a.warmup, timer, dev)
-            return {"samples_s": round(B * world / sec, 2), "ms_per_step": round(sec * 1e3, 1), "loss": round(tl, 4), "hbm_gib": round(mem, 1),
+            return {"samples_s": round(B * world / sec, 3), "ms_per_step": round(sec * 1e3, 2), "seconds_per_step": sec, "loss": round(tl, 4),
+                    "hbm_gib": round(mem, 1), "allreduce": lora_leg.exposed,
                     "trainable_params": ntr, "tflops": round(2 * fl["total"] * world / sec / 1e12, 1), "mfma_frac": round(2 * fl["total"] / sec / MFMA_PEAK_BF16, 4),
                     "config": f"configs[2]: LoRA r=16 on all 7 decoder linears + norms + projector trainable, base frozen bf16, bs={B}/GPU, dp{world}",
                     "flop_convention": "2 x forward FLOPs (forward + input-gradient GEMMs; no weight-gradient GEMMs for frozen matrices)"}
@@ -773,7 +847,8 @@ def main():
         def _train():
             sec, tl, mem, ntr, rec = train_leg(m, B, T, image, tokens, a.steps, a.warmup, timer)
             return {"samples_s": round(B * world / sec, 3), "ms_per_step": round(sec * 1e3, 2), "seconds_per_step": sec, "loss": round(tl, 4),
-                    "hbm_gib": round(mem, 1), "trainable_params": ntr, "tflops": round(3 * fl["total"] * world / sec / 1e12, 1),
+                    "hbm_gib": round(mem, 1), "allreduce": train_leg.exposed, "trainable_params": ntr,
+                    "tflops": round(3 * fl["total"] * world / sec / 1e12, 1),
                     "mfma_frac": round(3 * fl["total"] / sec / MFMA_PEAK_BF16, 4),
                     "config": f"full fine-tune of decoder+projector, bs={B}/GPU, {T}-token prompts + {W} image words, fp32 masters + bf16 GEMMs, "
                               + ("per-block recompute" if rec else "block activations kept in HBM (no recompute)")
@@ -784,21 +859,30 @@ def main():
         res["train"] = train
     # ---- roofline of the headline step's dominant kernel family (rank 0)
     roof = None
-    if rank == 0:
+    headline = "lora" if (res.get("train_lora") or {}).get("seconds_per_step") else ("train" if train and train.get("seconds_per_step") else "forward")
+    if rank == 0 and not a.no_roofline:
         def _roof():
-            fam, table = time_gemm_shapes(args, B, T, W, dev, train="train" in legs)
-            tot_f = sum(v[0] for v in fam.values())
-            tot_t = sum(v[1] for v in fam.values())
+            fam, table = time_gemm_shapes(args, B, T, W, dev, train=bool({"train", "lora"} & legs))
+            # families of the headline step: LoRA = forward (NT) + input gradients (NN), the frozen matrices have no weight-gradient
+            # GEMMs; full fine-tune adds TN; inference forward = NT only
+            use = {"lora": ("nt", "nn"), "train": ("nt", "nn", "tn"), "forward": ("nt",)}[headline]
+            tot_f = sum(fam[k][0] for k in use)
+            tot_t = sum(fam[k][1] for k in use)
+            all_f = sum(v[0] for v in fam.values())
+            all_t = sum(v[1] for v in fam.values())
             return {"kernel": "MFMA GEMM family of the step: gemm_nt_bf16_ring_kernel (256x256x64 ping-pong over a 160-KiB LDS ring; forward linears), "
                               "gemm_tn_bf16_pp_kernel<A_ROWS> (NN input gradients / TN weight gradients), gemm_nt_bf16_kernel<128,128> on tail rows and small shapes",
                     "bound": "mfma", "achieved": round(tot_f / tot_t / 1e12, 1), "peak": MFMA_PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-                    "frac": round(tot_f / tot_t / MFMA_PEAK_BF16, 4), "traffic": pmc_traffic(),
+                    "frac": round(tot_f / tot_t / MFMA_PEAK_BF16, 4), "traffic": pmc_traffic(), "families_of_the_headline_step": list(use),
+                    "frac_full_fine_tune_mix": round(all_f / all_t / MFMA_PEAK_BF16, 4),
                     "families": {k: {"tflops": round(v[0] / v[1] / 1e12, 1), "frac": round(v[0] / v[1] / MFMA_PEAK_BF16, 4), "ms_per_step": round(v[1] * 1e3, 2)}
                                  for k, v in fam.items() if v[1] > 0},
-                    "gemm_ms_per_step": round(tot_t * 1e3, 2), "gemm_calls_per_step": sum(r["count"] for r in table),
-                    "note": "achieved = algorithmic 2MNK of every GEMM call of one step / its HIP-event duration on the launch stream (FLOP-weighted "
-                            "over the step's shapes = total GEMM FLOP / total GEMM time); traffic = rocprofv3 PMC bytes per launch of the dominant "
-                            "w1|w3 forward shape (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction), newest summary under profiles/",
+                    "gemm_ms_per_step": round(tot_t * 1e3, 2), "gemm_calls_per_step": sum(r["count"] for r in table if r["kind"] in use),
+                    "note": "achieved = algorithmic 2MNK of every GEMM call of one headline step / its HIP-event duration on the launch stream "
+                            "(FLOP-weighted over the step's shapes = total GEMM FLOP / total GEMM time), each shape timed alone after a clock "
+                            "warm-up; the in-step kernel table of the same command is profiles/r03*_kernel_stats_*; traffic = rocprofv3 PMC bytes "
+                            "per launch of the dominant w1|w3 forward shape (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch "
+                            "correction), newest summary under profiles/",
                     "shapes": table}
         del m
         gc.collect(); torch.cuda.empty_cache()
@@ -809,22 +893,36 @@ def main():
     if "m13b" in legs:
         res["m13b"] = guarded("m13b", lambda: m13b_leg(B, T, a.steps, a.warmup, timer, dev))
     if rank == 0:
-        if train and train.get("seconds_per_step"):
-            head_s, what = train.pop("seconds_per_step"), "train"
+        lora = res.get("train_lora") or {}
+        if headline == "lora":
+            head_s = lora.pop("seconds_per_step")
+            (train or {}).pop("seconds_per_step", None)
+            metric = "image-text samples/sec (train) + articulation-decode tok/s"
+            wl = (f"configs[2]: ViT-L/14@336 (577+2 image words) + Llama-2-{a.model.upper()} LoRA r=16 fine-tune step bf16 (adapters on all 7 decoder "
+                  f"linears, norms + projector trainable, base frozen), bs={B} per GPU (global {B * world} at dp{world}), {T}-token prompt, S={S}")
+        elif headline == "train":
+            head_s = train.pop("seconds_per_step")
+            metric = "image-text samples/sec (train) + articulation-decode tok/s"
+            wl = (f"configs[1] backbone (ViT-L/14@336, 577+2 image words, + Llama-2-{a.model.upper()}), FULL FINE-TUNE step, bs={B} per GPU, "
+                  f"{T}-token prompt, S={S}")
         else:
-            head_s, what = res.get("forward", {}).get("ms_per_step", float("nan")) * 1e-3, "forward"
+            head_s = res.get("forward", {}).get("ms_per_step", float("nan")) * 1e-3
+            metric = "image-text samples/sec (inference forward; training legs skipped) + articulation-decode tok/s"
+            wl = (f"configs[1]: ViT-L/14@336 (577+2 image words) + Llama-2-{a.model.upper()} bf16 inference forward step, bs={B} per GPU, "
+                  f"{T}-token prompt, S={S}")
+        exposed = (lora.get("allreduce") if headline == "lora" else train.get("allreduce") if headline == "train" else None) if world > 1 else None
         out = {
-            "metric": "image-text samples/sec (train) + articulation-decode tok/s" if what == "train"
-                      else "image-text samples/sec (inference forward; training legs skipped) + articulation-decode tok/s",
+            "metric": metric,
             "value": round(B * world / head_s, 3), "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(head_s * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic (uint8-uniform 336x336 images, uniform token ids, N(0,0.02) weights)",
-            "config": {"workload": (f"configs[1] backbone (ViT-L/14@336, 577+2 image words, + Llama-2-{a.model.upper()}), "
-                                    + ("FULL FINE-TUNE step" if what == "train" else "inference forward step")
-                                    + f", bs={B} per GPU, {T}-token prompt, S={S}"),
+            "config": {"workload": wl,
                        "geometry": "S (single 336x336 crop); geometry R (W=1455) in `geometry_R`",
                        "global_batch": B * world, "seq_len": S,
                        "parallelism": f"dp{world}" + (" (bucketed RCCL gradient all-reduce overlapped with backward)" if world > 1 else "")},
+            "rccl_ranks": world,
+            "exposed_allreduce_ms": exposed["exposed_allreduce_ms"] if exposed else None,
+            "allreduce": exposed,
             "decode_tok_s": res.get("decode", {}).get("tok_s"),
             "generate_tok_s": (res.get("generate") or {}).get("tok_s_end_to_end"),
             "roofline": roof,

@@ -52,14 +52,42 @@ def test_committed_bench_lines_follow_the_contract():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["unit"] == "samples/s" and c["sample"]
     assert abs(d["value"] - 8 * 1000.0 / d["ms_per_step"]) / d["value"] < 0.01
-    if os.path.basename(files[-1]) >= "r02":
-        # round 2 on: the headline IS the BASELINE metric (train samples/s of the configs[1] backbone), the other configs are named legs
+    if os.path.basename(files[-1]) >= "r03":
+        # round 3 on: the headline is BASELINE configs[2] (LoRA fine-tune step), the full fine-tune is a leg; launch fields present
+        assert "(train)" in d["metric"] and d["config"]["workload"].startswith("configs[2]")
+        assert abs(d["train_lora"]["samples_s"] - d["value"]) / d["value"] < 1e-3 and d["train"]["samples_s"] > 0
+        assert d["rccl_ranks"] == d["n_gpus"] and "exposed_allreduce_ms" in d
+        assert d["roofline"]["families_of_the_headline_step"] == ["nt", "nn"]
+    elif os.path.basename(files[-1]) >= "r02":
+        # round 2: the headline was the full fine-tune step of the configs[1] backbone
         assert "(train)" in d["metric"] and "FULL FINE-TUNE" in d["config"]["workload"]
         assert abs(d["train"]["samples_s"] - d["value"]) / d["value"] < 1e-3
+    if os.path.basename(files[-1]) >= "r02":
         for leg in ("forward", "decode", "generate", "decode_fp8", "geometry_R", "config5", "train_lora", "m13b"):
             assert leg in d and "error" not in d[leg], leg
         assert d["geometry_R"]["image_words"] == 1455 and d["config5"]["seq_len"] == 1024 + 2 * 579
         assert d["m13b"]["train_replica"]["hbm_gib"] < 288 and d["m13b"]["train_replica"]["trainable_params"] > 13e9
-        assert set(r["families"]) == {"nt", "nn", "tn"} and r["traffic"]["file"].startswith("r02")
+        assert set(r["families"]) == {"nt", "nn", "tn"} and r["traffic"]["file"][:3] in ("r02", "r03")
         assert c["c1"]["ids_equal"] is True and c["decode_tok_s"] > 0
         assert d["generate"]["tok_s_end_to_end"] > 0 and d["decode"]["roofline"]["bound"] == "hbm"
+
+
+def test_gpus_n_without_a_launcher_starts_n_ranks():
+    """`python bench.py --gpus 2` with NO torchrun around it and no rank environment must end in a 2-rank job (the driver's scaling
+    run may call it either way).  A3V_BENCH_LAUNCH_ONLY=1 stops after the rendezvous (gloo, no GPU work): rank 0 reports how many
+    ranks joined."""
+    import subprocess
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "LOCAL_WORLD_SIZE", "GROUP_RANK", "TORCHELASTIC_RUN_ID"):
+        e.pop(k, None)
+    e["A3V_BENCH_LAUNCH_ONLY"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--model", "tiny"], cwd=ROOT, env=e, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["gpus_arg"] == 2
+    # one rank: no launcher is started, the line says one
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--model", "tiny"], cwd=ROOT, env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])["n_gpus"] == 1
