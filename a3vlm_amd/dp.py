@@ -146,6 +146,17 @@ class GradReducer:
         if self._stream is not None:
             torch.cuda.current_stream().wait_stream(self._stream)
 
+    def any_rank(self, flag: torch.Tensor) -> torch.Tensor:
+        """Logical OR of a per-rank boolean device scalar over all ranks (one tiny MAX all-reduce, no host read).  The trainer's
+        non-finite flag must be GLOBAL before the optimizer step: a NaN loss on rank A reaches rank B through the averaged
+        gradients, so B has to skip the same update A skips (the reference exits before backward on the rank that sees it,
+        engine_finetune.py:54-58, and the job dies with it)."""
+        if self.world == 1:
+            return flag
+        t = flag.to(torch.float32).reshape(1)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        return t[0] > 0
+
     def reduce_all_now(self) -> None:
         """Reduce every bucket at once (no overlap): for callers that ran the whole cycle with ``enabled = False``."""
         was = self.enabled
@@ -177,13 +188,50 @@ class GradSquareSums:
         self._fused_all: Optional[torch.Tensor] = None
         self._fused_used = 0
         self._covered: List[Tuple[int, int]] = []                 # flat ranges whose sums came out of a GEMM this step
+        self.reducer, self._fused, self._chained, self._attached = reducer, fused, None, False
+        self.attach()
+
+    def attach(self) -> None:
+        """Link into the gradient path: behind the reducer's buckets (DP: sums over the REDUCED gradients, and the engine's fused
+        GEMM-epilogue sums are switched OFF because they would be over the local ones), or onto the engine's bucket hook + fused
+        epilogue sums (one rank).  Idempotent; ``detach()`` undoes it (the trainer detaches at the end of every epoch, so a later
+        epoch with another reducer -- or none -- never inherits this object's hooks)."""
+        if self._attached:
+            return
+        engine, reducer = self.eng, self.reducer
+        self.seen.clear()
+        self._covered.clear()
         if reducer is not None and (reducer.world > 1 or reducer.reduce_single_rank):
             reducer.sumsq = self
+            if hasattr(engine, "sumsq_sink"):
+                engine.sumsq_sink = None
         else:
             self._chained = engine.on_layer_grads_ready
             engine.on_layer_grads_ready = self._on_ready
-            if fused and hasattr(engine, "sumsq_sink"):
+            if self._fused and hasattr(engine, "sumsq_sink"):
                 engine.sumsq_sink = self
+        self._attached = True
+
+    def detach(self) -> None:
+        if not self._attached:
+            return
+        engine, reducer = self.eng, self.reducer
+        if reducer is not None and reducer.sumsq is self:
+            reducer.sumsq = None
+        if engine.on_layer_grads_ready == self._on_ready:
+            engine.on_layer_grads_ready = self._chained
+        if getattr(engine, "sumsq_sink", None) is self:
+            engine.sumsq_sink = None
+        self._chained = None
+        self.seen.clear()
+        self._covered.clear()
+        self._attached = False
+
+    def begin_backward(self) -> None:
+        """A new backward starts (called by the engine): whatever an earlier backward left behind without a ``norm()`` -- covered
+        ranges of fused slots, buckets marked seen -- belongs to another step."""
+        self._covered.clear()
+        self.seen.clear()
 
     def _layout(self):
         if self.part is None:
@@ -233,6 +281,8 @@ class GradSquareSums:
         i = self.slot.get(key)
         if i is None:
             return
+        if key in self.seen:                       # the same bucket again without a norm() in between: a new step began
+            self.seen.clear()
         if seg.is_cuda:
             from . import ops
             rest = self._uncovered(key[0], key[1]) if self._covered else [key]

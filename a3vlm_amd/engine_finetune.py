@@ -14,6 +14,9 @@ Changed:
     gradient coefficient (negative coefficient = ``a3v_adamw_scaled`` does nothing), so a bad step is a no-op on masters,
     moments and bf16 weight images, and the host reads the flag at every logging boundary, before every checkpoint callback
     and at the end of the epoch -- exiting then, before anything poisoned can be written;
+  * under DP the flag is made GLOBAL (``GradReducer.any_rank``: one tiny MAX all-reduce per optimizer step) before it is folded into
+    the coefficient: a rank whose own loss was finite still skips the update its peers skip, so no rank ever applies the averaged
+    NaN gradients or checkpoints past them;
   * with ``accum_iter > 1`` the DP all-reduce still overlaps the backward: the reducer is enabled on the LAST micro-step of a
     cycle, when each layer's bucket holds the cycle's accumulated sum as soon as that layer's backward is done.
 """
@@ -71,76 +74,90 @@ def train_one_epoch(model, data_loader, optimizer, epoch: int, start_iter: int, 
     sumsq = None
     if engine is not None and clip > 0 and takes_scale and optimizer.engine is engine:
         sumsq = getattr(engine, "_grad_square_sums", None)
-        if sumsq is None:
+        if sumsq is None or sumsq.reducer is not reducer:       # bound to ONE reducer: another (or none) this epoch = a new object
+            if sumsq is not None:
+                sumsq.detach()
             sumsq = engine._grad_square_sums = GradSquareSums(engine, reducer)
+        sumsq.attach()
     overlap = takes_scale and engine is not None and getattr(optimizer, "engine", None) is engine \
         and os.environ.get("A3V_ADAMW_OVERLAP", "0") == "1"
-    for step, batch in enumerate(data_loader, start=start_iter):
-        examples, labels, imgs, depth = _unpack(batch)
-        if trim is not None and not examples.is_cuda:
-            examples, labels = trim(examples, labels)
-        if step % accum_iter == 0:
-            stats["lr"] = adjust_learning_rate_epoch(optimizer, step / n_iter + epoch, lr=args.lr, min_lr=args.min_lr,
-                                                     warmup_epochs=args.warmup_epochs, epochs=args.epochs)
-        update_grad = (step + 1) % accum_iter == 0
-        if reducer is not None:
-            reducer.enabled = update_grad
-        if sumsq is not None:
-            sumsq.enabled = update_grad
-        examples, labels = examples.to(dev, non_blocking=True), labels.to(dev, non_blocking=True)
-        imgs = imgs.to(dev, non_blocking=True) if imgs is not None else None
-        if trim is not None:
-            c_loss, extra = model(examples, labels, images=imgs, depth_imgs=depth, trimmed=True)
-        else:
-            c_loss, extra = model(examples, labels, images=imgs, depth_imgs=depth)
-        loss = c_loss
-        for add_loss, weight in extra.values():
-            loss = loss + add_loss * weight
-        bad |= ~torch.isfinite(loss.detach())
-        (loss / accum_iter).backward()
-        if update_grad:
+    try:
+        for step, batch in enumerate(data_loader, start=start_iter):
+            examples, labels, imgs, depth = _unpack(batch)
+            if trim is not None and not examples.is_cuda:
+                examples, labels = trim(examples, labels)
+            if step % accum_iter == 0:
+                stats["lr"] = adjust_learning_rate_epoch(optimizer, step / n_iter + epoch, lr=args.lr, min_lr=args.min_lr,
+                                                         warmup_epochs=args.warmup_epochs, epochs=args.epochs)
+            update_grad = (step + 1) % accum_iter == 0
             if reducer is not None:
-                reducer.finish()
-            coef = None
-            if clip > 0:
-                if takes_scale:
-                    # one norm over the engine's flat gradient buffer; the coefficient stays on the device and is applied by the
-                    # optimizer kernel as it reads the gradients (a3v_adamw_scaled): no grad.mul_ pass, no host sync
-                    eng = optimizer.engine
-                    stats["grad_norm"], coef = clip_grad_norm(params, clip, flat=eng.flat_grads() if eng is not None else None, defer=True,
-                                                              sumsq=sumsq if eng is engine else None)
-                else:
-                    stats["grad_norm"] = clip_grad_norm(params, clip)
-                bad |= ~torch.isfinite(torch.as_tensor(stats["grad_norm"]).to(dev))
-            if takes_scale:
-                one = coef if coef is not None else torch.ones((), dtype=torch.float32, device=dev)
-                # overlap (A3V_ADAMW_OVERLAP=1, off by default): the update of layer i+1.. runs on the optimizer's stream under the
-                # next forward's layers ..i (optim.py)
-                optimizer.step(grad_scale=torch.where(bad, -one.new_ones(()), one).reshape(1), overlap=overlap)
+                reducer.enabled = update_grad
+            if sumsq is not None:
+                sumsq.enabled = update_grad
+            examples, labels = examples.to(dev, non_blocking=True), labels.to(dev, non_blocking=True)
+            imgs = imgs.to(dev, non_blocking=True) if imgs is not None else None
+            if trim is not None:
+                c_loss, extra = model(examples, labels, images=imgs, depth_imgs=depth, trimmed=True)
             else:
-                stop_if_bad(step)                  # a stock optimizer cannot skip on a device flag: pay the host read
-                optimizer.step()
-            model.zero_grad(set_to_none=True)
-        boundary_idx = (step + 1) // accum_iter
-        last = step + 1 == n_iter
-        if update_grad and (boundary_idx % print_freq == 0 or last):
-            stop_if_bad(step)
-            lv = float(c_loss.detach())            # the loop's host sync: once per print_freq optimizer steps
-            if not math.isfinite(lv):
-                log(f"Loss is {lv}, stopping training")
-                sys.exit(1)
-            stats["closs"] += lv
-            stats["n"] += 1
-            gn = float(stats["grad_norm"]) if torch.is_tensor(stats["grad_norm"]) else stats["grad_norm"]
-            log(f"Epoch: [{epoch}] [{step + 1}/{n_iter}] lr: {stats['lr']:.6f} closs: {lv:.4f} grad_norm: {gn:.4f}")
-        if on_save is not None and update_grad and getattr(args, "save_iteration_interval", 0):
-            if boundary_idx % max(args.save_iteration_interval // accum_iter, 1) == 0:
-                stop_if_bad(step)                  # never checkpoint past a bad step
-                if engine is not None:
-                    engine.sync_optimizer()        # the checkpoint reads parameters and optimizer state on this stream
-                on_save(step)
+                c_loss, extra = model(examples, labels, images=imgs, depth_imgs=depth)
+            loss = c_loss
+            for add_loss, weight in extra.values():
+                loss = loss + add_loss * weight
+            bad |= ~torch.isfinite(loss.detach())
+            (loss / accum_iter).backward()
+            if update_grad:
+                if reducer is not None:
+                    reducer.finish()
+                    if hasattr(reducer, "any_rank"):
+                        # DP: the flag must be the same on every rank BEFORE the update -- a NaN loss on one rank is in everybody's
+                        # averaged gradients (one tiny MAX all-reduce on the stream, no host read)
+                        bad = reducer.any_rank(bad)
+                coef = None
+                if clip > 0:
+                    if takes_scale:
+                        # one norm over the engine's flat gradient buffer; the coefficient stays on the device and is applied by the
+                        # optimizer kernel as it reads the gradients (a3v_adamw_scaled): no grad.mul_ pass, no host sync
+                        eng = optimizer.engine
+                        stats["grad_norm"], coef = clip_grad_norm(params, clip, flat=eng.flat_grads() if eng is not None else None, defer=True,
+                                                                  sumsq=sumsq if eng is engine else None)
+                    else:
+                        stats["grad_norm"] = clip_grad_norm(params, clip)
+                    bad |= ~torch.isfinite(torch.as_tensor(stats["grad_norm"]).to(dev))
+                if takes_scale:
+                    one = coef if coef is not None else torch.ones((), dtype=torch.float32, device=dev)
+                    # overlap (A3V_ADAMW_OVERLAP=1, off by default): the update of layer i+1.. runs on the optimizer's stream under the
+                    # next forward's layers ..i (optim.py)
+                    optimizer.step(grad_scale=torch.where(bad, -one.new_ones(()), one).reshape(1), overlap=overlap)
+                else:
+                    stop_if_bad(step)                  # a stock optimizer cannot skip on a device flag: pay the host read
+                    optimizer.step()
+                model.zero_grad(set_to_none=True)
+            boundary_idx = (step + 1) // accum_iter
+            last = step + 1 == n_iter
+            if update_grad and (boundary_idx % print_freq == 0 or last):
+                stop_if_bad(step)
+                lv = float(c_loss.detach())            # the loop's host sync: once per print_freq optimizer steps
+                if not math.isfinite(lv):
+                    log(f"Loss is {lv}, stopping training")
+                    sys.exit(1)
+                stats["closs"] += lv
+                stats["n"] += 1
+                gn = float(stats["grad_norm"]) if torch.is_tensor(stats["grad_norm"]) else stats["grad_norm"]
+                log(f"Epoch: [{epoch}] [{step + 1}/{n_iter}] lr: {stats['lr']:.6f} closs: {lv:.4f} grad_norm: {gn:.4f}")
+            if on_save is not None and update_grad and getattr(args, "save_iteration_interval", 0):
+                if boundary_idx % max(args.save_iteration_interval // accum_iter, 1) == 0:
+                    stop_if_bad(step)                  # never checkpoint past a bad step
+                    if engine is not None:
+                        engine.sync_optimizer()        # the checkpoint reads parameters and optimizer state on this stream
+                    on_save(step)
+    finally:
+        # nothing of this epoch's wiring outlives it: the fused sums of squares and the static loss scale would otherwise leak into
+        # bench / evaluation backward passes (or the next epoch's other reducer)
+        if sumsq is not None:
+            sumsq.detach()
+        if engine is not None:
+            engine.static_grad_scale = None
     if engine is not None:
-        engine.static_grad_scale = None
         engine.sync_optimizer()                    # whatever runs next (checkpoint, evaluation) sees the last update
     stop_if_bad(n_iter - 1)                        # the caller writes the epoch-end checkpoint next
     return {"closs": stats["closs"] / max(stats["n"], 1), "lr": stats["lr"]}

@@ -181,6 +181,22 @@ class MetaModel(nn.Module):
             self._anchor = torch.zeros((), dtype=torch.float32, device=self._device, requires_grad=True)
         return self._engine
 
+    def _sync_engine(self):
+        eng = getattr(self, "_engine", None)
+        if eng is not None:
+            eng.sync_optimizer()
+
+    def zero_grad(self, set_to_none: bool = True):
+        """``set_to_none=False`` WRITES the gradients: an overlapped optimizer step (``FusedAdamW.step(overlap=True)``) may still
+        be reading them on its own stream, so it is joined first (``set_to_none=True`` only drops references)."""
+        if not set_to_none:
+            self._sync_engine()
+        return super().zero_grad(set_to_none=set_to_none)
+
+    def state_dict(self, *args, **kwargs):
+        self._sync_engine()            # checkpoints read the parameters on the current stream
+        return super().state_dict(*args, **kwargs)
+
     def forward(self, examples, labels, images=None, depth_imgs=None, trimmed: bool = False):
         """``trimmed=True`` (not in the reference's signature): the caller already cut the batch after its last labelled column
         (``MetaModel._trim`` on the CPU batch, as ``engine_finetune.train_one_epoch`` does) -- skips the host read of the

@@ -13,7 +13,14 @@ parameters (``TrainEngine.forward_order``), one event per gradient bucket; ``Tra
 bucket by bucket, so the 28-B/parameter HBM stream of the update runs under the MFMA-bound GEMMs of the next forward instead of
 in front of it.  Same arithmetic, same order per parameter.  The caller's contract: between ``step(overlap=True)`` and the next
 ``forward_loss`` / ``backward`` only the host and ``zero_grad(set_to_none=True)`` touch parameters or gradients; anything else
-(checkpoints, evaluation through the model, a stock ``zero_grad(set_to_none=False)``) calls ``engine.sync_optimizer()`` first."""
+(checkpoints, evaluation through the model, a stock ``zero_grad(set_to_none=False)``) calls ``engine.sync_optimizer()`` first
+(``MetaModel.zero_grad(set_to_none=False)``, ``MetaModel.state_dict`` and this optimizer's ``state_dict`` do so themselves).
+
+Skipped steps: a negative or NaN ``grad_scale`` makes ``a3v_adamw_scaled`` a no-op on masters, moments and bf16 images (the trainer's
+device-side non-finite guard).  The host cannot know that without reading the flag, so ``state[p]["step"]`` counts LAUNCHES, not
+applied updates, and the weight images are marked current either way (they are: nothing changed).  The trainer reads the flag at
+its logging / checkpoint / epoch boundaries and exits there, before anything is saved, so a skipped step is never followed by a
+step whose bias correction would be off by one."""
 from __future__ import annotations
 
 import os

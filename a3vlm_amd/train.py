@@ -695,6 +695,8 @@ class TrainEngine:
         self.sync_optimizer()                    # the update reads the gradients this backward overwrites
         im = self._images()
         self.ensure_grads()
+        if self.sumsq_sink is not None:
+            self.sumsq_sink.begin_backward()
         B, T, W, S = s["B"], s["T"], s["W"], s["S"]
         rows, dim, V = B * S, a.dim, a.vocab_size
         # ---- CE + LM head + final norm
@@ -719,7 +721,9 @@ class TrainEngine:
         self._notify("embed")
         if s["vis"] is not None:
             self._encode_image_backward(dh, s["vis"], B, S)
-            self._notify("vision_proj")
+        # announced on EVERY backward, image or not: under accumulation an earlier micro-step of the cycle may have put projector
+        # gradients there, and every rank must hand the same buckets to the collective on the boundary micro-step
+        self._notify("vision_proj")
         self._saved = None
 
     def _notify(self, bucket: str):

@@ -202,3 +202,67 @@ def test_dp_replica_fits_288_gib():
     # an fp32 wire needs no extra buckets (reduced in place); 13B with stored activations at micro-batch 8 does NOT fit -> recompute
     assert hbm_budget(5120, 40, 40, 13824, 32000, 4, 1091, 512, recompute=True, world=8, wire_bytes=4)["wire_buckets"] == 0
     assert hbm_budget(5120, 40, 40, 13824, 32000, 8, 1091, 512, recompute=False, world=8)["total"] > 288 * G
+
+
+# ------------------------------------------------------------------ the non-finite flag is global under DP
+class _ToyDP(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.tensor([1.0, -2.0, 0.5]))
+
+    def forward(self, examples, labels, images=None, depth_imgs=None):
+        loss = ((examples.float() @ self.w - labels.float()) ** 2).mean()
+        if bool((examples == 77).any()):
+            loss = loss * float("nan")
+        return loss, {}
+
+
+class _ParamReducer(GradReducer):
+    """The real reducer's flag collective; the toy model's one gradient is averaged in finish()."""
+
+    def __init__(self, model, dist_):
+        super().__init__(FakeEngine([4]), dist_)
+        self.model = model
+
+    def finish(self):
+        super().finish()
+        g = self.model.w.grad
+        g.mul_(1.0 / self.world)
+        self.dist.all_reduce(g)
+
+
+def _nan_worker(rank, world, port, outdir):
+    from a3vlm_amd.engine_finetune import train_one_epoch
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    code, saved = 0, []
+    try:
+        g = torch.Generator().manual_seed(3 + rank)
+        data = [(torch.randint(0, 5, (4, 3), generator=g), torch.randint(0, 5, (4,), generator=g), torch.ones(4, 3)) for _ in range(4)]
+        if rank == 0:
+            data[2][0][0, 0] = 77                  # ONLY rank 0 sees a NaN loss, in the second optimizer step
+        m = _ToyDP()
+        args = types.SimpleNamespace(accum_iter=1, lr=1e-2, min_lr=0.0, warmup_epochs=0.0, epochs=1, clip_grad=-1, print_freq=100,
+                                     save_iteration_interval=1)
+        try:
+            train_one_epoch(m, data, torch.optim.SGD(m.parameters(), lr=0.1), epoch=0, start_iter=0, args=args, reducer=_ParamReducer(m, dist),
+                            log=lambda s: None, on_save=lambda step: saved.append((step, m.w.detach().clone())))
+        except SystemExit as e:
+            code = e.code
+        torch.save({"code": code, "w": m.w.detach().clone(), "saved": saved}, os.path.join(outdir, f"nan{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_nan_loss_on_one_rank_stops_every_rank_before_the_update(tmp_path):
+    """clip_grad <= 0 (the reference default): rank 0's loss is NaN in step 2, rank 1's own loss is finite but the averaged gradient
+    it receives is NaN.  Both ranks must stop with exit code 1 BEFORE applying that update; only the two clean steps' checkpoints
+    exist and the weights are the finite ones of step 1 on both ranks."""
+    world, port = 2, 29650 + os.getpid() % 200
+    mp.spawn(_nan_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = (torch.load(os.path.join(str(tmp_path), f"nan{r}.pt")) for r in range(world))
+    for r in (r0, r1):
+        assert r["code"] == 1
+        assert torch.isfinite(r["w"]).all()
+        assert [s for s, _ in r["saved"]] == [0, 1]
+    assert torch.equal(r0["w"], r1["w"]) and torch.equal(r0["w"], r0["saved"][-1][1])
