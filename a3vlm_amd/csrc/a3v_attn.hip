@@ -795,7 +795,7 @@ inline void decode_plan(int B, int H, int Sk, int* nsplit, int* chunk) {
 #endif
   int want = (A3V_DECODE_BLOCKS + B * H - 1) / (B * H);
 #ifdef A3V_ABLATION
-  { static const char* e = getenv("A3V_DECODE_WANT"); if (e) want = atoi(e); }
+  { const int e = A3V_ENV_INT("A3V_DECODE_WANT", 0); if (e) want = e; }
 #endif
   int maxs = (Sk + 127) / 128;
   int ns = want < maxs ? want : maxs;
@@ -833,8 +833,8 @@ static int attention_impl(const void* q, const void* k, const void* vt, void* ou
   p.scale_log2 = p.scale * 1.4426950408889634f;
   p.lse = lse;
   p.head_group = 1;
-  { const char* e = getenv("A3V_ATTN_STAGED_O"); p.staged_o = !(e && e[0] == '0'); }
-  { const char* e = getenv("A3V_ATTN_LAZY"); p.lazy_rescale = !(e && e[0] == '0'); }
+  p.staged_o = A3V_ENV_INT("A3V_ATTN_STAGED_O", 1) != 0;
+  p.lazy_rescale = A3V_ENV_INT("A3V_ATTN_LAZY", 1) != 0;
   if (lse && Sq == 1 && dtype == A3V_BF16 && (hd == 64 || hd == 128)) return A3V_ERR_ARG;  // decode kernel has no LSE output
   if (dtype == A3V_F32) {
     if (hd > 256) return A3V_ERR_SHAPE;
@@ -857,8 +857,8 @@ static int attention_impl(const void* q, const void* k, const void* vt, void* ou
     int ns, ch;
     decode_plan(B, H, Sk, &ns, &ch);
     const size_t shm = (size_t)(ch + 8) * sizeof(float);
-    const char* we = getenv("A3V_ATTN_DECODE_WAVE_STANDALONE");     // tuning runs (tools/attn_decode_bench.py): the wave-streaming form here too
-    if (we && we[0] == '1' && dtype == A3V_BF16) {
+    const bool we = A3V_ENV_INT("A3V_ATTN_DECODE_WAVE_STANDALONE", 0) == 1;     // tuning runs (tools/attn_decode_bench.py): the wave-streaming form here too
+    if (we && dtype == A3V_BF16) {
       int ns2 = (256 + B * H - 1) / (B * H);
       if (ns2 > ns) ns2 = ns;
       int ch2 = (((Sk + ns2 - 1) / ns2) + 63) & ~63;
@@ -889,17 +889,16 @@ static int attention_impl(const void* q, const void* k, const void* vt, void* ou
   if (causal && (grid.x & 7) == 0 && ((B * H) & 7) == 0) {
     // default: the largest power of two (<= 16) whose K + V^T fit ~9 MB (measured best: 16 heads at S = 1091, 8 at S ~ 2000 --
     // twice the 4-MB L2, the Infinity Cache absorbs the rest; tools/ab_attn_order.py): 160.8 -> 142.3 us at S = 1091
-    const char* ge = getenv("A3V_ATTN_HEAD_GROUP");      // read per launch (A/B runs)
+    const int ge = A3V_ENV_INT("A3V_ATTN_HEAD_GROUP", 0);      // > 0: forces the group size (A/B runs)
     int want = 16;
     while (want > 1 && (int64_t)want * Sk * hd * 4 > (9 << 20)) want >>= 1;
-    if (ge) want = atoi(ge);
+    if (ge > 0) want = ge;
     int G = want < 1 ? 1 : want;
     while (G > 1 && ((B * H) / 8) % G) G >>= 1;            // groups must not straddle an XCD's range of heads
     p.head_group = G;
   }
   if (hd == 128) {
-    const char* pe = getenv("A3V_ATTN_PSWAP");          // A3V_ATTN_PSWAP=0: the 8-B-half V^T reads (A/B runs)
-    const bool ps = !(pe && pe[0] == '0');
+    const bool ps = A3V_ENV_INT("A3V_ATTN_PSWAP", 1) != 0;          // A3V_ATTN_PSWAP=0: the 8-B-half V^T reads (A/B runs)
     if (causal) {
       if (ps) hipLaunchKernelGGL((attn_prefill_bf16_kernel<128, true, true>), grid, dim3(256), 0, st, p);
       else hipLaunchKernelGGL((attn_prefill_bf16_kernel<128, true, false>), grid, dim3(256), 0, st, p);
@@ -950,10 +949,8 @@ int a3v_attention_decode_fused(const void* q, const void* k, const void* vt, voi
   decode_plan(B, H, Sk, &ns, &ch);
   const size_t shm = (size_t)(ch + 8) * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
-  const char* nte = getenv("A3V_ATTN_DECODE_NT");       // default: non-temporal KV stream (A3V_ATTN_DECODE_NT=0 for A/B runs)
-  const bool nt = !(nte && nte[0] == '0');
-  const char* v2e = getenv("A3V_ATTN_DECODE_WAVE");     // default: the wave-streaming form (A3V_ATTN_DECODE_WAVE=0: the two-phase form)
-  if (!(v2e && v2e[0] == '0')) {
+  const bool nt = A3V_ENV_INT("A3V_ATTN_DECODE_NT", 1) != 0;       // default: non-temporal KV stream (=0 for A/B runs)
+  if (A3V_ENV_INT("A3V_ATTN_DECODE_WAVE", 1) != 0) {     // default: the wave-streaming form (=0: the two-phase form)
     // one block per (batch, head) when that alone covers the CUs, else the fewest splits that do (never more than the
     // two-phase plan: the scratch buffer is sized for that one)
     int ns2 = (256 + B * H - 1) / (B * H);

@@ -508,10 +508,10 @@ static int attention_bwd_mfma_impl(const void* q, const void* k, int64_t k_sb, i
   dim3 gq(((S + 127) / 128) * H * B), gk(((S + 127) / 128) * Hkv * B);
   auto group_of = [&](int heads, unsigned blocks) {         // as in the forward (a3v_attn.hip), with Q + dO + K + V per head: 8 heads at S = 1091 (592.8 -> 550.2 us for the three kernels)
     if (!causal || (blocks & 7) || (heads & 7)) return 1;
-    const char* ge = getenv("A3V_ATTN_HEAD_GROUP");
+    const int ge = A3V_ENV_INT("A3V_ATTN_HEAD_GROUP", 0);
     int want = 16;
     while (want > 1 && (int64_t)want * S * hd * 4 > (9 << 19)) want >>= 1;
-    if (ge) want = atoi(ge);
+    if (ge > 0) want = ge;
     int G = want < 1 ? 1 : want;
     while (G > 1 && (heads / 8) % G) G >>= 1;
     return G;

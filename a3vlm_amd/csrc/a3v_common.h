@@ -16,6 +16,19 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 #define A3V_WAVE 64
 
+// ---- A3V_* environment switches (A/B runs, tuning scripts and equality tests; the defaults are the product path and none of
+// them selects a CPU path).  A switch is read ONCE per call site and cached: no launch calls getenv in steady state.  A process
+// that flips a switch after the first launch calls a3v_reload_env() (C-ABI; a3vlm_amd.lib.env(...) does it) to have them re-read.
+int a3v_env_generation();
+#include <stdlib.h>
+#define A3V_ENV_INT(name, dflt)                                                        \
+  ([]() -> int {                                                                       \
+    static int gen_ = -1, v_ = 0;                                                      \
+    const int g_ = a3v_env_generation();                                               \
+    if (gen_ != g_) { const char* e_ = getenv(name); v_ = e_ ? atoi(e_) : (dflt); gen_ = g_; } \
+    return v_;                                                                         \
+  }())
+
 __device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }
 __device__ __forceinline__ bf16_t f2bf(float v) { return (bf16_t)v; }  // RNE (v_cvt_pk_bf16_f32)
 // round-trip: the value a bf16 store of v would hold

@@ -32,7 +32,7 @@ extern "C" int a3v_llama_decode_step(const a3v_llama_layer* layers, int n_layers
                                      void* act, float* attn_scratch, void* skinny_ws, const float* cos_sin, int B, int dim, int H, int Hkv,
                                      int hd, int ffn, int Smax, int pos, float eps, void* stream) {
   if (!layers || n_layers <= 0 || !h || !xn || !qkv || !att || !act || !attn_scratch || !skinny_ws || !cos_sin) return A3V_ERR_ARG;
-  if (B <= 0 || B > 16 || pos < 0 || pos >= Smax) return A3V_ERR_SHAPE;
+  if (B <= 0 || B > 32 || pos < 0 || pos >= Smax) return A3V_ERR_SHAPE;   // the plugin contract's max_batch_size = 32 (meta.py:34-52)
   const int64_t ldq = (int64_t)(H + 2 * Hkv) * hd;
   const int64_t strides[12] = {ldq, ldq, hd,
                                (int64_t)Hkv * Smax * hd, (int64_t)Smax * hd, hd,
@@ -45,28 +45,43 @@ extern "C" int a3v_llama_decode_step(const a3v_llama_layer* layers, int n_layers
     const int q8 = (L.wqkv_q != nullptr) + (L.wo_q != nullptr) + (L.w13_q != nullptr) + (L.w2_q != nullptr);
     if (q8 != (w8 ? 4 : 0) || (w8 && (!L.wqkv_s || !L.wo_s || !L.w13_s || !L.w2_s))) return A3V_ERR_ARG;   // all four or none
   }
+  // The GEMV kernels take up to 16 activation rows.  Batch rows are independent through the whole stack (each has its own KV
+  // cache rows), so a batch of 17..32 runs as two row chunks through the same fused launches: the weights are streamed once per
+  // chunk (a 32-row batch costs two 16-row steps, i.e. the 16-row tok/s), every buffer is addressed at its row offset.
+  const int Bc = B > 16 ? (B + 1) / 2 : B;
   const bool fused = (hd == 64 || hd == 128) && dim % 16 == 0 && dim / 16 * 16 * 4 <= A3V_WS_PARTIALS - A3V_WS_SSQ &&
-                     a3v_gemv_supported(B, (int)ldq, dim, 0, w8) && a3v_gemv_supported(B, dim, H * hd, A3V_EPI_RESIDUAL, w8) &&
-                     a3v_gemv_supported(B, 2 * ffn, dim, A3V_EPI_SWIGLU, w8) && a3v_gemv_supported(B, dim, ffn, A3V_EPI_RESIDUAL, w8) &&
+                     a3v_gemv_supported(Bc, (int)ldq, dim, 0, w8) && a3v_gemv_supported(Bc, dim, H * hd, A3V_EPI_RESIDUAL, w8) &&
+                     a3v_gemv_supported(Bc, 2 * ffn, dim, A3V_EPI_SWIGLU, w8) && a3v_gemv_supported(Bc, dim, ffn, A3V_EPI_RESIDUAL, w8) &&
                      ldq % 16 == 0 && (2 * ffn) % 32 == 0;
   if (w8 && !fused) return A3V_ERR_SHAPE;          // the fp8 images exist only for the fused form
+  if (B > 16 && !fused) return A3V_ERR_SHAPE;      // the per-kernel form below is for <= 16 rows (the host takes its general path)
   if (fused) {
     float* ssq = (float*)((char*)skinny_ws + A3V_WS_SSQ);
     int* actr = (int*)((char*)skinny_ws + A3V_WS_ATTN_COUNTERS);
-    if (B * H * (int)sizeof(int) > A3V_WS_SSQ - A3V_WS_ATTN_COUNTERS) return A3V_ERR_SHAPE;
-    hipLaunchKernelGGL(rows_ssq_kernel, dim3((dim / 16 * 16 + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h, (int64_t)dim, B, dim, ssq);
-    A3V_LAUNCH_CHECK();
-    for (int i = 0; i < n_layers; ++i) {
-      const a3v_llama_layer& L = layers[i];
-      if ((rc = a3v_gemv_fused(h, dim, w8 ? L.wqkv_q : L.wqkv, dim, L.wqkv_s, qkv, ldq, B, (int)ldq, dim, nullptr, 0, 0, L.attn_norm_w, ssq, eps,
-                               nullptr, 1, cos_sin, L.k_cache, L.vt_cache, H, Hkv, hd, Smax, pos, skinny_ws, stream))) return rc;
-      if ((rc = a3v_attention_decode_fused(qkv, L.k_cache, L.vt_cache, att, B, pos + 1, H, Hkv, hd, strides, attn_scratch, actr, stream))) return rc;
-      if ((rc = a3v_gemv_fused(att, (int64_t)H * hd, w8 ? L.wo_q : L.wo, (int64_t)H * hd, L.wo_s, h, dim, B, dim, H * hd, h, dim, A3V_EPI_RESIDUAL,
-                               nullptr, nullptr, eps, ssq, 0, nullptr, nullptr, nullptr, H, Hkv, hd, Smax, pos, skinny_ws, stream))) return rc;
-      if ((rc = a3v_gemv_fused(h, dim, w8 ? L.w13_q : L.w13, dim, L.w13_s, act, ffn, B, 2 * ffn, dim, nullptr, 0, A3V_EPI_SWIGLU, L.ffn_norm_w, ssq,
-                               eps, nullptr, 0, nullptr, nullptr, nullptr, H, Hkv, hd, Smax, pos, skinny_ws, stream))) return rc;
-      if ((rc = a3v_gemv_fused(act, ffn, w8 ? L.w2_q : L.w2, ffn, L.w2_s, h, dim, B, dim, ffn, h, dim, A3V_EPI_RESIDUAL, nullptr, nullptr, eps, ssq,
-                               0, nullptr, nullptr, nullptr, H, Hkv, hd, Smax, pos, skinny_ws, stream))) return rc;
+    if (Bc * H * (int)sizeof(int) > A3V_WS_SSQ - A3V_WS_ATTN_COUNTERS) return A3V_ERR_SHAPE;
+    const int64_t kv_b = (int64_t)Hkv * Smax * hd;       // elements per batch row of a K / V^T cache
+    for (int b0 = 0; b0 < B; b0 += Bc) {
+      const int nb = B - b0 < Bc ? B - b0 : Bc;
+      bf16_t* hc = (bf16_t*)h + (int64_t)b0 * dim;
+      bf16_t* qc = (bf16_t*)qkv + (int64_t)b0 * ldq;
+      bf16_t* ac = (bf16_t*)att + (int64_t)b0 * H * hd;
+      bf16_t* fc = (bf16_t*)act + (int64_t)b0 * ffn;
+      hipLaunchKernelGGL(rows_ssq_kernel, dim3((dim / 16 * 16 + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)hc, (int64_t)dim, nb, dim, ssq);
+      A3V_LAUNCH_CHECK();
+      for (int i = 0; i < n_layers; ++i) {
+        const a3v_llama_layer& L = layers[i];
+        bf16_t* kc = (bf16_t*)L.k_cache + b0 * kv_b;
+        bf16_t* vc = (bf16_t*)L.vt_cache + b0 * kv_b;
+        if ((rc = a3v_gemv_fused(hc, dim, w8 ? L.wqkv_q : L.wqkv, dim, L.wqkv_s, qc, ldq, nb, (int)ldq, dim, nullptr, 0, 0, L.attn_norm_w, ssq, eps,
+                                 nullptr, 1, cos_sin, kc, vc, H, Hkv, hd, Smax, pos, skinny_ws, stream))) return rc;
+        if ((rc = a3v_attention_decode_fused(qc, kc, vc, ac, nb, pos + 1, H, Hkv, hd, strides, attn_scratch, actr, stream))) return rc;
+        if ((rc = a3v_gemv_fused(ac, (int64_t)H * hd, w8 ? L.wo_q : L.wo, (int64_t)H * hd, L.wo_s, hc, dim, nb, dim, H * hd, hc, dim, A3V_EPI_RESIDUAL,
+                                 nullptr, nullptr, eps, ssq, 0, nullptr, nullptr, nullptr, H, Hkv, hd, Smax, pos, skinny_ws, stream))) return rc;
+        if ((rc = a3v_gemv_fused(hc, dim, w8 ? L.w13_q : L.w13, dim, L.w13_s, fc, ffn, nb, 2 * ffn, dim, nullptr, 0, A3V_EPI_SWIGLU, L.ffn_norm_w, ssq,
+                                 eps, nullptr, 0, nullptr, nullptr, nullptr, H, Hkv, hd, Smax, pos, skinny_ws, stream))) return rc;
+        if ((rc = a3v_gemv_fused(fc, ffn, w8 ? L.w2_q : L.w2, ffn, L.w2_s, hc, dim, nb, dim, ffn, hc, dim, A3V_EPI_RESIDUAL, nullptr, nullptr, eps, ssq,
+                                 0, nullptr, nullptr, nullptr, H, Hkv, hd, Smax, pos, skinny_ws, stream))) return rc;
+      }
     }
     return A3V_OK;
   }

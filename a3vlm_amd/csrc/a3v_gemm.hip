@@ -911,6 +911,7 @@ __device__ __forceinline__ void gemm_epilogue32(f32x16 (&acc)[TM][TN], const Gem
     asm volatile("" ::: "memory");         \
   } while (0)
 
+#ifdef A3V_EXPERIMENTS   // measured and not dispatched: built only with `make EXPERIMENTS=1`
 template <int DBG, int SCHED>
 __global__ __launch_bounds__(512) void gemm_nt_bf16_pp_kernel(GemmArgs p) {
   constexpr int TBM = 256, TBN = 256, NW = 8, WTM = 128, WTN = 64, TM = 8, TN = 4;
@@ -1137,6 +1138,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_pp_kernel(GemmArgs p) {
 #undef PP_READ_FRAGS
 #undef PP_MFMA_ALL
 }
+#endif  // A3V_EXPERIMENTS
 
 // ------------------------------------------------------------------------------------
 // "Ring" form of the ping-pong kernel: the same tile, fragments, MFMA stream and epilogue, but the LDS is cut into three
@@ -1464,6 +1466,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
 //                 cycles per sub-stage: the CU's address unit takes ~16 cycles per piece and the issuing wave stalls
 //   LDS read traffic per K-tile and CU: 128 KiB (8-wave kernels: 192 KiB).
 // ------------------------------------------------------------------------------------
+#ifdef A3V_EXPERIMENTS   // measured and not dispatched: built only with `make EXPERIMENTS=1`
 template <int DBG, int SET = EPI_SET_COMMON>   // DBG 4: cycle stamps; 8: no DMA in the k-loop, 9: no DMA and no fragment reads, 10: every k-loop piece out of bounds = issued but fetching nothing (timing experiments, wrong results)
 __global__ __launch_bounds__(256) void gemm_nt_bf16_w4_kernel(GemmArgs p) {
   constexpr int TBM = 256, TBN = 256, KS = 32, NST = 5;
@@ -1638,6 +1641,7 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_w4_kernel(GemmArgs p) {
 #undef W4_VMCNT
 #undef W4_STAMP
 }
+#endif  // A3V_EXPERIMENTS
 
 // ------------------------------------------------------------------------------------
 // "Overlapped" form: the 8 waves and 128 x 64 wave tiles of the ring kernel on the 32-k sub-stage ring of the kernel above, but
@@ -1650,6 +1654,7 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_w4_kernel(GemmArgs p) {
 //   group 1, iteration s:  rows 0..3: 4 MFMAs (+ pieces on even s) ; vmcnt ; barrier(s) ; rows 4..7: 4 MFMAs + reads ; lgkmcnt(0)
 //   pieces: 16 rows x 64 B; even sub-stages issue stages s+4 and s+5 pairwise (both halves of a 128-B line back to back).
 // ------------------------------------------------------------------------------------
+#ifdef A3V_EXPERIMENTS   // measured and not dispatched: built only with `make EXPERIMENTS=1`
 template <int DBG, int SET = EPI_SET_COMMON>
 __global__ __launch_bounds__(512) void gemm_nt_bf16_ov_kernel(GemmArgs p) {
   constexpr int TBM = 256, TBN = 256, KS = 32, NST = 5;
@@ -1803,6 +1808,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ov_kernel(GemmArgs p) {
 #undef OV_READ
 #undef OV_VMCNT
 }
+#endif  // A3V_EXPERIMENTS
 
 // ------------------------------------------------------------------------------------
 // fp8 (OCP e4m3fn) form of the 256x256 ping-pong kernel: A [M][K] and W [N][K] are fp8 bytes, one k-tile is 128 elements =
@@ -2118,6 +2124,7 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_pp_kernel(GemmArgs p) {
 // transpose reads has to be issued from inline asm (s_mov_b32 m0 / buffer_load_dwordx4 ... offen lds).
 // Same schedule with v_mfma_f32_32x32x16_bf16 (8-pass, higher sustained rate than 16x16x32):
 // wave tile 128x64 = 4x2 tiles of 32x32, 4 k-steps of 16 per K-tile, 32 MFMAs per interval.
+#ifdef A3V_EXPERIMENTS   // measured and not dispatched: built only with `make EXPERIMENTS=1`
 template <int DBG>
 __global__ __launch_bounds__(512) void gemm_nt_bf16_pp32_kernel(GemmArgs p) {
   constexpr int TBM = 256, TBN = 256, NW = 8, WTM = 128, WTN = 64, TM = 4, TN = 2;
@@ -2247,6 +2254,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_pp32_kernel(GemmArgs p) {
 #undef PP_MFMA_ALL
   gemm_epilogue32<TM, TN>(acc, p, m0 + wr * WTM, n0 + wc * WTN, lane);
 }
+#endif  // A3V_EXPERIMENTS
 
 // ------------------------------------------------------------------------------------
 // Skinny GEMM, single launch: one 8-wave block per 16 (or 32 with SwiGLU: gate block + up block)
@@ -2793,6 +2801,19 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(GemmF32Args p) {
 
 extern "C" int a3v_version(void) { return 100; }
 
+// environment switches: see A3V_ENV_INT (a3v_common.h)
+static int g_env_generation = 0;
+int a3v_env_generation() { return g_env_generation; }
+extern "C" int a3v_reload_env(void) { return ++g_env_generation; }
+// bit 0: built with -DA3V_EXPERIMENTS (the measured-and-not-dispatched GEMM kernels and their switches are present)
+extern "C" int a3v_build_flags(void) {
+#ifdef A3V_EXPERIMENTS
+  return 1;
+#else
+  return 0;
+#endif
+}
+
 // Optional scratch for the split-K form of the hybrid dispatch's tail rows (a3v_gemm_set_workspace): the library never
 // allocates, so without it the tail runs as a plain 128x128 launch.
 static float* g_gemm_ws = nullptr;
@@ -2870,47 +2891,29 @@ static int cu_count() {
   }
   return n;
 }
-static bool pp_persistent() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("A3V_GEMM_PERSISTENT"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v != 0;
-}
+static bool pp_persistent() { return A3V_ENV_INT("A3V_GEMM_PERSISTENT", 1) != 0; }   // 0: one block per tile (A/B runs)
+static int nt_store_env() { return A3V_ENV_INT("A3V_GEMM_NT_STORE", 0); }
+static int slow_epi_env() { return A3V_ENV_INT("A3V_GEMM_FAST_EPI", 1) == 0 ? 1 : 0; }   // 0: every tile through the general epilogue
 
-static bool pp_ring() {       // the 160-KiB ring form of the ping-pong kernel (A3V_GEMM_RING=0: the two-stage kernel, for A/B runs)
-  const char* e = getenv("A3V_GEMM_RING");         // read per launch: tuning scripts flip it inside one process
-  return !(e && e[0] == '0');
-}
-
+#ifdef A3V_EXPERIMENTS
+static bool pp_ring() { return A3V_ENV_INT("A3V_GEMM_RING", 1) != 0; }       // 0: the two-stage ping-pong kernel
 static unsigned* xsync_buffer(hipStream_t st) {   // A3V_GEMM_LOCKSTEP=1: eight counters, zeroed on the launch stream before every launch
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("A3V_GEMM_LOCKSTEP"); on = (e && e[0] == '1') ? 1 : 0; }
-  if (!on) return nullptr;
+  if (!A3V_ENV_INT("A3V_GEMM_LOCKSTEP", 0)) return nullptr;
   static unsigned* buf = nullptr;
   if (!buf && hipMalloc(&buf, 64) != hipSuccess) { buf = nullptr; return nullptr; }
   if (hipMemsetAsync(buf, 0, 64, st) != hipSuccess) return nullptr;
   return buf;
 }
-
-static int w4_env() {          // A3V_GEMM_W4=1: the one-wave-per-SIMD kernel instead of the ring (2: with cycle stamps); read per launch
-  const char* e = getenv("A3V_GEMM_W4");
-  return e ? atoi(e) : 0;
-}
-
-static int nt_store_env() {
-  const char* e = getenv("A3V_GEMM_NT_STORE");
-  return e ? atoi(e) : 0;
-}
-
-static int slow_epi_env() {    // A3V_GEMM_FAST_EPI=0: every tile through the general epilogue (read per launch)
-  const char* e = getenv("A3V_GEMM_FAST_EPI");
-  return (e && e[0] == '0') ? 1 : 0;
-}
+static int w4_env() { return A3V_ENV_INT("A3V_GEMM_W4", 0); }   // 1: one-wave-per-SIMD kernel, 20: overlapped form, ... (tools/gemm_w4_ab.py)
+#else
+static bool pp_ring() { return true; }
+#endif
 
 template <bool A_ROWS>
 static void launch_tn(dim3 grid, hipStream_t st, const GemmArgs& q0) {
   GemmArgs q = q0;
   q.slow_epi = slow_epi_env(); q.nt_store = nt_store_env();
-  { const char* e = getenv("A3V_GEMM_XMAP_TN"); q.xmap = e ? atoi(e) : 1; }   // =0: one contiguous run of tiles per XCD (A/B); 1: round-major; +2: serpentine; +4: 16 x 16 super-tiles where they fit
+  q.xmap = A3V_ENV_INT("A3V_GEMM_XMAP_TN", 1);   // =0: one contiguous run of tiles per XCD (A/B); 1: round-major; +2: serpentine; +4: 16 x 16 super-tiles where they fit
   if (!((q.xmap & 4) && (q.tiles_m & 15) == 0 && (q.tiles_n & 15) == 0)) q.xmap &= ~4;
   hipLaunchKernelGGL(gemm_tn_bf16_pp_kernel<A_ROWS>, grid, dim3(512), 0, st, q);
 }
@@ -2961,55 +2964,66 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
     const int nt = q.tiles_m * q.tiles_n;
     // the ping-pong kernel is persistent: one block per CU walks its tiles (A3V_GEMM_PERSISTENT=0: one block per tile, for A/B runs)
     const dim3 g(cfg == 257 && pp_persistent() ? std::min(nt, cu_count()) : nt), b(512);
-    if (cfg == 256) hipLaunchKernelGGL((gemm_nt_bf16_kernel<256, 256, 2, 4>), g, b, 0, st, q);
-    else if (cfg == 258) hipLaunchKernelGGL(gemm_nt_bf16_pp32_kernel<0>, g, b, 0, st, q);
-    else {
+    if (cfg == 256) { hipLaunchKernelGGL((gemm_nt_bf16_kernel<256, 256, 2, 4>), g, b, 0, st, q); return; }
+    q.xmap = (g.x & 63) ? 0 : A3V_ENV_INT("A3V_GEMM_XMAP", 1);   // =0: one contiguous run of tiles per XCD (A/B)
+    if (!((q.xmap & 4) && g.x == 256 && (q.tiles_m & 15) == 0 && (q.tiles_n & 15) == 0)) q.xmap &= ~4;
+    q.skew = 0; q.xsync = nullptr;
+#ifdef A3V_EXPERIMENTS
+    if (cfg == 258) { hipLaunchKernelGGL(gemm_nt_bf16_pp32_kernel<0>, g, b, 0, st, q); return; }
+    {
       int dbg = q.dbg;
       if (dbg == 0 && pp_ring()) dbg = 5;
-      { const char* e = getenv("A3V_GEMM_SKEW"); q.skew = e ? atoi(e) : 0; }
+      q.skew = A3V_ENV_INT("A3V_GEMM_SKEW", 0);
       q.xsync = (dbg == 5 && g.y == 1) ? xsync_buffer(st) : nullptr;
-      { const char* e = getenv("A3V_GEMM_XMAP"); q.xmap = (g.x & 63) ? 0 : e ? atoi(e) : 1;
-        if (!((q.xmap & 4) && g.x == 256 && (q.tiles_m & 15) == 0 && (q.tiles_n & 15) == 0)) q.xmap &= ~4; }   // =0: one contiguous run of tiles per XCD (A/B)
-      switch (dbg) {
-        case 0: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<0, 0>), g, b, 0, st, q); break;
-        case 5:
-          if (q.epi & GEMM_EPI_ROPEKV) hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0, true, EPI_SET_ROPE>), g, b, 0, st, q);
-          else if (q.epi & (A3V_EPI_BIAS | A3V_EPI_GELU | A3V_EPI_QUICKGELU))
-            hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0, true, EPI_SET_COMMON | EPI_SET_PRE>), g, b, 0, st, q);
-          else if (w4_env() == 1) hipLaunchKernelGGL((gemm_nt_bf16_w4_kernel<0>), g, dim3(256), 0, st, q);
-          else if (w4_env() == 2) hipLaunchKernelGGL((gemm_nt_bf16_w4_kernel<4>), g, dim3(256), 0, st, q);   // cycle stamps into `bias`
-          else if (w4_env() == 8) hipLaunchKernelGGL((gemm_nt_bf16_w4_kernel<8>), g, dim3(256), 0, st, q);
-          else if (w4_env() == 9) hipLaunchKernelGGL((gemm_nt_bf16_w4_kernel<9>), g, dim3(256), 0, st, q);
-          else if (w4_env() == 10) hipLaunchKernelGGL((gemm_nt_bf16_w4_kernel<10>), g, dim3(256), 0, st, q);   // every k-loop piece out of bounds
-          else if (w4_env() == 7) hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<7, false, 0>), g, b, 0, st, q);   // ring kernel, cache-resident operands (timing experiment, wrong results)
-          else if (w4_env() == 20) hipLaunchKernelGGL((gemm_nt_bf16_ov_kernel<0>), g, b, 0, st, q);            // overlapped 8-wave form
-          else if (w4_env() == 28) hipLaunchKernelGGL((gemm_nt_bf16_ov_kernel<8>), g, b, 0, st, q);
-          else if (w4_env() == 29) hipLaunchKernelGGL((gemm_nt_bf16_ov_kernel<9>), g, b, 0, st, q);
-          else if (w4_env() == 30) hipLaunchKernelGGL((gemm_nt_bf16_ov_kernel<10>), g, b, 0, st, q);
-          else if (w4_env() == 31) hipLaunchKernelGGL((gemm_nt_bf16_ov_kernel<11>), g, b, 0, st, q);
-          else if (w4_env() == 32) hipLaunchKernelGGL((gemm_nt_bf16_ov_kernel<12>), g, b, 0, st, q);
-          else if (w4_env() == 33) hipLaunchKernelGGL((gemm_nt_bf16_ov_kernel<13>), g, b, 0, st, q);
-          else hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0>), g, b, 0, st, q);
-          break;
-        case 11: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0, false>), g, b, 0, st, q); break;   // ring, direct (unstaged) epilogue stores
-        case 12: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0, true, EPI_SET_COMMON, true>), g, b, 0, st, q); break;   // ring, group 0 waits for its W half at the end of L
-        case 13: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<4, false, 0, true, EPI_SET_COMMON, true>), g, b, 0, st, q); break;   // ... with cycle stamps
-        case 14: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 1, true, EPI_SET_COMMON, true>), g, b, 0, st, q); break;   // ... + barrier 1 tile row before the last MFMA
-        case 15: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 2, true, EPI_SET_COMMON, true>), g, b, 0, st, q); break;   // ... 2 tile rows
-        case 8: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 4, true, EPI_SET_COMMON, true>), g, b, 0, st, q); break;    // ... 4 tile rows
-        case 7: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<0, 0>), g, b, 0, st, q); break;   // two-stage kernel, for A/B runs
-        case 9: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, true, 0>), g, b, 0, st, q); break;   // ring, 32x32x16 MFMA
-        case 10: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<4, true, 0>), g, b, 0, st, q); break;   // 32x32x16, stamps
-        case 6: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<4, false, 0>), g, b, 0, st, q); break;   // cycle stamps (tools/ring_stamps.py)
-#ifdef A3V_ABLATION
-        case 1: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<1, 0>), g, b, 0, st, q); break;
-        case 2: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<2, 0>), g, b, 0, st, q); break;
-        case 3: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<3, 0>), g, b, 0, st, q); break;
-        case 4: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<4, 0>), g, b, 0, st, q); break;
-#endif
-        default: break;
+      if (dbg != 5 || w4_env() != 0) {
+        switch (dbg) {
+          case 0: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<0, 0>), g, b, 0, st, q); break;
+          case 5:
+            if (q.epi & GEMM_EPI_ROPEKV) hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0, true, EPI_SET_ROPE>), g, b, 0, st, q);
+            else if (q.epi & (A3V_EPI_BIAS | A3V_EPI_GELU | A3V_EPI_QUICKGELU))
+              hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0, true, EPI_SET_COMMON | EPI_SET_PRE>), g, b, 0, st, q);
+            else if (w4_env() == 1) hipLaunchKernelGGL((gemm_nt_bf16_w4_kernel<0>), g, dim3(256), 0, st, q);
+            else if (w4_env() == 2) hipLaunchKernelGGL((gemm_nt_bf16_w4_kernel<4>), g, dim3(256), 0, st, q);   // cycle stamps into `bias`
+            else if (w4_env() == 8) hipLaunchKernelGGL((gemm_nt_bf16_w4_kernel<8>), g, dim3(256), 0, st, q);
+            else if (w4_env() == 9) hipLaunchKernelGGL((gemm_nt_bf16_w4_kernel<9>), g, dim3(256), 0, st, q);
+            else if (w4_env() == 10) hipLaunchKernelGGL((gemm_nt_bf16_w4_kernel<10>), g, dim3(256), 0, st, q);   // every k-loop piece out of bounds
+            else if (w4_env() == 7) hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<7, false, 0>), g, b, 0, st, q);   // ring kernel, cache-resident operands (timing experiment, wrong results)
+            else if (w4_env() == 20) hipLaunchKernelGGL((gemm_nt_bf16_ov_kernel<0>), g, b, 0, st, q);            // overlapped 8-wave form
+            else if (w4_env() == 28) hipLaunchKernelGGL((gemm_nt_bf16_ov_kernel<8>), g, b, 0, st, q);
+            else if (w4_env() == 29) hipLaunchKernelGGL((gemm_nt_bf16_ov_kernel<9>), g, b, 0, st, q);
+            else if (w4_env() == 30) hipLaunchKernelGGL((gemm_nt_bf16_ov_kernel<10>), g, b, 0, st, q);
+            else if (w4_env() == 31) hipLaunchKernelGGL((gemm_nt_bf16_ov_kernel<11>), g, b, 0, st, q);
+            else if (w4_env() == 32) hipLaunchKernelGGL((gemm_nt_bf16_ov_kernel<12>), g, b, 0, st, q);
+            else if (w4_env() == 33) hipLaunchKernelGGL((gemm_nt_bf16_ov_kernel<13>), g, b, 0, st, q);
+            else hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0>), g, b, 0, st, q);
+            break;
+          case 11: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0, false>), g, b, 0, st, q); break;   // ring, direct (unstaged) epilogue stores
+          case 12: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0, true, EPI_SET_COMMON, true>), g, b, 0, st, q); break;   // ring, group 0 waits for its W half at the end of L
+          case 13: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<4, false, 0, true, EPI_SET_COMMON, true>), g, b, 0, st, q); break;   // ... with cycle stamps
+          case 14: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 1, true, EPI_SET_COMMON, true>), g, b, 0, st, q); break;   // ... + barrier 1 tile row before the last MFMA
+          case 15: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 2, true, EPI_SET_COMMON, true>), g, b, 0, st, q); break;   // ... 2 tile rows
+          case 8: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 4, true, EPI_SET_COMMON, true>), g, b, 0, st, q); break;    // ... 4 tile rows
+          case 7: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<0, 0>), g, b, 0, st, q); break;   // two-stage kernel, for A/B runs
+          case 9: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, true, 0>), g, b, 0, st, q); break;   // ring, 32x32x16 MFMA
+          case 10: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<4, true, 0>), g, b, 0, st, q); break;   // 32x32x16, stamps
+          case 6: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<4, false, 0>), g, b, 0, st, q); break;   // cycle stamps (tools/ring_stamps.py)
+  #ifdef A3V_ABLATION
+          case 1: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<1, 0>), g, b, 0, st, q); break;
+          case 2: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<2, 0>), g, b, 0, st, q); break;
+          case 3: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<3, 0>), g, b, 0, st, q); break;
+          case 4: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<4, 0>), g, b, 0, st, q); break;
+  #endif
+          default: break;
+        }
+        return;
       }
     }
+#endif
+    // the product path: the ring kernel, instantiated per set of fast epilogue forms
+    if (q.epi & GEMM_EPI_ROPEKV) hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0, true, EPI_SET_ROPE>), g, b, 0, st, q);
+    else if (q.epi & (A3V_EPI_BIAS | A3V_EPI_GELU | A3V_EPI_QUICKGELU))
+      hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0, true, EPI_SET_COMMON | EPI_SET_PRE>), g, b, 0, st, q);
+    else hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0>), g, b, 0, st, q);
   };
   const int64_t bytesA = ((int64_t)(M - 1) * lda + K) * 2, bytesW = ((int64_t)(N - 1) * ldw + K) * 2;
   const bool desc_ok = bytesA < (1LL << 31) && bytesW < (1LL << 31);   // buffer descriptors: 32-bit offsets
@@ -3054,7 +3068,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
       if (S3 > 8) S3 = 8;
       while (S3 > 1 && K / 64 < 8 * S3) --S3;
       const int okbits = A3V_EPI_BIAS | A3V_EPI_RESIDUAL | A3V_EPI_RES_F32 | A3V_EPI_OUT_F32;
-      static const bool on = [] { const char* e = getenv("A3V_GEMM_RING_SPLIT"); return !(e && e[0] == '0'); }();
+      const bool on = A3V_ENV_INT("A3V_GEMM_RING_SPLIT", 1) != 0;
       if (on && eligible && S3 >= 3 && !(p.epi & ~okbits) && pp_ring() && pp_persistent() && g_gemm_ws && N % 4 == 0 &&
           (int64_t)S3 * M * N * 4 <= g_gemm_ws_bytes && (!(p.epi & A3V_EPI_BIAS) || !(reinterpret_cast<uintptr_t>(bias) & 7)))
         c_spl = 1.0 / S3 + 0.2;
@@ -3098,7 +3112,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
       int S2 = big_tiles > 0 ? cu_count() / big_tiles : 0;
       if (S2 > 8) S2 = 8;
       while (S2 > 1 && K / 64 < 8 * S2) --S2;
-      static const bool ring_tail = [] { const char* e = getenv("A3V_GEMM_RING_TAIL"); return !(e && e[0] == '0'); }();
+      const bool ring_tail = A3V_ENV_INT("A3V_GEMM_RING_TAIL", 1) != 0;
       if (ring_tail && pp_ring() && pp_persistent() && S2 >= 3 && !(p.epi & ~simple) && g_gemm_ws && (int64_t)S2 * r.M * N * 4 <= g_gemm_ws_bytes && N % 4 == 0) {
         GemmArgs t = r;
         t.C = g_gemm_ws; t.ldc = N; t.res = nullptr; t.bias = nullptr;
@@ -3198,8 +3212,7 @@ static bool gemv_launch(GemvArgs& g, void* ws, hipStream_t st) {
   const bool pro = g.norm_w != nullptr;
   void (*kern)(GemvArgs);
   // weights are streamed once per step by ONE CU each: non-temporal policy on their LDS-DMA (A3V_GEMV_NT=0: default policy, A/B)
-  const char* nte = getenv("A3V_GEMV_NT");
-  const bool nt = !(nte && nte[0] == '0');
+  const bool nt = A3V_ENV_INT("A3V_GEMV_NT", 1) != 0;
 #define GEMV_PICK(AUX)                                                                                                      \
   (w8 ? (arows == 8 ? (pro ? gemv_dma_bf16_kernel<8, true, true, AUX> : gemv_dma_bf16_kernel<8, false, true, AUX>)          \
                     : (pro ? gemv_dma_bf16_kernel<16, true, true, AUX> : gemv_dma_bf16_kernel<16, false, true, AUX>))       \
@@ -3335,7 +3348,7 @@ extern "C" int a3v_gemm_nt_splitk(const void* A, int64_t lda, const void* W, int
   p.lda = lda; p.ldw = ldw; p.ldc = N; p.ldr = 0;
   p.M = M; p.N = N; p.K = K; p.epi = A3V_EPI_OUT_F32 | GEMM_EPI_RAW; p.dbg = 0;
   p.c_split = (int64_t)M * N * 4;
-  static const int narrow = [] { const char* e = getenv("A3V_SKINNY_NARROW"); return e ? atoi(e) : 1; }();
+  const int narrow = A3V_ENV_INT("A3V_SKINNY_NARROW", 1);
   if (N <= 64 && M >= 512 && narrow) {
     // adapter-sized output (rank pad 64): 256 x 64 tiles -- 80 % of the LDS-DMA traffic is the streamed operand (50 % with the
     // 128 x 128 tile, whose second operand tile is half padding)
@@ -3399,7 +3412,7 @@ static int gemm_tn_impl(const void* At, int64_t lda, const void* Wt, int64_t ldw
   while (S > 1 && ((K + 63) / 64) < 16 * S) --S;
   if (S < 1) S = 1;
   const int m_big = (int)(mt_h * 256);
-  static const bool tail_on = [] { const char* e = getenv("A3V_TN_TAIL"); return !(e && e[0] == '0'); }();
+  const bool tail_on = A3V_ENV_INT("A3V_TN_TAIL", 1) != 0;
   if (tail_on && mt_h >= 1 && m_big < M && S > 1 && rem_tiles * 4 < 3 * ncu && g_gemm_ws && (int64_t)S * (M - m_big) * N * 4 <= g_gemm_ws_bytes) {
     GemmArgs q = p;
     q.M = m_big; q.tiles_m = (int)mt_h;

@@ -653,8 +653,7 @@ __global__ __launch_bounds__(256) void sumsq_partials_kernel(const float* __rest
 extern "C" int a3v_sumsq_partials(const float* x, int64_t n, float* out, void* stream) {
   if (!x || !out || n <= 0) return A3V_ERR_ARG;
   if ((uintptr_t)x & 15) return A3V_ERR_SHAPE;
-  const char* e = getenv("A3V_SUMSQ_BLOCKS");                 // launch width (read per launch): default 1024 = one block per slot
-  int nb = e ? atoi(e) : A3V_SUMSQ_SLOTS;
+  int nb = A3V_ENV_INT("A3V_SUMSQ_BLOCKS", A3V_SUMSQ_SLOTS);                 // launch width: default 1024 = one block per slot
   if (nb < 1 || nb > A3V_SUMSQ_SLOTS) nb = A3V_SUMSQ_SLOTS;
   // short ranges (the norm weights left over next to the GEMM-summed matrices): one block per slot that has data -- 1024 blocks for
   // 8 K floats only queue behind the GEMM the call runs beside (same sums: slot s always adds the same vectors)
@@ -769,8 +768,7 @@ extern "C" int a3v_layernorm_bwd(const void* x, int64_t ldx, const float* w, con
 
 // cache policy of the streaming training kernels (A3V_STREAM_NT: bit 0 non-temporal loads, bit 1 stores; read per launch)
 static int stream_nt() {
-  const char* e = getenv("A3V_STREAM_NT");
-  return e ? (atoi(e) & 3) : 3;      // default: both (SwiGLU forward 102 -> 91 us, backward 174 -> 154 us at 7B size, tools/stream_nt_bench.py)
+  return A3V_ENV_INT("A3V_STREAM_NT", 3) & 3;      // default: both (SwiGLU forward 102 -> 91 us, backward 174 -> 154 us at 7B size, tools/stream_nt_bench.py)
 }
 
 extern "C" int a3v_swiglu_fwd(const void* gu, int64_t ldg, void* act, int64_t lda, int rows, int F, int interleaved, int dtype, void* stream) {
@@ -988,8 +986,7 @@ extern "C" int a3v_adamw_scaled(float* param, const float* grad, float* exp_avg,
   if (blocks < 1) blocks = 1;
   // every byte of p / g / m / v / image is touched once per step: non-temporal loads AND stores (default 3) are 6.8 % faster than
   // the default cache policy (271.6 -> 253.2 us on a 45-M-element tensor, tools/adamw_bench.py; either alone: nothing)
-  const char* nte = getenv("A3V_ADAMW_NT");               // 0..3 (bit 0 loads, bit 1 stores), read per launch for A/B runs
-  const int nt = nte ? atoi(nte) : 3;
+  const int nt = A3V_ENV_INT("A3V_ADAMW_NT", 3);               // 0..3 (bit 0 loads, bit 1 stores; A/B runs)
 #define A3V_ADAMW_LAUNCH(V) hipLaunchKernelGGL(adamw_kernel<V>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n4, n, decay, \
                      beta1, beta2, step_size, inv_bc2_sqrt, eps, (bf16_t*)bf16_image, grad_scale)
   switch (nt & 3) {

@@ -22,6 +22,8 @@ P, I, L, F = c_void_p, c_int, c_int64, c_float
 # name -> (restype, argtypes); mirrors include/a3vlm_hip.h one to one
 SIGNATURES = {
     "a3v_version": (I, []),
+    "a3v_reload_env": (I, []),
+    "a3v_build_flags": (I, []),
     "a3v_gemm_nt": (I, [P, L, P, L, P, L, I, I, I, P, P, L, I, I, P]),
     "a3v_gemm_qkv_rope": (I, [P, L, P, L, I, P, L, P, P, P, L, P, L, P, I, I, I, I, I, I, I, I, P]),
     "a3v_gemm_nt_fp8": (I, [P, L, P, P, L, P, P, L, I, I, I, P, P, L, I, P]),
@@ -111,6 +113,36 @@ def load() -> ctypes.CDLL:
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def has_experiments() -> bool:
+    """True when the library was built with `make EXPERIMENTS=1` (the measured-and-not-dispatched GEMM kernels exist)."""
+    return bool(load().a3v_build_flags() & 1)
+
+
+class env:
+    """``with lib.env(A3V_GEMM_FAST_EPI="0"): ...`` -- set A3V_* switches for a block and have the library re-read them (the
+    library caches every switch after its first read), restoring both on exit.  A/B runs and equality tests only."""
+
+    def __init__(self, **kw):
+        self.kw = {k: str(v) for k, v in kw.items()}
+        self.old = {}
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            self.old[k] = os.environ.get(k)
+            os.environ[k] = v
+        load().a3v_reload_env()
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        load().a3v_reload_env()
+        return False
 
 
 class A3VError(RuntimeError):

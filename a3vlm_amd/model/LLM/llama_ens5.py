@@ -29,6 +29,7 @@ from typing import Callable, Dict, List, Optional
 import torch
 from torch import nn
 
+from ... import lib as _lib
 from ... import ops
 
 
@@ -485,9 +486,10 @@ class Transformer(nn.Module):
         att = self._buf("att", (B, H * hd))
         act = self._buf("act", (B, self.ffn))
         scratch = self._buf("attn_scratch", (2 * ops.attention_scratch_floats(B, H, hd, a.max_seq_len + 64),), torch.float32)
-        sws = self._skinny_ws(B, max((H + 2 * Hkv) * hd, 2 * self.ffn, a.dim), max(a.dim, self.ffn))
+        Bc = B if B <= 16 else (B + 1) // 2          # 17..32 rows run as two row chunks inside the C call
+        sws = self._skinny_ws(Bc, max((H + 2 * Hkv) * hd, 2 * self.ffn, a.dim), max(a.dim, self.ffn))
         for (n_, k_) in (((H + 2 * Hkv) * hd, a.dim), (a.dim, H * hd), (2 * self.ffn, a.dim), (a.dim, self.ffn)):
-            sws = self._skinny_ws(B, n_, k_)
+            sws = self._skinny_ws(Bc, n_, k_)
         rc = _l.load().a3v_llama_decode_step(self._layer_tab, self.n_layers, h.data_ptr(), xn.data_ptr(), qkv.data_ptr(),
                                              att.data_ptr(), act.data_ptr(), scratch.data_ptr(), sws.data_ptr(), self._cos_sin_dev().data_ptr(),
                                              B, a.dim, H, Hkv, hd, self.ffn, smax, pos, a.norm_eps,
@@ -718,9 +720,16 @@ class Transformer(nn.Module):
         ops.embed_assemble(tokens.contiguous(), self.tok_embeddings.weight, h, B, T, W, a.dim)
         if image is not None:
             self.encode_image_into(h, image, B, S, qformer_feats, extra_feats, slots)
-        if (S == 1 and B <= 16 and self._dtype == torch.bfloat16 and self.head_dim in (64, 128) and a.dim % 32 == 0 and self.ffn % 32 == 0
+        if (S == 1 and (B <= 16 or (B <= 32 and a.dim % 128 == 0 and self.ffn % 128 == 0)) and self._dtype == torch.bfloat16
+                and self.head_dim in (64, 128) and a.dim % 32 == 0 and self.ffn % 32 == 0
                 and not getattr(self, "_per_kernel_decode", False)):     # test hook: run the step kernel by kernel
-            self._decode_step(h, B, start_pos)
+            try:
+                self._decode_step(h, B, start_pos)
+            except _lib.A3VError:
+                if B <= 16:
+                    raise
+                # 17..32 rows need the fused GEMV forms (two row chunks); a geometry they do not take goes through the general kernels
+                self._decoder_layers(h, B, S, start_pos, rope0, self._k_cache, self._vt_cache, True)
         else:
             self._decoder_layers(h, B, S, start_pos, rope0, self._k_cache, self._vt_cache, True)
         last = h.view(B, S, a.dim)[:, -1, :]            # strided rows, no copy

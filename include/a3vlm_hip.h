@@ -59,6 +59,14 @@ enum {
 
 int a3v_version(void);
 
+/* A3V_* environment switches (A/B runs, tuning scripts, equality tests) are read once per call site and
+ * cached: a process that changes one after its first launch calls this to have them re-read.  Returns the new generation.
+ * (No reference counterpart: the reference has no native code.) */
+int a3v_reload_env(void);
+/* bit 0: the library was built with -DA3V_EXPERIMENTS (`make EXPERIMENTS=1`): the measured-and-not-dispatched GEMM kernels
+ * (two-stage ping-pong, one wave per SIMD, overlapped, 32x32x16 forms, stamped builds) and their switches exist. */
+int a3v_build_flags(void);
+
 /* C[M,N] = epilogue(A[M,K] @ W[N,K]^T).  Replaces every F.linear on the path:
  * wq/wk/wv/wo (LLM/llama_ens5.py:63-90,112,169), w1/w2/w3 (:202-217), output (:267-269,
  * 486,530), visual_proj[0] (:330-333), the open_clip in_proj/out_proj/c_fc/c_proj, and

@@ -274,7 +274,8 @@ def test_vit_single_crop_geometry_bf16():
     assert rel_err(outb, want.numpy()) < 5e-2
 
 
-@pytest.mark.parametrize("heads,kv,dim,B", [(4, 4, 256, 5), (4, 2, 512, 8), (2, 1, 256, 1), (8, 8, 512, 11), (2, 2, 128, 2)])
+@pytest.mark.parametrize("heads,kv,dim,B", [(4, 4, 256, 5), (4, 2, 512, 8), (2, 1, 256, 1), (8, 8, 512, 11), (2, 2, 128, 2),
+                                            (4, 2, 512, 27), (4, 4, 256, 32)])      # 17..32 rows: two row chunks inside the C call
 def test_fused_decode_step_matches_per_kernel_path(heads, kv, dim, B):
     """a3v_llama_decode_step's fused form (RMSNorm folded into the consuming GEMV, RoPE + KV write in the QKV epilogue,
     attention combine in-kernel; dim = 128 has a single 128-wide K block, so the step falls back to the per-kernel sequence

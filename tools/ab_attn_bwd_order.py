@@ -19,6 +19,7 @@ for (B, S, H, hd) in [(8, 1091, 32, 128), (8, 2182, 32, 128)]:
     for r in range(5):
         for g in groups:
             os.environ["A3V_ATTN_HEAD_GROUP"] = str(g)
+            __import__("a3vlm_amd.lib", fromlist=["load"]).load().a3v_reload_env()   # the library caches its switches
             f()
             cur = (dq.clone(), dk.clone(), dv.clone())
             if ref is None:
@@ -31,3 +32,4 @@ for (B, S, H, hd) in [(8, 1091, 32, 128), (8, 2182, 32, 128)]:
             times[g].append(e0.elapsed_time(e1) / 3 * 1e3)
     print(json.dumps(dict(B=B, S=S, H=H, **{f"g{g}_us": round(sorted(t)[2], 1) for g, t in times.items()})), flush=True)
 os.environ.pop("A3V_ATTN_HEAD_GROUP", None)
+__import__("a3vlm_amd.lib", fromlist=["load"]).load().a3v_reload_env()   # the library caches its switches

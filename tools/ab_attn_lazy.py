@@ -20,6 +20,7 @@ for (B, S, H, hd, causal, amp) in [(8, 1091, 32, 128, True, 1.0), (8, 1091, 32, 
     for r in range(5):
         for v in ("1", "0"):
             os.environ["A3V_ATTN_LAZY"] = v
+            __import__("a3vlm_amd.lib", fromlist=["load"]).load().a3v_reload_env()   # the library caches its switches
             f = lambda: ops.attention_lse(q, k, vt, o, lse, B, S, S, H, H, hd, st, causal)
             o.zero_(); f()
             if v not in errs:
@@ -41,3 +42,4 @@ for (B, S, H, hd, causal, amp) in [(8, 1091, 32, 128, True, 1.0), (8, 1091, 32, 
     print(json.dumps(dict(B=B, S=S, H=H, hd=hd, q_scale=amp, lazy_us=round(sorted(times["1"])[2], 1), every_tile_us=round(sorted(times["0"])[2], 1),
                           relerr_lse_lazy=errs["1"], relerr_lse_every=errs["0"])), flush=True)
 os.environ.pop("A3V_ATTN_LAZY", None)
+__import__("a3vlm_amd.lib", fromlist=["load"]).load().a3v_reload_env()   # the library caches its switches

@@ -18,6 +18,7 @@ for (B, S, H, hd) in [(8, 1091, 32, 128), (8, 2182, 32, 128), (8, 1967, 32, 128)
     for r in range(5):
         for g in groups:
             os.environ["A3V_ATTN_HEAD_GROUP"] = str(g)
+            __import__("a3vlm_amd.lib", fromlist=["load"]).load().a3v_reload_env()   # the library caches its switches
             f = lambda: ops.attention_lse(q, k, vt, o, lse, B, S, S, H, H, hd, st, True)
             f()
             if ref is None:
@@ -32,3 +33,4 @@ for (B, S, H, hd) in [(8, 1091, 32, 128), (8, 2182, 32, 128), (8, 1967, 32, 128)
     print(json.dumps(dict(B=B, S=S, H=H, **{f"g{g}_us": round(sorted(t)[2], 1) for g, t in times.items()},
                           **{f"g{g}_tf": round(fl / sorted(t)[2] / 1e6, 1) for g, t in times.items()})), flush=True)
 os.environ.pop("A3V_ATTN_HEAD_GROUP", None)
+__import__("a3vlm_amd.lib", fromlist=["load"]).load().a3v_reload_env()   # the library caches its switches

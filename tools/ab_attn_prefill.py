@@ -15,6 +15,7 @@ for (B, S, H, hd, causal) in [(8, 1091, 32, 128, True), (8, 2182, 32, 128, True)
     outs, times = {}, {"1": [], "0": []}
     for v in ("1", "0"):
         os.environ["A3V_ATTN_PSWAP"] = v
+        __import__("a3vlm_amd.lib", fromlist=["load"]).load().a3v_reload_env()   # the library caches its switches
         outs[v] = torch.empty_like(q)
         lse = torch.empty(B, H, S, device=dev)
         ops.attention_lse(q, k, vt, outs[v], lse, B, S, S, H, H, hd, st, causal)
@@ -23,6 +24,7 @@ for (B, S, H, hd, causal) in [(8, 1091, 32, 128, True), (8, 2182, 32, 128, True)
     for r in range(5):
         for v in ("1", "0"):
             os.environ["A3V_ATTN_PSWAP"] = v
+            __import__("a3vlm_amd.lib", fromlist=["load"]).load().a3v_reload_env()   # the library caches its switches
             f = lambda: ops.attention_lse(q, k, vt, o, lse, B, S, S, H, H, hd, st, causal)
             f()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

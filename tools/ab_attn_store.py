@@ -17,6 +17,7 @@ for (B, S, H, hd, causal) in [(8, 1091, 32, 128, True), (8, 2182, 32, 128, True)
     for r in range(5):
         for v in ("1", "0"):
             os.environ["A3V_ATTN_STAGED_O"] = v
+            __import__("a3vlm_amd.lib", fromlist=["load"]).load().a3v_reload_env()   # the library caches its switches
             f = lambda: ops.attention_lse(q, k, vt, o, lse, B, S, S, H, H, hd, st, causal)
             o.zero_(); f()
             if ref is None:
@@ -29,3 +30,4 @@ for (B, S, H, hd, causal) in [(8, 1091, 32, 128, True), (8, 2182, 32, 128, True)
             times[v].append(e0.elapsed_time(e1) / 5 * 1e3)
     print(json.dumps(dict(B=B, S=S, H=H, hd=hd, staged_us=round(sorted(times["1"])[2], 1), per_lane_us=round(sorted(times["0"])[2], 1))), flush=True)
 os.environ.pop("A3V_ATTN_STAGED_O", None)
+__import__("a3vlm_amd.lib", fromlist=["load"]).load().a3v_reload_env()   # the library caches its switches

@@ -24,6 +24,7 @@ res = {}
 for r in range(4):
     for nt in ("0", "1", "2", "3"):
         os.environ["A3V_ADAMW_NT"] = nt
+        __import__("a3vlm_amd.lib", fromlist=["load"]).load().a3v_reload_env()   # the library caches its switches
         for i in range(3): f(i)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

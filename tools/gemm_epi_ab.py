@@ -14,8 +14,10 @@ def both(fn):
     outs = []
     for fast in ("1", "0"):
         os.environ["A3V_GEMM_FAST_EPI"] = fast
+        __import__("a3vlm_amd.lib", fromlist=["load"]).load().a3v_reload_env()   # the library caches its switches
         outs.append(fn())
     os.environ["A3V_GEMM_FAST_EPI"] = "1"
+    __import__("a3vlm_amd.lib", fromlist=["load"]).load().a3v_reload_env()   # the library caches its switches
     return outs
 
 
@@ -121,6 +123,7 @@ for (name, fam, M, N, K, epi) in shapes:
     for r in range(6):
         for fast in ("1", "0"):
             os.environ["A3V_GEMM_FAST_EPI"] = fast
+            __import__("a3vlm_amd.lib", fromlist=["load"]).load().a3v_reload_env()   # the library caches its switches
             f(a, w, out, **kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -133,3 +136,4 @@ for (name, fam, M, N, K, epi) in shapes:
     tf = {k: fl / sorted(v)[3] / 1e12 for k, v in times.items()}
     print(json.dumps({"case": name, "fast_tf": round(tf["1"], 1), "general_tf": round(tf["0"], 1), "ratio": round(tf["1"] / tf["0"], 3)}), flush=True)
 os.environ["A3V_GEMM_FAST_EPI"] = "1"
+__import__("a3vlm_amd.lib", fromlist=["load"]).load().a3v_reload_env()   # the library caches its switches

@@ -34,6 +34,7 @@ for (name, fam, M, N, K, epi) in cases:
     for r in range(6):
         for v in ("0", "1"):
             os.environ["A3V_GEMM_NT_STORE"] = v
+            __import__("a3vlm_amd.lib", fromlist=["load"]).load().a3v_reload_env()   # the library caches its switches
             f(a, w, out, **kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -44,3 +45,4 @@ for (name, fam, M, N, K, epi) in cases:
     m = {v: sorted(t)[3] for v, t in ts.items()}
     print(json.dumps({"case": name, "plain_us": round(m["0"] * 1e3, 1), "nt_us": round(m["1"] * 1e3, 1), "nt_tf": round(fl / m["1"] / 1e9, 1), "ratio": round(m["0"] / m["1"], 3)}), flush=True)
 os.environ.pop("A3V_GEMM_NT_STORE", None)
+__import__("a3vlm_amd.lib", fromlist=["load"]).load().a3v_reload_env()   # the library caches its switches

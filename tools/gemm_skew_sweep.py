@@ -21,6 +21,7 @@ for (M, N, K, epi) in shapes:
     for r in range(6):
         for k in skews:
             os.environ["A3V_GEMM_SKEW"] = str(k)
+            __import__("a3vlm_amd.lib", fromlist=["load"]).load().a3v_reload_env()   # the library caches its switches
             ops.gemm_nt(a, w, out, epilogue=epi | f)
             if ref is None:
                 ref = out.clone()
@@ -35,3 +36,4 @@ for (M, N, K, epi) in shapes:
     fl = 2.0 * M * N * K
     print(json.dumps({"M": M, "N": N, "K": K, **{f"skew{k}_tf": round(fl / sorted(times[k])[3] / 1e12, 1) for k in skews}}), flush=True)
 os.environ["A3V_GEMM_SKEW"] = "0"
+__import__("a3vlm_amd.lib", fromlist=["load"]).load().a3v_reload_env()   # the library caches its switches

@@ -17,6 +17,7 @@ for M, N, K in shapes:
     line = f"{M}x{N}x{K}:"
     for mode in os.environ.get("W4_MODES", "0,1,0,1").split(","):
         os.environ["A3V_GEMM_W4"] = mode
+        __import__("a3vlm_amd.lib", fromlist=["load"]).load().a3v_reload_env()   # the library caches its switches
         c = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
         for _ in range(3):
             ops.gemm_nt(a, w, c)

@@ -45,8 +45,10 @@ while time.time() - t0 < 0.6:          # clock ramp: the first few hundred ms af
 res = {}
 for fast in ("1", "0"):
     os.environ["A3V_GEMM_FAST_EPI"] = fast
+    __import__("a3vlm_amd.lib", fromlist=["load"]).load().a3v_reload_env()   # the library caches its switches
     res["plain_" + fast] = timed(lambda: ops.gemm_nt(x, w, qkv))
     res["rope_" + fast] = timed(lambda: ops.gemm_qkv_rope(x, w, qkv, kc, vt, cs, B, S, H, H, hd, 0, 0))
     res["rope_vrows_" + fast] = timed(lambda: ops.gemm_qkv_rope(x, w, qkv, kc, vt, cs, B, S, H, H, hd, 0, 0, v_rows=vr))
 os.environ["A3V_GEMM_FAST_EPI"] = "1"
+__import__("a3vlm_amd.lib", fromlist=["load"]).load().a3v_reload_env()   # the library caches its switches
 print(json.dumps({k: {"us": round(v * 1e3, 1), "tf": round(fl / v / 1e9, 1)} for k, v in res.items()}))

@@ -12,6 +12,7 @@ res = {}
 for r in range(3):
     for nt in ("0", "1", "3"):
         os.environ["A3V_STREAM_NT"] = nt
+        __import__("a3vlm_amd.lib", fromlist=["load"]).load().a3v_reload_env()   # the library caches its switches
         for name, fn in (("fwd", lambda s: ops.swiglu_fwd(s[0], s[3], F, False)), ("bwd", lambda s: ops.swiglu_bwd(s[0], s[1], s[2], F, False))):
             for i in range(2): fn(sets[i % 2])
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

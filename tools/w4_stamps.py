@@ -6,6 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from a3vlm_amd import lib
 os.environ["A3V_GEMM_W4"] = "2"
+__import__("a3vlm_amd.lib", fromlist=["load"]).load().a3v_reload_env()   # the library caches its switches
 shapes = [(8192, 8192, 8192), (8728, 22016, 4096)]
 for (M, N, K) in shapes:
     a = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
@@ -31,6 +32,7 @@ for (M, N, K) in shapes:
     print(f"  stamped kernel {us:.1f} us, {rounds} tile rounds, {us / rounds / (K // 32) * 1e3:.1f} ns per sub-stage if tiles cost nothing else")
     for mode in ("2", "9", "8", "10"):
         os.environ["A3V_GEMM_W4"] = mode
+        __import__("a3vlm_amd.lib", fromlist=["load"]).load().a3v_reload_env()   # the library caches its switches
         for _ in range(3):
             lib.load().a3v_gemm_nt(a.data_ptr(), K, w.data_ptr(), K, o.data_ptr(), N, M, N, K, buf.data_ptr(), None, 0,
                                    lib.EPI_TILE_256PP, 0, torch.cuda.current_stream().cuda_stream)
@@ -39,6 +41,7 @@ for (M, N, K) in shapes:
         cyc, rt = int(pr[2] - pr[0]), int(pr[3] - pr[1])
         print(f"  clock probe mode {mode}: block 0 ran {cyc} s_memtime ticks in {rt * 10} ns = {cyc / (rt * 10) :.3f} ticks/ns")
     os.environ["A3V_GEMM_W4"] = "2"
+    __import__("a3vlm_amd.lib", fromlist=["load"]).load().a3v_reload_env()   # the library caches its switches
     lib.load().a3v_gemm_nt(a.data_ptr(), K, w.data_ptr(), K, o.data_ptr(), N, M, N, K, buf.data_ptr(), None, 0,
                            lib.EPI_TILE_256PP, 0, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
