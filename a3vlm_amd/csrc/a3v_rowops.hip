@@ -443,6 +443,176 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
   }
 }
 
+// ---------------------------------------------------------------- nucleus (top-p) sampling on the device
+// model/meta.py:456-459 + sample_top_p (:568-583) for one batch row per 1024-thread block, WITHOUT the full-vocabulary sort:
+//   probs = softmax(logits / temperature)                     e_i = exp(l_i / T - max_j l_j / T),  Z = sum e_i
+//   sort descending, cumsum, drop where cumsum - p > top_p    token kept  <=>  mass of the tokens ranked before it <= top_p
+//   renormalise, draw one                                     inverse CDF over the kept tokens in sorted order at u * M,
+//                                                             u = the caller's uniform [0, 1) number for this row
+// Both questions ("which token is the last one kept", "which token does u * M fall on") are the same selection: find the element
+// whose predecessors in (value descending, index ascending) order weigh <= target < predecessors + itself.  It is answered by a
+// radix descent over the 32 bits of e_i (non-negative floats order like their bit patterns): four passes, each a 256-bin histogram
+// of MASS restricted to the prefix chosen so far, then a scan from the heaviest bin down.  Ties (equal e_i; common in the bf16-
+// rounded tail, rare at the boundary) are ranked by token index.  Histograms are per wave and merged in wave order, so the sums
+// -- and the chosen token -- are reproducible run to run.
+struct TopPSel { unsigned key; float above; int rank; int id; };
+
+__device__ __forceinline__ float topp_e(const float* __restrict__ r, int i, float T, float xm) { return expf(r[i] / T - xm); }
+
+// shared scratch of the selection (one block = one row)
+struct TopPShared {
+  float hist[16][256];        // per-wave mass histograms of the current digit
+  float bin[256];
+  unsigned long long ball[64][16];   // tie ballots per (iteration, wave) of the last pass
+  int wcnt[64][16];
+  float red[16];
+  unsigned sel_key; float sel_above; int sel_bin; int found;
+  int tie_n;
+};
+
+// target in units of Z.  want_id: also locate the token (selection 2); else only (key, above, rank) are needed (selection 1).
+__device__ void topp_select(const float* __restrict__ r, int V, float T, float xm, float target, bool want_id, TopPShared& sh, TopPSel& out) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  unsigned prefix = 0;
+  float above = 0.f;
+  bool all_kept = false;
+  for (int level = 3; level >= 0; --level) {
+    for (int b = tid; b < 16 * 256; b += 1024) (&sh.hist[0][0])[b] = 0.f;
+    __syncthreads();
+    const int shift = level * 8;
+    for (int i = tid; i < V; i += 1024) {
+      const float e = topp_e(r, i, T, xm);
+      const unsigned k = __float_as_uint(e);
+      if (level == 3 || (k >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&sh.hist[wave][(k >> shift) & 255], e);
+    }
+    __syncthreads();
+    if (tid < 256) {
+      float m = 0.f;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) m += sh.hist[w][tid];
+      sh.bin[tid] = m;
+    }
+    if (tid == 0) sh.found = -1;
+    __syncthreads();
+    if (wave == 0) {
+      // lane l owns bins 4 l .. 4 l + 3; suffix sums from bin 255 down
+      float b4[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) b4[q] = sh.bin[lane * 4 + q];
+      const float own = (b4[0] + b4[1]) + (b4[2] + b4[3]);
+      float suf = own;                                   // inclusive suffix over lanes >= l
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const float v = __shfl_down(suf, o, 64);
+        if (lane + o < 64) suf += v;
+      }
+      const float nxt = __shfl_down(suf, 1, 64);
+      float excl = above + (lane < 63 ? nxt : 0.f);      // mass of everything ranked before bin 4 l + 3
+      int hi = -1, lo = 0x7fffffff;                      // highest bin whose inclusive mass passes the target / lowest non-empty bin
+      float hi_excl = 0.f, lo_excl = 0.f;
+#pragma unroll
+      for (int q = 3; q >= 0; --q) {
+        const float incl = excl + b4[q];
+        if (b4[q] > 0.f) {
+          if (hi < 0 && incl > target) { hi = lane * 4 + q; hi_excl = excl; }
+          lo = lane * 4 + q; lo_excl = excl;
+        }
+        excl = incl;
+      }
+      int best_hi = hi, best_lo = lo;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        best_hi = max(best_hi, __shfl_xor(best_hi, o, 64));
+        best_lo = min(best_lo, __shfl_xor(best_lo, o, 64));
+      }
+      // no bin passes: at the top level the target is beyond the total mass (cut: nothing is cut; draw: clamp onto the last
+      // token); below it, the sub-bins' sum fell an ulp short of their parent's -- take the last non-empty one
+      const bool clamp_lo = best_hi < 0 && (level < 3 || want_id) && best_lo != 0x7fffffff;
+      if (best_hi >= 0 && best_hi == hi) { sh.found = hi; sh.sel_above = hi_excl; }
+      if (clamp_lo && best_lo == lo) { sh.found = lo; sh.sel_above = lo_excl; }
+    }
+    __syncthreads();
+    if (sh.found < 0) { all_kept = true; break; }        // target >= total mass: nothing is cut (top_p >= 1)
+    prefix |= (unsigned)sh.found << shift;
+    above = sh.sel_above;
+    __syncthreads();
+  }
+  if (all_kept) { out.key = 0u; out.above = -1.f; out.rank = 0; out.id = -1; return; }
+  const float ek = __uint_as_float(prefix);
+  // ties on the selected value: rank inside them by token index
+  int rank = ek > 0.f ? (int)floorf((target - above) / ek) : 0;
+  if (rank < 0) rank = 0;
+  out.key = prefix; out.above = above; out.rank = rank; out.id = -1;
+  const int iters = (V + 1023) / 1024;
+  for (int k = 0; k < iters; ++k) {
+    const int i = k * 1024 + tid;
+    const bool tie = i < V && __float_as_uint(topp_e(r, i, T, xm)) == prefix;
+    const unsigned long long bl = __ballot(tie);
+    if (lane == 0) { sh.ball[k][wave] = bl; sh.wcnt[k][wave] = __popcll(bl); }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int n = 0;
+    for (int k = 0; k < iters; ++k)
+      for (int w = 0; w < 16; ++w) n += sh.wcnt[k][w];
+    if (rank >= n) rank = n - 1;                         // float division landed past the last tied element
+    sh.tie_n = rank;
+    int id = -1, left = rank;
+    if (want_id) {
+      for (int k = 0; k < iters && id < 0; ++k)
+        for (int w = 0; w < 16 && id < 0; ++w) {
+          const int c = sh.wcnt[k][w];
+          if (left >= c) { left -= c; continue; }
+          unsigned long long bl = sh.ball[k][w];
+          for (int q = 0; q < left; ++q) bl &= bl - 1;   // drop the `left` lowest set bits
+          id = k * 1024 + w * 64 + __ffsll((long long)bl) - 1;
+        }
+    }
+    sh.sel_bin = id;
+  }
+  __syncthreads();
+  out.rank = sh.tie_n;
+  out.id = sh.sel_bin;
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void sample_top_p_kernel(const float* __restrict__ logits, int64_t ld, int V, float T, float top_p,
+                                                            const float* __restrict__ u, int64_t* __restrict__ out) {
+  __shared__ TopPShared sh;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const float* r = logits + (int64_t)blockIdx.x * ld;
+  // x_max and Z, fixed summation order (per thread, then lanes, then waves)
+  float xm = -INFINITY;
+  for (int i = tid; i < V; i += 1024) xm = fmaxf(xm, r[i] / T);
+  xm = wave_max(xm);
+  if (lane == 0) sh.red[wave] = xm;
+  __syncthreads();
+  xm = sh.red[0];
+#pragma unroll
+  for (int w = 1; w < 16; ++w) xm = fmaxf(xm, sh.red[w]);
+  __syncthreads();
+  float z = 0.f;
+  for (int i = tid; i < V; i += 1024) z += topp_e(r, i, T, xm);
+  z = wave_sum(z);
+  if (lane == 0) sh.red[wave] = z;
+  __syncthreads();
+  z = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) z += sh.red[w];
+  __syncthreads();
+  // 1. the nucleus: the last kept token is the one the cumulative mass passes top_p on (meta.py:571-573)
+  TopPSel cut, pick;
+  topp_select(r, V, T, xm, top_p * z, false, sh, cut);
+  const float M = cut.above < 0.f ? z : cut.above + (float)(cut.rank + 1) * __uint_as_float(cut.key);
+  // 2. one draw from the renormalised nucleus (meta.py:574-577): inverse CDF at u * M
+  float uu = u[blockIdx.x];
+  uu = uu < 0.f ? 0.f : (uu >= 1.f ? 0.99999994f : uu);
+  topp_select(r, V, T, xm, uu * M, true, sh, pick);
+  if (tid == 0) {
+    out[blockIdx.x] = pick.id < 0 ? 0 : pick.id;        // (id < 0 only for a row without any finite logit)
+  }
+}
+
 // ---------------------------------------------------------------- one step of MetaModel.generate's token bookkeeping
 // model/meta.py:456-477 for one batch row per block, after the row's argmax (temperature 0, :460) or with an externally
 // sampled id (top-p branch, :457-459):
@@ -800,6 +970,15 @@ extern "C" int a3v_generate_step(const float* logits, int64_t ld, const int64_t*
   if (n_stop > 0 && (!stop_seq || !stop_off)) return A3V_ERR_ARG;
   hipLaunchKernelGGL(generate_step_kernel, dim3(B), dim3(1024), 0, ST, logits, ld, sampled, V, tokens, ld_tok, text_mask, ld_mask, cur_pos,
                      stop_seq, stop_off, n_stop, stopped, stop_pos, live);
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}
+
+extern "C" int a3v_sample_top_p(const float* logits, int64_t ld, int B, int V, float temperature, float top_p, const float* u,
+                                int64_t* out, void* stream) {
+  if (!logits || !u || !out || B <= 0 || V <= 0) return A3V_ERR_ARG;
+  if (V > 65536 || !(temperature > 0.f) || !(top_p > 0.f)) return A3V_ERR_SHAPE;
+  hipLaunchKernelGGL(sample_top_p_kernel, dim3(B), dim3(1024), 0, ST, logits, ld, V, temperature, top_p, u, out);
   A3V_LAUNCH_CHECK();
   return A3V_OK;
 }

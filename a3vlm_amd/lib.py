@@ -59,6 +59,7 @@ SIGNATURES = {
     "a3v_split_views": (I, [P, P, I, I, I, I, P]),
     "a3v_vit_embed": (I, [P, P, P, P, I, I, I, I, P]),
     "a3v_argmax": (I, [P, L, P, I, I, P]),
+    "a3v_sample_top_p": (I, [P, L, I, I, F, F, P, P, P]),
     "a3v_preprocess_image": (I, [P, I, I, I, I, I, P, P, P, I, P, P, I, I, P, P, I, P, P, P]),
     "a3v_generate_step": (I, [P, L, P, I, I, P, L, P, L, I, P, P, I, P, P, P, P]),
     "a3v_count_valid": (I, [P, I, P, P]),

@@ -266,9 +266,14 @@ class MetaModel(nn.Module):
     def generate(self, prompts: List[str], images: Optional[torch.Tensor] = None,
                  depth_images: Optional[torch.Tensor] = None, max_gen_len: int = 512,
                  temperature: float = 0.0, top_p: float = 0.95,
-                 additional_stop_symbols: Iterable[str] = (), return_ids: bool = False, poll_every: int = 4) -> List[str]:
+                 additional_stop_symbols: Iterable[str] = (), return_ids: bool = False, poll_every: int = 4,
+                 sample_uniforms: Optional[torch.Tensor] = None) -> List[str]:
         """meta.py:379-485.  ``return_ids`` additionally returns the generated id lists (the
         arguments of tokenizer.decode at :482-484) for bit-exact parity checks.
+        ``temperature > 0`` (the eval script's default recipe, T 0.1 / top-p 0.75): the nucleus draw of :456-459 / :568-583 runs on
+        the device (``a3v_sample_top_p``: no full-vocabulary sort, no host-visible op per token); its one random ingredient is a
+        uniform number per row and step, drawn up front from torch's device generator (``torch.manual_seed`` reproduces a run) or
+        handed in as ``sample_uniforms`` [steps, bsz] (parity tests replay the oracle with the same numbers).
         ``poll_every``: the all-rows-stopped flag lives on the device and is read back (a host sync) only every
         ``poll_every`` steps instead of every step (:478-479); steps taken after every row has stopped write past
         ``stop_pos`` and are discarded, so the outputs are identical for any value (1 = the reference's cadence)."""
@@ -312,6 +317,13 @@ class MetaModel(nn.Module):
         stopped = torch.zeros(bsz, dtype=torch.bool, device=dev)
         stop_pos = torch.full((bsz,), start_pos + 1, dtype=torch.long, device=dev)
         live = torch.full((1,), bsz, dtype=torch.int32, device=dev)      # rows still generating (device counter)
+        uni = sampled = None
+        if temperature > 0:
+            n_steps = max(total_len - start_pos, 1)
+            uni = (torch.rand(n_steps, bsz, device=dev, dtype=torch.float32) if sample_uniforms is None
+                   else sample_uniforms.to(device=dev, dtype=torch.float32).contiguous())
+            assert uni.shape[0] >= total_len - start_pos and uni.shape[1] == bsz, tuple(uni.shape)
+            sampled = torch.empty(bsz, dtype=torch.long, device=dev)
 
         # One iteration = the model step (one C call for a decode step) + ONE launch of a3v_generate_step, which does everything
         # meta.py:456-477 does with a dozen small torch ops: argmax, teacher forcing of longer prompts, the tokens[:, cur_pos]
@@ -325,10 +337,8 @@ class MetaModel(nn.Module):
             else:
                 logits = self.llma.forward_inference(tokens[:, prev_pos:cur_pos], prev_pos,
                                                      images if prev_pos == 0 else None)
-            sampled = None
             if temperature > 0:
-                probs = torch.softmax(logits / temperature, dim=-1)
-                sampled = self.sample_top_p(probs, top_p).reshape(-1).contiguous()
+                ops.sample_top_p(logits, temperature, top_p, uni[cur_pos - start_pos], sampled)
             ops.generate_step(logits, sampled, tokens, text_mask, cur_pos, stop_seq, stop_off, len(l_stop), stopped, stop_pos, live)
             if ((cur_pos - start_pos) % poll_every == poll_every - 1 or cur_pos == total_len - 1) and int(live.item()) == 0:
                 break
@@ -370,7 +380,7 @@ class MetaModel(nn.Module):
             logits = self.llma.forward_inference(tokens[None, prev_pos:cur_pos], prev_pos,
                                                  image if prev_pos == 0 else None)
             if temperature > 0:
-                nt = self.sample_top_p(torch.softmax(logits / temperature, dim=-1), top_p)
+                nt = ops.sample_top_p(logits, temperature, top_p, torch.rand(1, device=dev), nt_buf)
             else:
                 nt = ops.argmax(logits, nt_buf)
             nt = int(nt.reshape(-1)[0].item())
@@ -390,14 +400,13 @@ class MetaModel(nn.Module):
         yield {"text": generated, "end_of_content": True}
 
     def sample_top_p(self, probs: torch.Tensor, p: float) -> torch.Tensor:
-        """meta.py:568-583 (stochastic branch; not on the greedy parity path)."""
-        probs_sort, probs_idx = torch.sort(probs, dim=-1, descending=True)
-        probs_sum = torch.cumsum(probs_sort, dim=-1)
-        mask = probs_sum - probs_sort > p
-        probs_sort[mask] = 0.0
-        probs_sort.div_(probs_sort.sum(dim=-1, keepdim=True))
-        nt = torch.multinomial(probs_sort, num_samples=1)
-        return torch.gather(probs_idx, -1, nt)
+        """meta.py:568-583, kept for callers of the reference's method (torch ops; ``generate`` itself draws on the device with
+        ``a3v_sample_top_p``, same nucleus, explicit uniforms)."""
+        ranked, order = probs.sort(dim=-1, descending=True)
+        before = ranked.cumsum(dim=-1) - ranked                 # mass ranked ahead of each token
+        kept = ranked.masked_fill(before > p, 0.0)
+        draw = torch.multinomial(kept / kept.sum(dim=-1, keepdim=True), num_samples=1)
+        return order.gather(-1, draw)
 
     def get_image_words(self) -> int:
         return self.llma.image_words

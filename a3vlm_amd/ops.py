@@ -334,6 +334,18 @@ def generate_step(logits, sampled, tokens, text_mask, cur_pos: int, stop_seq, st
     _l.check(rc, "a3v_generate_step")
 
 
+def sample_top_p(logits, temperature: float, top_p: float, u, out):
+    """out[b] = one draw from the top-p nucleus of softmax(logits[b] / temperature) at the uniform number u[b] (a3v_sample_top_p;
+    model/meta.py:456-459, 568-583 without the full-vocabulary sort)."""
+    _dev(logits, u, out)
+    assert logits.dtype == torch.float32 and logits.stride(1) == 1 and u.dtype == torch.float32 and out.dtype == torch.int64
+    B, V = logits.shape
+    assert u.numel() >= B and out.numel() >= B and u.is_contiguous() and out.is_contiguous()
+    rc = _l.load().a3v_sample_top_p(_p(logits), logits.stride(0), B, V, float(temperature), float(top_p), _p(u), _p(out), _stream())
+    _l.check(rc, "a3v_sample_top_p")
+    return out
+
+
 def argmax(logits, out):
     _dev(logits, out)
     assert logits.dtype == torch.float32 and out.dtype == torch.int64

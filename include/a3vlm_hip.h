@@ -255,6 +255,14 @@ int a3v_generate_step(const float* logits, int64_t ld, const int64_t* sampled, i
                       const uint8_t* text_mask, int64_t ld_mask, int cur_pos, const int64_t* stop_seq, const int32_t* stop_off,
                       int n_stop, uint8_t* stopped, int64_t* stop_pos, int32_t* live, void* stream);
 
+/* The sampled branch of MetaModel.generate (model/meta.py:456-459) with sample_top_p (model/meta.py:568-583) on the device, one
+ * launch for the batch and no full-vocabulary sort: probs = softmax(logits / temperature); a token is kept iff the probability
+ * mass ranked before it (value descending, index ascending on ties) is <= top_p; out[b] = the kept token the inverse CDF of the
+ * renormalised nucleus reaches at u[b] (u[b] uniform in [0, 1), supplied by the caller's generator: torch.multinomial's own
+ * random stream is not part of the contract).  logits fp32 [B, V] (V <= 65536), temperature > 0, top_p > 0 (>= 1 keeps all). */
+int a3v_sample_top_p(const float* logits, int64_t ld, int B, int V, float temperature, float top_p, const float* u,
+                     int64_t* out, void* stream);
+
 /* torch.argmax(logits, -1) with first-index tie break (model/meta.py:460).  fp32 [B,V]. */
 int a3v_argmax(const float* logits, int64_t ld, int64_t* out, int B, int V, void* stream);
 

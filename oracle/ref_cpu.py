@@ -388,10 +388,37 @@ def meta_forward_loss(dec: OracleDecoder, examples: Tensor, labels: Tensor,
     return F.cross_entropy(output.reshape(-1, V).float(), labels.flatten(), ignore_index=0)
 
 
+def top_p_nucleus(probs: torch.Tensor, p: float):
+    """model/meta.py:569-573 (sample_top_p up to the draw): probabilities sorted descending, everything whose PRECEDING mass
+    exceeds p zeroed, the rest renormalised.  Returns (renormalised sorted probabilities, their token ids).  Pinned against the
+    nucleus sets the reference produced (tests/golden/sampling.json)."""
+    probs_sort, probs_idx = torch.sort(probs, dim=-1, descending=True, stable=True)
+    probs_sum = torch.cumsum(probs_sort, dim=-1)
+    mask = probs_sum - probs_sort > p
+    probs_sort = probs_sort.masked_fill(mask, 0.0)
+    probs_sort = probs_sort / probs_sort.sum(dim=-1, keepdim=True)
+    return probs_sort, probs_idx
+
+
+def sample_top_p_at(probs: torch.Tensor, p: float, u: torch.Tensor) -> torch.Tensor:
+    """model/meta.py:568-583 with the one random ingredient made explicit: ``torch.multinomial(probs_sort, 1)`` (:576) draws from
+    the renormalised nucleus; here the draw is the inverse CDF of that same distribution at the given uniforms u [B] (first sorted
+    position whose cumulative mass exceeds u), so a device sampler fed the same u must return the same ids.  The reference's own
+    ids depend on torch's generator stream (different on CPU and GPU), which is not part of the contract; its nucleus is."""
+    ps, idx = top_p_nucleus(probs, p)
+    n_kept = (ps > 0).sum(-1)
+    cdf = torch.cumsum(ps.double(), dim=-1)
+    pos = (cdf <= u.double().reshape(-1, 1)).sum(-1)
+    pos = torch.minimum(pos, n_kept - 1)
+    return idx.gather(-1, pos.unsqueeze(-1)).squeeze(-1)
+
+
 def generate_greedy(dec: OracleDecoder, prompt_tokens: List[List[int]], *, image_tokens=None,
                     image_words: int = 0, max_gen_len: int = 512, eos_id: int = 2,
-                    extra_stop: Sequence[Sequence[int]] = ()):
-    """model/meta.py:413-485 with temperature == 0 (argmax branch :459-460).
+                    extra_stop: Sequence[Sequence[int]] = (), sampler=None):
+    """model/meta.py:413-485 with temperature == 0 (argmax branch :459-460); ``sampler(step, logits) -> ids [B]`` replaces the
+    argmax by the sampled branch (:456-458) with whatever draw the caller defines (``sample_top_p_at`` with recorded uniforms, or
+    ids recorded from another run = teacher forcing), ``step`` counting from 0 at the first generated position.
 
     Works on token ids (tokenizer encode/decode stay in the caller).  Returns
     (tokens [B,total_len] int64, per-row generated id lists) -- the id lists are
@@ -417,7 +444,10 @@ def generate_greedy(dec: OracleDecoder, prompt_tokens: List[List[int]], *, image
     for cur_pos in range(start_pos, total_len):
         logits = dec.forward_inference(tokens[:, prev_pos:cur_pos], prev_pos,
                                        image_tokens if prev_pos == 0 else None).float()
-        next_token = torch.argmax(logits, dim=-1).reshape(-1)
+        if sampler is None:
+            next_token = torch.argmax(logits, dim=-1).reshape(-1)
+        else:
+            next_token = sampler(cur_pos - start_pos, logits).reshape(-1)
         next_token = torch.where(text_mask[:, cur_pos], tokens[:, cur_pos], next_token)
         tokens[:, cur_pos] = next_token
         stop_pos = torch.where(stopped, stop_pos, cur_pos + 1)

@@ -148,7 +148,8 @@ def test_two_image_fp8_weights_1024_context():
     assert m.image_words == 2 * (64 + 1 + 2)
     B, T = 2, 1024
     g = torch.Generator().manual_seed(17)
-    ex = torch.randint(3, 640, (B, T + 2), generator=g)
+    ND = 12                                                     # teacher-forced decode steps after the prefill
+    ex = torch.randint(3, 640, (B, T + ND), generator=g)
     ex[:, 0] = 1
     img, depth = synth_image(B, size=112, seed=3), synth_image(B, size=112, seed=4)
     exd, imgd, depd = ex.to(DEV), img.to(DEV), depth.to(DEV)
@@ -157,7 +158,7 @@ def test_two_image_fp8_weights_1024_context():
     m.quantize_decode_weights("fp8", prefill=True)
     got = m.forward_inference(exd[:, :T], 0, imgd, depd).float().clone()
     assert m.cache_image_words == m.image_words
-    nxt = [m.forward_inference(exd[:, t:t + 1], t).float().clone() for t in range(T, T + 2)]
+    nxt = [m.forward_inference(exd[:, t:t + 1], t).float().clone() for t in range(T, T + ND)]
     # oracle: bf16 weights, the same image words, W8A8 arithmetic in the decoder linears
     bf = torch.bfloat16
     vb = {k: v.to(bf) for k, v in vsd.items()}
@@ -170,12 +171,31 @@ def test_two_image_fp8_weights_1024_context():
     def rms(a, b):
         a, b = a.float().cpu(), b.float().cpu()
         return float((a - b).norm() / b.norm())
+    # the yardstick comes from the oracle alone: how far ITS W8A8 arithmetic moves the logits away from ITS bf16 run
+    dec_bf = ref_cpu.OracleDecoder(oargs, {k: v.to(bf) for k, v in sd.items()})
+    want_bf = dec_bf.forward_inference(ex[:, :T], 0, itok).float()
+    e_q = rms(want, want_bf)
     e_bf, e_or = rms(got, base), rms(got, want)
-    print(f"2 images + fp8 @ T=1024: rms vs bf16 plugin {e_bf:.4f}, vs W8A8 oracle {e_or:.4f}")
-    assert 0 < e_bf < 0.4 and e_or < 0.7 * e_bf, (e_bf, e_or)
-    assert rms(nxt[0], base_next) < 0.4
-    for i, t in enumerate(range(T, T + 2)):
+    print(f"2 images + fp8 @ T=1024: oracle W8A8 vs oracle bf16 {e_q:.4f}; device fp8 vs device bf16 {e_bf:.4f}, vs W8A8 oracle {e_or:.4f}")
+    assert 0 < e_bf <= 1.5 * e_q, (e_bf, e_q)                  # quantisation moves the device's logits no further than the oracle's
+    assert e_or <= 0.75 * e_q and e_or < 0.7 * e_bf, (e_or, e_q, e_bf)      # and the device sits closer to the W8A8 oracle than to bf16
+    assert rms(nxt[0], base_next) <= 1.5 * e_q + 0.02
+    # greedy ids of the decode steps (weight-only fp8 on the W8A8-written cache) against the W8A8 oracle: equal wherever the
+    # oracle's top-2 margin exceeds the measured deviation, and on most positions outright
+    agree = clear = 0
+    for i, t in enumerate(range(T, T + ND)):
         w2 = dec.forward_inference(ex[:, t:t + 1], t).float()
-        assert rms(nxt[i], w2) < 0.25, (i, rms(nxt[i], w2))
+        e_t = rms(nxt[i], w2)
+        assert e_t <= 1.5 * e_q + 0.02, (i, e_t, e_q)
+        dev_ids, ora_ids = nxt[i].argmax(-1).cpu(), w2.argmax(-1)
+        top2 = w2.topk(2, dim=-1).values
+        noise = (nxt[i].cpu() - w2).abs().max(dim=-1).values
+        for b in range(B):
+            agree += int(dev_ids[b] == ora_ids[b])
+            if float(top2[b, 0] - top2[b, 1]) > 2 * float(noise[b]):
+                clear += 1
+                assert int(dev_ids[b]) == int(ora_ids[b]), (i, b)
+    print(f"fp8 greedy ids: {agree}/{B * ND} equal to the W8A8 oracle, {clear} positions with a clear margin")
+    assert agree >= 0.75 * B * ND
     m.quantize_decode_weights(None)
     assert torch.equal(m.forward_inference(exd[:, :T], 0, imgd, depd).float(), base)

@@ -84,3 +84,55 @@ def test_sample_top_p_matches_reference(golden_dir):
             assert seen[r] <= set(c["nucleus"][r])
             if len(c["nucleus"][r]) <= 2:
                 assert seen[r] == set(c["nucleus"][r]) or len(c["nucleus"][r]) == 2
+
+
+def test_oracle_nucleus_is_the_references(golden_dir):
+    """oracle.top_p_nucleus / sample_top_p_at (the checker of the device sampler a3v_sample_top_p) against what the reference's
+    sample_top_p produced (sampling.json): the kept set is exactly the reference's nucleus, every inverse-CDF draw lies in it, and
+    over a grid of uniforms the draws follow the renormalised probabilities."""
+    cases = json.load(open(os.path.join(golden_dir, "sampling.json")))["cases"]
+    for c in cases:
+        gg = torch.Generator().manual_seed(c["seed"])
+        logits = torch.randn(c["rows"], c["vocab"], generator=gg) * 3
+        probs = torch.softmax(logits / c["temperature"], dim=-1)
+        ps, idx = ref_cpu.top_p_nucleus(probs, c["p"])
+        for r in range(c["rows"]):
+            kept = set(idx[r][ps[r] > 0].tolist())
+            assert kept == set(c["nucleus"][r]), (c["seed"], r)
+        # the reference's own draws are inside it (same fixture), and so is every inverse-CDF draw
+        grid = (torch.arange(400, dtype=torch.float32) + 0.5) / 400
+        counts = torch.zeros(c["rows"], c["vocab"])
+        for u in grid.tolist():
+            d = ref_cpu.sample_top_p_at(probs, c["p"], torch.full((c["rows"],), u))
+            for r, t in enumerate(d.tolist()):
+                assert t in c["nucleus"][r]
+                counts[r, t] += 1
+        want = torch.zeros(c["rows"], c["vocab"]).scatter_(1, idx, ps)
+        assert float((counts / 400 - want).abs().max()) < 1.0 / 400 + 1e-6          # a CDF on a 400-point grid
+
+
+def test_deep_decoder_oracle_matches_the_reference_at_every_depth(golden_dir):
+    """Round-3 fixture (oracle/gen_golden_r3.py, generated by running the reference): a 12-layer head_dim-128 GQA decoder and its
+    4- and 8-layer truncations -- the oracle reproduces the reference's fp32 logits at each depth, the cached-inference logits and
+    the reference's greedy ids; the reference's OWN bf16-vs-fp32 deviation grows with depth (the yardstick of the GPU test)."""
+    from oracle.gen_golden_r3 import DEEP
+    fx = np.load(os.path.join(golden_dir, "decoder_deep.npz"))
+    j = json.load(open(os.path.join(golden_dir, "deep_meta.json")))
+    V = j["vocab_size"]
+    sd = ref_cpu.make_decoder_weights(ref_cpu.OracleArgs(vocab_size=V, **DEEP), seed=31, std=0.04)
+    assert abs(checksum(sd) - float(fx["weight_checksum"])) < 1e-6 * float(fx["weight_checksum"])
+    ex = torch.from_numpy(fx["examples"])
+    pos = fx["positions"].tolist()
+    devs = []
+    for depth in fx["depths"].tolist():
+        sub = {k: v for k, v in sd.items() if not k.startswith("layers.") or int(k.split(".")[1]) < depth}
+        d = ref_cpu.OracleDecoder(ref_cpu.OracleArgs(vocab_size=V, **{**DEEP, "n_layers": depth}), sub)
+        np.testing.assert_allclose(d.forward(ex)[:, pos].numpy(), fx[f"logits_L{depth}"], atol=1e-4, rtol=2e-5)
+        devs.append(float(np.abs(fx[f"logits_bf16_L{depth}"] - fx[f"logits_L{depth}"]).max() / np.abs(fx[f"logits_L{depth}"]).max()))
+    assert devs[0] < devs[-1] < 0.05, devs               # error growth with depth is real and bounded: 4 -> 12 layers
+    d = ref_cpu.OracleDecoder(ref_cpu.OracleArgs(vocab_size=V, **DEEP), sd)
+    P = j["P"]
+    got = [d.forward_inference(ex[:, :P], 0)]
+    for t in range(P, P + 4):
+        got.append(d.forward_inference(ex[:, t:t + 1], t))
+    np.testing.assert_allclose(torch.stack(got).numpy(), fx["inf_logits"], atol=1e-4, rtol=2e-5)
