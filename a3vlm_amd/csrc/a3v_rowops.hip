@@ -944,6 +944,92 @@ __global__ __launch_bounds__(256) void resample_v_norm_kernel(const uint8_t* __r
 }
 }  // namespace
 
+// ---- the same two passes for a BATCH of decoded images in two launches per 16 images (blockIdx.y = image): the descriptors travel
+// by value in the kernel arguments, so a loader hands over one list per batch and nothing is staged per image
+namespace {
+constexpr int PRE_CHUNK = 16;
+struct PreBatch { a3v_image_desc d[PRE_CHUNK]; };
+
+__global__ __launch_bounds__(256) void resample_h_batch_kernel(PreBatch pb, int fill_r, int fill_g, int fill_b, int out, uint8_t* __restrict__ tmp,
+                                                               int64_t tmp_stride) {
+  const a3v_image_desc& im = pb.d[blockIdx.y];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= im.side * out) return;
+  const int y = i / out, x = i - y * out;
+  const int lo = im.bounds[2 * x], n = im.bounds[2 * x + 1];
+  const int32_t* k = im.coeffs + (int64_t)x * im.ksize;
+  int sr = 1 << 21, sg = 1 << 21, sb = 1 << 21;
+  const int sy = y - im.pad_y;
+  const bool row_in = sy >= 0 && sy < im.H;
+  for (int t = 0; t < n; ++t) {
+    const int sx = lo + t - im.pad_x;
+    int r = fill_r, g = fill_g, b = fill_b;
+    if (row_in && sx >= 0 && sx < im.W) {
+      const uint8_t* q = im.src + ((int64_t)sy * im.W + sx) * 3;
+      r = q[0]; g = q[1]; b = q[2];
+    }
+    sr += r * k[t]; sg += g * k[t]; sb += b * k[t];
+  }
+  uint8_t* o = tmp + blockIdx.y * tmp_stride + (int64_t)i * 3;
+  o[0] = (uint8_t)clip8(sr); o[1] = (uint8_t)clip8(sg); o[2] = (uint8_t)clip8(sb);
+}
+
+template <typename TO>
+__global__ __launch_bounds__(256) void resample_v_norm_batch_kernel(PreBatch pb, const uint8_t* __restrict__ tmp, int64_t tmp_stride, int out,
+                                                                    float m0, float m1, float m2, float s0, float s1, float s2,
+                                                                    TO* __restrict__ dst, int64_t dst_stride) {
+  const a3v_image_desc& im = pb.d[blockIdx.y];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= out * out) return;
+  const int y = i / out, x = i - y * out;
+  const int lo = im.bounds[2 * y], n = im.bounds[2 * y + 1];
+  const int32_t* k = im.coeffs + (int64_t)y * im.ksize;
+  const uint8_t* tm = tmp + blockIdx.y * tmp_stride;
+  int sr = 1 << 21, sg = 1 << 21, sb = 1 << 21;
+  for (int t = 0; t < n; ++t) {
+    const uint8_t* q = tm + ((int64_t)(lo + t) * out + x) * 3;
+    sr += q[0] * k[t]; sg += q[1] * k[t]; sb += q[2] * k[t];
+  }
+  const int64_t plane = (int64_t)out * out;
+  TO* d = dst + blockIdx.y * dst_stride;
+  Cvt<TO>::st(d + i, __fdiv_rn(__fsub_rn(__fdiv_rn((float)clip8(sr), 255.f), m0), s0));
+  Cvt<TO>::st(d + plane + i, __fdiv_rn(__fsub_rn(__fdiv_rn((float)clip8(sg), 255.f), m1), s1));
+  Cvt<TO>::st(d + 2 * plane + i, __fdiv_rn(__fsub_rn(__fdiv_rn((float)clip8(sb), 255.f), m2), s2));
+}
+}  // namespace
+
+extern "C" int a3v_preprocess_batch(const a3v_image_desc* images, int n, const int* fill_rgb, int out_size, uint8_t* tmp, int64_t tmp_stride,
+                                    void* dst, int64_t dst_stride, int dst_dtype, const float* mean, const float* std_, void* stream) {
+  if (!images || n <= 0 || !fill_rgb || !tmp || !dst || !mean || !std_ || out_size <= 0) return A3V_ERR_ARG;
+  if (dst_dtype != A3V_F32 && dst_dtype != A3V_BF16) return A3V_ERR_DTYPE;
+  if (dst_stride < (int64_t)3 * out_size * out_size) return A3V_ERR_SHAPE;
+  for (int i0 = 0; i0 < n; i0 += PRE_CHUNK) {
+    const int nc = n - i0 < PRE_CHUNK ? n - i0 : PRE_CHUNK;
+    PreBatch pb{};
+    int max_side = 0;
+    for (int j = 0; j < nc; ++j) {
+      const a3v_image_desc& im = images[i0 + j];
+      if (!im.src || !im.coeffs || !im.bounds) return A3V_ERR_ARG;
+      if (im.H <= 0 || im.W <= 0 || im.side < im.H || im.side < im.W || im.pad_x < 0 || im.pad_y < 0 || im.pad_x + im.W > im.side ||
+          im.pad_y + im.H > im.side || im.ksize <= 0 || (int64_t)im.side * out_size * 3 > tmp_stride) return A3V_ERR_SHAPE;
+      pb.d[j] = im;
+      max_side = im.side > max_side ? im.side : max_side;
+    }
+    uint8_t* tm = tmp + (int64_t)i0 * tmp_stride;
+    const int n1 = max_side * out_size, n2 = out_size * out_size;
+    hipLaunchKernelGGL(resample_h_batch_kernel, dim3((n1 + 255) / 256, nc), dim3(256), 0, ST, pb, fill_rgb[0], fill_rgb[1], fill_rgb[2], out_size,
+                       tm, tmp_stride);
+    if (dst_dtype == A3V_F32)
+      hipLaunchKernelGGL(resample_v_norm_batch_kernel<float>, dim3((n2 + 255) / 256, nc), dim3(256), 0, ST, pb, tm, tmp_stride, out_size, mean[0],
+                         mean[1], mean[2], std_[0], std_[1], std_[2], (float*)dst + (int64_t)i0 * dst_stride, dst_stride);
+    else
+      hipLaunchKernelGGL(resample_v_norm_batch_kernel<bf16_t>, dim3((n2 + 255) / 256, nc), dim3(256), 0, ST, pb, tm, tmp_stride, out_size, mean[0],
+                         mean[1], mean[2], std_[0], std_[1], std_[2], (bf16_t*)dst + (int64_t)i0 * dst_stride, dst_stride);
+  }
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}
+
 extern "C" int a3v_preprocess_image(const uint8_t* src, int H, int W, int side, int pad_x, int pad_y, const int* fill_rgb,
                                     const int32_t* kx, const int32_t* bx, int ksize_x, const int32_t* ky, const int32_t* by, int ksize_y,
                                     int out_size, uint8_t* tmp, void* dst, int dst_dtype, const float* mean, const float* std_, void* stream) {

@@ -100,7 +100,12 @@ class T_random_resized_crop:
         return to_normalized_tensor(img)
 
 
-def get_transform(transform_type: str, size: int = 224):
+def get_transform(transform_type: str, size: int = 224, on_device: bool = False):
+    """``on_device`` (padded_resize only): the DataLoader workers only DECODE (``T_decode_rgb``: uint8 HWC); pad / bicubic resize /
+    ToTensor / Normalize run on the GPU over the whole batch (``GpuPaddedResize.batch`` through ``DevicePreprocessLoader``) and give
+    bit for bit the tensor ``T_padded_resize`` gives."""
+    if on_device and transform_type == "padded_resize":
+        return T_decode_rgb(size)
     if transform_type == "random_resized_crop":
         return T_random_resized_crop(size)
     if transform_type == "resized_center_crop":
@@ -152,6 +157,48 @@ def pillow_bicubic_coeffs(in_size: int, out_size: int):
     return kk, bounds
 
 
+class T_decode_rgb:
+    """Worker-side half of the on-device padded_resize: the decoded RGB pixels as uint8 [H, W, 3], nothing else."""
+    deferred = "padded_resize"
+
+    def __init__(self, size: int = 224):
+        self.size = size
+
+    def __call__(self, img: Image.Image) -> torch.Tensor:
+        return torch.from_numpy(np.asarray(img.convert("RGB"), dtype=np.uint8).copy())
+
+
+def _is_raw_image(x) -> bool:
+    return torch.is_tensor(x) and x.dtype == torch.uint8 and x.dim() == 3 and x.shape[-1] == 3
+
+
+def collate_raw_images(samples):
+    """default_collate for everything but raw decoded images (uint8 HWC tensors of differing sizes), which stay a list per field."""
+    from torch.utils.data import default_collate
+    if not isinstance(samples[0], (tuple, list)):
+        return default_collate(samples)
+    fields = list(zip(*samples))
+    return type(samples[0])([list(f) if _is_raw_image(f[0]) else default_collate(list(f)) for f in fields])
+
+
+class DevicePreprocessLoader:
+    """Wraps a DataLoader whose dataset decodes only (``T_decode_rgb``): every list of raw images in a batch becomes the normalised
+    ``[B, 3, size, size]`` tensor on the device (one host-to-device copy + two launches per 16 images).  ``len`` and the sampler
+    contract are the inner loader's."""
+
+    def __init__(self, loader, size: int, device, dtype: torch.dtype = torch.float32):
+        self.loader, self.pre = loader, GpuPaddedResize(size, device, dtype)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        for batch in self.loader:
+            if isinstance(batch, (tuple, list)):
+                batch = type(batch)([self.pre.batch(f) if isinstance(f, list) and f and _is_raw_image(f[0]) else f for f in batch])
+            yield batch
+
+
 class GpuPaddedResize:
     """``T_padded_resize`` evaluated on the device: takes a decoded RGB image (PIL image, HWC uint8 array or tensor) and returns the
     normalised ``[3, size, size]`` tensor on ``device`` -- bit-identical to the PIL path (tests/test_gpu_preprocess.py).  The
@@ -167,6 +214,58 @@ class GpuPaddedResize:
             kk, bounds = pillow_bicubic_coeffs(side, self.size)
             self._tables[side] = (torch.from_numpy(kk).to(self.device), torch.from_numpy(bounds).to(self.device), kk.shape[1])
         return self._tables[side]
+
+    def batch(self, images) -> torch.Tensor:
+        """A list of decoded RGB images (uint8 [H, W, 3] tensors / arrays, any sizes) -> ``[n, 3, size, size]`` on the device: the
+        pixels of all images cross PCIe in ONE copy of a pinned staging buffer, then a3v_preprocess_batch (two launches per 16)."""
+        import ctypes
+        from .. import lib as _l
+        from ..ops import dt
+        imgs = [torch.as_tensor(np.asarray(im.convert("RGB"), dtype=np.uint8)) if isinstance(im, Image.Image) else torch.as_tensor(im) for im in images]
+        for t in imgs:
+            if not _is_raw_image(t):
+                raise TypeError("GpuPaddedResize.batch takes RGB images as uint8 [H, W, 3]")
+        n = len(imgs)
+        sizes = [int(t.numel()) for t in imgs]
+        offs = [0]
+        for sz in sizes:
+            offs.append(offs[-1] + (sz + 255) // 256 * 256)
+        stage = getattr(self, "_stage", None)
+        if stage is None or stage.numel() < offs[-1]:
+            stage = self._stage = torch.empty(max(offs[-1], 1 << 20), dtype=torch.uint8).pin_memory()
+        ev = getattr(self, "_copied", None)
+        if ev is not None:
+            ev.synchronize()                       # the previous batch's copy has left the staging buffer
+        for t, o, sz in zip(imgs, offs, sizes):
+            stage[o:o + sz].copy_(t.reshape(-1))
+        dbuf = getattr(self, "_dbuf", None)
+        if dbuf is None or dbuf.numel() < offs[-1]:
+            dbuf = self._dbuf = torch.empty(stage.numel(), dtype=torch.uint8, device=self.device)
+        dbuf[:offs[-1]].copy_(stage[:offs[-1]], non_blocking=True)
+        self._copied = torch.cuda.Event()
+        self._copied.record()
+        descs = (_l.ImageDesc * n)()
+        max_side = 0
+        for i, t in enumerate(imgs):
+            H, W = int(t.shape[0]), int(t.shape[1])
+            side = max(H, W)
+            kk, bounds, ksize = self._table(side)
+            px, py = ((side - W) // 2, 0) if H > W else (0, (side - H) // 2)
+            d = descs[i]
+            d.src, d.coeffs, d.bounds = dbuf.data_ptr() + offs[i], kk.data_ptr(), bounds.data_ptr()
+            d.H, d.W, d.side, d.pad_x, d.pad_y, d.ksize = H, W, side, px, py, ksize
+            max_side = max(max_side, side)
+        tmp_stride = max_side * self.size * 3
+        tmp = torch.empty(n * tmp_stride, dtype=torch.uint8, device=self.device)
+        out = torch.empty(n, 3, self.size, self.size, dtype=self.dtype, device=self.device)
+        fill = (ctypes.c_int * 3)(*self.fill)
+        mean = (ctypes.c_float * 3)(*CLIP_MEAN)
+        std = (ctypes.c_float * 3)(*CLIP_STD)
+        rc = _l.load().a3v_preprocess_batch(ctypes.cast(descs, ctypes.c_void_p), n, ctypes.cast(fill, ctypes.c_void_p), self.size, tmp.data_ptr(),
+                                            tmp_stride, out.data_ptr(), 3 * self.size * self.size, dt(out), ctypes.cast(mean, ctypes.c_void_p),
+                                            ctypes.cast(std, ctypes.c_void_p), torch.cuda.current_stream().cuda_stream)
+        _l.check(rc, "a3v_preprocess_batch")
+        return out
 
     def __call__(self, img) -> torch.Tensor:
         import ctypes

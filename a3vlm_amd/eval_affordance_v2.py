@@ -23,7 +23,7 @@ from PIL import Image
 
 from .checkpoint import load_tensor_parallel_model_list
 from .data.conversation import default_conversation
-from .data.transform import T_padded_resize
+from .data.transform import GpuPaddedResize, T_decode_rgb, T_padded_resize
 from .model.meta import MetaModel
 
 
@@ -62,7 +62,7 @@ def postprocess_answer(answer: str) -> str:
 class VQADataset(torch.utils.data.Dataset):
     """eval_affordance_v2.py:109-180 (without the resample-on-corrupt-image fallback's undefined-field access)."""
 
-    def __init__(self, test: str, img_size: int = 224, sampled_num: int = 5000, result=None, image_root: str = ""):
+    def __init__(self, test: str, img_size: int = 224, sampled_num: int = 5000, result=None, image_root: str = "", decode_only: bool = False):
         with open(test, "r") as f:
             self.test = json.load(f)
         if len(self.test) > sampled_num:
@@ -71,7 +71,8 @@ class VQADataset(torch.utils.data.Dataset):
         if result is not None:
             done = {r["image"] for r in result}
             self.test = [t for t in self.test if t["image"] not in done]
-        self.transform_val = T_padded_resize(img_size)
+        # decode_only: the worker hands over the decoded pixels (uint8 HWC); pad / resize / normalise run on the device per batch
+        self.transform_val = T_decode_rgb(img_size) if decode_only else T_padded_resize(img_size)
         self.image_root = image_root
 
     def __len__(self):
@@ -89,7 +90,10 @@ class VQADataset(torch.utils.data.Dataset):
 
 
 def collate_fn(batches):
-    return (torch.stack([b["image"] for b in batches]), [b["question_id"] for b in batches], [b["question"] for b in batches],
+    images = [b["image"] for b in batches]
+    if images[0].dtype != torch.uint8:
+        images = torch.stack(images)          # CPU transform: [B, 3, size, size]; decode-only: a list of uint8 HWC images
+    return (images, [b["question_id"] for b in batches], [b["question"] for b in batches],
             [b["annotation"] for b in batches], [b["image_path"] for b in batches])
 
 
@@ -123,6 +127,9 @@ def get_args_parser():
     p.add_argument("--image_root", type=str, default="", help="directory to look images up by basename (demo.json paths are absolute)")
     p.add_argument("--output_root", type=str, default="vqa_logs")
     p.add_argument("--precision", type=str, choices=["bf16", "tf32"], default="bf16", help="tf32 = fp32 parity path")
+    p.add_argument("--preprocess", type=str, choices=["gpu", "cpu"], default="gpu",
+                   help="gpu: workers decode only, PadToSquare / bicubic resize / normalise run on the device per batch (a3v_preprocess_batch, "
+                        "bit-identical to the PIL transform); cpu: the PIL transform in the workers (data/transform.py:59-68)")
     return p
 
 
@@ -154,14 +161,18 @@ def main(args):
     results_file = os.path.join(save_dir, f"{name}.json")
     result = json.load(open(results_file)) if os.path.exists(results_file) else None
     random.seed(args.seed)
-    dataset = VQADataset(args.dataset, img_size=args.input_size, sampled_num=args.sampled_num, result=result, image_root=args.image_root)
+    on_gpu = getattr(args, "preprocess", "gpu") == "gpu"
+    dataset = VQADataset(args.dataset, img_size=args.input_size, sampled_num=args.sampled_num, result=result, image_root=args.image_root,
+                         decode_only=on_gpu)
+    pre = GpuPaddedResize(args.input_size, dev, torch.float32) if on_gpu else None
     idx = list(shard_range(len(dataset), world, rank))
     loader = torch.utils.data.DataLoader(torch.utils.data.Subset(dataset, idx), batch_size=args.batch_size, shuffle=False,
                                          num_workers=args.num_workers, pin_memory=True, drop_last=False, collate_fn=collate_fn)
     outputs = []
     with torch.no_grad():
         for image, qids, prompts, annotations, paths in loader:
-            answers = model.generate(prompts, image.to(dev), max_gen_len=args.max_gen_len, temperature=args.temperature, top_p=args.top_p)
+            image = pre.batch(image) if isinstance(image, list) else image.to(dev)
+            answers = model.generate(prompts, image, max_gen_len=args.max_gen_len, temperature=args.temperature, top_p=args.top_p)
             for answer, annotation, question, path in zip(answers, annotations, prompts, paths):
                 answer = postprocess_answer(answer)
                 box = format_bounding_box(answer)

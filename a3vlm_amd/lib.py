@@ -61,6 +61,7 @@ SIGNATURES = {
     "a3v_argmax": (I, [P, L, P, I, I, P]),
     "a3v_sample_top_p": (I, [P, L, I, I, F, F, P, P, P]),
     "a3v_preprocess_image": (I, [P, I, I, I, I, I, P, P, P, I, P, P, I, I, P, P, I, P, P, P]),
+    "a3v_preprocess_batch": (I, [P, I, P, I, P, L, P, L, I, P, P, P]),
     "a3v_generate_step": (I, [P, L, P, I, I, P, L, P, L, I, P, P, I, P, P, P, P]),
     "a3v_count_valid": (I, [P, I, P, P]),
     "a3v_cross_entropy": (I, [P, L, P, P, P, L, P, F, I, I, I, P]),
@@ -86,6 +87,12 @@ class LlamaLayer(ctypes.Structure):
     """a3v_llama_layer of include/a3vlm_hip.h"""
     _fields_ = [(n, c_void_p) for n in ("attn_norm_w", "wqkv", "wo", "ffn_norm_w", "w13", "w2", "k_cache", "vt_cache",
                                         "wqkv_q", "wqkv_s", "wo_q", "wo_s", "w13_q", "w13_s", "w2_q", "w2_s")]
+
+
+class ImageDesc(ctypes.Structure):
+    """a3v_image_desc of include/a3vlm_hip.h"""
+    _fields_ = [("src", c_void_p), ("coeffs", c_void_p), ("bounds", c_void_p), ("H", c_int), ("W", c_int), ("side", c_int), ("pad_x", c_int),
+                ("pad_y", c_int), ("ksize", c_int)]
 
 
 SIGNATURES["a3v_llama_decode_step"] = (I, [ctypes.POINTER(LlamaLayer), I, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, F, P])

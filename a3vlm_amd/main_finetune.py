@@ -53,6 +53,9 @@ def get_args_parser():
     p.add_argument("--dialog", action="store_true", default=False)
     p.add_argument("--data_config", default=None, type=str)
     p.add_argument("--image_transform", default="padded_resize", type=str)
+    p.add_argument("--preprocess", default="gpu", choices=["gpu", "cpu"],
+                   help="gpu (padded_resize only): DataLoader workers decode to uint8 HWC, PadToSquare / bicubic resize / normalise run on the "
+                        "device per batch (a3v_preprocess_batch), bit-identical to the PIL transform; cpu: the PIL transform in the workers")
     p.add_argument("--cache_ann_on_disk", action="store_true")
     p.add_argument("--output_dir", default="./output_dir")
     p.add_argument("--save_interval", default=1, type=int)
@@ -152,15 +155,24 @@ def main(args):
     elif args.data_config:                                               # main_finetune.py:289-293
         from .data.conversation.dataset import FinetuneDialogDataset
         from .data.transform import get_transform
-        dataset = FinetuneDialogDataset(args.data_config, get_transform(args.image_transform, getattr(model.llma, "image_size", 224)),
+        dataset = FinetuneDialogDataset(args.data_config, get_transform(args.image_transform, getattr(model.llma, "image_size", 224),
+                                                                        on_device=args.preprocess == "gpu"),
                                         max_words=args.max_words, image_words=image_words, tokenizer=model.tokenizer,
                                         cache_on_disk=args.cache_ann_on_disk, rank=rank)
     else:
         raise SystemExit("give --data_config <yaml> (dialog dataset) or --synthetic N")
     sampler = FinetuneDistSampler(dataset, num_replicas=world, rank=rank, shuffle=True, batch_size=args.batch_size,
                                   acc_grad=args.accum_iter, seed=args.seed)
-    loader = torch.utils.data.DataLoader(dataset, batch_size=args.batch_size, sampler=sampler, num_workers=args.num_workers,
-                                         pin_memory=args.pin_mem, drop_last=True)
+    deferred = getattr(getattr(dataset, "transform", None), "deferred", None) == "padded_resize"
+    if deferred:
+        from .data.transform import DevicePreprocessLoader, collate_raw_images
+        loader = torch.utils.data.DataLoader(dataset, batch_size=args.batch_size, sampler=sampler, num_workers=args.num_workers,
+                                             pin_memory=args.pin_mem, drop_last=True, collate_fn=collate_raw_images)
+        # workers decode to uint8 HWC; the device pads / resizes / normalises the batch (same tensor as T_padded_resize, bit for bit)
+        loader = DevicePreprocessLoader(loader, getattr(model.llma, "image_size", 224), dev, torch.float32)
+    else:
+        loader = torch.utils.data.DataLoader(dataset, batch_size=args.batch_size, sampler=sampler, num_workers=args.num_workers,
+                                             pin_memory=args.pin_mem, drop_last=True)
     start_epoch, start_iter = 0, 0
     if args.resume:
         d = latest_checkpoint_dir(args.resume) or args.resume

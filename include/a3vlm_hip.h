@@ -244,6 +244,21 @@ int a3v_preprocess_image(const uint8_t* src, int H, int W, int side, int pad_x, 
                          const int32_t* kx, const int32_t* bx, int ksize_x, const int32_t* ky, const int32_t* by, int ksize_y,
                          int out_size, uint8_t* tmp, void* dst, int dst_dtype, const float* mean, const float* std, void* stream);
 
+/* The same transform for a BATCH of decoded images (the loaders of eval_affordance_v2.py:109-180 and main_finetune.py's dataset
+ * build: workers decode to uint8 HWC, the device does the rest), two launches per 16 images.  Each image carries the tables of ITS
+ * padded side (coeffs / bounds of a3vlm_amd/data/transform.py:pillow_bicubic_coeffs, used for both passes: the square is resized
+ * to a square).  `images` is a HOST array of n descriptors whose pointers are DEVICE pointers.  tmp: uint8 scratch, tmp_stride bytes
+ * per image (>= side x out_size x 3); dst: [n][3][out_size][out_size] in dst_dtype, dst_stride ELEMENTS per image.  Same arithmetic,
+ * bit for bit, as a3v_preprocess_image. */
+typedef struct {
+  const uint8_t* src;        /* [H][W][3] */
+  const int32_t* coeffs;     /* [out_size][ksize] */
+  const int32_t* bounds;     /* [out_size][2] */
+  int H, W, side, pad_x, pad_y, ksize;
+} a3v_image_desc;
+int a3v_preprocess_batch(const a3v_image_desc* images, int n, const int* fill_rgb, int out_size, uint8_t* tmp, int64_t tmp_stride,
+                         void* dst, int64_t dst_stride, int dst_dtype, const float* mean, const float* std, void* stream);
+
 /* One step of the token bookkeeping of MetaModel.generate (model/meta.py:456-477), one launch for the whole batch: greedy argmax of
  * logits [B, V] (fp32, row stride ld) -- or, when `sampled` is non-NULL, the externally sampled ids of the top-p branch (:457-459) --
  * then, per row: teacher forcing of prompt positions (text_mask[row, cur_pos], :463-465), tokens[row, cur_pos] = next,

@@ -46,6 +46,12 @@ def test_eval_affordance_v2_demo(tmp_path):
                        cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "'missing_keys': [], 'unexpected_keys': []" in r.stdout
+    # the default is the device-side preprocessing (--preprocess gpu: workers decode, a3v_preprocess_batch pads / resizes / normalises);
+    # the PIL transform in the workers (--preprocess cpu) must give byte-identical records
+    cmd = r.args
+    r2 = subprocess.run([a if a != "t" else "tcpu" for a in cmd] + ["--preprocess", "cpu"], cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-3000:]
+    assert open(tmp_path / "logs" / "t" / "demo.json", "rb").read() == open(tmp_path / "logs" / "tcpu" / "demo.json", "rb").read()
     recs = json.load(open(tmp_path / "logs" / "t" / "demo.json"))
     assert len(recs) == 3 and set(recs[0]) == {"answer", "format_answer", "annotation", "question", "image", "fail"}
     # oracle: same image pipeline + prompt + greedy decode on the CPU

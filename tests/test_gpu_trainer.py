@@ -61,6 +61,16 @@ def test_main_finetune_dialog_dataset(tmp_path):
     assert "closs" in log and "total length: 13" in log
     line = json.loads(open(out / "log.txt").read().strip().splitlines()[-1])
     assert 0 < line["train_closs"] < 20
+    # that run preprocessed on the device (--preprocess gpu, the default: workers decode to uint8 HWC); the PIL transform in the
+    # workers feeds bit-identical image tensors, so the logged loss of the same seeded run is the same
+    out2 = tmp_path / "out_cpu"
+    run(["--llama_type", "llama_ens5", "--llama_config", os.path.join(gd, "tiny_params.json"), str(extra),
+         "--tokenizer_path", os.path.join(gd, "tokenizer.model"), "--batch_size", "2", "--accum_iter", "1", "--epochs", "1",
+         "--warmup_epochs", "0.5", "--lr", "1e-3", "--min_lr", "0", "--clip_grad", "8", "--weight_decay", "0.02",
+         "--max_words", "220", "--precision", "bf16", "--output_dir", str(out2), "--data_config", dialog_yaml(str(tmp_path)),
+         "--image_transform", "padded_resize", "--num_workers", "0", "--dialog", "--model_parallel_size", "1", "--preprocess", "cpu"])
+    line2 = json.loads(open(out2 / "log.txt").read().strip().splitlines()[-1])
+    assert abs(line2["train_closs"] - line["train_closs"]) < 2e-3 * line["train_closs"], (line, line2)      # (bf16 backward atomics: not bit-reproducible)
 
 
 def test_main_finetune_lora_only_save_trainable(tmp_path):
