@@ -3352,8 +3352,19 @@ extern "C" int a3v_gemm_nt_splitk(const void* A, int64_t lda, const void* W, int
   if (N <= 64 && M >= 512 && narrow) {
     // adapter-sized output (rank pad 64): 256 x 64 tiles -- 80 % of the LDS-DMA traffic is the streamed operand (50 % with the
     // 128 x 128 tile, whose second operand tile is half padding)
-    p.tiles_m = (M + 255) / 256; p.tiles_n = 1;
-    hipLaunchKernelGGL((gemm_nt_bf16_kernel<256, 64, 4, 1>), dim3(p.tiles_m, S), dim3(256), 0, (hipStream_t)stream, p);
+    // narrow = 2 / 3: 128- / 64-row tiles (48 / 32 KiB of LDS per block instead of 80: more blocks in flight per CU -- these
+    // launches are bound by how many k-tile loads the chip has outstanding, not by MFMA)
+    p.tiles_n = 1;
+    if (narrow == 3) {
+      p.tiles_m = (M + 63) / 64;
+      hipLaunchKernelGGL((gemm_nt_bf16_kernel<64, 64, 4, 1>), dim3(p.tiles_m, S), dim3(256), 0, (hipStream_t)stream, p);
+    } else if (narrow == 2) {
+      p.tiles_m = (M + 127) / 128;
+      hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 64, 4, 1>), dim3(p.tiles_m, S), dim3(256), 0, (hipStream_t)stream, p);
+    } else {
+      p.tiles_m = (M + 255) / 256;
+      hipLaunchKernelGGL((gemm_nt_bf16_kernel<256, 64, 4, 1>), dim3(p.tiles_m, S), dim3(256), 0, (hipStream_t)stream, p);
+    }
     A3V_LAUNCH_CHECK();
     return A3V_OK;
   }

@@ -1000,6 +1000,113 @@ extern "C" int a3v_adamw_scaled(float* param, const float* grad, float* exp_avg,
   return A3V_OK;
 }
 
+// ------------------------------------------------------------------ adapter gradients: the diagonal blocks of a fused group's dB^T
+// dB^T [Rp, N] = t^T . dy is computed for the whole fused group (block-diagonal B: only rows j r .. (j+1) r of the columns of module j
+// matter); module j's gradient [n_j, r] += the transpose of its block.  One launch per group (was one torch add_ per module).
+namespace {
+struct GbScatter { float* dst[4]; int row0[4]; int nj[4]; int n; };
+__global__ __launch_bounds__(256) void lora_gb_scatter_kernel(const float* __restrict__ gbt, int64_t ld, int r, GbScatter sc) {
+  const int j = blockIdx.y;
+  const int e = blockIdx.x * 256 + threadIdx.x;          // element of module j's [n_j, r] gradient
+  if (e >= sc.nj[j] * r) return;
+  const int n = e / r, c = e - n * r;
+  sc.dst[j][e] += gbt[(int64_t)(j * r + c) * ld + sc.row0[j] + n];
+}
+}  // namespace
+
+extern "C" int a3v_lora_gb_scatter(const float* gbt, int64_t ld, int r, int n_mods, float* const* dst, const int* row0, const int* nj, void* stream) {
+  if (!gbt || !dst || !row0 || !nj || r <= 0 || n_mods <= 0 || n_mods > 4) return A3V_ERR_ARG;
+  GbScatter sc{};
+  int mx = 0;
+  for (int j = 0; j < n_mods; ++j) {
+    if (!dst[j] || nj[j] <= 0 || row0[j] < 0) return A3V_ERR_ARG;
+    sc.dst[j] = dst[j]; sc.row0[j] = row0[j]; sc.nj[j] = nj[j];
+    mx = nj[j] > mx ? nj[j] : mx;
+  }
+  hipLaunchKernelGGL(lora_gb_scatter_kernel, dim3((mx * r + 255) / 256, n_mods), dim3(256), 0, (hipStream_t)stream, gbt, ld, r, sc);
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}
+
+// ------------------------------------------------------------------ multi-tensor AdamW (the small tensors of a step in ONE launch)
+// A LoRA step updates ~520 tensors of 4 K .. 176 K elements (adapters, norm weights): one launch each was 519 launches per step,
+// plus one a3v_lora_refresh per adapter to re-write its rows / columns of the fused bf16 group images.  Here blockIdx.y walks a
+// device-resident table of tensors that share the hyper-parameters (one torch param group), and the bf16 value of every updated
+// element goes to up to TWO strided destinations: element (i, j) of a [rows, cols] parameter -> d1[i s1r + j s1c], d2[i s2r + j s2c]
+// (lora_a [r, in]: its rows of A and its columns of A^T; lora_b [n_j, r]: its columns of B and its rows of B^T).  Same arithmetic
+// as adamw_kernel, element for element.
+namespace {
+__global__ __launch_bounds__(256) void adamw_multi_kernel(const a3v_adamw_tensor* __restrict__ tab, float decay, float b1, float b2,
+                                                          float step_size, float inv_bc2_sqrt, float eps, const float* __restrict__ gscale) {
+  const float gs = gscale ? *gscale : 1.f;
+  if (!(gs >= 0.f)) return;
+  const a3v_adamw_tensor t = tab[blockIdx.y];
+  const int64_t n4 = t.n / 4;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const bool vec_img = t.d1 && !t.d2 && t.s1c == 1 && t.s1r == t.cols && (t.cols & 3) == 0;      // contiguous same-shape image
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    f32x4 pp = reinterpret_cast<const f32x4*>(t.p)[i];
+    f32x4 gg = reinterpret_cast<const f32x4*>(t.g)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) gg[e] = __fmul_rn(gg[e], gs);
+    f32x4 mm = reinterpret_cast<const f32x4*>(t.m)[i];
+    f32x4 vv = reinterpret_cast<const f32x4*>(t.v)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      pp[e] *= decay;
+      mm[e] += (1.f - b1) * (gg[e] - mm[e]);
+      vv[e] = b2 * vv[e] + (1.f - b2) * gg[e] * gg[e];
+      pp[e] -= step_size * mm[e] / (sqrtf(vv[e]) * inv_bc2_sqrt + eps);
+    }
+    reinterpret_cast<f32x4*>(t.p)[i] = pp;
+    reinterpret_cast<f32x4*>(t.m)[i] = mm;
+    reinterpret_cast<f32x4*>(t.v)[i] = vv;
+    if (vec_img) {
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = f2bf(pp[e]);
+      reinterpret_cast<bf16x4*>(t.d1)[i] = o;
+    } else if (t.d1 || t.d2) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int64_t idx = i * 4 + e, r = idx / t.cols, c = idx - r * t.cols;
+        const bf16_t o = f2bf(pp[e]);
+        if (t.d1) reinterpret_cast<bf16_t*>(t.d1)[r * t.s1r + c * t.s1c] = o;
+        if (t.d2) reinterpret_cast<bf16_t*>(t.d2)[r * t.s2r + c * t.s2c] = o;
+      }
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(t.n - n4 * 4)) {
+    const int64_t i = n4 * 4 + threadIdx.x;
+    float pp = t.p[i] * decay;
+    const float gg = __fmul_rn(t.g[i], gs);
+    const float mm = t.m[i] + (1.f - b1) * (gg - t.m[i]);
+    const float vv = b2 * t.v[i] + (1.f - b2) * gg * gg;
+    pp -= step_size * mm / (sqrtf(vv) * inv_bc2_sqrt + eps);
+    t.p[i] = pp; t.m[i] = mm; t.v[i] = vv;
+    const int64_t r = i / t.cols, c = i - r * t.cols;
+    if (t.d1) reinterpret_cast<bf16_t*>(t.d1)[r * t.s1r + c * t.s1c] = f2bf(pp);
+    if (t.d2) reinterpret_cast<bf16_t*>(t.d2)[r * t.s2r + c * t.s2c] = f2bf(pp);
+  }
+}
+}  // namespace
+
+extern "C" int a3v_adamw_multi(const a3v_adamw_tensor* table_dev, int n_tensors, int64_t max_n, float lr, float beta1, float beta2, float eps,
+                               float weight_decay, int64_t step, const float* grad_scale, void* stream) {
+  if (!table_dev || n_tensors <= 0 || max_n <= 0 || step < 1) return A3V_ERR_ARG;
+  if (n_tensors > 65535) return A3V_ERR_SHAPE;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr / bc1), inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+  const float decay = (float)(1.0 - (double)lr * (double)weight_decay);
+  int64_t blocks = (max_n / 4 + 255) / 256;
+  if (blocks > 64) blocks = 64;            // a tensor's blocks stride over it; with hundreds of tensors in the grid the chip is full anyway
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)blocks, (unsigned)n_tensors), dim3(256), 0, (hipStream_t)stream, table_dev, decay, beta1,
+                     beta2, step_size, inv_bc2_sqrt, eps, grad_scale);
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}
+
 // ------------------------------------------------------------------ LoRA step images: one adapter's share of a fused group
 // After an optimizer step the bf16 images of a fused adapter group (A [Rp, in] stacked lora_a, B [N, Rp] block-diagonal lora_b,
 // and their transposes At [in, Rp], Bt [Rp, Npad] for the backward GEMMs; model/peft.py:40-64 parameters) only change in the r

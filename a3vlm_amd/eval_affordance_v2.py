@@ -169,6 +169,10 @@ def main(args):
     loader = torch.utils.data.DataLoader(torch.utils.data.Subset(dataset, idx), batch_size=args.batch_size, shuffle=False,
                                          num_workers=args.num_workers, pin_memory=True, drop_last=False, collate_fn=collate_fn)
     outputs = []
+    # the sampled recipe (default: temperature 0.1 / top-p 0.75) draws its uniform numbers from torch's device generator inside
+    # generate(): seeded here, per rank, so that a run with the same --seed reproduces its answers (the reference seeds only the
+    # dataset shuffle, :304; its sampling stream is whatever the process left in the generator)
+    torch.manual_seed(args.seed + rank)
     with torch.no_grad():
         for image, qids, prompts, annotations, paths in loader:
             image = pre.batch(image) if isinstance(image, list) else image.to(dev)

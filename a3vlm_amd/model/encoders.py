@@ -64,19 +64,23 @@ def attach_qformer(model, pretrained: bool = False, config=None):
 def convnext_tokens(feat_map: torch.Tensor) -> torch.Tensor:
     """[N, 3072, 8, 8] trunk output -> [N, 257, 3072] tokens (llama_ens5.py:406-418): 2x nearest upsampling to 16x16, flatten,
     mean token prepended as "cls"."""
-    assert feat_map.shape[1:] == (3072, 8, 8), feat_map.shape
+    assert feat_map.dim() == 4 and feat_map.shape[2:] == (8, 8), feat_map.shape      # (3072, 8, 8) for the real ConvNeXt-XXL trunk
     x = feat_map.repeat_interleave(2, dim=-1).repeat_interleave(2, dim=-2).flatten(-2).permute(0, 2, 1)
     return torch.cat([x.mean(dim=1, keepdim=True), x], dim=1)
 
 
-def attach_convnext_xxl(model, pretrained: bool = False):
-    """``model.openclip_convnext_xxl`` = open_clip 'convnext_xxlarge' visual trunk with identity pooling (llama_ens5.py:304-315)."""
-    try:
-        import open_clip
-    except ImportError as e:
-        raise ImportError("attach_convnext_xxl needs the `open_clip` package (open_clip_torch) and `timm`") from e
-    net, _, _ = open_clip.create_model_and_transforms("convnext_xxlarge", pretrained="laion2b_s34b_b82k_augreg_soup" if pretrained else None)
-    trunk = net.visual.trunk
+def attach_convnext_xxl(model, pretrained: bool = False, trunk: Optional[torch.nn.Module] = None):
+    """``model.openclip_convnext_xxl`` = open_clip 'convnext_xxlarge' visual trunk with identity pooling (llama_ens5.py:304-315).
+    ``trunk``: an already built timm-style ConvNeXt trunk (``trunk.head.global_pool`` / ``.flatten`` present, stride 32) to use
+    instead of building the open_clip model -- an environment without ``open_clip`` can hand in its own copy; its channel count must
+    equal the plugin's ``extra_feat_dim`` share."""
+    if trunk is None:
+        try:
+            import open_clip
+        except ImportError as e:
+            raise ImportError("attach_convnext_xxl needs the `open_clip` package (open_clip_torch) and `timm`") from e
+        net, _, _ = open_clip.create_model_and_transforms("convnext_xxlarge", pretrained="laion2b_s34b_b82k_augreg_soup" if pretrained else None)
+        trunk = net.visual.trunk
     trunk.head.global_pool = torch.nn.Identity()
     trunk.head.flatten = torch.nn.Identity()
     model.openclip_convnext_xxl = _freeze(trunk, model.norm.weight)
@@ -95,11 +99,14 @@ def dinov2_input(views: torch.Tensor) -> torch.Tensor:
     return (views * t(CLIP_STD) + t(CLIP_MEAN) - t(DINO_MEAN)) / t(DINO_STD)
 
 
-def attach_dinov2(model, pretrained: bool = False, repo: str = "facebookresearch/dinov2", source: Optional[str] = None):
+def attach_dinov2(model, pretrained: bool = False, repo: str = "facebookresearch/dinov2", source: Optional[str] = None,
+                  net: Optional[torch.nn.Module] = None):
     """``model.dinov2_vitg14`` via torch.hub (llama_ens5.py:317-322); tokens = [x_norm_clstoken | x_norm_patchtokens] (:429-434).
-    ``source='local'`` with ``repo`` = a checkout of the hub repository works without network access."""
-    kw = dict(source=source) if source else {}
-    net = torch.hub.load(repo, "dinov2_vitg14", pretrained=pretrained, **kw)
+    ``source='local'`` with ``repo`` = a checkout of the hub repository works without network access; ``net``: an already built
+    module with DINOv2's ``forward_features`` contract (dict with ``x_norm_clstoken`` [N, D] and ``x_norm_patchtokens`` [N, 256, D])."""
+    if net is None:
+        kw = dict(source=source) if source else {}
+        net = torch.hub.load(repo, "dinov2_vitg14", pretrained=pretrained, **kw)
     model.dinov2_vitg14 = _freeze(net, model.norm.weight)
 
     @torch.no_grad()
@@ -118,9 +125,10 @@ def _set_extra(model, slot: int, fn) -> None:
     model.extra_feat_fns = [f for f in slots if f is not None]
 
 
-def attach_reference_encoders(model, pretrained: bool = False):
-    """All three, as ``Transformer.__init__`` of the reference does with ``with_visual=True``."""
-    attach_qformer(model, pretrained)
-    attach_convnext_xxl(model, pretrained)
-    attach_dinov2(model, pretrained)
+def attach_reference_encoders(model, pretrained: bool = False, qformer_config=None, convnext_trunk=None, dinov2_net=None):
+    """All three, as ``Transformer.__init__`` of the reference does with ``with_visual=True`` (llama_ens5.py:283-322).  The keyword
+    arguments hand in pre-built modules / a Q-Former config (reduced-width runs, environments without open_clip / torch.hub access)."""
+    attach_qformer(model, pretrained, config=qformer_config)
+    attach_convnext_xxl(model, pretrained, trunk=convnext_trunk)
+    attach_dinov2(model, pretrained, net=dinov2_net)
     return model

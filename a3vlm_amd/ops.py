@@ -516,6 +516,20 @@ def rows_sum(src, row_idx, n_rows, out):
     _l.check(rc, "a3v_rows_sum")
 
 
+def lora_gb_scatter(gbt, r: int, views, row0s):
+    """views[j] ([n_j, r] fp32 contiguous) += gbt[j*r:(j+1)*r, row0s[j]:row0s[j]+n_j].T for the modules of a fused adapter group."""
+    import ctypes
+    _dev(gbt, *views)
+    n = len(views)
+    assert gbt.dtype == torch.float32 and gbt.stride(1) == 1 and all(v.dtype == torch.float32 and v.is_contiguous() and v.shape[1] == r for v in views)
+    dst = (ctypes.c_void_p * n)(*[v.data_ptr() for v in views])
+    r0 = (ctypes.c_int * n)(*[int(x) for x in row0s])
+    nj = (ctypes.c_int * n)(*[int(v.shape[0]) for v in views])
+    rc = _l.load().a3v_lora_gb_scatter(_p(gbt), gbt.stride(0), int(r), n, ctypes.cast(dst, ctypes.c_void_p), ctypes.cast(r0, ctypes.c_void_p),
+                                       ctypes.cast(nj, ctypes.c_void_p), _stream())
+    _l.check(rc, "a3v_lora_gb_scatter")
+
+
 def lora_refresh(wa, wb, A, At, B, Bt, col0: int, row0: int):
     """One adapter's rows / columns of the fused group images (A, At, B, Bt; bf16) from its fp32 lora_a [r, in], lora_b [nj, r]."""
     _dev(wa, wb, A, At, B, Bt)

@@ -44,6 +44,10 @@ class FusedAdamW(torch.optim.Optimizer):
         self.engine = engine
         self.image_of = image_of if engine is None else engine.image_sink
         self._stream: Optional[torch.cuda.Stream] = None
+        # small tensors (adapters, norm weights, ...) of a param group go through ONE a3v_adamw_multi launch per step instead of one
+        # launch each; A3V_ADAMW_MULTI=0 (A/B runs, equality tests) keeps the per-tensor launches
+        self.multi_threshold = int(os.environ.get("A3V_ADAMW_MULTI", str(1 << 20)))
+        self._tables = {}                      # param-group index -> (key, device table, max_n, [params])
 
     def state_dict(self):
         if self.engine is not None:
@@ -98,13 +102,35 @@ class FusedAdamW(torch.optim.Optimizer):
         else:
             stream = cur.cuda_stream
         written = set()
+        adapters = set()
         last = None
+        small = {}                             # id(group) -> [(p, sink)] handled by the multi-tensor launch (not with overlap: per-bucket events)
+        if not overlap and self.multi_threshold > 0:
+            for gi, group in enumerate(self.param_groups):
+                lst = []
+                for p in group["params"]:
+                    if p.grad is None or p.numel() > self.multi_threshold:
+                        continue
+                    img = self.image_of(p) if self.image_of is not None else None
+                    sink = None
+                    if img is not None:
+                        if img.dtype != torch.bfloat16 or img.shape != p.shape or not img.is_contiguous():
+                            raise RuntimeError("image_of must return a contiguous bf16 tensor of the parameter's shape")
+                        sink = (img.data_ptr(), p.shape[-1] if p.dim() > 1 else p.numel(), 1, 0, 0, 0)
+                    elif self.engine is not None and hasattr(self.engine, "adapter_sink"):
+                        sink = self.engine.adapter_sink(p)          # (d1, s1r, s1c, d2, s2r, s2c) inside the fused LoRA group images
+                        if sink is not None:
+                            adapters.add(id(p))
+                    lst.append((p, sink, img is not None))
+                if len(lst) >= 2:
+                    small[gi] = lst
+        in_multi = {id(p) for lst in small.values() for p, _, _ in lst}
         for bucket, group, p in order:
             if overlap and bucket != last:
                 if last is not None:
                     self.engine._weights_ready[last] = self._stream.record_event()
                 last = bucket
-            if p.grad is None:
+            if p.grad is None or id(p) in in_multi:
                 continue
             b1, b2 = group["betas"]
             st = self.state[p]
@@ -120,8 +146,39 @@ class FusedAdamW(torch.optim.Optimizer):
             torch.autograd.graph.increment_version(p)
             if img is not None:
                 written.add(id(p))
+        for gi, lst in small.items():
+            group = self.param_groups[gi]
+            b1, b2 = group["betas"]
+            steps = set()
+            for p, _, _ in lst:
+                st = self.state[p]
+                st["step"] += 1
+                steps.add(int(st["step"].item()))
+            if len(steps) != 1:
+                raise RuntimeError("FusedAdamW multi-tensor launch: the small tensors of a param group must share their step count")
+            key = tuple((p.data_ptr(), p.grad.data_ptr(), sink) for p, sink, _ in lst)
+            ent = self._tables.get(gi)
+            if ent is None or ent[0] != key:
+                rows = []
+                for p, sink, _ in lst:
+                    st = self.state[p]
+                    cols = p.shape[-1] if p.dim() > 1 else p.numel()
+                    d = sink if sink is not None else (0, 0, 0, 0, 0, 0)
+                    rows.append([p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(), cols,
+                                 d[0], d[1], d[2], d[3], d[4], d[5]])
+                tab = torch.tensor(rows, dtype=torch.int64).to(lst[0][0].device)
+                ent = self._tables[gi] = (key, tab, max(p.numel() for p, _, _ in lst))
+            rc = lib.a3v_adamw_multi(ent[1].data_ptr(), len(lst), ent[2], float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                     float(group["weight_decay"]), steps.pop(), gs_ptr, stream)
+            _l.check(rc, "a3v_adamw_multi")
+            for p, sink, same_shape in lst:
+                torch.autograd.graph.increment_version(p)
+                if same_shape:
+                    written.add(id(p))
         if overlap:
             self.engine._weights_ready[last if last is not None else "head"] = self._stream.record_event()
         if self.engine is not None:
             self.engine.images_adopted(written)
+            if adapters and hasattr(self.engine, "adapters_adopted"):
+                self.engine.adapters_adopted(adapters)
         return loss

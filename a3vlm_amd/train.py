@@ -19,7 +19,7 @@ from typing import Callable, Dict, List, Optional, Tuple
 import torch
 
 from . import ops
-from .util import install_param_epoch_hook, param_state_key
+from .util import install_param_epoch_hook, optimizer_steps, param_state_key
 
 
 def _pad64(n: int) -> int:
@@ -33,6 +33,10 @@ class TrainEngine:
     nn_dgrad = os.environ.get("A3V_NN_DGRAD", "1") != "0"              # input gradients by a3v_gemm_nn (else NT on W^T images)
     packed_attn_bwd = os.environ.get("A3V_PACKED_ATTN_BWD", "1") != "0"  # attention backward writes the rotated-back qkv gradient itself
     lora_kext = os.environ.get("A3V_LORA_KEXT", "1") != "0"            # adapters inside the main GEMMs: [x | t] . [W | B]^T (K extended by Rp)
+    # LoRA input gradients dx = [dy | dt] . [W ; A]: the base matrices are FROZEN, so a transposed image [W^T | A^T] can be kept for
+    # free and the product runs on the NT ring kernel (1.38-1.42 PF) instead of the NN kernel (1.28-1.30) for the groups named here
+    # ("0": none, "all", or a comma list of qkv / wo / w13 / w2).  Same-box LoRA step: 253.0 ms without, 248.9 with wo,w13,w2, 247.9 all
+    lora_nt_dgrad = os.environ.get("A3V_LORA_NT_DGRAD", "all")
 
     def __init__(self, model, compute_dtype: torch.dtype = torch.bfloat16, recompute: Optional[bool] = None):
         """``recompute``: True = keep only each block's input and re-run the block in backward (the reference's
@@ -106,6 +110,20 @@ class TrainEngine:
         n = {"qkv": 3, "wo": 1, "w13": 2, "w2": 1}[key.split(".")[0]]
         return _pad64(n * int(self.m.lora_rank))
 
+    def _nt_dgrad(self, key: str) -> bool:
+        sel = self.lora_nt_dgrad
+        if not self._kext() or sel in ("", "0"):
+            return False
+        g = key.split(".")[0]
+        frozen = not any(q.requires_grad for q in self._group_base_params(key))
+        return frozen and (sel == "all" or g in sel.split(","))
+
+    def _group_base_params(self, key: str):
+        g, i = key.split(".")[0], int(key.split(".")[1])
+        a, f = self.m.layers[i].attention, self.m.layers[i].feed_forward
+        return {"qkv": (a.wq.weight, a.wk.weight, a.wv.weight), "wo": (a.wo.weight,), "w13": (f.w1.weight, f.w3.weight),
+                "w2": (f.w2.weight,)}[g]
+
     def _kext(self) -> int:
         """Columns appended to the inputs / weight images of the four decoder GEMMs when the adapters ride inside them
         (LoRA, bf16): y = [x | t] . [W | B]^T with t = x . A^T -- no separate read-modify-write pass over y."""
@@ -134,11 +152,16 @@ class TrainEngine:
                 (p + "feed_forward.w2.weight", l.feed_forward.w2.weight),
                 (p + "attention_norm.weight", l.attention_norm.weight), (p + "ffn_norm.weight", l.ffn_norm.weight)]))
             if self.lora:
-                for sub, mod in (("attention.wq", l.attention.wq), ("attention.wk", l.attention.wk), ("attention.wv", l.attention.wv),
-                                 ("attention.wo", l.attention.wo), ("feed_forward.w1", l.feed_forward.w1),
-                                 ("feed_forward.w3", l.feed_forward.w3), ("feed_forward.w2", l.feed_forward.w2)):
-                    items[-1][1].append((p + sub + ".lora_a.weight", mod.lora_a.weight))
-                    items[-1][1].append((p + sub + ".lora_b.weight", mod.lora_b.weight))
+                # group-major: the lora_a of the modules that share an input are adjacent ([n r, in] as one matrix: the group's dA
+                # GEMM writes the gradients in place), then their lora_b
+                for group in ((("attention.wq", l.attention.wq), ("attention.wk", l.attention.wk), ("attention.wv", l.attention.wv)),
+                              (("attention.wo", l.attention.wo),),
+                              (("feed_forward.w1", l.feed_forward.w1), ("feed_forward.w3", l.feed_forward.w3)),
+                              (("feed_forward.w2", l.feed_forward.w2),)):
+                    for sub, mod in group:
+                        items[-1][1].append((p + sub + ".lora_a.weight", mod.lora_a.weight))
+                    for sub, mod in group:
+                        items[-1][1].append((p + sub + ".lora_b.weight", mod.lora_b.weight))
         items.append(("head", [("norm.weight", m.norm.weight), ("output.weight", m.output.weight)]))
         if m.with_visual:
             vp0, vp1 = getattr(m.visual_proj, "0"), getattr(m.visual_proj, "1")
@@ -317,8 +340,14 @@ class TrainEngine:
         after an optimizer step only the r rows / columns each adapter owns are re-written in place (one a3v_lora_refresh
         launch per adapter) -- rebuilding the padded / block-diagonal images from scratch was ~2500 small launches per step."""
         m = self.m
-        ver = tuple(param_state_key(q) for n, q in m.named_parameters() if "lora_" in n)
+        if getattr(self, "_li_checked", False) and self._li_steps == optimizer_steps():
+            return self._li                                # validated for this forward / backward (flag reset at their entry), no step since
+        self._li_steps = optimizer_steps()
+        if getattr(self, "_lora_plist", None) is None:
+            self._lora_plist = [q for n, q in m.named_parameters() if "lora_" in n]
+        ver = tuple(param_state_key(q) for q in self._lora_plist)
         if getattr(self, "_li_ver", None) == ver:
+            self._li_checked = True
             return self._li
         li = getattr(self, "_li", None)
         if li is not None and getattr(self, "_li_act", None) == self.act:
@@ -340,6 +369,7 @@ class TrainEngine:
                                 Bt[j * r:(j + 1) * r, row:row + nj].copy_(wb.t())
                             row += nj
             self._li_ver = ver
+            self._li_checked = True
             return li
         src = m.lora_images(dtype=self.act, interleave_w13=False)
         li = {}
@@ -366,8 +396,49 @@ class TrainEngine:
                     rows_a = fy[fy.shape[0] - Rp:]
                     rows_a.copy_(li[key + ".A"])
                     li[key + ".A"] = rows_a
+                    if self._nt_dgrad(key):
+                        ft = im[key + ".yT"]                      # [K, N + Rp]: the A^T block lives in its tail columns
+                        cols_at = ft[:, ft.shape[1] - Rp:]
+                        cols_at.copy_(li[key + ".At"][:cols_at.shape[0]])
+                        li[key + ".At"] = cols_at
         self._li, self._li_ver, self._li_act = li, ver, self.act
+        self._li_checked = True
+        self._adapter_sinks = None
         return li
+
+    def adapter_sink(self, p: torch.Tensor):
+        """For ``FusedAdamW``'s multi-tensor launch: where the bf16 value of element (i, j) of adapter parameter ``p`` lives inside
+        the fused group images, as (d1, s1r, s1c, d2, s2r, s2c) in element strides -- lora_a [r, in]: its rows of A and its columns
+        of A^T; lora_b [n_j, r]: its columns of B and its rows of B^T.  None when ``p`` is not an adapter or the images are not
+        built yet (first step: a3v_lora_refresh does it)."""
+        li = getattr(self, "_li", None)
+        if li is None or self.act != torch.bfloat16 or getattr(self, "_li_act", None) != self.act:
+            return None
+        sinks = getattr(self, "_adapter_sinks", None)
+        if sinks is None:
+            sinks = {}
+            r = self.m.lora_rank
+            for i in range(self.m.n_layers):
+                for key, mods, _ in self.m.lora_groups(i):
+                    A, Bm, At, Bt = li[key + ".A"], li[key + ".B"], li[key + ".At"], li[key + ".Bt"]
+                    row = 0
+                    for j, mod in enumerate(mods):
+                        wa, wb = mod.lora_a.weight, mod.lora_b.weight
+                        sinks[id(wa)] = (A.data_ptr() + 2 * (j * r) * A.stride(0), A.stride(0), 1,
+                                         At.data_ptr() + 2 * (j * r), 1, At.stride(0))
+                        sinks[id(wb)] = (Bm.data_ptr() + 2 * (row * Bm.stride(0) + j * r), Bm.stride(0), 1,
+                                         Bt.data_ptr() + 2 * ((j * r) * Bt.stride(0) + row), 1, Bt.stride(0))
+                        row += wb.shape[0]
+            self._adapter_sinks = sinks
+        return sinks.get(id(p))
+
+    def adapters_adopted(self, written_ids) -> None:
+        """The optimizer wrote every adapter's bf16 values into the group images itself: they are current for the new parameters."""
+        plist = getattr(self, "_lora_plist", None)
+        if plist is None or getattr(self, "_li", None) is None:
+            return
+        if all(id(q) in written_ids for q in plist if q.requires_grad):
+            self._li_ver = tuple(param_state_key(q) for q in plist)
 
     def _lora_fwd(self, key: str, x: torch.Tensor, y: torch.Tensor, tag: str) -> torch.Tensor:
         """y += lora_b(lora_a(x)) for a fused adapter group; returns t = lora_a(x) (kept for the backward)."""
@@ -385,7 +456,11 @@ class TrainEngine:
         li = self._lora_step_images()
         dy, dt = dy_full[:, :N], dy_full[:, N:]
         self._dgrad(dy, li[key + ".Bt"], dt)
-        ops.gemm_nn(dy_full, self._images()[key + ".y"], dx)
+        im = self._images()
+        if self._nt_dgrad(key):
+            ops.gemm_nt(dy_full, im[key + ".yT"], dx)          # frozen base: the transposed image is free (built once)
+        else:
+            ops.gemm_nn(dy_full, im[key + ".y"], dx)
         self._lora_bwd(i, key, dy, x, t, None, dt=dt)
 
     def _lora_bwd(self, i: int, key: str, dy: torch.Tensor, x: torch.Tensor, t: torch.Tensor, dx: Optional[torch.Tensor], dt=None):
@@ -403,19 +478,32 @@ class TrainEngine:
         # dB is produced transposed ([Rp, N] = t^T dy): the strip with the adapter rank as its ROW index streams dy 1.2-1.5x
         # faster through the TN kernel than the [N, Rp] strip (tools/lora_skinny_bench.py); the r x N_j blocks are added
         # into the [N_j, r] gradient views below
-        gBt = self._buf("lora_gBt." + g, (Rp, N), torch.float32)
-        gA = self._buf("lora_gA." + g, (Rp, x.shape[1]), torch.float32)
-        self._wgrad(t, dy, gBt, "lb", store=True)
-        self._wgrad(dt, x, gA, "la", store=True)
         names = {"qkv": ["attention.wq", "attention.wk", "attention.wv"], "wo": ["attention.wo"],
                  "w13": ["feed_forward.w1", "feed_forward.w3"], "w2": ["feed_forward.w2"]}[g]
-        row = 0
-        for j, nm in enumerate(names):
-            vb = self._views[f"layers.{i}.{nm}.lora_b.weight"]
-            va = self._views[f"layers.{i}.{nm}.lora_a.weight"]
-            vb.add_(gBt[j * r:(j + 1) * r, row:row + vb.shape[0]].t())
-            ops.add2d(va, gA[j * r:(j + 1) * r])
+        vas = [self._views[f"layers.{i}.{nm}.lora_a.weight"] for nm in names]
+        vbs = [self._views[f"layers.{i}.{nm}.lora_b.weight"] for nm in names]
+        nr = len(names) * r
+        gBt = self._buf("lora_gBt." + g, (Rp, N), torch.float32)
+        self._wgrad(t, dy, gBt, "lb", store=True)
+        # dA of the whole group straight into the flat gradient buffer: the group's lora_a gradients are adjacent = ONE [n r, in] matrix
+        adjacent = all(vas[j + 1].data_ptr() == vas[j].data_ptr() + 4 * vas[j].numel() for j in range(len(vas) - 1))
+        if adjacent and dt.stride(0) % 8 == 0:
+            off = (vas[0].data_ptr() - self._flat.data_ptr()) // 4
+            self._wgrad(dt[:, :nr], x, self._flat[off:off + nr * x.shape[1]].view(nr, x.shape[1]), "la", store=False)
+        else:
+            gA = self._buf("lora_gA." + g, (Rp, x.shape[1]), torch.float32)
+            self._wgrad(dt, x, gA, "la", store=True)
+            for j, va in enumerate(vas):
+                ops.add2d(va, gA[j * r:(j + 1) * r])
+        row0s, row = [], 0
+        for vb in vbs:
+            row0s.append(row)
             row += vb.shape[0]
+        if gBt.is_cuda:
+            ops.lora_gb_scatter(gBt, r, vbs, row0s)          # one launch: each module's [n_j, r] += its diagonal block transposed
+        else:
+            for j, vb in enumerate(vbs):
+                vb.add_(gBt[j * r:(j + 1) * r, row0s[j]:row0s[j] + vb.shape[0]].t())
         if dx is not None:
             ops.gemm_nt(dt, At, dx, residual=dx)             # dx += dt @ A
 
@@ -628,6 +716,7 @@ class TrainEngine:
     def forward_loss(self, examples: torch.Tensor, labels: torch.Tensor, image: Optional[torch.Tensor] = None,
                      qformer_feats=None, extra_feats=None) -> torch.Tensor:
         self._check_dtypes()
+        self._li_checked = False
         m, a = self.m, self.m.args
         im = self._images()
         B, T = examples.shape
@@ -690,6 +779,7 @@ class TrainEngine:
     def backward(self, grad_scale: float = 1.0) -> None:
         s = self._saved
         self._dha_ready = False
+        self._li_checked = False
         assert s is not None, "backward() without forward_loss()"
         m, a = self.m, self.m.args
         self.sync_optimizer()                    # the update reads the gradients this backward overwrites
@@ -838,6 +928,12 @@ class _Images:
             self.store[key] = full[:N, :K]
             self.store[key + ".x"] = full[:N]
             self.store[key + ".y"] = full[:, :K]
+            if self.eng._nt_dgrad(key):
+                # [W^T | A^T]  [K, N + Rp]: dx = [dy | dt] . (this)^T on the NT ring kernel; W is frozen, the A^T block is re-written
+                # with the adapters (a3v_adamw_multi / a3v_lora_refresh)
+                ft = torch.zeros(K, N + ext, dtype=self.eng.act, device=w.device)
+                ft[:, :N] = full[:N, :K].t()
+                self.store[key + ".yT"] = ft
         else:
             self.store[key] = w.to(self.eng.act).contiguous()
 

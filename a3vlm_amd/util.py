@@ -48,7 +48,17 @@ _PARAM_EPOCH: "dict[int, int]" = {}
 _HOOKED = False
 
 
+_OPT_STEPS = [0]
+
+
+def optimizer_steps() -> int:
+    """How many optimizer steps (any torch.optim.Optimizer subclass) this process has taken: a cheap "nothing can have changed" test
+    in front of the per-parameter cache keys."""
+    return _OPT_STEPS[0]
+
+
 def _after_optimizer_step(optimizer, args, kwargs) -> None:
+    _OPT_STEPS[0] += 1
     if getattr(optimizer, "bumps_version", False):      # e.g. a3vlm_amd.optim.FusedAdamW: Tensor._version already moved
         return
     for group in optimizer.param_groups:

@@ -424,6 +424,28 @@ int a3v_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq
 int a3v_adamw_scaled(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
                      float eps, float weight_decay, int64_t step, void* bf16_image, const float* grad_scale, void* stream);
 
+/* Adapter weight gradients of a fused LoRA group (model/peft.py:58-159: lora_b of the n_mods <= 4 linears that share an input):
+ * gbt = t^T . dy, fp32 [>= n_mods*r, N] with row stride ld, holds the group's dB^T; module j owns rows j*r..(j+1)*r of columns
+ * row0[j]..row0[j]+nj[j]; dst[j] (fp32 [nj[j], r], contiguous: the parameter's gradient) += that block transposed.  dst / row0 / nj
+ * are HOST arrays (dst[j] device pointers). */
+int a3v_lora_gb_scatter(const float* gbt, int64_t ld, int r, int n_mods, float* const* dst, const int* row0, const int* nj, void* stream);
+
+/* The same update for MANY small tensors of one torch param group in ONE launch (a LoRA step: ~520 adapter / norm tensors; was one
+ * launch per tensor plus one a3v_lora_refresh per adapter).  `table` is a DEVICE array of n_tensors descriptors (built once by the
+ * host, a3vlm_amd/optim.py); every pointer 16-byte aligned, fp32 contiguous p / g / m / v of n elements viewed as [n / cols, cols].
+ * The bf16 value of updated element (i, j) is also stored to d1[i*s1r + j*s1c] and d2[i*s2r + j*s2c] when those are non-NULL
+ * (element strides): a same-shape image (s1r = cols, s1c = 1), or an adapter's rows / columns inside the fused group images and
+ * their transposes (model/peft.py:40-64 parameters; reference optimizer: main_finetune.py:138).  max_n = the largest n.
+ * Arithmetic identical to a3v_adamw_scaled. */
+typedef struct {
+  float* p; const float* g; float* m; float* v;
+  int64_t n, cols;
+  void* d1; int64_t s1r, s1c;
+  void* d2; int64_t s2r, s2c;
+} a3v_adamw_tensor;
+int a3v_adamw_multi(const a3v_adamw_tensor* table, int n_tensors, int64_t max_n, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, int64_t step, const float* grad_scale, void* stream);
+
 /* dst[i] = (dst_dtype)(src[i] * scale), n contiguous elements, both 16-B aligned: the wire-dtype conversions of the DP gradient
  * reducer (fp32 bucket -> bf16 wire bucket pre-scaled by 1/world, and back) -- FSDP's reduce_dtype = bf16 averaging
  * (main_finetune.py:251-255) without separate scale / cast / copy passes over the gradient buffer. */

@@ -351,6 +351,27 @@ def encode_image(image: Tensor, sd: Dict[str, Tensor], *, vit_layers: int, vit_h
     return list(torch.chunk(feats, n_views))
 
 
+def ensemble_extra_feats(views: Tensor, convnext_trunk, dinov2_net) -> List[Tensor]:
+    """LLM/llama_ens5.py:402-434: the two extra streams of the reference's ensemble from the per-view pixels, given the frozen nets
+    (any modules with the trunk / ``forward_features`` contracts -- the real ones are third-party and out of scope).
+    ConvNeXt: fp16 round trip of the input, F.interpolate to 256x256 (nearest, the default), trunk -> [N, C, 8, 8], 2x repeat to
+    16x16, flatten to 256 tokens, their mean prepended as "cls".  DINOv2: CLIP-normalised pixels re-normalised with the ImageNet
+    mean / std, tokens = [x_norm_clstoken | x_norm_patchtokens]."""
+    with torch.no_grad():
+        cf = convnext_trunk(F.interpolate(views.half(), size=(256, 256)).to(views))
+        assert cf.shape[2:] == (8, 8)
+        cf = cf.repeat_interleave(2, dim=-1).repeat_interleave(2, dim=-2)
+        cf = cf.flatten(-2).permute(0, 2, 1)
+        cf = torch.cat([cf.mean(dim=1, keepdim=True), cf], dim=1)
+        clip_mean = torch.tensor([0.48145466, 0.4578275, 0.40821073]).to(views).view(3, 1, 1)
+        clip_std = torch.tensor([0.26862954, 0.26130258, 0.27577711]).to(views).view(3, 1, 1)
+        d_mean = torch.tensor([0.485, 0.456, 0.406]).to(views).view(3, 1, 1)
+        d_std = torch.tensor([0.229, 0.224, 0.225]).to(views).view(3, 1, 1)
+        df = dinov2_net.forward_features((views * clip_std + clip_mean - d_mean) / d_std)
+        df = torch.cat([df["x_norm_clstoken"].unsqueeze(1), df["x_norm_patchtokens"]], dim=1)
+    return [cf, df]
+
+
 def assemble_image_tokens(views: List[Tensor], start_img: Tensor, end_img: Tensor) -> Tensor:
     """LLM/llama_ens5.py:471-476: per view cat(start_img, tokens, end_img); cat views."""
     bsz = views[0].shape[0]

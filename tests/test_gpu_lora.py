@@ -203,13 +203,20 @@ def test_lora_step_images_refresh_in_place_after_optimizer_step():
     lab[:, :4] = 0
     eng = TrainEngine(m, BF)
     params = [p for p in m.parameters() if p.requires_grad]
+    # FusedAdamW(engine=eng): the multi-tensor launch writes every adapter's bf16 values into the group images itself (strided sinks)
+    # and marks them current; without the engine (and for torch's optimizer) the engine re-writes them with a3v_lora_refresh
     for opt in (FusedAdamW(params, lr=1e-2, betas=(0.9, 0.95), weight_decay=0.0),
+                FusedAdamW(params, lr=1e-2, betas=(0.9, 0.95), weight_decay=0.0, engine=eng),
                 torch.optim.AdamW(params, lr=1e-2, betas=(0.9, 0.95), weight_decay=0.0, fused=True)):
         for _ in range(2):
             eng.forward_loss(ex.to(DEV), lab.to(DEV), None)
             eng.backward(1.0)
             opt.step()
             opt.zero_grad(set_to_none=True)
+            if getattr(opt, "engine", None) is eng:
+                ver = eng._li_ver
+                li = eng._lora_step_images()
+                assert eng._li_ver == ver             # nothing was refreshed: the optimizer's own writes are what is compared below
             li = eng._lora_step_images()                  # refreshed in place
             fresh = TrainEngine(m, BF)._lora_step_images()  # built from scratch from the updated parameters
             assert set(li) == set(fresh)

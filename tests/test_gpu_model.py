@@ -402,3 +402,128 @@ def test_attach_hf_qformer_provider(gold):
     xn = (x - torch.tensor(CLIP_MEAN).view(3, 1, 1)) / torch.tensor(CLIP_STD).view(3, 1, 1)
     want_d = (x - torch.tensor([0.485, 0.456, 0.406]).view(3, 1, 1)) / torch.tensor([0.229, 0.224, 0.225]).view(3, 1, 1)
     assert torch.allclose(dinov2_input(xn), want_d, atol=1e-5)
+
+
+# ------------------------------------------------------------------ N4: all three frozen encoders of the ensemble run once
+class _TinyConvNeXtTrunk(torch.nn.Module):
+    """Architecture-shaped stand-in for the timm ConvNeXt trunk open_clip builds (stem 4x4/4, three 2x2/2 down-samplings -> stride
+    32: 256 -> 8; depthwise 7x7 + pointwise MLP blocks; ``head`` with ``global_pool`` / ``flatten`` that the provider must neutralise).
+    Nothing of timm / open_clip is vendored: this only has the SHAPE CONTRACT the reference relies on (llama_ens5.py:304-315, 402-405)."""
+
+    class _Head(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.global_pool = torch.nn.AdaptiveAvgPool2d(1)
+            self.flatten = torch.nn.Flatten(1)
+
+        def forward(self, x):
+            return self.flatten(self.global_pool(x))
+
+    def __init__(self, out_ch):
+        super().__init__()
+        ch = [out_ch // 8, out_ch // 4, out_ch // 2, out_ch]
+        self.stem = torch.nn.Conv2d(3, ch[0], 4, 4)
+        self.down = torch.nn.ModuleList([torch.nn.Conv2d(ch[i], ch[i + 1], 2, 2) for i in range(3)])
+        self.dw = torch.nn.ModuleList([torch.nn.Conv2d(c, c, 7, padding=3, groups=c) for c in ch])
+        self.pw = torch.nn.ModuleList([torch.nn.Conv2d(c, c, 1) for c in ch])
+        self.head = self._Head()
+
+    def forward(self, x):
+        x = self.stem(x)
+        for i in range(4):
+            x = x + self.pw[i](torch.nn.functional.gelu(self.dw[i](x)))
+            if i < 3:
+                x = self.down[i](x)
+        return self.head(x)
+
+
+class _TinyDinoV2(torch.nn.Module):
+    """Stand-in with DINOv2's ``forward_features`` contract: patch 14 on 224 x 224 -> 256 patch tokens + cls, normalised."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.patch_embed = torch.nn.Conv2d(3, dim, 14, 14)
+        self.cls_token = torch.nn.Parameter(torch.randn(1, 1, dim) * 0.02)
+        self.pos = torch.nn.Parameter(torch.randn(1, 257, dim) * 0.02)
+        self.blocks = torch.nn.ModuleList([torch.nn.TransformerEncoderLayer(dim, 2, dim * 2, dropout=0.0, batch_first=True, norm_first=True)
+                                           for _ in range(2)])
+        self.norm = torch.nn.LayerNorm(dim)
+
+    def forward_features(self, x):
+        t = self.patch_embed(x).flatten(2).transpose(1, 2)
+        t = torch.cat([self.cls_token.expand(t.shape[0], -1, -1), t], dim=1) + self.pos
+        for b in self.blocks:
+            t = b(t)
+        t = self.norm(t)
+        return {"x_norm_clstoken": t[:, 0], "x_norm_patchtokens": t[:, 1:]}
+
+
+def test_attach_reference_encoders_end_to_end_with_stand_ins(gold):
+    """N4: ``attach_reference_encoders`` runs all three frozen streams of the reference's ensemble
+    (llama_ens5.py:283-322, 399-440) behind the plugin hooks -- the real BLIP-2 Q-Former class from ``transformers`` at reduced
+    width, and architecture-shaped stand-ins for the ConvNeXt trunk / DINOv2 (open_clip and torch.hub are not in this image; the
+    stand-ins carry exactly the contracts the reference relies on: trunk(256 x 256) -> [N, C, 8, 8] with a poolable head,
+    forward_features -> cls + 256 patch tokens).  Checked: modules registered under the reference's attribute names (checkpoint keys
+    load by name) and frozen; the pre/post-processing (fp16 round trip + nearest resize to 256, 2x repeat to 16 x 16, mean token,
+    CLIP -> ImageNet re-normalisation); and the ORDER of the concatenated ``visual_proj`` input [CLIP | ConvNeXt | DINOv2]
+    (:436-440, G8) -- logits equal the oracle fed the same modules' features, and differ when the two extra streams are swapped."""
+    pytest.importorskip("transformers")
+    import copy
+    from transformers import Blip2Config, Blip2QFormerConfig, Blip2VisionConfig, OPTConfig
+    from a3vlm_amd.model.encoders import attach_reference_encoders
+    V = gold["j"]["vocab_size"]
+    C_CNX, C_DINO = 48, 24
+    args = plugin.ModelArgs(vocab_size=V, **{**TINY, "max_seq_len": 1600}, vit_width=VIT["width"], vit_layers=VIT["layers"],
+                            vit_heads=VIT["heads"], vit_patch=VIT["patch"], vit_crop=224, n_views=5, qformer_tokens=32,
+                            extra_feat_dim=C_CNX + C_DINO)
+    m = plugin.Transformer(args, with_visual=True)
+    sd = ref_cpu.make_decoder_weights(ref_cpu.OracleArgs(vocab_size=V, **TINY), seed=0, std=0.08)
+    vsd = ref_cpu.make_vision_weights(64, width=VIT["width"], layers=VIT["layers"], patch=VIT["patch"], grid=VIT["grid"],
+                                      in_feat=VIT["width"] + C_CNX + C_DINO, with_qformer=True, seed=1, std=0.05)
+    m.load_state_dict({**sd, **vsd}, strict=True)
+    m.to(torch.float32).to(DEV)
+    torch.manual_seed(3)
+    cfg = Blip2Config(vision_config=Blip2VisionConfig(hidden_size=32, intermediate_size=64, num_hidden_layers=2, num_attention_heads=2,
+                                                      image_size=224, patch_size=14).to_dict(),
+                      qformer_config=Blip2QFormerConfig(hidden_size=768, num_hidden_layers=2, num_attention_heads=12, intermediate_size=128,
+                                                        encoder_hidden_size=32, vocab_size=100, max_position_embeddings=32).to_dict(),
+                      text_config=OPTConfig(vocab_size=64, hidden_size=16, num_hidden_layers=1, ffn_dim=16, num_attention_heads=2,
+                                            max_position_embeddings=32, word_embed_proj_dim=16).to_dict(), num_query_tokens=32)
+    trunk, dino = _TinyConvNeXtTrunk(C_CNX), _TinyDinoV2(C_DINO)
+    trunk_cpu, dino_cpu = copy.deepcopy(trunk), copy.deepcopy(dino)
+    attach_reference_encoders(m, qformer_config=cfg, convnext_trunk=trunk, dinov2_net=dino)
+    keys = set(m.state_dict())
+    for prefix in ("qformer.", "openclip_convnext_xxl.", "dinov2_vitg14."):
+        assert any(k.startswith(prefix) for k in keys), prefix
+        assert not any(n.startswith(prefix) for n in m.get_trainable_params())
+    assert isinstance(m.openclip_convnext_xxl.head.global_pool, torch.nn.Identity) and len(m.extra_feat_fns) == 2
+    assert not any(p.requires_grad for mod in (m.qformer, m.openclip_convnext_xxl, m.dinov2_vitg14) for p in mod.parameters())
+    B = 2
+    img = synth_image(B)
+    g = torch.Generator().manual_seed(5)
+    ex = torch.randint(3, V, (B, 9), generator=g)
+    ex[:, 0] = 1
+    out = m(ex.to(DEV), img.to(DEV)).float().cpu()
+    assert m.image_words == (32 + 257 + 2) * 5
+    # oracle: the reference's arithmetic around the same three modules (CPU copies) on the oracle's own views
+    views_px = ref_cpu.split_views(img, 224)
+    q_cpu = copy.deepcopy(m.qformer).to("cpu")
+    with torch.no_grad():
+        qf = q_cpu.get_qformer_features(pixel_values=views_px)
+        qf = getattr(qf, "last_hidden_state", qf)
+    trunk_cpu.head.global_pool = torch.nn.Identity()
+    trunk_cpu.head.flatten = torch.nn.Identity()
+    extra = ref_cpu.ensemble_extra_feats(views_px, trunk_cpu.eval(), dino_cpu.eval())
+    assert extra[0].shape == (5 * B, 257, C_CNX) and extra[1].shape == (5 * B, 257, C_DINO)
+    dec = ref_cpu.OracleDecoder(ref_cpu.OracleArgs(vocab_size=V, **{**TINY, "max_seq_len": 1600}), sd)
+
+    def oracle(extra_feats):
+        views = ref_cpu.encode_image(img, vsd, vit_layers=VIT["layers"], vit_heads=VIT["heads"], n_views=5, patch=VIT["patch"], qformer_feats=qf,
+                                     extra_feats=extra_feats)
+        return dec.forward(ex, ref_cpu.assemble_image_tokens(views, vsd["start_img"], vsd["end_img"])).float()
+    want = oracle(extra)
+    assert rel_err(out, want.numpy()) < 5e-3
+    # the column order [CLIP | ConvNeXt | DINOv2] matters: the swapped concatenation (widths permuting with it) is a different model
+    pad = torch.zeros(5 * B, 257, C_CNX - C_DINO)
+    swapped = oracle([torch.cat([extra[1], pad], dim=2), extra[0][:, :, :C_DINO]])
+    assert rel_err(out, swapped.numpy()) > 20 * rel_err(out, want.numpy())

@@ -8,7 +8,6 @@ random stream differs between CPU and GPU builds of torch and is not part of the
 import json
 import os
 import types
-from unittest import mock
 
 import pytest
 import torch
@@ -33,7 +32,9 @@ def _boundary_ok(probs_row, p, u, got, want, eps=2e-6):
         return False
     a = ids.index(got)
     if float(ps[0][a]) <= 0:
-        return False
+        # top_p >= 1: the reference's fp32 cumsum drifts past 1.0 somewhere in the tail and its `cumsum - p > top_p` test then cuts
+        # everything behind that point (an artefact of its summation order); a token from that tail is a legitimate draw of "keep all"
+        return p >= 1.0 and float(probs_row[got]) > 0 and float(probs_row[idx[0][ps[0] <= 0]].sum()) < 1e-3
     cdf = torch.cumsum(ps[0].double(), -1)
     lo = float(cdf[a - 1]) if a > 0 else 0.0
     return lo - eps <= u <= float(cdf[a]) + eps
@@ -85,7 +86,7 @@ def test_device_sampler_full_vocabulary_with_ties(T, p):
                 n_keep = int((ref_cpu.top_p_nucleus(probs[2:3], p)[0] > 0).sum())
                 assert abs(got[r] - uval * n_keep) <= 2 + 1e-4 * n_keep and got[r] < max(n_keep, 1) + 1, (uval, got[r], n_keep)
                 continue
-            if not _boundary_ok(probs[r], p, uval, got[r], want[r], eps=4e-5):
+            if not _boundary_ok(probs[r], p, uval, got[r], want[r], eps=4e-5 if p < 1.0 else 1e-3):
                 bad += 1
     assert bad == 0
     # reproducible: same inputs, same ids (per-wave histograms merged in a fixed order)
@@ -166,8 +167,11 @@ def test_generate_sampled_default_generator_is_seedable(tmp_path):
 
 def test_eval_entry_default_recipe_matches_the_oracle_replay(tmp_path):
     """The batch-inference entry point with its DEFAULT sampling recipe (temperature 0.1, top-p 0.75: eval_affordance_v2.py:46-49;
-    no --temperature flag), run in-process so that the uniforms generate() draws can be recorded: the oracle replayed with those
-    numbers through the same image pipeline / prompt / post-processing yields the same records."""
+    no --temperature flag), as a subprocess.  The entry seeds torch's device generator with --seed right before its generation loop
+    and generate() draws its [steps, batch] uniforms from it in one call, so the same seed + shape here yields the numbers it used:
+    the oracle replayed with them through the same image pipeline / prompt / post-processing yields the same records."""
+    import subprocess
+    import sys
     from PIL import Image
     from a3vlm_amd import checkpoint as ck
     from a3vlm_amd import eval_affordance_v2 as entry
@@ -175,7 +179,6 @@ def test_eval_entry_default_recipe_matches_the_oracle_replay(tmp_path):
     from a3vlm_amd.data.transform import T_padded_resize
     from a3vlm_amd.model.meta import MetaModel
     from oracle.gen_golden import TINY
-    import argparse
     gd = os.path.join(ROOT, "tests", "golden")
     vit = dict(vit_width=64, vit_layers=2, vit_heads=4, vit_crop=112, n_views=5)
     cfgp = tmp_path / "cfg.json"
@@ -186,27 +189,23 @@ def test_eval_entry_default_recipe_matches_the_oracle_replay(tmp_path):
     vsd = ref_cpu.make_vision_weights(64, width=64, layers=2, patch=14, grid=8, seed=1, std=0.05)
     mm.llma.load_state_dict({**sd, **vsd})
     ckdir = ck.save_checkpoint(str(tmp_path / "ck"), types.SimpleNamespace(precision="tf32", only_save_trainable=False), mm, None, None, None, epoch=0)
-    argv = ["--llama_type", "llama_ens5", "--llama_config", str(cfgp), "--tokenizer_path", os.path.join(gd, "tokenizer.model"),
-            "--pretrained_path", ckdir, "--batch_size", "3", "--num_workers", "0", "--dataset", os.path.join(gd, "demo", "demo.json"),
-            "--input_size", "224", "--addition_flag", "s", "--max_gen_len", "12", "--max_seq_len", "512",
-            "--image_root", os.path.join(gd, "demo"), "--output_root", str(tmp_path / "logs"), "--precision", "tf32"]
-    args = argparse.ArgumentParser(parents=[entry.get_args_parser()]).parse_args(argv)
-    assert args.temperature == 0.1 and args.top_p == 0.75
-    drawn = []
-    real_rand = torch.rand
-
-    def recording_rand(*a, **k):
-        t = real_rand(*a, **k)
-        if t.dim() == 2 and t.is_cuda:
-            drawn.append(t.detach().cpu().clone())
-        return t
+    SEED, GEN = 7, 12
+    e = dict(os.environ)
+    e["PYTHONPATH"] = ROOT + os.pathsep + e.get("PYTHONPATH", "")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
-        os.environ.pop(k, None)
-    torch.manual_seed(123)
-    with mock.patch("torch.rand", recording_rand):
-        recs = entry.main(args)
-    assert len(recs) == 3 and len(drawn) == 1 and drawn[0].shape[1] == 3
-    U = drawn[0]
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "a3vlm_amd.eval_affordance_v2", "--llama_type", "llama_ens5", "--llama_config", str(cfgp),
+                        "--tokenizer_path", os.path.join(gd, "tokenizer.model"), "--pretrained_path", ckdir, "--batch_size", "3",
+                        "--num_workers", "0", "--dataset", os.path.join(gd, "demo", "demo.json"), "--input_size", "224",
+                        "--addition_flag", "s", "--max_gen_len", str(GEN), "--max_seq_len", "512", "--seed", str(SEED),
+                        "--image_root", os.path.join(gd, "demo"), "--output_root", str(tmp_path / "logs"), "--precision", "tf32"],
+                       cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    recs = json.load(open(tmp_path / "logs" / "s" / "demo.json"))
+    assert len(recs) == 3
+    assert entry.get_args_parser().get_default("temperature") == 0.1 and entry.get_args_parser().get_default("top_p") == 0.75
+    torch.manual_seed(SEED)
+    U = torch.rand(GEN, 3, device=DEV, dtype=torch.float32).cpu()          # what generate() drew (all three prompts are equally long)
     img = T_padded_resize(224)(Image.open(os.path.join(gd, "demo", "render_336x300.png")).convert("RGB")).unsqueeze(0)
     conv = default_conversation()
     conv.load_qas([["Detect all manipulable object parts and provide their 3D bounding boxes.", None]])
@@ -218,11 +217,8 @@ def test_eval_entry_default_recipe_matches_the_oracle_replay(tmp_path):
 
     def sampler(step, logits):
         return ref_cpu.sample_top_p_at(torch.softmax(logits / 0.1, dim=-1), 0.75, U[step])
-    _, outs = ref_cpu.generate_greedy(dec, ids, image_tokens=itok, image_words=itok.shape[1], max_gen_len=12, eos_id=mm.tokenizer.eos_id,
+    _, outs = ref_cpu.generate_greedy(dec, ids, image_tokens=itok, image_words=itok.shape[1], max_gen_len=GEN, eos_id=mm.tokenizer.eos_id,
                                       sampler=sampler)
-    for r in range(3):
-        want = entry.postprocess_answer(mm.tokenizer.decode(outs[r]))
-        assert recs[r]["answer"] == want and recs[r]["format_answer"] == entry.format_bounding_box(want), r
-    # three identical requests, three different uniform streams: with std 0.3 weights at least one row leaves the greedy path
-    _, greedy = ref_cpu.generate_greedy(dec, ids[:1], image_tokens=itok[:1], image_words=itok.shape[1], max_gen_len=12, eos_id=mm.tokenizer.eos_id)
-    assert any(o != greedy[0] for o in outs) or True
+    for r_ in range(3):
+        want = entry.postprocess_answer(mm.tokenizer.decode(outs[r_]))
+        assert recs[r_]["answer"] == want and recs[r_]["format_answer"] == entry.format_bounding_box(want), r_

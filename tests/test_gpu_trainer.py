@@ -239,6 +239,70 @@ def test_fused_adamw_matches_torch_adamw():
         FusedAdamW([bad]).step()
 
 
+def test_fused_adamw_multi_tensor_launch_equals_per_tensor_launches():
+    """a3v_adamw_multi (all small tensors of a param group in one launch, bf16 values to same-shape images or to two strided sinks)
+    against one a3v_adamw_scaled launch per tensor: parameters, moments and images bit-equal over 4 steps, with a clip
+    coefficient, a skipped (negative-coefficient) step and odd sizes."""
+    import torch
+    from a3vlm_amd.optim import FusedAdamW
+    DEV = "cuda"
+    g = torch.Generator().manual_seed(2)
+    shapes = [(16, 4096), (4096, 16), (4096,), (11008, 16), (7,), (16, 11008), (130, 6)]
+
+    class Eng:          # stands in for TrainEngine: strided sinks for the 2-D "adapters", nothing for the rest
+        def __init__(self, ps):
+            self.A = {id(p): torch.zeros(p.shape[0] + 3, p.shape[1] + 5, dtype=torch.bfloat16, device=DEV) for p in ps if p.dim() == 2}
+            self.At = {id(p): torch.zeros(p.shape[1] + 2, p.shape[0] + 9, dtype=torch.bfloat16, device=DEV) for p in ps if p.dim() == 2}
+
+        def image_sink(self, p):
+            return None
+
+        def adapter_sink(self, p):
+            if id(p) not in self.A:
+                return None
+            a, at = self.A[id(p)], self.At[id(p)]
+            return (a.data_ptr() + 2 * (1 * a.stride(0) + 2), a.stride(0), 1, at.data_ptr() + 2 * (1 * at.stride(0) + 4), 1, at.stride(0))
+
+        def images_adopted(self, w):
+            pass
+
+        def adapters_adopted(self, w):
+            self.adopted = set(w)
+
+        def sync_optimizer(self):
+            pass
+    base = [torch.randn(*s, generator=g).to(DEV) for s in shapes]
+    runs = []
+    for multi in (True, False):
+        ps = [b.clone().requires_grad_(True) for b in base]
+        eng = Eng(ps)
+        opt = FusedAdamW([dict(params=ps[:4], weight_decay=0.05), dict(params=ps[4:], weight_decay=0.0)], lr=2e-3, betas=(0.9, 0.95), engine=eng)
+        if not multi:
+            opt.multi_threshold = 0
+        gg = torch.Generator().manual_seed(3)
+        for it in range(4):
+            for p in ps:
+                p.grad = (torch.randn(p.shape, generator=gg) * (0.1 + it)).to(DEV)
+            coef = torch.tensor([-1.0 if it == 2 else 0.37], device=DEV)
+            opt.step(grad_scale=coef)
+        if multi:
+            assert eng.adopted == {id(p) for p in ps if p.dim() == 2}
+        runs.append((ps, [opt.state[p] for p in ps], eng))
+    (pa, sa, ea), (pb, sb, eb) = runs
+    for i in range(len(shapes)):
+        assert torch.equal(pa[i], pb[i]) and torch.equal(sa[i]["exp_avg"], sb[i]["exp_avg"]) and torch.equal(sa[i]["exp_avg_sq"], sb[i]["exp_avg_sq"]), i
+        assert float(sa[i]["step"]) == 4
+        if pa[i].dim() == 2:
+            a, at = ea.A[id(pa[i])], ea.At[id(pa[i])]
+            r, c = pa[i].shape
+            want = pa[i].detach().to(torch.bfloat16)
+            assert torch.equal(a[1:1 + r, 2:2 + c], want) and torch.equal(at[1:1 + c, 4:4 + r], want.t())
+            a2, at2 = a.clone(), at.clone()
+            a2[1:1 + r, 2:2 + c] = 0
+            at2[1:1 + c, 4:4 + r] = 0
+            assert not bool(a2.any()) and not bool(at2.any())        # nothing outside the blocks was touched
+
+
 @pytest.mark.parametrize("opt_kind", ["torch_fused", "torch_plain", "hip", "hip_engine"])
 def test_engine_sees_updates_of_any_optimizer(opt_kind):
     """The engine's bf16 weight images are caches; torch.optim.AdamW(fused=True) updates parameters WITHOUT bumping
