@@ -3348,7 +3348,7 @@ extern "C" int a3v_gemm_nt_splitk(const void* A, int64_t lda, const void* W, int
   p.lda = lda; p.ldw = ldw; p.ldc = N; p.ldr = 0;
   p.M = M; p.N = N; p.K = K; p.epi = A3V_EPI_OUT_F32 | GEMM_EPI_RAW; p.dbg = 0;
   p.c_split = (int64_t)M * N * 4;
-  const int narrow = A3V_ENV_INT("A3V_SKINNY_NARROW", 1);
+  const int narrow = A3V_ENV_INT("A3V_SKINNY_NARROW", 3);   // 3: 64-row tiles (same-box sweep, tools/lora_skinny_bench.py: 20.5 / 42.8 / 41.9 / 111.5 us at S = 4 against 25.4 / 48.0 / 47.4 / 110.6 for the 256-row tile at its best S)
   if (N <= 64 && M >= 512 && narrow) {
     // adapter-sized output (rank pad 64): 256 x 64 tiles -- 80 % of the LDS-DMA traffic is the streamed operand (50 % with the
     // 128 x 128 tile, whose second operand tile is half padding)

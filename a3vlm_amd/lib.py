@@ -38,6 +38,8 @@ SIGNATURES = {
     "a3v_adamw_multi": (I, [P, I, L, F, F, F, F, F, L, P, P]),
     "a3v_scale_cast": (I, [P, I, P, I, L, F, P]),
     "a3v_sumsq_partials": (I, [P, L, P, P]),
+    "a3v_grad_bucket_allreduce": (I, [P, P, L, P, I, P]),
+    "a3v_rccl_available": (I, []),
     "a3v_gemm_nn": (I, [P, L, P, L, P, L, I, I, I, P, L, I, P]),
     "a3v_gemm_tn": (I, [P, L, P, L, P, L, I, I, I, P, L, I, P]),
     "a3v_gemm_tn_sumsq": (I, [P, L, P, L, P, L, I, I, I, P, L, I, P, L, P]),

@@ -301,6 +301,8 @@ class TrainEngine:
         S = 1
         while blocks * S < 512 and S * 2 <= nk and S < 32:
             S *= 2
+        if N <= 64 and M >= 512 and S > 4:
+            S = 4            # 64-row tiles (a3v_gemm_nt_splitk): M / 64 blocks per slice already fill the chip; more slices only add reduce work
         if S == 1 or self.act != torch.bfloat16 or K % 64:
             f32 = out.dtype == torch.float32 and self.act == torch.bfloat16
             ops.gemm_nt(a, w, out, residual=out if accumulate else None,

@@ -451,6 +451,17 @@ int a3v_adamw_multi(const a3v_adamw_tensor* table, int n_tensors, int64_t max_n,
  * (main_finetune.py:251-255) without separate scale / cast / copy passes over the gradient buffer. */
 int a3v_scale_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, float scale, void* stream);
 
+/* The exchange step of data-parallel fine-tuning for a host that owns an RCCL communicator itself (the
+ * reference reaches NCCL through FSDP's gradient reduction, main_finetune.py:241-263, reduce_dtype :251-255; the Python host of this
+ * repository goes through torch.distributed, a3vlm_amd/dp.py).  `grad`: one bucket (n fp32 elements, 16-byte aligned) of the flat
+ * gradient buffer, reduced IN PLACE over the ranks of `comm` (an ncclComm_t) on `stream`: average != 0 -> ncclAvg (FSDP's
+ * gradient average), else ncclSum.  `wire_bf16` (optional, n bf16 elements): the bucket crosses the wire in bf16 -- one fused cast
+ * in, all-reduce of the bf16 buffer, one widening cast back.  Skipping the call on accumulation micro-steps (util/misc.py:311-313)
+ * is the caller's decision.  RCCL is not linked into the library: ncclAllReduce is resolved at run time from the librccl already
+ * in the process (PyTorch-ROCm's), A3V_RCCL_LIB, or the loader path; A3V_ERR_ARG when none is found. */
+int a3v_grad_bucket_allreduce(void* comm, float* grad, int64_t n, void* wire_bf16, int average, void* stream);
+int a3v_rccl_available(void);
+
 /* Partial sums of squares of an fp32 range: out[0 .. A3V_SUMSQ_SLOTS) (every slot written).  The global-norm gradient clip
  * (reference util/clip_grad.py:59-210) = sqrt(sum of the partials of all gradient buckets); called per bucket on a side stream
  * while the backward still runs.  x 16-byte aligned. */

@@ -130,3 +130,42 @@ def test_two_ranks_equal_one_rank_with_the_double_batch(tmp_path):
     want = eng.flat_grads().cpu()
     assert float(want.abs().max()) > 1e-4
     assert torch.allclose(g0, want, rtol=2e-4, atol=2e-6 * float(want.abs().max()) + 1e-7), float((g0 - want).abs().max())
+
+
+def test_c_abi_bucket_allreduce_on_a_raw_rccl_communicator():
+    """a3v_grad_bucket_allreduce with an ncclComm_t the HOST created (no torch.distributed): a one-rank communicator from the RCCL
+    that ships with PyTorch-ROCm, fp32 wire (bucket unchanged by an average over one rank) and bf16 wire (bucket = its bf16
+    rounding), sum and average, on a side stream."""
+    import ctypes
+    from a3vlm_amd import lib as _l
+    lib = _l.load()
+    assert lib.a3v_rccl_available() == 1
+    rccl = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    comm = ctypes.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    torch.cuda.set_device(0)
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+    try:
+        g = torch.Generator(device="cuda").manual_seed(4)
+        n = (3 << 20) + 64
+        grad = torch.randn(n, device="cuda", generator=g)
+        want = grad.clone()
+        st = torch.cuda.Stream()
+        st.wait_stream(torch.cuda.current_stream())
+        for avg in (1, 0):
+            _l.check(lib.a3v_grad_bucket_allreduce(comm, grad.data_ptr(), n, None, avg, st.cuda_stream), "a3v_grad_bucket_allreduce")
+            st.synchronize()
+            assert torch.equal(grad, want)
+        wire = torch.empty(n, dtype=torch.bfloat16, device="cuda")
+        _l.check(lib.a3v_grad_bucket_allreduce(comm, grad.data_ptr(), n, wire.data_ptr(), 1, st.cuda_stream), "a3v_grad_bucket_allreduce")
+        st.synchronize()
+        assert torch.equal(grad, want.to(torch.bfloat16).float()) and torch.equal(wire, want.to(torch.bfloat16))
+        assert lib.a3v_grad_bucket_allreduce(None, grad.data_ptr(), n, None, 1, st.cuda_stream) != 0
+    finally:
+        rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        rccl.ncclCommDestroy(comm)

@@ -27,7 +27,7 @@ for K in (4096, 11008, 12288, 22016):
     a = (torch.randn(R, K, device=DEV) * 0.02).to(BF)
     t = torch.empty(T, R, device=DEV, dtype=BF)
     mb = T * K * 2 / 1e6
-    for S in ((int(os.environ["S"]),) if "S" in os.environ else (4, 8, 16)):
+    for S in ((int(os.environ["S"]),) if "S" in os.environ else (4, 8, 16, 32)):
         scratch = torch.empty(S * T * R, device=DEV, dtype=torch.float32)
         us = t_us(lambda: ops.gemm_nt_splitk(x, a, t, scratch, S))
         print(f"nt   [T,{K}] x [64,{K}]^T  S={S:2d}: {us:6.1f} us  ({mb / us:.2f} TB/s of the {mb:.0f} MB operand)", flush=True)
