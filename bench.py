@@ -711,8 +711,11 @@ def pmc_traffic():
         with open(files[-1]) as f:
             d = json.load(f)
         return {"bytes_per_launch": d["traffic_bytes_per_launch"], "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
-                "shape": d["shape"], "kernel": d.get("kernel"), "l2_hit_rate": d.get("l2_hit_rate"), "source": d["source"],
-                "file": os.path.basename(files[-1])}
+                "shape": d["shape"], "kernel": d.get("kernel"), "l2_hit_rate": d.get("l2_hit_rate"),
+                "mfma_busy_frac_of_gui_active": d.get("mfma_busy_frac_of_gui_active"), "source": d["source"],
+                "file": os.path.basename(files[-1]),
+                "other_kernels": [{k: o.get(k) for k in ("what", "kernel", "shape", "traffic_bytes_per_launch", "algorithmic_bytes_per_launch",
+                                                         "l2_hit_rate", "mfma_busy_frac_of_gui_active")} for o in d.get("other_kernels", [])]}
     except Exception:
         return None
 
