@@ -769,6 +769,7 @@ extern "C" int a3v_layernorm(const void* x, int64_t ldx, const void* w, const vo
     case 0: hipLaunchKernelGGL((layernorm_kernel<bf16_t, bf16_t, bf16_t>), g, t, 0, ST, (const bf16_t*)x, ldx, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)y, ldy, row_map, dim, eps); break;
     case 7: hipLaunchKernelGGL((layernorm_kernel<float, float, float>), g, t, 0, ST, (const float*)x, ldx, (const float*)w, (const float*)b, (float*)y, ldy, row_map, dim, eps); break;
     case 3: hipLaunchKernelGGL((layernorm_kernel<bf16_t, float, float>), g, t, 0, ST, (const bf16_t*)x, ldx, (const float*)w, (const float*)b, (float*)y, ldy, row_map, dim, eps); break;
+    case 2: hipLaunchKernelGGL((layernorm_kernel<bf16_t, float, bf16_t>), g, t, 0, ST, (const bf16_t*)x, ldx, (const float*)w, (const float*)b, (bf16_t*)y, ldy, row_map, dim, eps); break;   // fp32 masters, bf16 residual stream
     default: return A3V_ERR_DTYPE;
   }
   A3V_LAUNCH_CHECK();

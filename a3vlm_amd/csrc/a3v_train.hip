@@ -73,9 +73,9 @@ __global__ __launch_bounds__(256) void transpose_bf16_vec_kernel(const bf16_t* _
 // ------------------------------------------------------------------ RMSNorm backward
 // y = w * x * r, r = rsqrt(mean(x^2)+eps).  dx = r*dy*w - x * r^3 * sum(dy*w*x)/dim  (added into dh);
 // dw[j] += sum_rows dy*x*r  (thread-private partial over the block's rows, one atomic per column per block)
-template <typename TA, int RPB>
-__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ w,
-                                                          const TA* __restrict__ dy, int64_t lddy, float* __restrict__ dh,
+template <typename TA, int RPB, typename TS = float>     // TS: dtype of the residual stream (x and the accumulated dh)
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const TS* __restrict__ x, int64_t ldx, const float* __restrict__ w,
+                                                          const TA* __restrict__ dy, int64_t lddy, TS* __restrict__ dh,
                                                           int64_t lddh, float* __restrict__ dw, int rows, int dim, float eps) {
   __shared__ float red[8];
   const int tid = threadIdx.x;
@@ -87,14 +87,14 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
   for (int rr = 0; rr < RPB; ++rr) {
     const int row = row0 + rr;
     if (row >= rows) break;
-    const float* xr = x + (int64_t)row * ldx;
+    const TS* xr = x + (int64_t)row * ldx;
     const TA* dyr = dy + (int64_t)row * lddy;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
       const int c = tid + i * 256;
       if (c < dim) {
-        const float xv = xr[c], g = Cvt<TA>::ld(dyr + c) * w[c];
+        const float xv = Cvt<TS>::ld(xr + c), g = Cvt<TA>::ld(dyr + c) * w[c];
         s1 = fmaf(xv, xv, s1);
         s2 = fmaf(g, xv, s2);
       }
@@ -107,13 +107,13 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
     s2 = red[4] + red[5] + red[6] + red[7];
     const float r = rsqrtf(s1 / (float)dim + eps);
     const float k2 = r * r * r * s2 / (float)dim;
-    float* dhr = dh + (int64_t)row * lddh;
+    TS* dhr = dh + (int64_t)row * lddh;
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
       const int c = tid + i * 256;
       if (c < dim) {
-        const float xv = xr[c], dyv = Cvt<TA>::ld(dyr + c);
-        dhr[c] += r * dyv * w[c] - xv * k2;
+        const float xv = Cvt<TS>::ld(xr + c), dyv = Cvt<TA>::ld(dyr + c);
+        Cvt<TS>::st(dhr + c, Cvt<TS>::ld(dhr + c) + (r * dyv * w[c] - xv * k2));
         dwp[i] += dyv * xv * r;
       }
     }
@@ -130,9 +130,9 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
 
 // Vector form (dim % 4 == 0, 16-B aligned rows): a thread keeps its float4 slices of x and dy in registers across the two
 // passes of a row (one HBM read each), RPB rows per block for the weight-gradient partials.
-template <typename TA, int RPB, int MAXV, bool PART>
-__global__ __launch_bounds__(256) void rmsnorm_bwd_vec_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ w,
-                                                              const TA* __restrict__ dy, int64_t lddy, float* __restrict__ dh,
+template <typename TA, int RPB, int MAXV, bool PART, typename TS = float>     // TS: dtype of the residual stream (x, dh)
+__global__ __launch_bounds__(256) void rmsnorm_bwd_vec_kernel(const TS* __restrict__ x, int64_t ldx, const float* __restrict__ w,
+                                                              const TA* __restrict__ dy, int64_t lddy, TS* __restrict__ dh,
                                                               int64_t lddh, float* __restrict__ dw, int rows, int dim, float eps,
                                                               bf16_t* __restrict__ dh_bf = nullptr, int64_t ld_bf = 0) {
   __shared__ float red[2][8];
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_vec_kernel(const float* __res
   for (int rr = 0; rr < RPB; ++rr) {
     const int row = row0 + rr;
     if (row >= rows) break;
-    const f32x4* xr = reinterpret_cast<const f32x4*>(x + (int64_t)row * ldx);
+    const TS* xr = x + (int64_t)row * ldx;
     const TA* dyr = dy + (int64_t)row * lddy;
     f32x4 xv[MAXV], gv[MAXV];
     float s1 = 0.f, s2 = 0.f;
@@ -157,7 +157,13 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_vec_kernel(const float* __res
     for (int i = 0; i < MAXV; ++i) {
       const int c = tid + i * 256;
       if (c < nv) {
-        xv[i] = xr[c];
+        if constexpr (sizeof(TS) == 2) {
+          const bf16x4 xb = *reinterpret_cast<const bf16x4*>(xr + 4 * c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xv[i][e] = (float)xb[e];
+        } else {
+          xv[i] = *reinterpret_cast<const f32x4*>(xr + 4 * c);
+        }
         if constexpr (sizeof(TA) == 2) {
           const bf16x4 d = *reinterpret_cast<const bf16x4*>(dyr + 4 * c);
 #pragma unroll
@@ -183,18 +189,32 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_vec_kernel(const float* __res
     s2 = red[pb][4] + red[pb][5] + red[pb][6] + red[pb][7];
     const float r = rsqrtf(s1 / (float)dim + eps);
     const float k2 = r * r * r * s2 / (float)dim;
-    f32x4* dhr = reinterpret_cast<f32x4*>(dh + (int64_t)row * lddh);
+    TS* dhr = dh + (int64_t)row * lddh;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
       const int c = tid + i * 256;
       if (c < nv) {
-        f32x4 o = dhr[c];
+        f32x4 o;
+        if constexpr (sizeof(TS) == 2) {
+          const bf16x4 ob0 = *reinterpret_cast<const bf16x4*>(dhr + 4 * c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (float)ob0[e];
+        } else {
+          o = *reinterpret_cast<const f32x4*>(dhr + 4 * c);
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           o[e] += r * gv[i][e] * wv[i][e] - xv[i][e] * k2;
           dwp[i][e] += gv[i][e] * xv[i][e] * r;
         }
-        dhr[c] = o;
+        if constexpr (sizeof(TS) == 2) {       // bf16 stream: the accumulated gradient is rounded as autograd rounds it at the residual add
+          bf16x4 ob1;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ob1[e] = f2bf(o[e]);
+          *reinterpret_cast<bf16x4*>(dhr + 4 * c) = ob1;
+        } else {
+          *reinterpret_cast<f32x4*>(dhr + 4 * c) = o;
+        }
         if (dh_bf) {            // the bf16 copy the next weight / input gradient GEMMs read (was a cast pass of its own)
           bf16x4 ob;
 #pragma unroll
@@ -246,9 +266,9 @@ __global__ __launch_bounds__(256) void colsum_add_kernel(const float* __restrict
 
 // ------------------------------------------------------------------ LayerNorm backward (projector LN)
 // y = (x-mean)*rstd*w + b (fp32 math); dy rows are gathered through row_map from the fp32 stream.
-template <typename TA, int RPB>
+template <typename TA, int RPB, typename TD = float>     // TD: dtype of the stream gradient rows dy is gathered from
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TA* __restrict__ x, int64_t ldx, const float* __restrict__ w,
-                                                            const float* __restrict__ dy, int64_t lddy, const int32_t* __restrict__ row_map,
+                                                            const TD* __restrict__ dy, int64_t lddy, const int32_t* __restrict__ row_map,
                                                             TA* __restrict__ dx, int64_t lddx, float* __restrict__ dw, float* __restrict__ db,
                                                             int rows, int dim, float eps) {
   __shared__ float red[12];
@@ -262,7 +282,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TA* __restrict
     const int row = row0 + rr;
     if (row >= rows) break;
     const TA* xr = x + (int64_t)row * ldx;
-    const float* dyr = dy + (int64_t)(row_map ? row_map[row] : row) * lddy;
+    const TD* dyr = dy + (int64_t)(row_map ? row_map[row] : row) * lddy;
     float s = 0.f, ss = 0.f;
     for (int c = tid; c < dim; c += 256) { const float v = Cvt<TA>::ld(xr + c); s += v; ss = fmaf(v, v, ss); }
     s = wave_sum(s); ss = wave_sum(ss);
@@ -275,7 +295,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TA* __restrict
     const float rstd = rsqrtf(fmaxf(ss / (float)dim - mean * mean, 0.f) + eps);
     float a1 = 0.f, a2 = 0.f;    // sum(dxhat), sum(dxhat*xhat)
     for (int c = tid; c < dim; c += 256) {
-      const float xh = (Cvt<TA>::ld(xr + c) - mean) * rstd, g = dyr[c] * w[c];
+      const float xh = (Cvt<TA>::ld(xr + c) - mean) * rstd, g = Cvt<TD>::ld(dyr + c) * w[c];
       a1 += g; a2 = fmaf(g, xh, a2);
     }
     a1 = wave_sum(a1); a2 = wave_sum(a2);
@@ -289,7 +309,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TA* __restrict
     for (int i = 0; i < MAXC; ++i) {
       const int c = tid + i * 256;
       if (c < dim) {
-        const float xh = (Cvt<TA>::ld(xr + c) - mean) * rstd, dyv = dyr[c];
+        const float xh = (Cvt<TA>::ld(xr + c) - mean) * rstd, dyv = Cvt<TD>::ld(dyr + c);
         Cvt<TA>::st(dxr + c, rstd * (dyv * w[c] - a1 - xh * a2));
         dwp[i] += dyv * xh;
         dbp[i] += dyv;
@@ -501,13 +521,14 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_generic(AttnBwdArgs p) {
 
 // ------------------------------------------------------------------ embedding / row reductions
 // d_table[tok] += dh[row] for the text rows of [BOS | W image words | text]
-__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ tokens, int64_t ld_tok, const float* __restrict__ dh,
+template <typename TD>
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ tokens, int64_t ld_tok, const TD* __restrict__ dh,
                                                         float* __restrict__ dtable, int T, int W, int dim, int vocab) {
   const int S = T + W, row = blockIdx.x, b = row / S, s = row % S;
   if (s >= 1 && s <= W) return;
   int64_t tok = tokens[(int64_t)b * ld_tok + (s == 0 ? 0 : s - W)];
   tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
-  for (int c = threadIdx.x; c < dim; c += 256) atomicAdd(dtable + tok * dim + c, dh[(int64_t)row * dim + c]);
+  for (int c = threadIdx.x; c < dim; c += 256) atomicAdd(dtable + tok * dim + c, Cvt<TD>::ld(dh + (int64_t)row * dim + c));
 }
 
 // out[c] += sum_i src[row_idx ? row_idx[i] : i][c]
@@ -702,20 +723,22 @@ int a3v_transpose_2level(const bf16_t* src, int64_t ld_src, int64_t bs_in, int64
 
 extern "C" int64_t a3v_rmsnorm_bwd_scratch_floats(int rows, int dim) { return (int64_t)((rows + 7) / 8) * dim; }
 
-static int rmsnorm_bwd_impl(const float* x, int64_t ldx, const float* w, const void* dy, int64_t lddy, float* dh, int64_t lddh,
+template <typename TS>
+static int rmsnorm_bwd_impl(const TS* x, int64_t ldx, const float* w, const void* dy, int64_t lddy, TS* dh, int64_t lddh,
                             float* dw, float* dw_scratch, int rows, int dim, float eps, int act_dtype, void* stream, bf16_t* dh_bf,
                             int64_t ld_bf) {
   if (!x || !w || !dy || !dh || rows <= 0) return A3V_ERR_ARG;
   if (dim > 8192) return A3V_ERR_SHAPE;
+  constexpr uintptr_t SMASK = sizeof(TS) == 2 ? 7 : 15;
   if (dim % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && lddh % 4 == 0 && (act_dtype == A3V_BF16 || act_dtype == A3V_F32) &&
-      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dh) | reinterpret_cast<uintptr_t>(w)) & 15) == 0 &&
+      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dh)) & SMASK) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0 &&
       (reinterpret_cast<uintptr_t>(dy) & (act_dtype == A3V_BF16 ? 7 : 15)) == 0) {
     constexpr int RV = 8;
     const int nb = (rows + RV - 1) / RV;
     dim3 gv(nb);
     const bool part = dw && dw_scratch && (reinterpret_cast<uintptr_t>(dw_scratch) & 15) == 0;
     float* dwo = part ? dw_scratch : dw;
-#define A3V_RB(TT, MV, PP) hipLaunchKernelGGL((rmsnorm_bwd_vec_kernel<TT, RV, MV, PP>), gv, dim3(256), 0, ST, x, ldx, w, (const TT*)dy, lddy, dh, lddh, dwo, rows, dim, eps, dh_bf, ld_bf)
+#define A3V_RB(TT, MV, PP) hipLaunchKernelGGL((rmsnorm_bwd_vec_kernel<TT, RV, MV, PP, TS>), gv, dim3(256), 0, ST, x, ldx, w, (const TT*)dy, lddy, dh, lddh, dwo, rows, dim, eps, dh_bf, ld_bf)
     if (dim <= 4096) {
       if (act_dtype == A3V_BF16) { if (part) A3V_RB(bf16_t, 4, true); else A3V_RB(bf16_t, 4, false); }
       else { if (part) A3V_RB(float, 4, true); else A3V_RB(float, 4, false); }
@@ -733,37 +756,62 @@ static int rmsnorm_bwd_impl(const float* x, int64_t ldx, const float* w, const v
   }
   constexpr int RPB = 16;
   dim3 g((rows + RPB - 1) / RPB);
-  if (act_dtype == A3V_BF16) hipLaunchKernelGGL((rmsnorm_bwd_kernel<bf16_t, RPB>), g, dim3(256), 0, ST, x, ldx, w, (const bf16_t*)dy, lddy, dh, lddh, dw, rows, dim, eps);
-  else if (act_dtype == A3V_F32) hipLaunchKernelGGL((rmsnorm_bwd_kernel<float, RPB>), g, dim3(256), 0, ST, x, ldx, w, (const float*)dy, lddy, dh, lddh, dw, rows, dim, eps);
+  if (act_dtype == A3V_BF16) hipLaunchKernelGGL((rmsnorm_bwd_kernel<bf16_t, RPB, TS>), g, dim3(256), 0, ST, x, ldx, w, (const bf16_t*)dy, lddy, dh, lddh, dw, rows, dim, eps);
+  else if (act_dtype == A3V_F32) hipLaunchKernelGGL((rmsnorm_bwd_kernel<float, RPB, TS>), g, dim3(256), 0, ST, x, ldx, w, (const float*)dy, lddy, dh, lddh, dw, rows, dim, eps);
   else return A3V_ERR_DTYPE;
   A3V_LAUNCH_CHECK();
-  if (dh_bf) return a3v_cast(dh, lddh, A3V_F32, dh_bf, ld_bf, A3V_BF16, rows, dim, stream);     // (scalar form of the kernel: the copy as a pass)
+  if (dh_bf) {
+    if (sizeof(TS) != 4) return A3V_ERR_ARG;
+    return a3v_cast(dh, lddh, A3V_F32, dh_bf, ld_bf, A3V_BF16, rows, dim, stream);     // (scalar form of the kernel: the copy as a pass)
+  }
   return A3V_OK;
 }
 
 extern "C" int a3v_rmsnorm_bwd(const float* x, int64_t ldx, const float* w, const void* dy, int64_t lddy, float* dh, int64_t lddh,
                                float* dw, float* dw_scratch, int rows, int dim, float eps, int act_dtype, void* stream) {
-  return rmsnorm_bwd_impl(x, ldx, w, dy, lddy, dh, lddh, dw, dw_scratch, rows, dim, eps, act_dtype, stream, nullptr, 0);
+  return rmsnorm_bwd_impl<float>(x, ldx, w, dy, lddy, dh, lddh, dw, dw_scratch, rows, dim, eps, act_dtype, stream, nullptr, 0);
 }
 
 extern "C" int a3v_rmsnorm_bwd_cast(const float* x, int64_t ldx, const float* w, const void* dy, int64_t lddy, float* dh, int64_t lddh,
                                     float* dw, float* dw_scratch, int rows, int dim, float eps, int act_dtype, void* dh_bf16,
                                     int64_t ld_bf16, void* stream) {
   if (!dh_bf16 || (ld_bf16 & 3) || (reinterpret_cast<uintptr_t>(dh_bf16) & 7)) return A3V_ERR_ARG;
-  return rmsnorm_bwd_impl(x, ldx, w, dy, lddy, dh, lddh, dw, dw_scratch, rows, dim, eps, act_dtype, stream, (bf16_t*)dh_bf16, ld_bf16);
+  return rmsnorm_bwd_impl<float>(x, ldx, w, dy, lddy, dh, lddh, dw, dw_scratch, rows, dim, eps, act_dtype, stream, (bf16_t*)dh_bf16, ld_bf16);
 }
 
-extern "C" int a3v_layernorm_bwd(const void* x, int64_t ldx, const float* w, const float* dy, int64_t lddy, const int32_t* row_map,
-                                 void* dx, int64_t lddx, float* dw, float* db, int rows, int dim, float eps, int act_dtype, void* stream) {
+// bf16 residual stream (training under FSDP MixedPrecision(param_dtype=bf16) + autocast, main_finetune.py:241-263, engine_finetune.py:44-50:
+// embeddings, block outputs and therefore the stream and its gradient are bf16 tensors): x, dy and the accumulated dh all bf16
+extern "C" int a3v_rmsnorm_bwd_bf16(const void* x, int64_t ldx, const float* w, const void* dy, int64_t lddy, void* dh, int64_t lddh,
+                                    float* dw, float* dw_scratch, int rows, int dim, float eps, void* stream) {
+  return rmsnorm_bwd_impl<bf16_t>((const bf16_t*)x, ldx, w, dy, lddy, (bf16_t*)dh, lddh, dw, dw_scratch, rows, dim, eps, A3V_BF16, stream, nullptr, 0);
+}
+
+static int layernorm_bwd_impl(const void* x, int64_t ldx, const float* w, const void* dy, int dy_dtype, int64_t lddy, const int32_t* row_map,
+                              void* dx, int64_t lddx, float* dw, float* db, int rows, int dim, float eps, int act_dtype, void* stream) {
   if (!x || !w || !dy || !dx || !dw || !db || rows <= 0) return A3V_ERR_ARG;
   if (dim > 8192) return A3V_ERR_SHAPE;
   constexpr int RPB = 16;
   dim3 g((rows + RPB - 1) / RPB);
-  if (act_dtype == A3V_BF16) hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, RPB>), g, dim3(256), 0, ST, (const bf16_t*)x, ldx, w, dy, lddy, row_map, (bf16_t*)dx, lddx, dw, db, rows, dim, eps);
-  else if (act_dtype == A3V_F32) hipLaunchKernelGGL((layernorm_bwd_kernel<float, RPB>), g, dim3(256), 0, ST, (const float*)x, ldx, w, dy, lddy, row_map, (float*)dx, lddx, dw, db, rows, dim, eps);
-  else return A3V_ERR_DTYPE;
+  if (dy_dtype == A3V_F32) {
+    if (act_dtype == A3V_BF16) hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, RPB, float>), g, dim3(256), 0, ST, (const bf16_t*)x, ldx, w, (const float*)dy, lddy, row_map, (bf16_t*)dx, lddx, dw, db, rows, dim, eps);
+    else if (act_dtype == A3V_F32) hipLaunchKernelGGL((layernorm_bwd_kernel<float, RPB, float>), g, dim3(256), 0, ST, (const float*)x, ldx, w, (const float*)dy, lddy, row_map, (float*)dx, lddx, dw, db, rows, dim, eps);
+    else return A3V_ERR_DTYPE;
+  } else if (dy_dtype == A3V_BF16 && act_dtype == A3V_BF16) {
+    hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, RPB, bf16_t>), g, dim3(256), 0, ST, (const bf16_t*)x, ldx, w, (const bf16_t*)dy, lddy, row_map, (bf16_t*)dx, lddx, dw, db, rows, dim, eps);
+  } else return A3V_ERR_DTYPE;
   A3V_LAUNCH_CHECK();
   return A3V_OK;
+}
+
+extern "C" int a3v_layernorm_bwd(const void* x, int64_t ldx, const float* w, const float* dy, int64_t lddy, const int32_t* row_map,
+                                 void* dx, int64_t lddx, float* dw, float* db, int rows, int dim, float eps, int act_dtype, void* stream) {
+  return layernorm_bwd_impl(x, ldx, w, dy, A3V_F32, lddy, row_map, dx, lddx, dw, db, rows, dim, eps, act_dtype, stream);
+}
+
+// the same with the stream gradient in bf16 (bf16 residual stream, see a3v_rmsnorm_bwd_bf16)
+extern "C" int a3v_layernorm_bwd_bf16(const void* x, int64_t ldx, const float* w, const void* dy, int64_t lddy, const int32_t* row_map,
+                                      void* dx, int64_t lddx, float* dw, float* db, int rows, int dim, float eps, void* stream) {
+  return layernorm_bwd_impl(x, ldx, w, dy, A3V_BF16, lddy, row_map, dx, lddx, dw, db, rows, dim, eps, A3V_BF16, stream);
 }
 
 // cache policy of the streaming training kernels (A3V_STREAM_NT: bit 0 non-temporal loads, bit 1 stores; read per launch)
@@ -886,7 +934,15 @@ extern "C" int a3v_attention_bwd_packed(const void* q, const void* k, int64_t k_
 extern "C" int a3v_embed_bwd(const int64_t* tokens, int64_t ld_tok, const float* dh, float* dtable, int B, int T, int W, int dim,
                              int vocab, void* stream) {
   if (!tokens || !dh || !dtable || B <= 0 || T <= 0) return A3V_ERR_ARG;
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3(B * (T + W)), dim3(256), 0, ST, tokens, ld_tok, dh, dtable, T, W, dim, vocab);
+  hipLaunchKernelGGL(embed_bwd_kernel<float>, dim3(B * (T + W)), dim3(256), 0, ST, tokens, ld_tok, dh, dtable, T, W, dim, vocab);
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}
+
+extern "C" int a3v_embed_bwd_bf16(const int64_t* tokens, int64_t ld_tok, const void* dh, float* dtable, int B, int T, int W, int dim,
+                                  int vocab, void* stream) {
+  if (!tokens || !dh || !dtable || B <= 0 || T <= 0) return A3V_ERR_ARG;
+  hipLaunchKernelGGL(embed_bwd_kernel<bf16_t>, dim3(B * (T + W)), dim3(256), 0, ST, tokens, ld_tok, (const bf16_t*)dh, dtable, T, W, dim, vocab);
   A3V_LAUNCH_CHECK();
   return A3V_OK;
 }

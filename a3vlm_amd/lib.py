@@ -74,6 +74,9 @@ SIGNATURES = {
     "a3v_rmsnorm_bwd_scratch_floats": (L, [I, I]),
     "a3v_rmsnorm_bwd": (I, [P, L, P, P, L, P, L, P, P, I, I, F, I, P]),
     "a3v_rmsnorm_bwd_cast": (I, [P, L, P, P, L, P, L, P, P, I, I, F, I, P, L, P]),
+    "a3v_rmsnorm_bwd_bf16": (I, [P, L, P, P, L, P, L, P, P, I, I, F, P]),
+    "a3v_layernorm_bwd_bf16": (I, [P, L, P, P, L, P, P, L, P, P, I, I, F, P]),
+    "a3v_embed_bwd_bf16": (I, [P, L, P, P, I, I, I, I, I, P]),
     "a3v_layernorm_bwd": (I, [P, L, P, P, L, P, P, L, P, P, I, I, F, I, P]),
     "a3v_swiglu_fwd": (I, [P, L, P, L, I, I, I, I, P]),
     "a3v_swiglu_bwd": (I, [P, L, P, L, P, L, I, I, I, I, P]),

@@ -432,7 +432,7 @@ _rb_scratch = {}
 def rmsnorm_bwd(x, w, dy, dh, dw, eps, dh_lowp=None):
     """dh += d(rmsnorm)/dx . dy (fp32 stream), dw += ...; ``dh_lowp``: the updated dh also as bf16 (the next GEMMs' operand)."""
     _dev(x, w, dy, dh, dw, dh_lowp)
-    assert x.dtype == torch.float32 and w.dtype == torch.float32 and dh.dtype == torch.float32
+    assert w.dtype == torch.float32 and x.dtype == dh.dtype and x.dtype in (torch.float32, torch.bfloat16)
     rows, dim = x.shape
     scratch = None
     if dw is not None:                       # per-device scratch for the weight-gradient partial rows (grown on demand)
@@ -441,6 +441,12 @@ def rmsnorm_bwd(x, w, dy, dh, dw, eps, dh_lowp=None):
         if scratch is None or scratch.numel() < need:
             scratch = torch.empty(need, dtype=torch.float32, device=x.device)
             _rb_scratch[x.device] = scratch
+    if x.dtype == torch.bfloat16:            # bf16 residual stream: x, dy and the accumulated dh are bf16 (fp32 arithmetic inside)
+        assert dh_lowp is None and dy.dtype == torch.bfloat16
+        rc = _l.load().a3v_rmsnorm_bwd_bf16(_p(x), x.stride(0), _p(w), _p(dy), dy.stride(0), _p(dh), dh.stride(0), _p(dw), _p(scratch), rows,
+                                            dim, eps, _stream())
+        _l.check(rc, "a3v_rmsnorm_bwd_bf16")
+        return
     if dh_lowp is not None:
         assert dh_lowp.dtype == torch.bfloat16 and dh_lowp.shape == dh.shape
         rc = _l.load().a3v_rmsnorm_bwd_cast(_p(x), x.stride(0), _p(w), _p(dy), dy.stride(0), _p(dh), dh.stride(0), _p(dw), _p(scratch), rows,
@@ -455,6 +461,11 @@ def rmsnorm_bwd(x, w, dy, dh, dw, eps, dh_lowp=None):
 def layernorm_bwd(x, w, dy, row_map, dx, dw, db, eps=1e-5):
     _dev(x, w, dy, row_map, dx, dw, db)
     rows, dim = x.shape
+    if dy.dtype == torch.bfloat16:           # gradient rows gathered from a bf16 residual stream
+        rc = _l.load().a3v_layernorm_bwd_bf16(_p(x), x.stride(0), _p(w), _p(dy), dy.stride(0), _p(row_map), _p(dx), dx.stride(0),
+                                              _p(dw), _p(db), rows, dim, eps, _stream())
+        _l.check(rc, "a3v_layernorm_bwd_bf16")
+        return
     rc = _l.load().a3v_layernorm_bwd(_p(x), x.stride(0), _p(w), _p(dy), dy.stride(0), _p(row_map), _p(dx), dx.stride(0),
                                      _p(dw), _p(db), rows, dim, eps, dt(x), _stream())
     _l.check(rc, "a3v_layernorm_bwd")
@@ -506,7 +517,9 @@ def attention_bwd_packed(q, k, k_sb, k_sh, v, v_sb, v_ss, v_sh, out, dout, lse, 
 
 def embed_bwd(tokens, dh, dtable, B, T, W, dim):
     _dev(tokens, dh, dtable)
-    rc = _l.load().a3v_embed_bwd(_p(tokens), tokens.stride(0), _p(dh), _p(dtable), B, T, W, dim, dtable.shape[0], _stream())
+    assert dh.is_contiguous()
+    fn = _l.load().a3v_embed_bwd_bf16 if dh.dtype == torch.bfloat16 else _l.load().a3v_embed_bwd
+    rc = fn(_p(tokens), tokens.stride(0), _p(dh), _p(dtable), B, T, W, dim, dtable.shape[0], _stream())
     _l.check(rc, "a3v_embed_bwd")
 
 

@@ -38,8 +38,15 @@ class TrainEngine:
     # ("0": none, "all", or a comma list of qkv / wo / w13 / w2).  Same-box LoRA step: 253.0 ms without, 248.9 with wo,w13,w2, 247.9 all
     lora_nt_dgrad = os.environ.get("A3V_LORA_NT_DGRAD", "all")
 
-    def __init__(self, model, compute_dtype: torch.dtype = torch.bfloat16, recompute: Optional[bool] = None):
-        """``recompute``: True = keep only each block's input and re-run the block in backward (the reference's
+    def __init__(self, model, compute_dtype: torch.dtype = torch.bfloat16, recompute: Optional[bool] = None,
+                 stream_dtype: Optional[torch.dtype] = None):
+        """``stream_dtype``: dtype of the residual stream h, of its per-layer checkpoints and of its gradient dh.  Default = the compute
+        dtype: under ``--precision bf16`` the reference wraps the model in FSDP with MixedPrecision(param_dtype=bf16)
+        (main_finetune.py:241-263) and runs it under autocast (engine_finetune.py:44-50), so the embeddings come out in bf16 and every
+        ``h = h + block(h)`` -- and autograd's gradient of it -- is a bf16 tensor; the fp32 masters only exist for the optimizer.  fp32
+        (``A3V_STREAM_FP32=1`` or ``stream_dtype=torch.float32``) keeps the more precise stream of rounds 1-2 (+5 ms per step at 7B:
+        twice the bytes in every norm / norm-backward / residual epilogue pass).
+        ``recompute``: True = keep only each block's input and re-run the block in backward (the reference's
         activation checkpointing, main_finetune.py:268-276); False = keep every block's intermediates (about
         1.15 GB per 7B layer at 8 x 1091 tokens -- affordable in 288 GB of HBM and ~1/4 fewer GEMM FLOPs per step).
         None = decide from free HBM at the first step."""
@@ -47,6 +54,9 @@ class TrainEngine:
         self.m = model
         self.lora = int(getattr(model, "lora_rank", 0) or 0) > 0
         self.act = compute_dtype
+        if stream_dtype is None:
+            stream_dtype = torch.float32 if os.environ.get("A3V_STREAM_FP32", "0") == "1" else compute_dtype
+        self.stream = stream_dtype
         self.recompute = recompute
         self._img = None
         self._ws: Dict[tuple, torch.Tensor] = {}
@@ -570,8 +580,8 @@ class TrainEngine:
         ldo = att.stride(0)
         strides = (S * H * hd, H * hd, hd, Hkv * spad * hd, spad * hd, hd, Hkv * hd * spad, hd * spad, spad, S * ldo, ldo, hd)
         ops.attention_lse(qrot, kc, vc, att, lse, B, S, S, H, Hkv, hd, strides, True)
-        res_flag = ops.EPI_RES_F32 if self.act == torch.bfloat16 else 0
-        h_mid = self._buf("h_mid" + tag, (rows, dim), torch.float32) if keep else h
+        res_flag = ops.EPI_RES_F32 if (self.act == torch.bfloat16 and self.stream == torch.float32) else 0     # bf16 stream: plain bf16 residual
+        h_mid = self._buf("h_mid" + tag, (rows, dim), self.stream) if keep else h
         if kx:
             self._skinny(att, li[f"wo.{i}.A"], t_wo)
             ops.gemm_nt(att_full, im[f"wo.{i}.x"], h_mid, residual=h, epilogue=res_flag)
@@ -632,12 +642,16 @@ class TrainEngine:
         def ybuf(name, cols, key):      # gradient buffer with room for dt = dy . B behind it: full, dy view
             full = self._buf(name, (rows, cols + li[key + ".A"].shape[0]))
             return full, full[:, :cols]
-        if kx:
+        stream_lp = self.stream == torch.bfloat16 and self.act == torch.bfloat16     # dh itself is the bf16 operand of the GEMMs
+        if stream_lp:
+            dha = dh
+            dha_full = self._dh_full if kx else None
+        elif kx:
             dha_full, dha = ybuf("dh_act.x", dim, f"w2.{i}")
         else:
             dha = self._buf("dh_act", (rows, dim))
-        fuse_cast = self.act == torch.bfloat16       # the norm backward that produced dh also wrote its bf16 copy (a3v_rmsnorm_bwd_cast)
-        if not (fuse_cast and getattr(self, "_dha_ready", False)):
+        fuse_cast = self.act == torch.bfloat16 and not stream_lp   # fp32 stream: the norm backward that produced dh also wrote its bf16 copy
+        if not stream_lp and not (fuse_cast and getattr(self, "_dha_ready", False)):
             ops.cast(dh, dha)
         self._dha_ready = False
         if self._has(pre + "feed_forward.w2.weight"):
@@ -665,7 +679,7 @@ class TrainEngine:
         ops.rmsnorm_bwd(k["h_mid"], l.ffn_norm.weight, dxn, dh, self._views.get(pre + "ffn_norm.weight"), a.norm_eps,
                         dh_lowp=dha if fuse_cast else None)
         # ---- attention: h_mid = h_in + wo(attn(rope(qkv(norm(h_in)))))
-        if not fuse_cast:
+        if not fuse_cast and not stream_lp:
             ops.cast(dh, dha)
         if self._has(pre + "attention.wo.weight"):
             self._wgrad(dha, k["att"], self._views[pre + "attention.wo.weight"], "wo", (pre + "attention.wo.weight",))
@@ -727,7 +741,7 @@ class TrainEngine:
         S = T + W
         rows = B * S
         dim, V = a.dim, a.vocab_size
-        h = self._buf("h", (rows, dim), torch.float32)
+        h = self._buf("h", (rows, dim), self.stream)
         if self.lora or self.act != torch.bfloat16:
             self.sync_optimizer()          # adapter / fp32 images are rebuilt from all parameters at once
         self.await_weights("embed")
@@ -736,11 +750,11 @@ class TrainEngine:
         if image is not None:
             self.await_weights("vision_proj")
             vis = self._encode_image_train(h, image, B, S, qformer_feats, extra_feats)
-        hs = self._buf("h_saved", (m.n_layers + 1, rows, dim), torch.float32)
+        hs = self._buf("h_saved", (m.n_layers + 1, rows, dim), self.stream)
         if self.recompute is None:
             F_, Hq = m.ffn, (m.n_heads + 2 * m.n_kv_heads) * m.head_dim
             esz = 2 if self.act == torch.bfloat16 else 4
-            need = m.n_layers * rows * ((2 * dim + Hq + 2 * m.n_heads * m.head_dim + 3 * F_) * esz + dim * 4) * 1.1
+            need = m.n_layers * rows * ((2 * dim + Hq + 2 * m.n_heads * m.head_dim + 3 * F_) * esz + dim * (4 if self.stream == torch.float32 else 2)) * 1.1
             free, _ = torch.cuda.mem_get_info(m._device)
             self.recompute = need > 0.5 * free
         kept = []
@@ -798,7 +812,15 @@ class TrainEngine:
             self._wgrad(dlog, s["xt"], self._views["output.weight"], "out", ("output.weight",))
         dxt = self._buf("dxn_text", (B * T, dim))
         self._dgrad_w(dlog, "out", dxt)
-        dh = self._buf("dh", (rows, dim), torch.float32, zero=True)
+        kx = self._kext() > 0 and rows > 16 and m.head_dim in (64, 128) and self.fuse_qkv_rope       # as in _block_forward
+        self._dh_full = None
+        if self.stream == torch.bfloat16 and self.act == torch.bfloat16 and kx:
+            # bf16 stream + adapters inside the GEMMs: dh IS the dy operand of the wo / w2 groups, so it lives in the first `dim`
+            # columns of a buffer with room for dt = dy . B behind it (no copy of dh per layer)
+            self._dh_full = self._buf("dh.x", (rows, dim + self._kext()), self.stream, zero=True)
+            dh = self._dh_full[:, :dim]
+        else:
+            dh = self._buf("dh", (rows, dim), self.stream, zero=True)
         hv, dhv = s["h"].view(B, S, dim), dh.view(B, S, dim)
         for b in range(B):
             ops.rmsnorm_bwd(hv[b, W:], m.norm.weight, dxt[b * T:(b + 1) * T], dhv[b, W:], self._views.get("norm.weight"), a.norm_eps)
@@ -1058,13 +1080,15 @@ def step_loss(engine: TrainEngine, anchor: torch.Tensor, examples, labels, image
 
 
 def hbm_budget(dim: int, n_layers: int, n_heads: int, ffn: int, vocab: int, batch: int, seq: int, text: int, n_kv_heads: Optional[int] = None,
-               vit_params: int = 304_000_000, proj_in: int = 1024, world: int = 1, wire_bytes: int = 2, recompute: bool = False) -> Dict[str, int]:
+               vit_params: int = 304_000_000, proj_in: int = 1024, world: int = 1, wire_bytes: int = 2, recompute: bool = False,
+               stream_bytes: int = 2) -> Dict[str, int]:
     """Bytes of one pure-DP replica of the FULL fine-tune (every rank of a DP job holds exactly this; SURVEY 7 "13B full fine-tune
     memory", main_finetune.py:241-276): what ``TrainEngine`` + ``FusedAdamW`` + ``dp.GradReducer`` allocate, from their own layouts.
     fp32 masters / flat gradient buffer / two AdamW moments of every trainable parameter, the bf16 GEMM images of the decoder and
     head matrices, the frozen bf16 ViT, the reducer's persistent wire buckets (``wire_bytes`` per gradient element when world > 1
-    and the wire dtype is not fp32), the fp32 residual-stream checkpoints [L+1, rows, dim], the block intermediates (per layer when
-    activations are stored, once when blocks are recomputed), and the CE buffers.  Checked against the measured peaks of the bench
+    and the wire dtype is not fp32), the residual-stream checkpoints [L+1, rows, dim] (``stream_bytes`` per element: 2 = the bf16 stream
+    of round 3 on, 4 = the fp32 stream of rounds 1-2), the block intermediates (per layer when activations are stored, once when
+    blocks are recomputed), and the CE buffers.  Checked against the measured peaks of the bench
     (tests/test_dp_cpu.py::test_dp_replica_fits_288_gib)."""
     hkv = n_kv_heads or n_heads
     hd = dim // n_heads
@@ -1074,13 +1098,14 @@ def hbm_budget(dim: int, n_layers: int, n_heads: int, ffn: int, vocab: int, batc
     p_train = p_mat + dim * vocab + (2 * n_layers + 1) * dim + proj_in * dim + 4 * dim     # + embeddings, norms, projector, tags
     rows = batch * seq
     spad = (seq + 63) // 64 * 64
-    block = rows * (2 * dim * 2 + qkv * 2 + 2 * n_heads * hd * 2 + 3 * ffn * 2 + dim * 4) + batch * hkv * spad * hd * 2 + batch * n_heads * seq * 4
-    bwd_ws = rows * (dim * 2 + ffn * 2 + 2 * ffn * 2 + dim * 2 + n_heads * hd * 2 + qkv * 2 + dim * 4) + batch * hkv * hd * spad * 2
+    sb = stream_bytes
+    block = rows * (2 * dim * 2 + qkv * 2 + 2 * n_heads * hd * 2 + 3 * ffn * 2 + dim * sb) + batch * hkv * spad * hd * 2 + batch * n_heads * seq * 4
+    bwd_ws = rows * ((dim * 2 if sb == 4 else 0) + ffn * 2 + 2 * ffn * 2 + dim * 2 + n_heads * hd * 2 + qkv * 2 + dim * sb) + batch * hkv * hd * spad * 2
     out = {
         "masters_fp32": 4 * p_train, "grads_fp32": 4 * p_train, "adamw_moments_fp32": 8 * p_train, "images_bf16": 2 * p_mat,
         "vit_bf16": 2 * vit_params,
         "wire_buckets": wire_bytes * p_train if world > 1 and wire_bytes != 4 else 0,
-        "stream_checkpoints_fp32": (n_layers + 1) * rows * dim * 4 + rows * dim * 4,
+        "stream_checkpoints": (n_layers + 1) * rows * dim * sb + rows * dim * sb,
         "block_activations": block * (1 if recompute else n_layers),
         "backward_workspace": bwd_ws,
         "ce_buffers": batch * text * vocab * 2 * 2 + batch * text * dim * 2 * 2,

@@ -348,6 +348,17 @@ int a3v_rmsnorm_bwd_cast(const float* x, int64_t ldx, const float* w, const void
                          float* dh, int64_t lddh, float* dw, float* dw_scratch, int rows, int dim, float eps,
                          int act_dtype, void* dh_bf16, int64_t ld_bf16, void* stream);
 
+/* bf16 residual stream: under FSDP MixedPrecision(param_dtype = bf16) + autocast (main_finetune.py:241-263, engine_finetune.py:44-50)
+ * the reference's embeddings, block outputs and hence the residual stream AND ITS GRADIENT are bf16 tensors; these forms take the
+ * stream (x) and the accumulated stream gradient (dh, read-modify-write, rounded to bf16 as autograd rounds it at the residual add) in
+ * bf16, with fp32 arithmetic inside.  dy bf16.  Same formulas as a3v_rmsnorm_bwd / a3v_layernorm_bwd / a3v_embed_bwd. */
+int a3v_rmsnorm_bwd_bf16(const void* x, int64_t ldx, const float* w, const void* dy, int64_t lddy, void* dh, int64_t lddh,
+                         float* dw, float* dw_scratch, int rows, int dim, float eps, void* stream);
+int a3v_layernorm_bwd_bf16(const void* x, int64_t ldx, const float* w, const void* dy, int64_t lddy, const int32_t* row_map,
+                           void* dx, int64_t lddx, float* dw, float* db, int rows, int dim, float eps, void* stream);
+int a3v_embed_bwd_bf16(const int64_t* tokens, int64_t ld_tok, const void* dh, float* dtable, int B, int T, int W, int dim,
+                       int vocab, void* stream);
+
 /* backward of a3v_layernorm (x in act_dtype, fp32 w; dy fp32 rows gathered through row_map):
  * dx (act_dtype), dw += , db += . */
 int a3v_layernorm_bwd(const void* x, int64_t ldx, const float* w, const float* dy, int64_t lddy,
