@@ -264,7 +264,7 @@ def time_gemm_shapes(args, B, T, W, dev, train=True):
         (vr, 3 * w, w, Lv, 0), (vr, w, w, Lv, ops.EPI_RESIDUAL), (vr, 4 * w, w, Lv, ops.EPI_GELU), (vr, w, 4 * w, Lv, ops.EPI_RESIDUAL),
         (vr, d, w, 1, 0), (B * g * g, w, 640, 1, 0),
     ]
-    fam = {"nt": [0.0, 0.0], "nn": [0.0, 0.0], "tn": [0.0, 0.0]}
+    fam = {"nt": [0.0, 0.0], "nn": [0.0, 0.0], "tn": [0.0, 0.0], "nt_dgrad": [0.0, 0.0]}
     table = []
     # the legs before this one end with frees / allocator work on the host: bring the part back to its loaded clock first
     # (the first shape timed after an idle gap read 15 % low)
@@ -291,21 +291,28 @@ def time_gemm_shapes(args, B, T, W, dev, train=True):
     if train:
         # decoder linears only (the ViT is frozen: no gradient GEMMs); (rows, out features, in features)
         for (M, N, K) in [(rows, 3 * d, d), (rows, d, d), (rows, 2 * ffn, d), (rows, d, ffn)]:
-            dy = torch.randn(M, N, device=dev, dtype=torch.bfloat16)
+            dy = torch.randn(M, N + 64, device=dev, dtype=torch.bfloat16)
             x = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
             wimg = torch.randn(N, K, device=dev, dtype=torch.bfloat16) * 0.02
+            wt_img = torch.randn(K, N + 64, device=dev, dtype=torch.bfloat16) * 0.02     # [W^T | A^T] of a LoRA run (frozen base: built once)
             dx = torch.empty(M, K, device=dev, dtype=torch.bfloat16)
             gw = torch.zeros(N, K, device=dev, dtype=torch.float32)
             fl = 2.0 * M * N * K
-            dt = _events(lambda: ops.gemm_nn(dy, wimg, dx))
+            dt = _events(lambda: ops.gemm_nn(dy[:, :N], wimg, dx))
             fam["nn"][0] += fl * Lyr
             fam["nn"][1] += dt * Lyr
             table.append(dict(kind="nn", M=M, N=K, K=N, count=Lyr, us=round(dt * 1e6, 1), tflops=round(fl / dt / 1e12, 1)))
-            dt = _events(lambda: ops.gemm_tn(dy, x, gw, epilogue=ops.EPI_OUT_F32))
+            # the LoRA step's form of the same input gradient: dx = [dy | dt] . [W^T | A^T]^T on the NT ring kernel (K extended by the
+            # 64 adapter columns; the algorithmic FLOPs counted are those of the base product)
+            dt = _events(lambda: ops.gemm_nt(dy, wt_img, dx))
+            fam["nt_dgrad"][0] += fl * Lyr
+            fam["nt_dgrad"][1] += dt * Lyr
+            table.append(dict(kind="nt_dgrad", M=M, N=K, K=N + 64, count=Lyr, us=round(dt * 1e6, 1), tflops=round(fl / dt / 1e12, 1)))
+            dt = _events(lambda: ops.gemm_tn(dy[:, :N], x, gw, epilogue=ops.EPI_OUT_F32))
             fam["tn"][0] += fl * Lyr
             fam["tn"][1] += dt * Lyr
             table.append(dict(kind="tn", M=N, N=K, K=M, count=Lyr, us=round(dt * 1e6, 1), tflops=round(fl / dt / 1e12, 1)))
-            del dy, x, wimg, dx, gw
+            del dy, x, wimg, wt_img, dx, gw
     return fam, table
 
 
@@ -866,13 +873,15 @@ def main():
     if rank == 0 and not a.no_roofline:
         def _roof():
             fam, table = time_gemm_shapes(args, B, T, W, dev, train=bool({"train", "lora"} & legs))
-            # families of the headline step: LoRA = forward (NT) + input gradients (NN), the frozen matrices have no weight-gradient
-            # GEMMs; full fine-tune adds TN; inference forward = NT only
-            use = {"lora": ("nt", "nn"), "train": ("nt", "nn", "tn"), "forward": ("nt",)}[headline]
+            # families of the headline step: LoRA = forward (NT) + input gradients, which the LoRA engine runs on the NT ring kernel over
+            # the transposed frozen images (nt_dgrad); the frozen matrices have no weight-gradient GEMMs.  Full fine-tune = NT + NN
+            # (input gradients on the forward image) + TN (weight gradients); inference forward = NT only
+            use = {"lora": ("nt", "nt_dgrad"), "train": ("nt", "nn", "tn"), "forward": ("nt",)}[headline]
             tot_f = sum(fam[k][0] for k in use)
             tot_t = sum(fam[k][1] for k in use)
-            all_f = sum(v[0] for v in fam.values())
-            all_t = sum(v[1] for v in fam.values())
+            ft = ("nt", "nn", "tn")
+            all_f = sum(fam[k][0] for k in ft)
+            all_t = sum(fam[k][1] for k in ft)
             return {"kernel": "MFMA GEMM family of the step: gemm_nt_bf16_ring_kernel (256x256x64 ping-pong over a 160-KiB LDS ring; forward linears), "
                               "gemm_tn_bf16_pp_kernel<A_ROWS> (NN input gradients / TN weight gradients), gemm_nt_bf16_kernel<128,128> on tail rows and small shapes",
                     "bound": "mfma", "achieved": round(tot_f / tot_t / 1e12, 1), "peak": MFMA_PEAK_BF16 / 1e12, "unit": "TFLOP/s",

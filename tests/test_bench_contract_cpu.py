@@ -57,7 +57,7 @@ def test_committed_bench_lines_follow_the_contract():
         assert "(train)" in d["metric"] and d["config"]["workload"].startswith("configs[2]")
         assert abs(d["train_lora"]["samples_s"] - d["value"]) / d["value"] < 1e-3 and d["train"]["samples_s"] > 0
         assert d["rccl_ranks"] == d["n_gpus"] and "exposed_allreduce_ms" in d
-        assert d["roofline"]["families_of_the_headline_step"] == ["nt", "nn"]
+        assert d["roofline"]["families_of_the_headline_step"] in (["nt", "nn"], ["nt", "nt_dgrad"])
     elif os.path.basename(files[-1]) >= "r02":
         # round 2: the headline was the full fine-tune step of the configs[1] backbone
         assert "(train)" in d["metric"] and "FULL FINE-TUNE" in d["config"]["workload"]
@@ -67,7 +67,7 @@ def test_committed_bench_lines_follow_the_contract():
             assert leg in d and "error" not in d[leg], leg
         assert d["geometry_R"]["image_words"] == 1455 and d["config5"]["seq_len"] == 1024 + 2 * 579
         assert d["m13b"]["train_replica"]["hbm_gib"] < 288 and d["m13b"]["train_replica"]["trainable_params"] > 13e9
-        assert set(r["families"]) == {"nt", "nn", "tn"} and r["traffic"]["file"][:3] in ("r02", "r03")
+        assert {"nt", "nn", "tn"} <= set(r["families"]) and r["traffic"]["file"][:3] in ("r02", "r03")
         assert c["c1"]["ids_equal"] is True and c["decode_tok_s"] > 0
         assert d["generate"]["tok_s_end_to_end"] > 0 and d["decode"]["roofline"]["bound"] == "hbm"
 
