@@ -125,6 +125,20 @@ def gemm_nn(a, wt, out, *, residual=None, epilogue: int = 0):
     return out
 
 
+def gemm_tn_strip(t, x, out, scratch, S: int, accumulate: bool = False):
+    """out[R, N] (+)= t[Kt, R]^T @ x[Kt, N] for R <= 64 (adapter weight gradients) through the small-block streaming kernel
+    a3v_gemm_tn_strip + the split-K reduce; t's rows must hold 64 readable elements (the kernel loads 64 columns)."""
+    _dev(t, x, out, scratch)
+    Kt, R = t.shape
+    N = x.shape[1]
+    assert x.shape[0] == Kt and t.stride(1) == 1 and x.stride(1) == 1 and t.stride(0) >= 64
+    assert scratch.dtype == torch.float32 and scratch.numel() >= S * R * N
+    lib = _l.load()
+    _l.check(lib.a3v_gemm_tn_strip(_p(t), t.stride(0), _p(x), x.stride(0), _p(scratch), R, N, Kt, S, _stream()), f"a3v_gemm_tn_strip(R={R},N={N},Kt={Kt},S={S})")
+    _l.check(lib.a3v_splitk_reduce(_p(scratch), S, R, N, _p(out), out.stride(0), dt(out), 1 if accumulate else 0, _stream()), "a3v_splitk_reduce")
+    return out
+
+
 def gemm_tn_splitk(at, wt, out, scratch, S: int, accumulate: bool = False):
     """out[M, N] (+)= at[K, M]^T @ wt[K, N] through S split-K planes of the TN kernel (adapter-sized M or N, long K)."""
     _dev(at, wt, out, scratch)

@@ -37,6 +37,7 @@ class TrainEngine:
     # free and the product runs on the NT ring kernel (1.38-1.42 PF) instead of the NN kernel (1.28-1.30) for the groups named here
     # ("0": none, "all", or a comma list of qkv / wo / w13 / w2).  Same-box LoRA step: 253.0 ms without, 248.9 with wo,w13,w2, 247.9 all
     lora_nt_dgrad = os.environ.get("A3V_LORA_NT_DGRAD", "all")
+    strip_wgrad = os.environ.get("A3V_STRIP_WGRAD", "1") != "0"        # adapter weight gradients by a3v_gemm_tn_strip (0: the 256 x 256 TN split-K kernel)
 
     def __init__(self, model, compute_dtype: torch.dtype = torch.bfloat16, recompute: Optional[bool] = None,
                  stream_dtype: Optional[torch.dtype] = None):
@@ -274,6 +275,15 @@ class TrainEngine:
             sink = self.sumsq_sink            # dp.GradSquareSums (one rank): the clip's sum of squares comes out of this GEMM's epilogue
             sq = sink.wgrad_slots(grad, N, K) if sink is not None and grad.is_contiguous() else None
             ops.gemm_tn(dy, x, grad, residual=None if fresh else grad, epilogue=ops.EPI_OUT_F32 if fresh else ops.EPI_RES_F32, sumsq=sq)
+            return
+        if (tn_ok and self.strip_wgrad and N <= 64 and N % 4 == 0 and K >= 256 and dy.stride(0) >= 64
+                and (dy.data_ptr() | x.data_ptr()) % 16 == 0):
+            # adapter gradients [N <= 64, K]: the small-block streaming kernel (three blocks per CU; token slices chosen so that the
+            # grid holds ~2 blocks per CU: fewer slices = less reduce work, tools/lora_skinny_bench.py)
+            tiles = (K + 127) // 128
+            S = max(1, min(64, (M + 63) // 64, -(-512 // tiles)))
+            self._fresh.difference_update(names if fresh else ())
+            ops.gemm_tn_strip(dy, x, grad, self._buf("splitk", (S * N * K,), torch.float32), S, accumulate=not fresh)
             return
         if tn_ok and min(N, K) <= 64 and max(N, K) >= 256:
             # adapter gradients: a strip of 256 x 256 tiles, split over the tokens so the whole chip streams dy / x once

@@ -441,6 +441,14 @@ int a3v_adamw_scaled(float* param, const float* grad, float* exp_avg, float* exp
  * are HOST arrays (dst[j] device pointers). */
 int a3v_lora_gb_scatter(const float* gbt, int64_t ld, int r, int n_mods, float* const* dst, const int* row0, const int* nj, void* stream);
 
+/* The adapter weight gradients as a streaming kernel: partial[s][R][N] = T[k in slice s][0..R)^T . X[k in slice s][0..N), S token
+ * slices (raw fp32 planes, summed / rounded / accumulated by a3v_splitk_reduce exactly like those of a3v_gemm_tn_splitk).  T: bf16
+ * [Kt][ldt] with R <= 64 valid columns (the padded rank of a fused adapter group; the kernel always loads 64 columns per row, so
+ * ldt >= 64 and the row's first 64 elements must be readable), X: bf16 [Kt][ldx].  dB^T = t^T . dy and dA = dt^T . x of
+ * model/peft.py:58-159 (autograd's gradients of lora_b / lora_a, engine_finetune.py:55-57).  Small blocks (64 x 128 tile, 48 KiB of
+ * LDS: three per CU) so that the stream of X has several stages in flight per CU. */
+int a3v_gemm_tn_strip(const void* T, int64_t ldt, const void* X, int64_t ldx, float* partial, int R, int N, int Kt, int S, void* stream);
+
 /* The same update for MANY small tensors of one torch param group in ONE launch (a LoRA step: ~520 adapter / norm tensors; was one
  * launch per tensor plus one a3v_lora_refresh per adapter).  `table` is a DEVICE array of n_tensors descriptors (built once by the
  * host, a3vlm_amd/optim.py); every pointer 16-byte aligned, fp32 contiguous p / g / m / v of n elements viewed as [n / cols, cols].

@@ -868,3 +868,35 @@ def test_gemm_few_big_tiles_go_split_k_on_the_ring_kernel(M, N, K):
     o32 = torch.empty(M, N, device=DEV)
     ops.gemm_nt(ad, wd, o32, epilogue=ops.EPI_OUT_F32)
     assert_close(o32, rt(a @ w.t()), rtol=2 ** -7, atol=0.02, what="ring split-K, fp32 out")
+
+
+@pytest.mark.parametrize("Kt,R,N,S,ld_extra", [(8728, 64, 4096, 32, 0), (1000, 48, 1024, 5, 4096), (130, 16, 384, 3, 64), (64, 64, 128, 1, 0),
+                                                (700, 32, 22016 // 8, 4, 4160 - 64)])
+def test_gemm_tn_strip(Kt, R, N, S, ld_extra):
+    """a3v_gemm_tn_strip (adapter weight gradients: out[R, N] = T^T X over the token rows; 64 x 128 tiles, transposing LDS reads on both
+    operands with the 128- / 256-byte-row swizzles) against the fp32 product of the same bf16 operands and against the 256 x 256 TN
+    split-K kernel: ragged last k-tile, R < 64 inside a wider row (the view the engine passes: dt[:, :n r] / t inside the K-extended
+    buffers), store and accumulate, deterministic."""
+    wide = rt(gen(Kt, 64 + ld_extra, seed=111))
+    x = rt(gen(Kt, N, seed=112, scale=0.05))
+    td_full = wide.to(BF).to(DEV)
+    td = td_full[:, :R]                        # row stride 64 + ld_extra; columns R..63 hold other (finite) data
+    xd = x.to(BF).to(DEV)
+    want = wide[:, :R].t() @ x
+    tol = dict(rtol=2 ** -7, atol=2e-3 * math.sqrt(Kt) * 0.05 + 1e-3)
+    scratch = torch.full((S * R * N,), float("nan"), dtype=torch.float32, device=DEV)
+    of = torch.full((R, N), float("nan"), dtype=torch.float32, device=DEV)
+    ops.gemm_tn_strip(td, xd, of, scratch, S)
+    assert_close(of, want, what="tn strip store", **tol)
+    if R % 8 == 0:
+        ref = torch.empty_like(of)
+        S2 = min(S, (Kt + 63) // 64, 16)
+        ops.gemm_tn_splitk(td, xd, ref, torch.empty(S2 * R * N, dtype=torch.float32, device=DEV), S2)
+        assert_close(of, ref, rtol=2 ** -7, atol=tol["atol"], what="tn strip vs tn split-K")
+    acc0 = gen(R, N, seed=113)
+    og = acc0.to(DEV).clone()
+    ops.gemm_tn_strip(td, xd, og, scratch, S, accumulate=True)
+    assert_close(og.cpu() - acc0, want, what="tn strip accumulate", **tol)
+    of2 = torch.empty_like(of)
+    ops.gemm_tn_strip(td, xd, of2, scratch, S)
+    assert torch.equal(of, of2)

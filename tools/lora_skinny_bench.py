@@ -42,3 +42,8 @@ for K in (4096, 11008, 12288, 22016):
         sc = torch.empty(S2 * N_ * K_, device=DEV, dtype=torch.float32)
         us2 = t_us(lambda: ops.gemm_tn_splitk(at, wt, g, sc, S2))
         print(f"{nm} [{N_},{K_}] over T  S={S2:2d}: {us2:6.1f} us  ({mb / us2:.2f} TB/s)", flush=True)
+        if N_ <= 64:        # the small-block streaming kernel on the same product
+            for S3 in sorted({max(1, -(-512 // ((K_ + 127) // 128))), max(1, -(-768 // ((K_ + 127) // 128))), max(1, -(-1024 // ((K_ + 127) // 128))), max(1, -(-1536 // ((K_ + 127) // 128)))}):
+                sc3 = torch.empty(S3 * N_ * K_, device=DEV, dtype=torch.float32)
+                us3 = t_us(lambda: ops.gemm_tn_strip(at, wt, g, sc3, S3))
+                print(f"   strip [{N_},{K_}] over T  S={S3:2d}: {us3:6.1f} us  ({mb / us3:.2f} TB/s)", flush=True)
