@@ -1167,7 +1167,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_pp_kernel(GemmArgs p) {
 // EARLY: the barrier that ends an MFMA interval is executed EARLY tile-rows before the interval's last MFMA.  Nothing after it
 // needs the barrier (the tail MFMAs read registers only), and the partner wave on the SIMD -- released by the same barrier --
 // starts its own MFMA stream while this wave is still feeding the pipe: no matrix-pipe bubble at the hand-over.
-template <int DBG, bool M32, int EARLY, bool STAGED = true, int SET = EPI_SET_COMMON, bool LW = false>   // SET: which fast epilogue forms (gemm_epilogue_fast); M32: v_mfma_f32_32x32x16_bf16 (4x2 tiles per wave) instead of 16x16x32 (8x4)
+template <int DBG, bool M32, int EARLY, bool STAGED = true, int SET = EPI_SET_COMMON, bool LW = false, bool LATEW = true>   // LATEW (product; r03 A/B +1 % on every shape, bit-equal): group 0 waits for its W pieces of tile t+1 at the TOP of L(t+1) instead of between its last MFMA of M(t) and the barrier that hands the matrix pipe over; SET: which fast epilogue forms (gemm_epilogue_fast); M32: v_mfma_f32_32x32x16_bf16 (4x2 tiles per wave) instead of 16x16x32 (8x4)
 __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
   constexpr int TBM = 256, TBN = 256, WTM = 128, WTN = 64, TM = M32 ? 4 : 8, TN = M32 ? 2 : 4;
   constexpr int AH = 128 * BK * 2;                      // 16 KiB: one group's half of an A K-tile
@@ -1353,6 +1353,13 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
 #pragma unroll
           for (int c = 0; c < 4; ++c) piece_w((g4 * 4 + c) * 8, t + 2, c & 1, lds + WB + wn2 * WT + (g4 * 4 + c) * 1024);
         }
+        if constexpr (LATEW) {
+          // everything older than the bursts of L(t-1) and L(t) has landed: in particular this group's W half of tile t (the reads
+          // below); in steady state 8 + 8 pieces may stay in flight, the last two tiles issue shorter bursts
+          if (t + 2 < nk) RG_VMCNT(16);
+          else if (t + 2 == nk) RG_VMCNT(12);
+          else RG_VMCNT(4);
+        }
         RG_READ_FRAGS(lds + ATOP + (t & 1) * AH, lds + WB + wcur * WT);
         A3V_WAIT_LGKM0();
         RG_STAMP(t, 1);
@@ -1372,7 +1379,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
         RG_MFMA_PART(false);
         __builtin_amdgcn_s_setprio(0);                 // never wait (vmcnt / barrier) at raised priority: measured -20 %
         RG_STAMP(t, 4);
-        if constexpr (!LW) {
+        if constexpr (!LW && !LATEW) {
           if (t + 2 < nk) RG_VMCNT(8);
           else if (t + 2 == nk) RG_VMCNT(4);
           else RG_VMCNT(0);
@@ -3007,12 +3014,8 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
           case 9: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, true, 0>), g, b, 0, st, q); break;   // ring, 32x32x16 MFMA
           case 10: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<4, true, 0>), g, b, 0, st, q); break;   // 32x32x16, stamps
           case 6: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<4, false, 0>), g, b, 0, st, q); break;   // cycle stamps (tools/ring_stamps.py)
-  #ifdef A3V_ABLATION
-          case 1: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<1, 0>), g, b, 0, st, q); break;
-          case 2: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<2, 0>), g, b, 0, st, q); break;
-          case 3: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<3, 0>), g, b, 0, st, q); break;
-          case 4: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<4, 0>), g, b, 0, st, q); break;
-  #endif
+          case 1: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0, true, EPI_SET_COMMON, false, false>), g, b, 0, st, q); break;   // ablation: the wait after the MFMAs (round-2 form)
+          case 2: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<4, false, 0, true, EPI_SET_COMMON, false, false>), g, b, 0, st, q); break;   // same, stamps
           default: break;
         }
         return;
