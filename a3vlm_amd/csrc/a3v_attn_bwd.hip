@@ -15,6 +15,7 @@
 //      dV^T += dO^T . P ,  dK^T += Q^T . dS          (A = dO^T / Q^T fragments by transpose reads of the dO / Q row tiles, B = P / dS)
 // No transposed copies of K, Q or dO exist (ds_read_b64_tr_b16 delivers the transposed MFMA operands); no atomics anywhere.
 #include "a3v_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -29,7 +30,15 @@ struct BwdArgs {
   int B, S, Sp, H, Hkv, causal;
   float scale;
   int group_q, group_kv;     // causal: heads per tile-rank-major group of the block order (dQ kernel / dK, dV kernels); 1 = head-major
+#ifdef AB_STAMP
+  unsigned long long* stamps;   // timing experiment (make EXTRA=-DAB_STAMP=<block>): s_memtime stamps of that block's wave 0, [kernel][64 iterations][8]
+#endif
 };
+#ifdef AB_STAMP
+#define AB_ST(kern, it, k) do { if (stamps && (it) < 64) stamps[((kern) * 64 + (it)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define AB_ST(kern, it, k) do {} while (0)
+#endif
 
 // 16-B chunk swizzle of a row tile: logical chunk c of row r sits at physical chunk c ^ tile_swz(r).  Two access patterns must
 // both be conflict-free: (a) row fragments, ds_read_b128 by 16 lanes on 16 consecutive rows at one logical chunk -> the swizzle
@@ -56,33 +65,36 @@ __device__ __forceinline__ void buf_dma16(__amdgpu_buffer_rsrc_t rs, char* lds_d
 __device__ __forceinline__ void buf_dma4(__amdgpu_buffer_rsrc_t rs, void* lds_dst, unsigned voff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_dst, 4, voff, 0, 0, 0);
 }
+// Per-lane byte offset of DMA instruction 0 of a tile (thread id -> row id / KCH, physical chunk id % KCH, source chunk = physical ^
+// swizzle(row)).  Instruction i covers the rows 256 / KCH further down (16 at HD 128, 32 at HD 64): tile_swz only looks at row bits
+// below that, so its offset is this one + i * dma_step() -- ONE live VGPR per row stride instead of 64 KCH / 256 of them (the dK
+// kernel, which has no VGPR to spare, used to recompute the whole set with ~60 VALU instructions per loop iteration).
 template <int HD>
-__device__ __forceinline__ void dma_lane_offsets(unsigned (&voff)[64 * (HD / 8) / 256], int64_t row_stride, int tid) {
+__device__ __forceinline__ unsigned dma_lane_offset0(int64_t row_stride, int tid) {
   constexpr int KCH = HD / 8;
-#pragma unroll
-  for (int i = 0; i < 64 * KCH / 256; ++i) {
-    const int id = tid + i * 256;
-    const int row = id / KCH, pc = id % KCH;
-    const int sw = tile_swz<HD>(row);
-    voff[i] = (unsigned)((row * row_stride + ((pc ^ sw) << 3)) * 2);
-  }
+  const int row = tid / KCH, pc = tid % KCH;
+  return (unsigned)((row * row_stride + ((pc ^ tile_swz<HD>(row)) << 3)) * 2);
 }
+template <int HD>
+__device__ __forceinline__ unsigned dma_step(int64_t row_stride) { return (unsigned)((256 / (HD / 8)) * row_stride * 2); }
 // rows [row0, row0 + 64) of a [nrows, HD] matrix with `row_stride` elements between rows
 template <int HD>
-__device__ __forceinline__ void stage_rows_dma(const bf16_t* base, int64_t row_stride, int row0, int nrows, char* lds,
-                                               const unsigned (&voff)[64 * (HD / 8) / 256], int wave) {
+__device__ __forceinline__ void stage_rows_dma(const bf16_t* base, int64_t row_stride, int row0, int nrows, char* lds, unsigned voff0, int wave) {
   const int64_t left = ((int64_t)(nrows - 1 - row0) * row_stride + HD) * 2;          // bytes from the tile's first row to the end of the last valid row
   const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(base + (int64_t)row0 * row_stride), 0, (int)(left < 0x7fffffff ? left : 0x7fffffff), 0x00020000);
+  const unsigned step = dma_step<HD>(row_stride);
 #pragma unroll
-  for (int i = 0; i < 64 * (HD / 8) / 256; ++i) buf_dma16(rs, lds + (wave * 64 + i * 256) * 16, voff[i]);
+  for (int i = 0; i < 64 * (HD / 8) / 256; ++i) buf_dma16(rs, lds + (wave * 64 + i * 256) * 16, voff0 + i * step);
 }
 
-// A operand fragment of a row tile: row (32 tb + lane&31), 16-B chunk 2 ks + hh
+// A operand fragment of a row tile: row (32 tb + lane&31), 16-B chunk 2 ks + hh.  The chunk swizzle only looks at the row's low four
+// bits and (2 ks | hh) ^ sw == (2 ks) ^ (hh ^ sw), so the address is  tile + 32 tb ROWB + (frag_rows_base ^ (ks << 5)):  one per-lane
+// constant, one v_xor per fragment (the row / swizzle arithmetic per fragment was a third of the loops' VALU instructions).
 template <int HD>
-__device__ __forceinline__ bf16x8 frag_rows(const char* lds, int tb, int ks, int ql, int hh) {
-  const int row = tb * 32 + ql;
-  const int sw = tile_swz<HD>(row);
-  return *reinterpret_cast<const bf16x8*>(lds + row * (HD * 2) + (((2 * ks + hh) ^ sw) << 4));
+__device__ __forceinline__ int frag_rows_base(int ql, int hh) { return ql * (HD * 2) + ((hh ^ tile_swz<HD>(ql)) << 4); }
+template <int HD>
+__device__ __forceinline__ bf16x8 frag_rows(const char* lds, int fbase, int tb, int ks) {
+  return *reinterpret_cast<const bf16x8*>(lds + tb * 32 * (HD * 2) + (fbase ^ (ks << 5)));
 }
 
 // A operand of the accumulator-order contractions (dQ^T += K^T dS^T, dV^T += dO^T P^T, dK^T += Q^T dS^T), taken from the ROW tile
@@ -90,17 +102,25 @@ __device__ __forceinline__ bf16x8 frag_rows(const char* lds, int tb, int ks, int
 // T[kv = 32 tb + 16 c + 4 hh + (e & 3) + 8 (e >> 2)][d = 32 db + ql], i.e. four consecutive rows of one column -- what gfx950's
 // ds_read_b64_tr_b16 delivers: the 16 lanes of a group pass the addresses of a 4 x 16 block (lane i: row i >> 2, columns
 // 4 (i & 3)..+3) and lane i receives column i (tools/ubench/trread.hip).  Rows r..r+3 carry different chunk swizzles, so the four
-// 32-B row segments of one read fall on different banks.
+// 32-B row segments of one read fall on different banks.  Addressing as for frag_rows: the two row groups' (rows r, r + 8) per-lane
+// bases for db = tb = c = 0 are computed once (tr_bases); block (db, tb, c) is  tile + (32 tb + 16 c) ROWB + (base ^ (db << 6)).
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+struct TrBase { int lo, hi; };
 template <int HD>
-__device__ __forceinline__ bf16x8 frag_rows_tr(const char* lds, int db, int tb, int c, int lane) {
+__device__ __forceinline__ TrBase tr_bases(int lane) {
   const int hh = lane >> 5, ql = lane & 31, i = lane & 15;
-  const int chunk16 = ((db * 32 + 16 * (ql >> 4)) >> 3) + ((i & 3) >> 1);
-  const int row0 = 32 * tb + 16 * c + 4 * hh + (i >> 2);
-  const int row1 = row0 + 8;
-  const int sw0 = tile_swz<HD>(row0), sw1 = tile_swz<HD>(row1);
-  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(lds + row0 * (HD * 2) + ((chunk16 ^ sw0) << 4) + (i & 1) * 8));
-  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(lds + row1 * (HD * 2) + ((chunk16 ^ sw1) << 4) + (i & 1) * 8));
+  const int chunk16 = 2 * (ql >> 4) + ((i & 3) >> 1);
+  const int row0 = 4 * hh + (i >> 2), row1 = row0 + 8;
+  TrBase b;
+  b.lo = row0 * (HD * 2) + ((chunk16 ^ tile_swz<HD>(row0)) << 4) + (i & 1) * 8;
+  b.hi = row1 * (HD * 2) + ((chunk16 ^ tile_swz<HD>(row1)) << 4) + (i & 1) * 8;
+  return b;
+}
+template <int HD>
+__device__ __forceinline__ bf16x8 frag_rows_tr(const char* lds, TrBase tb0, int db, int tb, int c) {
+  const char* blk = lds + (32 * tb + 16 * c) * (HD * 2);
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(blk + (tb0.lo ^ (db << 6))));
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(blk + (tb0.hi ^ (db << 6))));
   bf16x8 f;
   const short v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   __builtin_memcpy(&f, v, 16);
@@ -218,22 +238,30 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs p) {
   int kv_end = p.S;
   if (p.causal) kv_end = min(p.S, min(qt * 128 + 127, p.S - 1) + 1);
   const int n_tiles = (kv_end + 63) / 64;
-  unsigned koff[64 * (HD / 8) / 256], voff[64 * (HD / 8) / 256];
-  dma_lane_offsets<HD>(koff, HD, tid);
-  dma_lane_offsets<HD>(voff, p.v_ss, tid);
+  const unsigned koff = dma_lane_offset0<HD>(HD, tid), voff = dma_lane_offset0<HD>(p.v_ss, tid);
+  const int fbase = frag_rows_base<HD>(ql, hh);
+  const TrBase trb = tr_bases<HD>(lane);
   stage_rows_dma<HD>(K, HD, 0, p.S, lds, koff, wave);
   stage_rows_dma<HD>(V, p.v_ss, 0, p.S, lds + TILE, voff, wave);
-  for (int t = 0; t < n_tiles; ++t) {
+#ifdef AB_STAMP
+  unsigned long long* stamps = (p.stamps && blockIdx.x == AB_STAMP && tid == 0) ? p.stamps : nullptr;
+#endif
+  auto body = [&](int t, auto bufc) {             // unrolled by two, compile-time buffer index (see the dK / dV kernel)
+    constexpr int BUF = decltype(bufc)::value;
+    AB_ST(0, t, 0);
     const int kv0 = t * 64;
-    const char* Ks = lds + (t & 1) * 2 * TILE;    // dQ^T += K^T . dS^T reads K^T fragments out of the K row tile (transpose reads)
+    const char* Ks = lds + BUF * 2 * TILE;        // dQ^T += K^T . dS^T reads K^T fragments out of the K row tile (transpose reads)
     const char* Vs = Ks + TILE;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    AB_ST(0, t, 1);
     __syncthreads();                              // tile t has landed; every wave is done with the other pair (tile t - 1)
+    AB_ST(0, t, 2);
     if (t + 1 < n_tiles) {
-      char* nx = lds + ((t + 1) & 1) * 2 * TILE;
+      char* nx = lds + (1 - BUF) * 2 * TILE;
       stage_rows_dma<HD>(K, HD, kv0 + 64, p.S, nx, koff, wave);
       stage_rows_dma<HD>(V, p.v_ss, kv0 + 64, p.S, nx + TILE, voff, wave);
     }
+    AB_ST(0, t, 3);
     // one 32-key block at a time: S^T and dP^T accumulators (32 VGPRs) are dead before the next block starts, which keeps
     // the kernel under 256 VGPRs = two waves per SIMD
     bf16x8 dsf[2][2];
@@ -244,8 +272,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs p) {
       for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
       for (int ks = 0; ks < HD / 16; ++ks) {
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<HD>(Ks, tb, ks, ql, hh), qf[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<HD>(Vs, tb, ks, ql, hh), dof[ks], dp, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<HD>(Ks, fbase, tb, ks), qf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<HD>(Vs, fbase, tb, ks), dof[ks], dp, 0, 0, 0);
       }
       // P = exp2(s * scale*log2e - lse*log2e) with the raw v_exp_f32; interior tiles (all 64 keys visible to all 32 query
       // rows of the wave) skip the compare/select per element
@@ -256,24 +284,39 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs p) {
           const int kv = kv0 + tb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
           const bool ok = (kv < p.S) && (!p.causal || kv <= qrow);
           const float ev = __builtin_amdgcn_exp2f(fmaf(s[r], sl2, -lse2));      // unconditional + select: no exec branch per element
-          dsf[tb][r >> 3][r & 7] = f2bf(ok ? ev * (dp[r] - Dq) * p.scale : 0.f);
+          dsf[tb][r >> 3][r & 7] = f2bf(ok ? ev * (dp[r] - Dq) : 0.f);
         }
       } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float pr = __builtin_amdgcn_exp2f(fmaf(s[r], sl2, -lse2));
-          dsf[tb][r >> 3][r & 7] = f2bf(pr * (dp[r] - Dq) * p.scale);
+          dsf[tb][r >> 3][r & 7] = f2bf(pr * (dp[r] - Dq));
         }
       }
     }
+    AB_ST(0, t, 4);
 #pragma unroll
     for (int d = 0; d < HD / 32; ++d)
 #pragma unroll
       for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
         for (int c = 0; c < 2; ++c)
-          acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_tr<HD>(Ks, d, tb, c, lane), dsf[tb][c], acc[d], 0, 0, 0);
+          acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_tr<HD>(Ks, trb, d, tb, c), dsf[tb][c], acc[d], 0, 0, 0);
+    AB_ST(0, t, 5);
+  };
+  {
+    int t = 0;
+    for (; t + 1 < n_tiles; t += 2) {
+      body(t, std::integral_constant<int, 0>{});
+      body(t + 1, std::integral_constant<int, 1>{});
+    }
+    if (t < n_tiles) body(t, std::integral_constant<int, 0>{});
   }
+  // dS was formed WITHOUT the 1 / sqrt(hd) factor (dS = P o (dP - D), one multiply less per score): it is applied to the sums here
+#pragma unroll
+  for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[d][r] *= p.scale;
   int q_e = qrow, hh_e = hh;                 // opaque copies: keeps the store's address arithmetic out of the key loop (see dK below)
   asm volatile("" : "+v"(q_e), "+v"(hh_e));
   if constexpr (PACKED) {
@@ -341,15 +384,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs p) {
   const int n_it = n_qt - q_begin, total = nrep * n_it;
   // pair `it` = (head repetition it / n_it, query tile q_begin + it % n_it) -> buffer it & 1:
   //   [Q rows | dO rows] (S^T recompute from row fragments; Q^T for dK / dO^T for dV by transpose reads) + lse[64] | D[64]
+  // (the pair indices are carried as counters: two integer divisions per iteration were ~50 instructions)
+  const unsigned qoff = dma_lane_offset0<HD>((int64_t)p.H * HD, tid);          // Q and dO rows share the row stride H*HD
+  const int fbase = frag_rows_base<HD>(kl, hh);
+  const TrBase trb = tr_bases<HD>(lane);
+  int rep_n = 0, qi_n = 0;                       // (head repetition, query tile index) of the next pair to issue
   auto issue = [&](int it) {
-    // per-lane offsets recomputed per issue from an opaque copy of the thread id (a dozen VALU ops per ~1.5 us iteration): as
-    // loop constants they would be live across the whole query loop, and the dK kernel has no VGPR to spare
-    int tid_o = tid;
-    asm volatile("" : "+v"(tid_o));
-    const int lane = tid_o & 63;
-    unsigned qoff[64 * (HD / 8) / 256];          // Q and dO rows share the row stride H*HD
-    dma_lane_offsets<HD>(qoff, (int64_t)p.H * HD, tid_o);
-    const int h = hk * nrep + it / n_it, q0 = (q_begin + it % n_it) * 64;
+    const int h = hk * nrep + rep_n, q0 = (q_begin + qi_n) * 64;
+    if (++qi_n == n_it) { qi_n = 0; ++rep_n; }
     char* buf = lds + (it & 1) * 2 * TILE;
     stage_rows_dma<HD>(p.q + ((int64_t)b * p.S * p.H + h) * HD, (int64_t)p.H * HD, q0, p.S, buf, qoff, wave);
     stage_rows_dma<HD>(p.dout + ((int64_t)b * p.S * p.H + h) * HD, (int64_t)p.H * HD, q0, p.S, buf + TILE, qoff, wave);
@@ -364,16 +406,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs p) {
     }
   };
   if (total > 0) issue(0);
-  for (int it = 0; it < total; ++it) {
+#ifdef AB_STAMP
+  unsigned long long* stamps = (p.stamps && blockIdx.x == AB_STAMP && tid == 0) ? p.stamps : nullptr;
+#endif
+  int qi_c = 0;                                  // query tile index of the pair being consumed
+  // The loop is unrolled by two with the buffer index a compile-time constant: every LDS read address is then (per-lane base ^ constant)
+  // + an instruction offset.  With a run-time buffer base each of the 40 - 64 fragment reads of an iteration paid its own v_or / v_add.
+  auto body = [&](int it, auto bufc) {
+    constexpr int BUF = decltype(bufc)::value;
+    AB_ST(1 + WHICH, it, 0);
     {
-      const int q0 = (q_begin + it % n_it) * 64;
-      const char* Qs = lds + (it & 1) * 2 * TILE;
+      const int q0 = (q_begin + qi_c) * 64;
+      if (++qi_c == n_it) qi_c = 0;
+      const char* Qs = lds + BUF * 2 * TILE;
       const char* T1 = Qs + TILE;
-      const float* lse_s = reinterpret_cast<const float*>(lds + 4 * TILE) + (it & 1) * 128;
+      const float* lse_s = reinterpret_cast<const float*>(lds + 4 * TILE) + BUF * 128;
       const float* D_s = lse_s + 64;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      AB_ST(1 + WHICH, it, 1);
       __syncthreads();                       // pair `it` has landed; every wave is done with the other buffer (pair it - 1)
+      AB_ST(1 + WHICH, it, 2);
       if (it + 1 < total) issue(it + 1);
+      AB_ST(1 + WHICH, it, 3);
       bf16x8 bf[2][2];                       // P (dV) or dS (dK) as the B operand of the accumulation products
       const int kv_hi = kt_ * 128 + wave * 32 + 31;                        // last key of this wave (wave-uniform)
       const bool interior = (q0 + 64 <= p.S) && (kv_hi < p.S) && (!p.causal || q0 >= kv_hi);
@@ -384,8 +438,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs p) {
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
         for (int ks = 0; ks < HD / 16; ++ks) {
-          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<HD>(Qs, tb, ks, kl, hh), kf[ks], s, 0, 0, 0);
-          if (WHICH == 1) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<HD>(T1, tb, ks, kl, hh), vf[ks], dp, 0, 0, 0);
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<HD>(Qs, fbase, tb, ks), kf[ks], s, 0, 0, 0);
+          if (WHICH == 1) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<HD>(T1, fbase, tb, ks), vf[ks], dp, 0, 0, 0);
         }
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
@@ -403,7 +457,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs p) {
             for (int e = 0; e < 4; ++e) {
               const int r = g4 * 4 + e;
               const float pr = __builtin_amdgcn_exp2f(fmaf(s[r], sl2, -l4[e]));
-              bf[tb][r >> 3][r & 7] = WHICH == 0 ? f2bf(pr) : f2bf(pr * (dp[r] - d4[e]) * p.scale);
+              bf[tb][r >> 3][r & 7] = WHICH == 0 ? f2bf(pr) : f2bf(pr * (dp[r] - d4[e]));
             }
           } else {
 #pragma unroll
@@ -412,12 +466,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs p) {
               const int qg = q0 + qb + e;
               const bool ok = (qg < p.S) && (kvrow < p.S) && (!p.causal || kvrow <= qg);
               const float ev = __builtin_amdgcn_exp2f(fmaf(s[r], sl2, -l4[e]));
-              const float val = WHICH == 0 ? ev : ev * (dp[r] - d4[e]) * p.scale;
+              const float val = WHICH == 0 ? ev : ev * (dp[r] - d4[e]);
               bf[tb][r >> 3][r & 7] = f2bf(ok ? val : 0.f);
             }
           }
         }
       }
+      AB_ST(1 + WHICH, it, 4);
       const char* At = WHICH == 0 ? T1 : Qs;      // dV^T += dO^T . P^T ; dK^T += Q^T . dS^T : transposed operands read out of the row tiles
 #pragma unroll
       for (int d = 0; d < HD / 32; ++d)
@@ -425,8 +480,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs p) {
         for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
           for (int c = 0; c < 2; ++c)
-            acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_tr<HD>(At, d, tb, c, lane), bf[tb][c], acc[d], 0, 0, 0);
+            acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_tr<HD>(At, trb, d, tb, c), bf[tb][c], acc[d], 0, 0, 0);
+      AB_ST(1 + WHICH, it, 5);
     }
+  };
+  {
+    int it = 0;
+    for (; it + 1 < total; it += 2) {
+      body(it, std::integral_constant<int, 0>{});
+      body(it + 1, std::integral_constant<int, 1>{});
+    }
+    if (it < total) body(it, std::integral_constant<int, 0>{});
+  }
+  if (WHICH == 1) {        // dS was formed without the 1 / sqrt(hd) factor (see the dQ kernel)
+#pragma unroll
+    for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[d][r] *= p.scale;
   }
   // (the stores are written out here rather than through store_grad_rows: routed through the helper, this kernel went from
   //  240 VGPRs to 256 + 18 spills inside the query loop -- two waves per SIMD leave the allocator no slack)
@@ -486,6 +556,10 @@ extern "C" int64_t a3v_attention_bwd_workspace_bytes(int B, int S, int H, int Hk
   return 256;
 }
 
+#ifdef AB_STAMP
+static unsigned long long* g_ab_stamps = nullptr;
+extern "C" void a3v_debug_set_bwd_stamps(void* ptr) { g_ab_stamps = (unsigned long long*)ptr; }   // >= 3 * 64 * 8 * 8 bytes, zeroed
+#endif
 // the three MFMA kernels; D must already hold rowsum(dO o O)
 static int attention_bwd_mfma_impl(const void* q, const void* k, int64_t k_sb, int64_t k_sh, const void* v, int64_t v_sb,
                                    int64_t v_ss, int64_t v_sh, const void* dout, const float* lse, const float* D, void* dq,
@@ -505,6 +579,9 @@ static int attention_bwd_mfma_impl(const void* q, const void* k, int64_t k_sb, i
   p.k_sb = k_sb; p.k_sh = k_sh; p.v_sb = v_sb; p.v_ss = v_ss; p.v_sh = v_sh;
   p.B = B; p.S = S; p.Sp = Sp; p.H = H; p.Hkv = Hkv; p.causal = causal;
   p.scale = 1.0f / sqrtf((float)hd);
+#ifdef AB_STAMP
+  p.stamps = g_ab_stamps;
+#endif
   dim3 gq(((S + 127) / 128) * H * B), gk(((S + 127) / 128) * Hkv * B);
   auto group_of = [&](int heads, unsigned blocks) {         // as in the forward (a3v_attn.hip), with Q + dO + K + V per head: 8 heads at S = 1091 (592.8 -> 550.2 us for the three kernels)
     if (!causal || (blocks & 7) || (heads & 7)) return 1;
