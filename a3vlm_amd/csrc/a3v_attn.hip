@@ -16,6 +16,7 @@
 //    K rows / V^T rows with 16-byte loads, + combine kernel.
 //  * attn_f32_kernel: fp32 parity path (any Sq), one wave per (b, h, q).
 #include "a3v_common.h"
+#include <type_traits>
 #include <cstdlib>
 
 namespace {
@@ -198,10 +199,18 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_bf16_kernel(AttnArgs p) {
 #define AP_ST(t, k) do {} while (0)
 #endif
   if (n_tiles > 0 && full_tile(0)) dma_tile(0, lds, lds + KVB * KROW);
-  for (int t = 0; t < n_tiles; ++t) {
+  // Per-lane fragment bases: the K chunk swizzle looks at row bits 0-3 (HD 128) / 1-3 (HD 64) and the V^T one at bits 1-3, which the
+  // block offsets (32 tb rows of K, 32 d rows of V^T) leave alone, and (2 ks | hh) ^ sw == (2 ks) ^ (hh ^ sw): every fragment
+  // address is tile + block offset + (base ^ constant).  The loop is unrolled by two so that the tile buffer is a compile-time
+  // constant too: the whole address becomes one v_xor + an instruction offset (the per-fragment row / swizzle / buffer arithmetic
+  // was ~125 of the ~330 VALU instructions of a tile).
+  const int kfb = ql * KROW + ((hh ^ ((HD == 128) ? (ql & 15) : ((ql >> 1) & 7))) << 4);
+  const int vfb = ql * 128 + ((hh ^ ((ql >> 1) & 7)) << 4);
+  auto body = [&](int t, auto bufc) {
+    constexpr int BUF = decltype(bufc)::value;
     AP_ST(t, 0);
     const int kv0 = t * KVB;
-    char* Ks = lds + (t & 1) * TILEB;
+    char* Ks = lds + BUF * TILEB;
     char* Vs = Ks + KVB * KROW;
     if (full_tile(t)) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -213,20 +222,21 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_bf16_kernel(AttnArgs p) {
       __syncthreads();
     }
     AP_ST(t, 5);
-    if (t + 1 < n_tiles && full_tile(t + 1)) dma_tile(kv0 + KVB, lds + ((t + 1) & 1) * TILEB, lds + ((t + 1) & 1) * TILEB + KVB * KROW);
+    if (t + 1 < n_tiles && full_tile(t + 1)) dma_tile(kv0 + KVB, lds + (1 - BUF) * TILEB, lds + (1 - BUF) * TILEB + KVB * KROW);
     AP_ST(t, 1);
+    // causal: a tile whose first key lies past this wave's LAST query row contributes nothing to the wave (the block walks the
+    // tiles its last wave needs); the wave only keeps the block's barrier / DMA cadence and leaves the SIMD to its partner
+    if (CAUSAL && kv0 > q0 + 31 + off) return;
     // ---- S^T = K . Q^T : two 32-row kv blocks ----
     f32x16 s[2];
 #pragma unroll
     for (int tb = 0; tb < 2; ++tb) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[tb][r] = 0.f;
-      const int row = tb * 32 + ql;
-      const int sw = (HD == 128) ? (row & 15) : ((row >> 1) & 7);
-      const char* kp = Ks + row * KROW;
+      const char* kp = Ks + tb * 32 * KROW;
 #pragma unroll
       for (int ks = 0; ks < HD / 16; ++ks) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kp + (((2 * ks + hh) ^ sw) << 4));
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kp + (kfb ^ (ks << 5)));
 #ifdef AP_NO_QK
         if (ks == 0)
 #endif
@@ -321,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_bf16_kernel(AttnArgs p) {
           const int c16 = 4 * tb + 2 * c;      // 16-B chunk of kv columns {0..7}; lane half hh takes its 8-B half (k = 4hh..4hh+3)
           bf16x8 vf;
           if constexpr (PSWAP) {               // lane half hh takes the WHOLE chunk c16 + hh (8 consecutive keys)
-            vf = *reinterpret_cast<const bf16x8*>(Vs + drow * 128 + (((c16 + hh) ^ g) << 4));
+            vf = *reinterpret_cast<const bf16x8*>(Vs + d * 32 * 128 + (vfb ^ (c16 << 4)));
           } else {
             const u32x2 a0 = *reinterpret_cast<const u32x2*>(vp + ((c16 ^ g) << 4));
             const u32x2 a1 = *reinterpret_cast<const u32x2*>(vp + (((c16 + 1) ^ g) << 4));
@@ -335,6 +345,14 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_bf16_kernel(AttnArgs p) {
         }
     }
     AP_ST(t, 4);
+  };
+  {
+    int t = 0;
+    for (; t + 1 < n_tiles; t += 2) {
+      body(t, std::integral_constant<int, 0>{});
+      body(t + 1, std::integral_constant<int, 1>{});
+    }
+    if (t < n_tiles) body(t, std::integral_constant<int, 0>{});
   }
 
 #ifdef AP_STAMP

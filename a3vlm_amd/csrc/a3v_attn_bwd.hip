@@ -262,6 +262,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs p) {
       stage_rows_dma<HD>(V, p.v_ss, kv0 + 64, p.S, nx + TILE, voff, wave);
     }
     AB_ST(0, t, 3);
+    if (p.causal && kv0 > qt * 128 + wave * 32 + 31) return;     // every key of the tile is past this wave's last query row: nothing to add
     // one 32-key block at a time: S^T and dP^T accumulators (32 VGPRs) are dead before the next block starts, which keeps
     // the kernel under 256 VGPRs = two waves per SIMD
     bf16x8 dsf[2][2];
@@ -428,6 +429,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs p) {
       AB_ST(1 + WHICH, it, 2);
       if (it + 1 < total) issue(it + 1);
       AB_ST(1 + WHICH, it, 3);
+      if (p.causal && q0 + 63 < kt_ * 128 + wave * 32) return;            // every query row of the tile is before this wave's first key
       bf16x8 bf[2][2];                       // P (dV) or dS (dK) as the B operand of the accumulation products
       const int kv_hi = kt_ * 128 + wave * 32 + 31;                        // last key of this wave (wave-uniform)
       const bool interior = (q0 + 64 <= p.S) && (kv_hi < p.S) && (!p.causal || q0 >= kv_hi);
