@@ -501,7 +501,10 @@ __device__ __forceinline__ bool gemm_epilogue_fast(f32x4 (&acc)[TM][TN], const G
               const bf16x8 v = *reinterpret_cast<const bf16x8*>(stage + d * 64 + ((c ^ ((d >> 2) & 3)) << 4));
               LDS_ORDER();
               bf16_t* const dst = vb + (int64_t)d * k.Smax;               // 2-byte-aligned 16-byte store: the compiler would split it
-              asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(v) : "memory");
+              // (s_nop 1 inside the statement: hipcc pads no hazards of an asm store, and a 16-byte store reads its data registers a
+              //  couple of states after issue -- without it the next instruction the compiler places here may overwrite them first;
+              //  seen as zeros / stale values in a few V^T rows per launch once a re-schedule put a register write right behind)
+              asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
             }
           } else {
             // the chunk's 32 tokens straddle two batch elements: element-wise, as the general form does
@@ -1167,7 +1170,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_pp_kernel(GemmArgs p) {
 // EARLY: the barrier that ends an MFMA interval is executed EARLY tile-rows before the interval's last MFMA.  Nothing after it
 // needs the barrier (the tail MFMAs read registers only), and the partner wave on the SIMD -- released by the same barrier --
 // starts its own MFMA stream while this wave is still feeding the pipe: no matrix-pipe bubble at the hand-over.
-template <int DBG, bool M32, int EARLY, bool STAGED = true, int SET = EPI_SET_COMMON, bool LW = false, bool LATEW = true>   // LATEW (product; r03 A/B +1 % on every shape, bit-equal): group 0 waits for its W pieces of tile t+1 at the TOP of L(t+1) instead of between its last MFMA of M(t) and the barrier that hands the matrix pipe over; SET: which fast epilogue forms (gemm_epilogue_fast); M32: v_mfma_f32_32x32x16_bf16 (4x2 tiles per wave) instead of 16x16x32 (8x4)
+template <int DBG, bool M32, int EARLY, bool STAGED = true, int SET = EPI_SET_COMMON, bool LW = false, bool LATEW = true, bool CONT = true>   // CONT (product; r03): the DMA stream runs on ACROSS the block's tiles -- the last two LOAD intervals of a tile fetch K-tiles 0 / 1 of the block's next tile into the ring slots they would have used anyway, so there is no prologue burst, no pipeline drain / refill and no block-wide barrier between tiles (see the boundary notes in the body); LATEW (product; r03 A/B +1 % on every shape, bit-equal): group 0 waits for its W pieces of tile t+1 at the TOP of L(t+1) instead of between its last MFMA of M(t) and the barrier that hands the matrix pipe over; SET: which fast epilogue forms (gemm_epilogue_fast); M32: v_mfma_f32_32x32x16_bf16 (4x2 tiles per wave) instead of 16x16x32 (8x4)
 __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
   constexpr int TBM = 256, TBN = 256, WTM = 128, WTN = 64, TM = M32 ? 4 : 8, TN = M32 ? 2 : 4;
   constexpr int AH = 128 * BK * 2;                      // 16 KiB: one group's half of an A K-tile
@@ -1241,12 +1244,13 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
     voW[par] = (unsigned)((lr * p.ldw + sl * 8) * 2);
   }
   // one 1-KiB piece = 8 rows x 128 B; `row` = first row inside the A (W) tile, `par` = its chunk index & 1 (swizzle key)
-  auto piece_a = [&](int row, int t, int par, char* dst) {
-    const unsigned so = (unsigned)(((int64_t)(sm0 + row) * p.lda + (DBG == 7 ? (t & 3) : t) * BK) * 2);   // DBG 7 (timing experiment): the same four K-tiles over and over = cache-resident operands
+  // (`tm0` / `tn0`: first row of the tile the K-tile belongs to -- the tile being computed, or with CONT the block's next one)
+  auto piece_a = [&](int tm0, int row, int t, int par, char* dst) {
+    const unsigned so = (unsigned)(((int64_t)(tm0 + row) * p.lda + (DBG == 7 ? (t & 3) : t) * BK) * 2);   // DBG 7 (timing experiment): the same four K-tiles over and over = cache-resident operands
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)dst, 16, voA[par] + so, 0, 0, 0);
   };
-  auto piece_w = [&](int row, int t, int par, char* dst) {
-    const unsigned so = (unsigned)(((int64_t)(sn0 + row) * p.ldw + (DBG == 7 ? (t & 3) : t) * BK) * 2);
+  auto piece_w = [&](int tn0, int row, int t, int par, char* dst) {
+    const unsigned so = (unsigned)(((int64_t)(tn0 + row) * p.ldw + (DBG == 7 ? (t & 3) : t) * BK) * 2);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)dst, 16, voW[par] + so, 0, 0, 0);
   };
   // tile prologue (all 8 waves, 14 pieces each): K-tile 0 whole, A_top and W of K-tile 1
@@ -1254,15 +1258,15 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int ch = wave * 4 + c;                      // 32 chunks of A(0): waves 0-3 -> A_top, waves 4-7 -> A_bot
-      piece_a(ch * 8, 0, c & 1, lds + (wr ? ABOT : ATOP) + (ch & 15) * 1024);
+      piece_a(sm0, ch * 8, 0, c & 1, lds + (wr ? ABOT : ATOP) + (ch & 15) * 1024);
     }
 #pragma unroll
-    for (int c = 0; c < 4; ++c) piece_w((wave * 4 + c) * 8, 0, c & 1, lds + WB + (wave * 4 + c) * 1024);
+    for (int c = 0; c < 4; ++c) piece_w(sn0, (wave * 4 + c) * 8, 0, c & 1, lds + WB + (wave * 4 + c) * 1024);
     if (nk > 1) {
 #pragma unroll
-      for (int c = 0; c < 2; ++c) piece_a((wave * 2 + c) * 8, 1, c & 1, lds + ATOP + AH + (wave * 2 + c) * 1024);
+      for (int c = 0; c < 2; ++c) piece_a(sm0, (wave * 2 + c) * 8, 1, c & 1, lds + ATOP + AH + (wave * 2 + c) * 1024);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) piece_w((wave * 4 + c) * 8, 1, c & 1, lds + WB + WT + (wave * 4 + c) * 1024);
+      for (int c = 0; c < 4; ++c) piece_w(sn0, (wave * 4 + c) * 8, 1, c & 1, lds + WB + WT + (wave * 4 + c) * 1024);
     }
   };
   prologue();
@@ -1319,6 +1323,21 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
   // tile-level stamps (DBG == 4), column 7 of rows 5 n .. 5 n + 4 for the block's n-th tile: k-loop entry, k-loop exit,
   // next tile's prologue issued, epilogue issued, (next row group) next k-loop entry
 #define RG_TSTAMP(k) do { if (DBG == 4 && stamps && tile_no < 12) stamps[(tile_no * 5 + (k)) * 8 + 7] = __builtin_amdgcn_s_memtime(); } while (0)
+  // Tile boundaries with CONT (cont: the block has a next tile and nk >= 2).  The ping-pong keeps its two barriers per K-tile,
+  //   X(t) = [group 0: end of L(t) | group 1: end of M(t-1)]      Y(t) = [group 0: end of M(t) | group 1: end of L(t)]
+  // and the boundary only stretches the interval between Y(nk-1) and X(0') of the next tile:
+  //   group 0:  ... M(nk-1) Y(nk-1) [store tile]          L(0') X(0') M(0') ...
+  //   group 1:  ... L(nk-1) Y(nk-1) M(nk-1) [store tile]        X(0') L(0') ...
+  // * the pieces of K-tiles 0' / 1' are issued by the LOAD intervals nk-2 / nk-1 exactly as those of t+1 / t+2 inside a tile (same
+  //   slots, same counts: the A parity `pa` of K-tile 0 and the W slot `wcur` simply run on), so the counted waits stay the steady ones;
+  // * the epilogue's staging patches live in the W slot of K-tile nk-1: every read of it is behind Y(nk-1), and it is the slot W(2')
+  //   goes to -- each wave's pieces of W(2') land in that wave's OWN 4-KiB patch (rows 8 (4 g4 + c) .. of its group's half), issued
+  //   after the wave's own epilogue, so no block-wide barrier is needed before the slot is reused;
+  // * the stores of the epilogue count in vmcnt like the DMA pieces: one vmcnt(0) behind them (they were issued thousands of cycles
+  //   after the last pieces) and the next k-loop's counted waits see DMA pieces only.
+  // Without CONT (and for nk == 1): prologue burst for the next tile before the epilogue, vmcnt(0) + block barrier at the k-loop entry.
+  int wcur = 0, pa = 0;                                  // W ring slot / A parity of K-tile 0 of the current tile
+  bool fresh = true;                                     // the tile's K-tiles 0 / 1 come from a prologue burst (first tile, or no CONT)
   for (int vb = blockIdx.x;;) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -1337,38 +1356,52 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
       for (int it = 0; it < 400 && __hip_atomic_load(p.xsync + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; ++it)
         __builtin_amdgcn_s_sleep(4);
     }
-    A3V_WAIT_VM0();
-    A3V_BARRIER();
-    int wcur = 0;                                        // W ring slot of K-tile t
+    const int nb = vb + (int)gridDim.x;
+    const bool more = nb < ntiles;
+    const bool cont = CONT && more && nk >= 2;           // K-tiles nk, nk+1 of this k-loop are K-tiles 0, 1 of the block's next tile
+    if (cont) tile_of(nb, sm0, sn0);                     // (sm0, sn0): the tile being staged = the next one from here on
+    if (fresh) {
+      A3V_WAIT_VM0();
+      A3V_BARRIER();
+      wcur = 0; pa = 0;
+    }
     RG_TSTAMP(0);
+    // The k-loop is split into its steady part (t + 2 < nk: every piece belongs to this tile, no condition, addresses advance by a
+    // constant) and the last two iterations, which may stage the next tile (TAIL): with the selects in every iteration the LOAD
+    // interval grew from ~900 to ~1140 cycles and the whole K-tile period with it (the two intervals are co-critical).
     if (wr == 0) {
-      for (int t = 0; t < nk; ++t) {
+      auto iter = [&](int t, auto tailc) {
+        constexpr bool TAIL = decltype(tailc)::value;
         RG_STAMP(t, 0);
         const int wn2 = wcur == 0 ? 2 : wcur - 1;        // slot of K-tile t + 2
-        if (t + 1 < nk) {
+        if (!TAIL || t + 1 < nk || cont) {
+          const bool nx = TAIL && t + 1 >= nk;
+          const int tm = nx ? sm0 : m0, tk = nx ? t + 1 - nk : t + 1;
 #pragma unroll
-          for (int c = 0; c < 4; ++c) piece_a(128 + (g4 * 4 + c) * 8, t + 1, c & 1, lds + ABOT + ((t + 1) & 1) * AH + (g4 * 4 + c) * 1024);
+          for (int c = 0; c < 4; ++c) piece_a(tm, 128 + (g4 * 4 + c) * 8, tk, c & 1, lds + ABOT + ((pa ^ (t + 1)) & 1) * AH + (g4 * 4 + c) * 1024);
         }
-        if (t + 2 < nk) {
+        if (!TAIL || t + 2 < nk || cont) {
+          const bool nx = TAIL && t + 2 >= nk;
+          const int tn = nx ? sn0 : n0, tk = nx ? t + 2 - nk : t + 2;
 #pragma unroll
-          for (int c = 0; c < 4; ++c) piece_w((g4 * 4 + c) * 8, t + 2, c & 1, lds + WB + wn2 * WT + (g4 * 4 + c) * 1024);
+          for (int c = 0; c < 4; ++c) piece_w(tn, (g4 * 4 + c) * 8, tk, c & 1, lds + WB + wn2 * WT + (g4 * 4 + c) * 1024);
         }
         if constexpr (LATEW) {
           // everything older than the bursts of L(t-1) and L(t) has landed: in particular this group's W half of tile t (the reads
-          // below); in steady state 8 + 8 pieces may stay in flight, the last two tiles issue shorter bursts
-          if (t + 2 < nk) RG_VMCNT(16);
+          // below); in steady state 8 + 8 pieces may stay in flight, the last two tiles of the block's last k-loop issue shorter bursts
+          if (!TAIL || t + 2 < nk || cont) RG_VMCNT(16);
           else if (t + 2 == nk) RG_VMCNT(12);
           else RG_VMCNT(4);
         }
-        RG_READ_FRAGS(lds + ATOP + (t & 1) * AH, lds + WB + wcur * WT);
+        RG_READ_FRAGS(lds + ATOP + ((pa ^ t) & 1) * AH, lds + WB + wcur * WT);
         A3V_WAIT_LGKM0();
         RG_STAMP(t, 1);
         if constexpr (LW) {                              // variant: W(t+1) is waited for HERE (one interval earlier), so nothing stands
-          if (t + 2 < nk) RG_VMCNT(8);                   // between this group's last MFMA and the barrier that releases the other group
+          if (!TAIL || t + 2 < nk || cont) RG_VMCNT(8);  // between this group's last MFMA and the barrier that releases the other group
           else if (t + 2 == nk) RG_VMCNT(4);
           else RG_VMCNT(0);
         } else {
-          if (t + 2 < nk) RG_VMCNT(12);
+          if (!TAIL || t + 2 < nk || cont) RG_VMCNT(12);
           else if (t + 2 == nk) RG_VMCNT(8);
           else RG_VMCNT(0);
         }
@@ -1380,7 +1413,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
         __builtin_amdgcn_s_setprio(0);                 // never wait (vmcnt / barrier) at raised priority: measured -20 %
         RG_STAMP(t, 4);
         if constexpr (!LW && !LATEW) {
-          if (t + 2 < nk) RG_VMCNT(8);
+          if (!TAIL || t + 2 < nk || cont) RG_VMCNT(8);
           else if (t + 2 == nk) RG_VMCNT(4);
           else RG_VMCNT(0);
         }
@@ -1395,23 +1428,29 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
           __builtin_amdgcn_s_setprio(0);
         }
         wcur = wcur == 2 ? 0 : wcur + 1;
-      }
-      A3V_BARRIER();
+      };
+      int t = 0;
+      for (; t + 2 < nk; ++t) iter(t, std::false_type{});
+      for (; t < nk; ++t) iter(t, std::true_type{});
+      if (!cont) A3V_BARRIER();                          // (with cont the other group's matching barrier is X(0') of the next tile)
     } else {
-      A3V_BARRIER();
-      for (int t = 0; t < nk; ++t) {
+      if (fresh) A3V_BARRIER();
+      auto iter = [&](int t, auto tailc) {
+        constexpr bool TAIL = decltype(tailc)::value;
         RG_STAMP(t, 0);
         const int wn2 = wcur == 0 ? 2 : wcur - 1;
-        if (t + 2 < nk) {
+        if (!TAIL || t + 2 < nk || cont) {
+          const bool nx = TAIL && t + 2 >= nk;
+          const int tn = nx ? sn0 : n0, tm = nx ? sm0 : m0, tk = nx ? t + 2 - nk : t + 2;
 #pragma unroll
-          for (int c = 0; c < 4; ++c) piece_w(128 + (g4 * 4 + c) * 8, t + 2, c & 1, lds + WB + wn2 * WT + AH + (g4 * 4 + c) * 1024);
+          for (int c = 0; c < 4; ++c) piece_w(tn, 128 + (g4 * 4 + c) * 8, tk, c & 1, lds + WB + wn2 * WT + AH + (g4 * 4 + c) * 1024);
 #pragma unroll
-          for (int c = 0; c < 4; ++c) piece_a((g4 * 4 + c) * 8, t + 2, c & 1, lds + ATOP + (t & 1) * AH + (g4 * 4 + c) * 1024);
+          for (int c = 0; c < 4; ++c) piece_a(tm, (g4 * 4 + c) * 8, tk, c & 1, lds + ATOP + ((pa ^ t) & 1) * AH + (g4 * 4 + c) * 1024);
         }
-        RG_READ_FRAGS(lds + ABOT + (t & 1) * AH, lds + WB + wcur * WT);
+        RG_READ_FRAGS(lds + ABOT + ((pa ^ t) & 1) * AH, lds + WB + wcur * WT);
         A3V_WAIT_LGKM0();
         RG_STAMP(t, 1);
-        if (t + 2 < nk) RG_VMCNT(8);
+        if (!TAIL || t + 2 < nk || cont) RG_VMCNT(8);
         else RG_VMCNT(0);
         RG_STAMP(t, 2);
         A3V_BARRIER();
@@ -1421,9 +1460,11 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
         __builtin_amdgcn_s_setprio(0);                 // never wait (vmcnt / barrier) at raised priority: measured -20 %
         RG_STAMP(t, 4);
         RG_STAMP(t, 5);
-        if constexpr (EARLY > 0) __builtin_amdgcn_sched_barrier(0);   // keep the tail MFMAs behind the barrier, the others before it
-        A3V_BARRIER();
-        if constexpr (EARLY > 0) __builtin_amdgcn_sched_barrier(0);
+        if (!TAIL || t + 1 < nk || !cont) {                       // X(t+1) (or the block barrier that ends a k-loop without cont); with cont X(0') follows the epilogue
+          if constexpr (EARLY > 0) __builtin_amdgcn_sched_barrier(0);   // keep the tail MFMAs behind the barrier, the others before it
+          A3V_BARRIER();
+          if constexpr (EARLY > 0) __builtin_amdgcn_sched_barrier(0);
+        }
         RG_STAMP(t, 6);
         if constexpr (EARLY > 0) {
           __builtin_amdgcn_s_setprio(1);
@@ -1431,12 +1472,14 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
           __builtin_amdgcn_s_setprio(0);
         }
         wcur = wcur == 2 ? 0 : wcur + 1;
-      }
+      };
+      int t = 0;
+      for (; t + 2 < nk; ++t) iter(t, std::false_type{});
+      for (; t < nk; ++t) iter(t, std::true_type{});
     }
-    // every read of the rings is behind the last barrier: stage the next tile now, store this one after
-    const int nb = vb + (int)gridDim.x;
     RG_TSTAMP(1);
-    if (nb < ntiles) {
+    // every read of the rings is behind the last barrier.  No cont: stage the next tile now (prologue burst), store this one after.
+    if (more && !cont) {
       tile_of(nb, sm0, sn0);
       prologue();
     }
@@ -1444,12 +1487,24 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
     {
       int lane_e = lane;
       asm volatile("" : "+v"(lane_e));
+      // staging patches: the W slot of K-tile nk - 1 (cont: the one slot no piece of the next tile is in flight to); the slot behind the
+      // prologue's two otherwise
+      const int wst = cont ? (wcur == 0 ? 2 : wcur - 1) : 2;
       if constexpr (M32) gemm_epilogue32<TM, TN>(acc, p, m0 + wr * WTM, n0 + wc * WTN, lane_e);
-      else gemm_epilogue<TM, TN, false, SET>(acc, p, m0 + wr * WTM, n0 + wc * WTN, lane_e, STAGED ? lds + WB + 2 * WT + wave * 4096 : nullptr);
+      else gemm_epilogue<TM, TN, false, SET>(acc, p, m0 + wr * WTM, n0 + wc * WTN, lane_e, STAGED ? lds + WB + wst * WT + wave * 4096 : nullptr);
     }
     RG_TSTAMP(3);
     ++tile_no;
-    if (nb >= ntiles) break;
+    if (!more) break;
+    if (cont) {
+      A3V_WAIT_LGKM0();                                  // the wave's own patch reads are done: its next pieces may land in the patch
+      A3V_WAIT_VM0();                                    // stores (and every older piece) retired: the counted waits count pieces again
+      if (wr == 1) A3V_BARRIER();                        // X(0')
+      pa ^= nk & 1;
+      fresh = false;
+    } else {
+      fresh = true;
+    }
     vb = nb; m0 = sm0; n0 = sn0;
   }
 #undef RG_TSTAMP
@@ -2603,7 +2658,7 @@ __global__ __launch_bounds__(256) void gemv_dma_bf16_kernel(GemvArgs p) {
     // tile (of its gate/up tile PAIR with SwiGLU).  The wave that arrives last reloads all partials in one round trip,
     // sums them in slice order (bit-identical whichever wave is last), resets the counter and runs the epilogue.
     float* mine = p.part + (((int64_t)(tg * p.S + sl) * 4 + wave) * 64 + lane) * 4;
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(mine), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(mine), "v"(v) : "memory");   // (s_nop: the store's data registers, see the V^T store of the fused-qkv epilogue)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int* ctr = p.counters + (swiglu ? tg * 2 + (wave >> 1) : tg * 4 + wave);
     const int expect = swiglu ? 2 * p.S : p.S;
@@ -3016,6 +3071,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
           case 6: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<4, false, 0>), g, b, 0, st, q); break;   // cycle stamps (tools/ring_stamps.py)
           case 1: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0, true, EPI_SET_COMMON, false, false>), g, b, 0, st, q); break;   // ablation: the wait after the MFMAs (round-2 form)
           case 2: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<4, false, 0, true, EPI_SET_COMMON, false, false>), g, b, 0, st, q); break;   // same, stamps
+          case 3: hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0, true, EPI_SET_COMMON, false, true, false>), g, b, 0, st, q); break;   // ablation: prologue burst + block barrier per tile (no cross-tile DMA stream)
           default: break;
         }
         return;

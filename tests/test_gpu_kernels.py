@@ -772,6 +772,37 @@ def test_gemm_ring_ragged_rows_over_several_tiles_per_block():
         assert_close(o, r.cpu() + rt(want.cpu()), rtol=2 ** -7, atol=0.04, what="ring ragged res_f32")   # 1 bf16 ulp of the product at |y| < 8
 
 
+@pytest.mark.parametrize("M,N,K", [(4608, 4096, 128), (4608, 4096, 192), (8728, 4096, 320), (2048, 12288, 256), (6000, 5120 + 256, 704)])
+def test_gemm_ring_stream_runs_on_across_the_tiles_of_a_block(M, N, K):
+    """The persistent ring kernel keeps its DMA stream going ACROSS a block's tiles: the last two K-tile iterations of a tile fetch
+    K-tiles 0 / 1 of the block's next tile (no prologue burst, no block barrier between tiles), the A parity and the W slot run on,
+    and the epilogue stages through the one W slot no piece is in flight to.  Shapes with several tiles per block and short K loops
+    (nk = 2, 3, 5, 4, 11: many boundaries per launch, odd and even nk, a ragged last tile row / column) must equal the 128 x 128
+    kernel bit for bit (same MFMA, same K order) for every output kind of the fast epilogue, twice in a row (races show as flakes)."""
+    from a3vlm_amd import lib
+    a, w = gen(M, K, seed=90).to(BF).to(DEV), gen(N, K, seed=91, scale=0.05).to(BF).to(DEV)
+    res_b, res_f = gen(M, N, seed=92).to(BF).to(DEV), gen(M, N, seed=93).to(DEV)
+
+    def run(tile, kind):
+        if kind == "plain":
+            o = torch.full((M, N), 3.0, dtype=BF, device=DEV)
+            return ops.gemm_nt(a, w, o, epilogue=tile)
+        if kind == "residual":
+            o = torch.empty(M, N, dtype=BF, device=DEV)
+            return ops.gemm_nt(a, w, o, residual=res_b, epilogue=tile | ops.EPI_RESIDUAL)
+        if kind == "res_f32":
+            o = res_f.clone()
+            return ops.gemm_nt(a, w, o, residual=o, epilogue=tile | ops.EPI_RES_F32)
+        o = torch.empty(M, N, dtype=torch.float32, device=DEV)
+        return ops.gemm_nt(a, w, o, epilogue=tile | ops.EPI_OUT_F32)
+
+    for kind in ("plain", "residual", "res_f32", "out_f32"):
+        want = run(lib.EPI_TILE_128, kind)
+        for rep in range(2):
+            got = run(lib.EPI_TILE_256PP, kind)
+            assert torch.equal(got, want), (kind, rep, int((got != want).sum()))
+
+
 def test_gemm_one_wave_per_simd_kernel_equals_ring_kernel():
     """(Also the overlapped 8-wave form, A3V_GEMM_W4=20.)  The opt-in 4-wave (one wave per SIMD, 128 x 128 per wave, 5 x 32-KiB sub-stage ring) form of the NT kernel
     (A3V_GEMM_W4=1; DESIGN.md section 4: measured, slower than the ring kernel, kept for the record) accumulates in the same
