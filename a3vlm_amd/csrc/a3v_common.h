@@ -31,6 +31,13 @@ int a3v_env_generation();
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }
 __device__ __forceinline__ bf16_t f2bf(float v) { return (bf16_t)v; }  // RNE (v_cvt_pk_bf16_f32)
+// d(gate), d(up) of act = silu(gate) * up for one element (a3v_swiglu_bwd and the A3V_EPI_SWIGLU_BWD GEMM epilogue share this
+// expression so that the fused and the un-fused path round identically)
+__device__ __forceinline__ void swiglu_bwd_pair(float g, float u, float da, float& dg, float& du) {
+  const float sig = 1.f / (1.f + __expf(-g));
+  dg = da * u * (sig * (1.f + g * (1.f - sig)));
+  du = da * (g * sig);
+}
 // round-trip: the value a bf16 store of v would hold
 __device__ __forceinline__ float rbf(float v) { return (float)((bf16_t)v); }
 

@@ -143,12 +143,13 @@ __device__ __forceinline__ bool gemm_epilogue_fast(f32x4 (&acc)[TM][TN], const G
     const int pre = (SET & EPI_SET_PRE) ? kind & (A3V_EPI_BIAS | A3V_EPI_GELU | A3V_EPI_QUICKGELU) : 0;   // applied in the accumulator layout
     if (pre) kind &= ~pre;
     if constexpr ((SET & EPI_SET_COMMON) != 0) {
-    if (kind == 0 || kind == A3V_EPI_RESIDUAL || kind == A3V_EPI_RES_F32) {
+    if (kind == 0 || kind == A3V_EPI_RESIDUAL || kind == A3V_EPI_RES_F32 || kind == A3V_EPI_SWIGLU_BWD) {
       // bf16 staging: chunk = two 16-row tiles x 64 columns = 32 rows x 128 B; 8-byte slot s of row r at slot s ^ (r & 14),
       // read back as 16-byte pairs: pair q of row r from physical pair q ^ ((r >> 1) & 7) (see the general form)
       const bool f32 = kind == A3V_EPI_RES_F32;
       if (f32 ? ((ldc_ & 3) || (ldr_ & 3) || (r_ & 15)) : (ldc_ & 7)) return false;       // (before anything touches the accumulators)
-      if (kind == A3V_EPI_RESIDUAL && ((ldr_ & 7) || (r_ & 15))) return false;
+      if ((kind == A3V_EPI_RESIDUAL || kind == A3V_EPI_SWIGLU_BWD) && ((ldr_ & 7) || (r_ & 15))) return false;
+      if (kind == A3V_EPI_SWIGLU_BWD && (p.N & 7)) return false;
       uintptr_t b_ = reinterpret_cast<uintptr_t>(p.bias);
       asm volatile("" : "+s"(b_));
       if ((pre & A3V_EPI_BIAS) && (b_ & 7)) return false;
@@ -208,6 +209,38 @@ __device__ __forceinline__ bool gemm_epilogue_fast(f32x4 (&acc)[TM][TN], const G
             put(ic);
 #pragma unroll
             for (int it = 0; it < 4; ++it) { st_c(reinterpret_cast<bf16x8*>(cp), get(it)); cp += cstep; }
+          }
+        } else if (kind == A3V_EPI_SWIGLU_BWD) {
+          // the tile is d(act): gate / up read from `res` (gu [M, 2 N]) as whole 16-byte row segments, d(gate) -> C[., n], d(up) -> C[., N + n]
+          const bf16_t* gp = reinterpret_cast<const bf16_t*>(r_) + (int64_t)(mbase + l3) * ldr_ + nbase + q * 8;
+          const int64_t rstep = 8 * ldr_;
+          int un = p.N;                                     // columns between the gate and the up half (gu and C alike)
+          asm volatile("" : "+s"(un));
+#pragma unroll
+          for (int ic = 0; ic < TM / 2; ++ic) {             // one 32-row chunk's gate + up in flight at a time (32 VGPRs)
+            bf16x8 gg[4], uu[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+              gg[it] = *reinterpret_cast<const bf16x8*>(gp);
+              uu[it] = *reinterpret_cast<const bf16x8*>(gp + un);
+              gp += rstep;
+            }
+            put(ic);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+              const bf16x8 v = get(it);
+              bf16x8 og, ou;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                float dg, du;
+                swiglu_bwd_pair(bf2f(gg[it][e]), bf2f(uu[it][e]), bf2f(v[e]), dg, du);
+                og[e] = f2bf(dg);
+                ou[e] = f2bf(du);
+              }
+              st_c(reinterpret_cast<bf16x8*>(cp), og);
+              st_c(reinterpret_cast<bf16x8*>(cp + un), ou);
+              cp += cstep;
+            }
           }
         } else {
           const bf16_t* rp = reinterpret_cast<const bf16_t*>(r_) + (int64_t)(mbase + l3) * ldr_ + nbase + q * 8;
@@ -591,6 +624,51 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GemmAr
           o[r] = f2bf(rbf(silu(g)) * u);
         }
         *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + oc) = o;
+      }
+    }
+    return;
+  }
+  if (epi & A3V_EPI_SWIGLU_BWD) {
+    // the product is d(act): d(gate) / d(up) from the forward's gate / up (res = gu [M, 2 N]); loads of half the tile before its stores
+    constexpr int HM = TM >= 2 ? TM / 2 : 1, NH = TM / HM;
+#pragma unroll
+    for (int half = 0; half < NH; ++half) {
+      bf16x4 gg[HM][TN], uu[HM][TN];
+#pragma unroll
+      for (int ih = 0; ih < HM; ++ih) {
+        const int m = mbase + (half * HM + ih) * 16 + mrow;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = nbase + j * 16 + ncol;
+          gg[ih][j] = bf16x4{};
+          uu[ih][j] = bf16x4{};
+          if (m < p.M && n < p.N) {
+            const bf16_t* gr = reinterpret_cast<const bf16_t*>(p.res) + (int64_t)m * p.ldr + n;
+            gg[ih][j] = *reinterpret_cast<const bf16x4*>(gr);
+            uu[ih][j] = *reinterpret_cast<const bf16x4*>(gr + p.N);
+          }
+        }
+      }
+#pragma unroll
+      for (int ih = 0; ih < HM; ++ih) {
+        const int i = half * HM + ih, m = mbase + i * 16 + mrow;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = nbase + j * 16 + ncol;
+          if (n >= p.N) continue;
+          bf16x4 og, ou;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float dg, du;
+            swiglu_bwd_pair(bf2f(gg[ih][j][r]), bf2f(uu[ih][j][r]), rbf(acc[i][j][r]), dg, du);
+            og[r] = f2bf(dg);
+            ou[r] = f2bf(du);
+          }
+          bf16_t* cr = reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + n;
+          *reinterpret_cast<bf16x4*>(cr) = og;
+          *reinterpret_cast<bf16x4*>(cr + p.N) = ou;
+        }
       }
     }
     return;
@@ -2986,6 +3064,10 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
   if (M <= 0 || N <= 0 || K <= 0 || !A || !W || !C) return A3V_ERR_ARG;
   if ((epilogue & A3V_EPI_BIAS) && !bias) return A3V_ERR_ARG;
   if ((epilogue & (A3V_EPI_RESIDUAL | A3V_EPI_RES_F32)) && !residual) return A3V_ERR_ARG;
+  if (epilogue & A3V_EPI_SWIGLU_BWD) {     // alone (no bias / activation / residual kinds), bf16, gate / up rows in `residual`
+    if (!residual || dtype != A3V_BF16 || (epilogue & 0xffff & ~A3V_EPI_SWIGLU_BWD)) return A3V_ERR_ARG;
+    if ((N % 8) || (ldr % 4) || ldr < 2 * (int64_t)N || ldc < 2 * (int64_t)N) return A3V_ERR_SHAPE;
+  }
   hipStream_t st = (hipStream_t)stream;
   if (dtype == A3V_F32) {
     if (K % 16 || lda % 4 || ldw % 4) return A3V_ERR_SHAPE;

@@ -357,9 +357,7 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const TA* __restrict__ 
     load8_s<(NT & 1) != 0>(dact + (int64_t)r * lda + c, da);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float sig = 1.f / (1.f + __expf(-g[e]));
-      dg[e] = da[e] * u[e] * (sig * (1.f + g[e] * (1.f - sig)));
-      du[e] = da[e] * (g[e] * sig);
+      swiglu_bwd_pair(g[e], u[e], da[e], dg[e], du[e]);
     }
     store8_s<(NT & 2) != 0>(dgu + (int64_t)r * lddg + o, dg);
     store8_s<(NT & 2) != 0>(dgu + (int64_t)r * lddg + o + ustep, du);

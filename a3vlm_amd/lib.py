@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "liba3vlm_hip.so")
 
 BF16, F32 = 0, 1
 EPI_NONE, EPI_BIAS, EPI_GELU, EPI_QUICKGELU, EPI_RESIDUAL, EPI_SWIGLU, EPI_OUT_F32, EPI_RES_F32 = 0, 1, 2, 4, 8, 16, 32, 64
+EPI_SWIGLU_BWD = 128
 
 EPI_TILE_128, EPI_TILE_256, EPI_TILE_256PP, EPI_TILE_256PP32 = 1 << 16, 1 << 17, 1 << 18, 1 << 19
 

@@ -11,7 +11,7 @@ from typing import Optional
 import torch
 
 from . import lib as _l
-from .lib import BF16, F32, EPI_BIAS, EPI_GELU, EPI_QUICKGELU, EPI_RESIDUAL, EPI_SWIGLU, EPI_OUT_F32, EPI_RES_F32  # noqa: F401
+from .lib import BF16, F32, EPI_BIAS, EPI_GELU, EPI_QUICKGELU, EPI_RESIDUAL, EPI_SWIGLU, EPI_OUT_F32, EPI_RES_F32, EPI_SWIGLU_BWD  # noqa: F401
 
 _DT = {torch.bfloat16: BF16, torch.float32: F32}
 
@@ -60,7 +60,7 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, r
     ep = epilogue
     if bias is not None:
         ep |= EPI_BIAS
-    if residual is not None and not (ep & EPI_RES_F32):
+    if residual is not None and not (ep & (EPI_RES_F32 | EPI_SWIGLU_BWD)):      # (EPI_SWIGLU_BWD: `residual` carries the forward's gate | up rows)
         ep |= EPI_RESIDUAL
     rc = _l.load().a3v_gemm_nt(_p(a), a.stride(0), _p(w), w.stride(0), _p(out), out.stride(0), M, N, K,
                                _p(bias), _p(residual), residual.stride(0) if residual is not None else 0,

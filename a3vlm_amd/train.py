@@ -38,6 +38,7 @@ class TrainEngine:
     # ("0": none, "all", or a comma list of qkv / wo / w13 / w2).  Same-box LoRA step: 253.0 ms without, 248.9 with wo,w13,w2, 247.9 all
     lora_nt_dgrad = os.environ.get("A3V_LORA_NT_DGRAD", "all")
     strip_wgrad = os.environ.get("A3V_STRIP_WGRAD", "1") != "0"        # adapter weight gradients by a3v_gemm_tn_strip (0: the 256 x 256 TN split-K kernel)
+    fuse_swiglu_bwd = os.environ.get("A3V_FUSE_SWIGLU_BWD", "1") != "0"   # LoRA: SwiGLU backward in the epilogue of w2's input-gradient GEMM (0: separate pass, A/B)
 
     def __init__(self, model, compute_dtype: torch.dtype = torch.bfloat16, recompute: Optional[bool] = None,
                  stream_dtype: Optional[torch.dtype] = None):
@@ -472,14 +473,18 @@ class TrainEngine:
         ops.gemm_nt(t, Bm, y, residual=y, epilogue=ops.EPI_RES_F32 if f32 else 0)
         return t
 
-    def _kx_group_bwd(self, i: int, key: str, dy_full: torch.Tensor, N: int, x: torch.Tensor, t: torch.Tensor, dx: torch.Tensor):
+    def _kx_group_bwd(self, i: int, key: str, dy_full: torch.Tensor, N: int, x: torch.Tensor, t: torch.Tensor, dx: torch.Tensor,
+                      swiglu_gu: Optional[torch.Tensor] = None):
         """Input gradient of a decoder GEMM with the adapters inside it: dy_full = [dy | dt] (dt = dy . B in the tail columns)
-        times [W ; A] in ONE NN GEMM (dx = dy W + dt A), then the adapter weight gradients."""
+        times [W ; A] in ONE NN GEMM (dx = dy W + dt A), then the adapter weight gradients.  ``swiglu_gu`` (w2 only): the product is
+        d(act) of the SwiGLU and ``dx`` the [rows, 2 F] gradient of the gate | up rows -- the SwiGLU backward runs in the GEMM epilogue."""
         li = self._lora_step_images()
         dy, dt = dy_full[:, :N], dy_full[:, N:]
         self._dgrad(dy, li[key + ".Bt"], dt)
         im = self._images()
-        if self._nt_dgrad(key):
+        if swiglu_gu is not None:
+            ops.gemm_nt(dy_full, im[key + ".yT"], dx, residual=swiglu_gu, epilogue=ops.EPI_SWIGLU_BWD)
+        elif self._nt_dgrad(key):
             ops.gemm_nt(dy_full, im[key + ".yT"], dx)          # frozen base: the transposed image is free (built once)
         else:
             ops.gemm_nn(dy_full, im[key + ".y"], dx)
@@ -666,16 +671,22 @@ class TrainEngine:
         self._dha_ready = False
         if self._has(pre + "feed_forward.w2.weight"):
             self._wgrad(dha, k["act"], self._views[pre + "feed_forward.w2.weight"], "w2", (pre + "feed_forward.w2.weight",))
-        dact = self._buf("dact", (rows, F))
-        if kx:
-            self._kx_group_bwd(i, f"w2.{i}", dha_full, dim, k["act"], lt["w2"], dact)
+        if kx and self.fuse_swiglu_bwd and self._nt_dgrad(f"w2.{i}") and F % 8 == 0:
+            # d(act) never reaches HBM: the input-gradient GEMM of w2 applies the SwiGLU backward in its epilogue (a3v_swiglu_bwd on
+            # the bf16-rounded product, bit for bit) and writes d(gate) | d(up) straight into the w1|w3 gradient buffer
             dgu_full, dgu = ybuf("dgu.x", 2 * F, f"w13.{i}")
+            self._kx_group_bwd(i, f"w2.{i}", dha_full, dim, k["act"], lt["w2"], dgu, swiglu_gu=k["gu"])
         else:
-            self._dgrad_w(dha, f"w2.{i}", dact)
-            if self.lora:
-                self._lora_bwd(i, f"w2.{i}", dha, k["act"], lt["w2"], dact)
-            dgu = self._buf("dgu", (rows, 2 * F))
-        ops.swiglu_bwd(k["gu"], dact, dgu, F, interleaved=False)
+            dact = self._buf("dact", (rows, F))
+            if kx:
+                self._kx_group_bwd(i, f"w2.{i}", dha_full, dim, k["act"], lt["w2"], dact)
+                dgu_full, dgu = ybuf("dgu.x", 2 * F, f"w13.{i}")
+            else:
+                self._dgrad_w(dha, f"w2.{i}", dact)
+                if self.lora:
+                    self._lora_bwd(i, f"w2.{i}", dha, k["act"], lt["w2"], dact)
+                dgu = self._buf("dgu", (rows, 2 * F))
+            ops.swiglu_bwd(k["gu"], dact, dgu, F, interleaved=False)
         if self._has(pre + "feed_forward.w1.weight", pre + "feed_forward.w3.weight"):
             self._wgrad(dgu, k["xn2"], self._gview(pre + "feed_forward.w1.weight", pre + "feed_forward.w3.weight"), "w13",
                         (pre + "feed_forward.w1.weight", pre + "feed_forward.w3.weight"))

@@ -51,6 +51,11 @@ enum {
   A3V_EPI_OUT_F32 = 32,    /* store fp32 (logits .float(), LLM/llama_ens5.py:531)     */
   A3V_EPI_RES_F32 = 64,    /* residual stream (and output) kept in fp32 (training
                               under autocast: engine_finetune.py:44-50)               */
+  A3V_EPI_SWIGLU_BWD = 128, /* the GEMM's [M, N] product is d(act) of the SwiGLU (the input gradient of w2, llama_ens5.py:213-217
+                               backward): `residual` = gu [M, 2N] bf16 (gate columns 0..N-1, up columns N..2N-1, as the forward's
+                               un-fused w1|w3 output keeps them), C [M, >= 2N] bf16 receives d(gate) in columns 0..N-1 and d(up)
+                               in N..2N-1 -- a3v_swiglu_bwd applied to the bf16-rounded product, bit for bit, without the
+                               d(act) round trip through HBM.  bf16 only; N % 8 == 0.                                   */
   A3V_EPI_TILE_128 = 1 << 16,  /* force the 128x128 tile kernel (tuning / tests)       */
   A3V_EPI_TILE_256 = 1 << 17,  /* force the 256x256 tile kernel (tuning / tests)       */
   A3V_EPI_TILE_256PP = 1 << 18,/* force the 256x256 ping-pong kernel (tuning / tests)  */

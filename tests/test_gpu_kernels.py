@@ -803,6 +803,32 @@ def test_gemm_ring_stream_runs_on_across_the_tiles_of_a_block(M, N, K):
             assert torch.equal(got, want), (kind, rep, int((got != want).sum()))
 
 
+@pytest.mark.parametrize("M,F,K,tile", [(600, 1024, 256, "auto"), (600, 1024, 256, "pp"), (8728, 1280, 192, "auto"), (8728, 1280, 192, "pp"),
+                                          (300, 528, 128, "t128"), (4608, 2816, 4160, "auto")])
+def test_gemm_swiglu_backward_epilogue_equals_gemm_then_swiglu_bwd(M, F, K, tile):
+    """A3V_EPI_SWIGLU_BWD (the input-gradient GEMM of w2 applies the SwiGLU backward to its own bf16-rounded product and writes
+    d(gate) | d(up) into the w1|w3 gradient rows; llama_ens5.py:213-217 backward) == a3v_gemm_nt followed by a3v_swiglu_bwd, bit for
+    bit: interior tiles of the ring kernel (fast form), ragged last tile rows / columns (general form), the 128 x 128 kernel, the
+    hybrid dispatch with its tail rows; gu and the output inside wider rows (the K-extended buffers of the LoRA step)."""
+    from a3vlm_amd import lib
+    t = {"auto": 0, "pp": lib.EPI_TILE_256PP, "t128": lib.EPI_TILE_128}[tile]
+    dy = gen(M, K, seed=131).to(BF).to(DEV)
+    w = gen(F, K, seed=132, scale=0.05).to(BF).to(DEV)
+    gu = gen(M, 2 * F, seed=133).to(BF).to(DEV)
+    dact = torch.empty(M, F, dtype=BF, device=DEV)
+    ops.gemm_nt(dy, w, dact, epilogue=t)
+    want = torch.full((M, 2 * F + 64), 5.0, dtype=BF, device=DEV)
+    ops.swiglu_bwd(gu, dact, want[:, :2 * F], F, interleaved=False)
+    got = torch.full((M, 2 * F + 64), 5.0, dtype=BF, device=DEV)
+    ops.gemm_nt(dy, w, got[:, :2 * F], residual=gu, epilogue=t | ops.EPI_SWIGLU_BWD)
+    assert torch.equal(got, want), int((got != want).sum())
+    # against the fp32 formula on the bf16-rounded product (the reference's autograd through F.silu(w1 x) * w3 x)
+    g, u, da = gu[:, :F].float().cpu(), gu[:, F:].float().cpu(), rt(dy.float().cpu() @ w.float().cpu().t())
+    sig = torch.sigmoid(g)
+    assert_close(got[:, :F], da * u * (sig * (1 + g * (1 - sig))), rtol=2 ** -6, atol=2e-2, what="d gate")
+    assert_close(got[:, F:2 * F], da * (g * sig), rtol=2 ** -6, atol=2e-2, what="d up")
+
+
 def test_gemm_one_wave_per_simd_kernel_equals_ring_kernel():
     """(Also the overlapped 8-wave form, A3V_GEMM_W4=20.)  The opt-in 4-wave (one wave per SIMD, 128 x 128 per wave, 5 x 32-KiB sub-stage ring) form of the NT kernel
     (A3V_GEMM_W4=1; DESIGN.md section 4: measured, slower than the ring kernel, kept for the record) accumulates in the same

@@ -302,3 +302,42 @@ def test_lora_kext_adapters_inside_the_gemms_match_oracle_and_separate_path():
         a, b, c = got[True][n].flatten(), got[False][n].flatten(), osd[n].grad.flatten()
         cos = lambda x, y: float(torch.dot(x, y) / (x.norm() * y.norm() + 1e-20))
         assert cos(a, b) > 0.995 and cos(a, c) > 0.98, (n, cos(a, b), cos(a, c))
+
+
+def test_lora_swiglu_backward_in_the_w2_dgrad_epilogue_equals_the_separate_pass():
+    """The LoRA step (adapters inside the GEMMs) runs the SwiGLU backward in the epilogue of w2's input-gradient GEMM
+    (A3V_EPI_SWIGLU_BWD: d(act) never reaches HBM).  Same arithmetic on the same bf16-rounded product, so the loss and every
+    trainable gradient are IDENTICAL to the path with the separate a3v_swiglu_bwd pass (fuse_swiglu_bwd = False)."""
+    big = dict(dim=256, n_layers=2, n_heads=4, n_kv_heads=2, vocab_size=320, multiple_of=256, max_seq_len=256)
+    oargs = ref_cpu.OracleArgs(**big)
+    sd = ref_cpu.make_decoder_weights(oargs, seed=3, std=0.05)
+    lsd = ref_cpu.make_lora_weights(oargs, RANK, seed=6, std_a=0.05, std_b=0.05)
+    g = torch.Generator().manual_seed(17)
+    B, T = 5, 61                                   # 305 rows: ragged against the 256-row tiles
+    ex = torch.randint(3, 320, (B, T), generator=g)
+    ex[:, 0] = 1
+    lab = ex.clone()
+    lab[:, :6] = 0
+    got, losses = {}, {}
+    for fuse in (True, False):
+        m = peft.Transformer(peft.ModelArgs(**big, lora_rank=RANK), with_visual=False)
+        m.load_state_dict({**sd, **lsd}, strict=True)
+        train = m.get_trainable_params()
+        for n, p in m.named_parameters():
+            p.requires_grad = n in train
+        m.to(BF).to(DEV)
+        promote_trainable_params_to_fp32(m)
+        eng = TrainEngine(m, BF)
+        eng.fuse_swiglu_bwd = fuse
+        assert eng._kext() > 0
+        losses[fuse] = float(eng.forward_loss(ex.to(DEV), lab.to(DEV), None))
+        eng.backward(1.0)
+        got[fuse] = {n: p.grad.float().cpu().clone() for n, p in train.items()}
+    assert losses[True] == losses[False]
+    exact = 0
+    for n in got[True]:
+        a, b = got[True][n], got[False][n]
+        exact += int(torch.equal(a, b))
+        # (the norm-weight gradients are summed with atomics: equal up to the order of fp32 additions, run to run, on either path)
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()) + 1e-12, (n, float((a - b).abs().max()), float(b.abs().max()))
+    assert exact >= len(got[True]) - 2 * big["n_layers"] - 1, exact      # every adapter gradient bit for bit

@@ -14,11 +14,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 BUDGET = [   # (substring of the mangled kernel name, max scratch bytes per lane)
-    ("gemm_nt_bf16_ring_kernelILi0ELb0ELi0ELb1ELi1ELb0E", 64),     # ring, common epilogue forms: the decoder's linears
-    ("gemm_nt_bf16_ring_kernelILi0ELb0ELi0ELb1ELi3ELb0E", 64),     # ring, bias / activation in front (the ViT)
+    # (ring kernels: ~40 scratch instructions per kernel, all at the tile boundary / in the epilogue -- none inside the K-tile loops,
+    #  checked on the ISA when the cross-tile DMA stream went in (80 B) and again with the SwiGLU-backward form)
+    ("gemm_nt_bf16_ring_kernelILi0ELb0ELi0ELb1ELi1ELb0E", 96),     # ring, common epilogue forms: the decoder's linears
+    ("gemm_nt_bf16_ring_kernelILi0ELb0ELi0ELb1ELi3ELb0E", 96),     # ring, bias / activation in front (the ViT)
     ("gemm_tn_bf16_pp_kernelILb0E", 128),                          # weight gradients (+ sums of squares: epilogue-only spills, none in the k-loop)
     ("gemm_tn_bf16_pp_kernelILb1E", 0),                            # input gradients
-    ("gemm_nt_bf16_ring_kernelILi0ELb0ELi0ELb1ELi4ELb0E", 64),     # fused-qkv form (its own instantiation: DESIGN.md section 4)
+    ("gemm_nt_bf16_ring_kernelILi0ELb0ELi0ELb1ELi4ELb0E", 96),     # fused-qkv form (its own instantiation: DESIGN.md section 4)
     ("gemm_nt_fp8_pp_kernel", 0),
     ("gemm_nt_bf16_kernelILi128ELi128ELi2ELi2E", 0),
 ]
