@@ -230,19 +230,20 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_bf16_kernel(AttnArgs p) {
     // ---- S^T = K . Q^T : two 32-row kv blocks ----
     f32x16 s[2];
 #pragma unroll
-    for (int tb = 0; tb < 2; ++tb) {
+    for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[tb][r] = 0.f;
-      const char* kp = Ks + tb * 32 * KROW;
+    // the two key blocks' accumulation chains alternate (back-to-back MFMAs on ONE accumulator issue at ~72 cycles, not 32)
 #pragma unroll
-      for (int ks = 0; ks < HD / 16; ++ks) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kp + (kfb ^ (ks << 5)));
+    for (int ks = 0; ks < HD / 16; ++ks)
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + tb * 32 * KROW + (kfb ^ (ks << 5)));
 #ifdef AP_NO_QK
         if (ks == 0)
 #endif
         s[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[tb], 0, 0, 0);
       }
-    }
     AP_ST(t, 2);
     // ---- mask + online softmax (lane owns query column ql; kv = 32tb + (r&3)+8(r>>2)+4hh) ----
     const int qlim = CAUSAL ? (qrow + off) : 0x7fffffff;
@@ -320,14 +321,14 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_bf16_kernel(AttnArgs p) {
     AP_ST(t, 3);
     // ---- O^T += V^T . P^T ----
 #pragma unroll
-    for (int d = 0; d < HD / 32; ++d) {
-      const int drow = d * 32 + ql;
-      const int g = (drow >> 1) & 7;
-      const char* vp = Vs + drow * 128 + hh * 8;
+    for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
-      for (int tb = 0; tb < 2; ++tb)
+      for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int d = 0; d < HD / 32; ++d) {   // (the d blocks' chains interleaved, see the QK product)
+          const int drow = d * 32 + ql;
+          const int g = (drow >> 1) & 7;
+          const char* vp = Vs + drow * 128 + hh * 8;
           const int c16 = 4 * tb + 2 * c;      // 16-B chunk of kv columns {0..7}; lane half hh takes its 8-B half (k = 4hh..4hh+3)
           bf16x8 vf;
           if constexpr (PSWAP) {               // lane half hh takes the WHOLE chunk c16 + hh (8 consecutive keys)
@@ -343,7 +344,6 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_bf16_kernel(AttnArgs p) {
 #endif
           o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[tb][c], o[d], 0, 0, 0);
         }
-    }
     AP_ST(t, 4);
   };
   {
@@ -410,6 +410,363 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_bf16_kernel(AttnArgs p) {
       }
   }
 }
+
+#ifdef A3V_EXPERIMENTS
+// ------------------------------------------------------------------------------------
+// Ping-pong prefill kernel (hd = 128; round 3) -- EXPERIMENT, built only with `make EXPERIMENTS=1` and selected by A3V_ATTN_PP=1: correct
+// (the attention tests pass on it) but 160-168 us at the 7B shape against 134-138 for the 128-row kernel; what the stamps of its
+// segments say is recorded in profiles/r03f_attn_pp_experiment.txt and DESIGN.md section 9.
+//  The kernel above is paced by the dependency chain of ONE wave per tile (fragment
+// latency -> 16 MFMAs -> ~230 VALU of softmax -> 16 MFMAs) with one partner wave from an unrelated block as its only cover: cycle
+// stamps put a tile at ~4400 cycles per SIMD for 2 x 1024 cycles of MFMA.  Here a block is 8 waves = two groups of four on the
+// schedule of the ring GEMM: a group's iteration is ONE MFMA segment [S(t+1) = K(t+1) Q^T ; O += V(t) P(t)] (32 MFMAs, its fragment
+// reads inside) and ONE VALU segment [softmax of tile t+1, DMA issue, counted wait], the two groups are half a period apart and a
+// block barrier separates the segments -- while one wave of a SIMD feeds the matrix pipe its partner exponentiates.
+//   * 256 query rows per block (group g: rows 128 g .., wave: 32 rows), the blocks aligned to the END of the sequence so that the
+//     ragged block is the cheapest one of a causal head (S = 1091: 18 + 14 + 10 + 6 + 2 tiles instead of 4 + 8 + 12 + 16 + 18);
+//     both groups read the SAME K / V^T tiles (half the DMA and L2 traffic per query row of the 128-row kernel);
+//   * K / V^T stages of 32 KiB in a ring of FIVE (all 160 KiB of the CU): stage u is issued three (group 0) / four (group 1)
+//     iterations before its K tile is read, 4 LDS-DMA pieces per wave and stage, and every wave only ever waits for its OWN pieces
+//     (counted vmcnt at the end of its VALU segment: everything but the last two stages it issued), the barrier publishes them;
+//   * a wave whose rows lie wholly before a tile's first key (causal) keeps the barrier / DMA cadence and skips the arithmetic.
+// Group g runs  M(-1) V(0) M(0) V(1) ... V(n-1) M(n-1)  on the block steps g, g+1, ...;  M(t) = [QK(t+1), PV(t)], V(t) = softmax(t).
+// ------------------------------------------------------------------------------------
+#ifndef PP_PRIO_ON
+#define PP_PRIO_ON 0
+#endif
+#define PP_PRIO(x) do { if (PP_PRIO_ON) __builtin_amdgcn_s_setprio(x); } while (0)
+template <bool CAUSAL>
+__global__ __launch_bounds__(512) void attn_prefill_pp_kernel(AttnArgs p) {
+  constexpr int HD = 128, KVB = 64, KROW = HD * 2, NST = 5;
+  constexpr int TILEB = KVB * KROW + HD * 128;          // 32 KiB: K tile [64][128] + V^T tile [128][64]
+  __shared__ __attribute__((aligned(1024))) char lds[NST * TILEB];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), grp = wave >> 2;
+  const int nqb = (p.Sq + 255) / 256;
+  int vb;
+  {
+    const int total = gridDim.x, id = blockIdx.x;
+    const int xcd = id & 7, q = total >> 3, r = total & 7;
+    vb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  }
+  int head_slot = vb / nqb, j = vb - head_slot * nqb;   // j = 0: the LAST 256 rows (heaviest under the causal mask) first
+  if (CAUSAL && p.head_group > 1) {                     // tile-rank-major walk over groups of heads (see the kernel above)
+    const int G = p.head_group, per = G * nqb;
+    const int g2 = vb / per, r = vb - g2 * per;
+    head_slot = g2 * G + r % G;
+    j = r / G;
+  }
+  const int b = head_slot / p.H, h = head_slot - b * p.H;
+  const int hk = h / (p.H / p.Hkv);
+  const int hi = p.Sq - 256 * j, lo = max(0, hi - 256);  // the block's query rows [lo, hi)
+  const int q0 = lo + wave * 32;                          // this wave's rows [q0, q0 + 32) ∩ [lo, hi)
+  const int off = p.Sk - p.Sq;
+  const bf16_t* Q = (const bf16_t*)p.q + b * p.q_sb + h * p.q_sh;
+  const bf16_t* K = (const bf16_t*)p.k + b * p.k_sb + hk * p.k_sh;
+  const bf16_t* VT = (const bf16_t*)p.vt + b * p.v_sb + hk * p.v_sh;
+  const int ql = lane & 31, hh = lane >> 5;
+  const int qrow = q0 + ql;
+  const int qrow_c = qrow < hi ? qrow : hi - 1;
+  const bool wave_live = q0 < hi;
+  bf16x8 qf[HD / 16];
+#pragma unroll
+  for (int ks = 0; ks < HD / 16; ++ks)
+    qf[ks] = *reinterpret_cast<const bf16x8*>(Q + (int64_t)qrow_c * p.q_ss + ks * 16 + hh * 8);
+  f32x16 o[HD / 32];
+#pragma unroll
+  for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  // tiles of the block (its last row decides) and of this wave (its own last row)
+  const int kv_end = CAUSAL ? min(p.Sk, hi - 1 + off + 1) : p.Sk;
+  const int n = (kv_end + KVB - 1) / KVB;
+  const int q_last = min(q0 + 31, hi - 1);
+  const int nw = !wave_live ? 0 : (CAUSAL ? min(n, (min(p.Sk, q_last + off + 1) + KVB - 1) / KVB) : n);
+  // DMA: 4 pieces of 1 KiB per wave and stage -- K rows 8 (wave) .. + 7 twice 4 rows?  a piece = 64 lanes x 16 B: K: 4 rows x 256 B,
+  // V^T: 8 rows x 128 B.  The chunk swizzles of the 128-row kernel, applied on the source side.
+  const auto rsK = __builtin_amdgcn_make_buffer_rsrc((void*)K, 0, (int)min((int64_t)0x7fffffff, ((int64_t)(p.Sk - 1) * p.k_ss + HD) * 2), 0x00020000);
+  const auto rsV = __builtin_amdgcn_make_buffer_rsrc((void*)VT, 0, (int)min((int64_t)0x7fffffff, ((int64_t)(HD - 1) * p.v_sd + p.Sk) * 2), 0x00020000);
+  unsigned koff[2], voff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int id = tid + i * 512;                       // 1024 16-byte chunks per K tile: row = id / 16, physical chunk id % 16
+    const int row = id >> 4, slot = id & 15;
+    koff[i] = (unsigned)((row * p.k_ss + (slot ^ (row & 15)) * 8) * 2);
+    const int d = id >> 3, vs = id & 7;                 // 1024 chunks per V^T tile: row d = id / 8, physical chunk id % 8
+    voff[i] = (unsigned)((d * p.v_sd + (vs ^ ((d >> 1) & 7)) * 8) * 2);
+  }
+  auto dma_stage = [&](int u) {
+    char* Ks = lds + (u % NST) * TILEB;
+    char* Vs = Ks + KVB * KROW;
+    const unsigned ks_off = (unsigned)((int64_t)u * KVB * p.k_ss * 2), vs_off = (unsigned)(u * KVB * 2);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) buf_dma16(rsK, Ks + (wave * 64 + i * 512) * 16, koff[i], ks_off);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) buf_dma16(rsV, Vs + (wave * 64 + i * 512) * 16, voff[i], vs_off);
+  };
+  const int kfb = ql * KROW + ((hh ^ (ql & 15)) << 4);
+  const int vfb = ql * 128 + ((hh ^ ((ql >> 1) & 7)) << 4);
+  f32x16 s[2];
+  bf16x8 pf[2][2];
+
+  // (slot = ring slot of the tile; the slot base only has bits above the per-lane fragment bases, so base | slot base is formed once
+  //  per segment and every fragment address is one v_xor + an instruction offset)
+  // Fragment order i = 0..15.  QK: (ks = i >> 1, tb = i & 1) -- the two key blocks' chains ALTERNATE, and PV: (tb, c = i >> 2, d = i & 3)
+  // -- the four d blocks' chains interleave: back-to-back MFMAs on one accumulator issue at ~72 cycles instead of 32, and in this
+  // kernel no partner wave fills the gaps (the other group is in its VALU segment).  The fragments are read AHEAD of the MFMAs
+  // that use them, pinned by sched_group_barrier: left to itself hipcc reads every fragment into the same four registers right
+  // before its MFMA (read, lgkmcnt(0), MFMA, read, ... = one LDS latency per MFMA: 2300 cycles per segment by the stamps).
+  auto k_frag = [&](int kb, int i) {
+    return *reinterpret_cast<const bf16x8*>(lds + (i & 1) * 32 * KROW + (kb ^ ((i >> 1) << 5)));
+  };
+  auto v_frag = [&](int vbs, int i) {
+    const int d = i & 3, c16 = 4 * (i >> 3) + 2 * ((i >> 2) & 1);
+    return *reinterpret_cast<const bf16x8*>(lds + KVB * KROW + d * 32 * 128 + (vbs ^ (c16 << 4)));
+  };
+  auto zero_s = [&]() {
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[tb][r] = 0.f;
+  };
+  auto qk = [&](int slot) {                             // S^T = K . Q^T of the tile in `slot` (first and only product of the segment)
+    const int kb = kfb | (slot * TILEB);
+    bf16x8 kf[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) kf[i] = k_frag(kb, i);
+    zero_s();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i], qf[i >> 1], s[i & 1], 0, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+  };
+  auto pv = [&](int slot) {                             // O^T += V^T . P^T of the tile in `slot` (alone in its segment: the last one)
+    const int vbs = vfb | (slot * TILEB);
+    bf16x8 vf[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) vf[i] = v_frag(vbs, i);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i], pf[i >> 3][(i >> 2) & 1], o[i & 3], 0, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+  };
+  auto qk_pv = [&](int slot1, int slot) {               // the steady segment: S^T of tile t + 1, then O^T += of tile t
+    const int kb = kfb | (slot1 * TILEB), vbs = vfb | (slot * TILEB);
+    bf16x8 kf[16], vf[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) kf[i] = k_frag(kb, i);
+    zero_s();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      s[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i], qf[i >> 1], s[i & 1], 0, 0, 0);
+      vf[i] = v_frag(vbs, i);                            // the V^T fragments arrive under the QK MFMAs
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i], pf[i >> 3][(i >> 2) & 1], o[i & 3], 0, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);   // 16 K reads
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one QK MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one V^T read
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);   // 16 PV MFMAs
+  };
+  auto softmax = [&](int t) {                           // s (tile t) -> pf, running max / sum, lazy O rescale (see the kernel above)
+    const int kv0 = t * KVB;
+    const int qlim = CAUSAL ? (qrow + off) : 0x7fffffff;
+    const bool need_mask = (kv0 + KVB > p.Sk) || (CAUSAL && kv0 + KVB - 1 > q0 + off);
+    float mx = -INFINITY;
+    if (need_mask) {
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kv = kv0 + tb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          const bool ok = (kv < p.Sk) && (kv <= qlim);
+          s[tb][r] = ok ? s[tb][r] : -INFINITY;
+        }
+    }
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[tb][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const bool grow = p.lazy_rescale ? ((m_new - m_run) * p.scale_log2 > 8.f || m_run == -INFINITY) : true;
+    const bool resc = __builtin_amdgcn_ballot_w64(grow && m_new != m_run) != 0;
+    const float m_tgt = resc ? m_new : m_run;
+    const float m_use = (m_tgt == -INFINITY) ? 0.f : m_tgt;
+    float alpha = 1.f;
+    if (resc) alpha = __builtin_amdgcn_exp2f((m_run - m_use) * p.scale_log2);
+    m_run = m_tgt;
+    float lsum = 0.f;
+    const float mb = m_use * p.scale_log2;
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pr = __builtin_amdgcn_exp2f(fmaf(s[tb][r], p.scale_log2, -mb));
+        lsum += pr;
+        pf[tb][r >> 3][r & 7] = f2bf(pr);
+      }
+    l_run = resc ? l_run * alpha + lsum : l_run + lsum;
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        u32x4 w;
+        __builtin_memcpy(&w, &pf[tb][c], 16);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(w[e], w[2 + e], false, false);
+          w[e] = sw[0];
+          w[2 + e] = sw[1];
+        }
+        __builtin_memcpy(&pf[tb][c], &w, 16);
+      }
+    if (resc) {
+#pragma unroll
+      for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+    }
+  };
+  // counted wait at the end of V(t): everything but the stages this group issued beyond t + 1 + grp may stay in flight
+  auto wait_own = [&](int t) {
+    const int last = min(n - 1, t + 3 + grp), allowed = last - (t + 1 + grp);
+    if (allowed >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (allowed == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  // V^T columns past Sk of a ragged last tile are zeroed in LDS (0 x garbage must stay 0): by group 0 in its V(n-1), when every
+  // piece of the stage has landed (its own: confirmed in V(n-2), group 1's in V(n-3)) and before anyone's PV(n-1)
+  auto zero_ragged = [&]() {
+    const int c0 = p.Sk - (n - 1) * KVB;                 // first invalid column of the tile
+    if (c0 >= KVB || grp != 0) return;
+    char* Vs = lds + ((n - 1) % NST) * TILEB + KVB * KROW;
+    const int d = tid >> 1, half = tid & 1;
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      const int c = half * 4 + cc;
+      char* chunk = Vs + d * 128 + ((c ^ ((d >> 1) & 7)) << 4);
+      if (c * 8 >= c0) {
+        *reinterpret_cast<u32x4*>(chunk) = u32x4{0u, 0u, 0u, 0u};
+      } else if (c * 8 + 8 > c0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (c * 8 + e >= c0) reinterpret_cast<unsigned short*>(chunk)[e] = 0;
+      }
+    }
+  };
+
+  // ---- prologue: group 0 issues stages 0..2, group 1 stages 0..3; stage 0 (group 1: and 1) confirmed before the first barrier
+  {
+    const int pre = min(n, 3 + grp);
+    for (int u = 0; u < pre; ++u) dma_stage(u);
+    const int keep = max(0, pre - 1 - grp);              // stages that may stay in flight
+    if (keep >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (keep == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  // ---- the 2 n + 2 block steps.  Every wave executes every barrier; a group's segments are M(-1) V(0) M(0) ... V(n-1) M(n-1), group 1
+  // one step behind group 0.  Straight-line code per segment kind (a single loop that picked M or V by the step's parity made
+  // hipcc shuffle all 96 accumulator registers through v_mov at every merge: 216 moves per iteration, 2.8x slower than the
+  // 128-row kernel).  A wave's live part covers its own nw tiles; the rest of the block's n tiles it only paces (barriers, DMA).
+  // raw s_barrier: __syncthreads() would also wait for vmcnt(0), i.e. for every LDS-DMA piece in flight (the whole point of the ring);
+  // LDS hazards are covered by the counted vmcnt (DMA -> reads) and by the lgkmcnt(0) behind the one segment that writes LDS.
+#ifdef PP_STAMP
+  unsigned long long* stamps = (vb == PP_STAMP && (tid == 0 || tid == 256)) ? reinterpret_cast<unsigned long long*>(p.lse) + (tid ? 512 : 0) : nullptr;
+  int sti = 0;
+#define PP_ST(code) do { if (stamps && sti < 250) { stamps[2 * sti] = (code); stamps[2 * sti + 1] = __builtin_amdgcn_s_memtime(); ++sti; } } while (0)
+#else
+#define PP_ST(code) do {} while (0)
+#endif
+  auto bar = [&]() { PP_ST(1); __builtin_amdgcn_s_barrier(); PP_ST(2); };
+  auto next = [&](int sl) { return sl + 1 == NST ? 0 : sl + 1; };
+  auto vseg_io = [&](int t) {                            // the part of V(t) every wave does: issue stage t + 3 + grp, zero the ragged tail, counted wait
+    if (t + 3 + grp < n) dma_stage(t + 3 + grp);
+    if (t == n - 1) {
+      zero_ragged();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    wait_own(t);
+  };
+  if (grp == 1) bar();
+  int slot = 0;                                          // slot of tile t in the loop below
+  if (nw > 0) {
+    bar();                                               // M(-1)
+    PP_PRIO(1);
+    qk(0);
+    PP_PRIO(0);
+    bar();                                               // V(0)
+    softmax(0);
+    vseg_io(0);
+    int t = 0;
+    for (; t + 1 < nw; ++t) {
+      const int slot1 = next(slot);
+      bar();                                             // M(t)
+      PP_PRIO(1);
+      qk_pv(slot1, slot);
+      PP_ST(3);
+      PP_PRIO(0);
+      PP_ST(4);
+      bar();                                             // V(t + 1)
+      softmax(t + 1);
+      PP_ST(5);
+      vseg_io(t + 1);
+      PP_ST(6);
+      slot = slot1;
+    }
+    bar();                                               // M(nw - 1)
+    PP_PRIO(1);
+    pv(slot);
+    PP_PRIO(0);
+  }
+  // pacing part: segments 2 nw + 1 .. 2 n of this wave's group (or all 2 n + 1 of them for a wave with no rows)
+  for (int seg = nw > 0 ? 2 * nw + 1 : 0; seg <= 2 * n; ++seg) {
+    bar();
+    if (seg & 1) vseg_io(seg >> 1);
+  }
+  if (grp == 0) bar();
+  // ---- normalise and store O[q][d], d = 32*db + 8*g + 4*hh + {0..3} (through the wave's LDS patch as whole rows)
+  float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+#ifdef PP_STAMP
+  if (stamps) return;
+  if (false)
+#else
+  if (p.lse && qrow < hi && hh == 0)
+#endif
+    p.lse[((int64_t)b * p.H + h) * p.Sq + qrow] = m_run * p.scale + __logf(l_tot);
+  __syncthreads();
+  {
+    constexpr int ROWB = HD * 2, NPAIR = HD / 8, RPI = 64 / NPAIR;
+    char* patch = lds + wave * (32 * ROWB);
+    char* wrow = patch + ql * ROWB;
+    const int wx = (ql & (NPAIR - 1)) << 1;
+#pragma unroll
+    for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        bf16x4 ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ov[e] = f2bf(o[d][g4 * 4 + e] * inv);
+        *reinterpret_cast<bf16x4*>(wrow + (((d * 8 + g4 * 2 + hh) ^ wx) << 3)) = ov;
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int pr = lane % NPAIR, rr = lane / NPAIR;
+    bf16_t* Ob = (bf16_t*)p.out + b * p.o_sb + h * p.o_sh + pr * 8;
+#pragma unroll
+    for (int it = 0; it < 32 / RPI; ++it) {
+      const int r = it * RPI + rr;
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(patch + r * ROWB + ((pr ^ (r & (NPAIR - 1))) << 4));
+      if (q0 + r < hi) *reinterpret_cast<bf16x8*>(Ob + (int64_t)(q0 + r) * p.o_ss) = v;
+    }
+  }
+}
+
+#endif  // A3V_EXPERIMENTS
 
 // Fused combine of the decode kernels (all threads of the block call it; `po` = this block's partial, already written with plain stores)
 template <int HD>
@@ -903,6 +1260,26 @@ static int attention_impl(const void* q, const void* k, const void* vt, void* ou
     A3V_LAUNCH_CHECK();
     return A3V_OK;
   }
+#ifdef A3V_EXPERIMENTS
+  // hd 128, long enough sequences, vector-aligned output: the 8-wave ping-pong kernel (experiment, A3V_ATTN_PP=1)
+  if (hd == 128 && Sq >= 256 && A3V_ENV_INT("A3V_ATTN_PP", 0) != 0 && !(strides[9] % 8) && !(strides[10] % 8) && !(strides[11] % 8) &&
+      !(reinterpret_cast<uintptr_t>(out) & 15) && (int64_t)Sk * strides[5] * 2 < (1LL << 31) && (int64_t)hd * strides[8] * 2 < (1LL << 31)) {
+    dim3 gp(((Sq + 255) / 256) * H * B);
+    if (causal && (gp.x & 7) == 0 && ((B * H) & 7) == 0) {
+      const int ge = A3V_ENV_INT("A3V_ATTN_HEAD_GROUP", 0);
+      int want = 16;
+      while (want > 1 && (int64_t)want * Sk * hd * 4 > (9 << 20)) want >>= 1;
+      if (ge > 0) want = ge;
+      int G = want < 1 ? 1 : want;
+      while (G > 1 && ((B * H) / 8) % G) G >>= 1;
+      p.head_group = G;
+    }
+    if (causal) hipLaunchKernelGGL(attn_prefill_pp_kernel<true>, gp, dim3(512), 0, st, p);
+    else hipLaunchKernelGGL(attn_prefill_pp_kernel<false>, gp, dim3(512), 0, st, p);
+    A3V_LAUNCH_CHECK();
+    return A3V_OK;
+  }
+#endif
   dim3 grid(((Sq + 127) / 128) * H * B);
   if (causal && (grid.x & 7) == 0 && ((B * H) & 7) == 0) {
     // default: the largest power of two (<= 16) whose K + V^T fit ~9 MB (measured best: 16 heads at S = 1091, 8 at S ~ 2000 --
