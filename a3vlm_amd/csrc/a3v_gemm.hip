@@ -3714,7 +3714,12 @@ extern "C" int a3v_gemm_nn(const void* A, int64_t lda, const void* Wt, int64_t l
   if (!A || !Wt || !C || M <= 0 || N <= 0 || K <= 0) return A3V_ERR_ARG;
   if (K % 64 || lda % 8 || ldw % 8 || N % 8 || ldc % 4) return A3V_ERR_SHAPE;
   const int simple = A3V_EPI_RESIDUAL | A3V_EPI_RES_F32 | A3V_EPI_OUT_F32;
-  if (epilogue & ~simple) return A3V_ERR_ARG;
+  const bool swb = epilogue == A3V_EPI_SWIGLU_BWD;     // the product is d(act): `residual` = the forward's [gate | up] rows, C = [d gate | d up] (see a3v_gemm_nt)
+  if (swb) {
+    if (!residual || (ldr % 4) || ldr < 2 * (int64_t)N || ldc < 2 * (int64_t)N) return A3V_ERR_ARG;
+  } else if (epilogue & ~simple) {
+    return A3V_ERR_ARG;
+  }
   if ((epilogue & (A3V_EPI_RESIDUAL | A3V_EPI_RES_F32)) && (!residual || ldr % 4)) return A3V_ERR_ARG;
   if (((int64_t)(M - 1) * lda + K) * 2 >= (1LL << 31) || ((int64_t)(K - 1) * ldw + N) * 2 >= (1LL << 31)) return A3V_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
@@ -3733,7 +3738,7 @@ extern "C" int a3v_gemm_nn(const void* A, int64_t lda, const void* Wt, int64_t l
   while (S > 1 && (K / 64) < 16 * S) --S;
   if (S < 1) S = 1;
   const int m_big = (int)(mt_h * 256);
-  if (mt_h >= 1 && m_big < M && S > 1 && rem_tiles * 4 < 3 * ncu && g_gemm_ws && (int64_t)S * (M - m_big) * N * 4 <= g_gemm_ws_bytes) {
+  if (!swb && mt_h >= 1 && m_big < M && S > 1 && rem_tiles * 4 < 3 * ncu && g_gemm_ws && (int64_t)S * (M - m_big) * N * 4 <= g_gemm_ws_bytes) {
     GemmArgs q = p;
     q.M = m_big; q.tiles_m = (int)mt_h;
     launch_tn<true>(dim3(q.tiles_m * q.tiles_n), st, q);

@@ -117,7 +117,7 @@ def gemm_nn(a, wt, out, *, residual=None, epilogue: int = 0):
     assert wt.shape[0] == K and a.stride(1) == 1 and wt.stride(1) == 1 and out.stride(1) == 1
     _ensure_gemm_workspace(a.device)
     ep = epilogue
-    if residual is not None and not (ep & EPI_RES_F32):
+    if residual is not None and not (ep & (EPI_RES_F32 | EPI_SWIGLU_BWD)):
         ep |= EPI_RESIDUAL
     rc = _l.load().a3v_gemm_nn(_p(a), a.stride(0), _p(wt), wt.stride(0), _p(out), out.stride(0), M, N, K,
                                _p(residual), residual.stride(0) if residual is not None else 0, ep, _stream())

@@ -676,6 +676,12 @@ class TrainEngine:
             # the bf16-rounded product, bit for bit) and writes d(gate) | d(up) straight into the w1|w3 gradient buffer
             dgu_full, dgu = ybuf("dgu.x", 2 * F, f"w13.{i}")
             self._kx_group_bwd(i, f"w2.{i}", dha_full, dim, k["act"], lt["w2"], dgu, swiglu_gu=k["gu"])
+        elif (not self.lora and self.fuse_swiglu_bwd and self.nn_dgrad and self.act == torch.bfloat16 and dim % 64 == 0 and F % 8 == 0 and F >= 256
+              and dha.stride(0) % 8 == 0 and 2 * rows * dha.stride(0) < 2 ** 31 and 2 * F * dim < 2 ** 31
+              and tuple(im[f"w2.{i}"].shape) == (dim, F)):
+            # full fine-tune: the same epilogue on the NN kernel (dX = dY . W on the forward image)
+            dgu = self._buf("dgu", (rows, 2 * F))
+            ops.gemm_nn(dha, im[f"w2.{i}"], dgu, residual=k["gu"], epilogue=ops.EPI_SWIGLU_BWD)
         else:
             dact = self._buf("dact", (rows, F))
             if kx:

@@ -827,6 +827,15 @@ def test_gemm_swiglu_backward_epilogue_equals_gemm_then_swiglu_bwd(M, F, K, tile
     sig = torch.sigmoid(g)
     assert_close(got[:, :F], da * u * (sig * (1 + g * (1 - sig))), rtol=2 ** -6, atol=2e-2, what="d gate")
     assert_close(got[:, F:2 * F], da * (g * sig), rtol=2 ** -6, atol=2e-2, what="d up")
+    if K % 64 == 0 and tile == "auto":     # the NN form (full fine-tune: dX = dY . W on the forward image W [K, F])
+        wt = w.t().contiguous()
+        dact2 = torch.empty(M, F, dtype=BF, device=DEV)
+        ops.gemm_nn(dy, wt, dact2)
+        want2 = torch.full((M, 2 * F + 64), 5.0, dtype=BF, device=DEV)
+        ops.swiglu_bwd(gu, dact2, want2[:, :2 * F], F, interleaved=False)
+        got2 = torch.full((M, 2 * F + 64), 5.0, dtype=BF, device=DEV)
+        ops.gemm_nn(dy, wt, got2[:, :2 * F], residual=gu, epilogue=ops.EPI_SWIGLU_BWD)
+        assert torch.equal(got2, want2), int((got2 != want2).sum())
 
 
 def test_gemm_one_wave_per_simd_kernel_equals_ring_kernel():
