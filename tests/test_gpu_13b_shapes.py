@@ -154,3 +154,48 @@ def test_qkv_rope_and_attention_13b_heads():
             want = ref_cpu.sdpa(q, k, v, mask)[0, 0]
             got = att[b * S:(b + 1) * S, h * HD:(h + 1) * HD].float().cpu()
             assert float((got - want).abs().max()) < 2 ** -6 * float(want.abs().max()) + 4e-3, (b, h)
+
+
+@pytest.mark.parametrize("form", ["nt", "nn"])
+def test_gemm_swiglu_backward_epilogue_13b(form):
+    """The input gradient of w2 with the SwiGLU backward in its epilogue (A3V_EPI_SWIGLU_BWD) at the 13B shape: d(act) = dy [8728, 5120]
+    . W2 [5120, 13824], then d(gate) | d(up) from the forward's gate | up rows.  NT form (LoRA: over the transposed frozen image, with
+    the 64 adapter columns appended to K) and NN form (full fine-tune: on the forward image); a row sample against the fp32 formula on
+    the bf16-rounded product (llama_ens5.py:213-217 backward through autocast), every column."""
+    K = DIM + (64 if form == "nt" else 0)
+    dy = gen(ROWS, K, seed=41).to(BF)
+    w = gen(FFN, K, seed=42, scale=0.05).to(BF)                       # rows = ffn columns of d(act)
+    gu = gen(ROWS, 2 * FFN, seed=43).to(BF)
+    dyd, gud = dy.to(DEV), gu.to(DEV)
+    out = torch.full((ROWS, 2 * FFN + 64), float("nan"), dtype=BF, device=DEV)
+    if form == "nt":
+        ops.gemm_nt(dyd, w.to(DEV), out[:, :2 * FFN], residual=gud, epilogue=ops.EPI_SWIGLU_BWD)
+    else:
+        ops.gemm_nn(dyd, w.t().contiguous().to(DEV), out[:, :2 * FFN], residual=gud, epilogue=ops.EPI_SWIGLU_BWD)
+    assert bool(torch.isnan(out[:, 2 * FFN:].float()).all())          # nothing written past the [d gate | d up] window
+    rows = row_sample(ROWS, 44)
+    da = (dy[rows].float() @ w.float().t()).to(BF).float()            # the bf16 d(act) the un-fused path stores
+    g, u = gu[rows, :FFN].float(), gu[rows, FFN:].float()
+    sig = torch.sigmoid(g)
+    got = out[rows.to(DEV)].float().cpu()
+    for what, have, want in (("d gate", got[:, :FFN], da * u * (sig * (1 + g * (1 - sig)))), ("d up", got[:, FFN:2 * FFN], da * (g * sig))):
+        err = (have - want).abs()
+        # da itself carries the product's accumulation-order noise (one bf16 ulp of |da| where a rounding boundary is crossed)
+        bound = 2 ** -6 * want.abs() + 2 ** -7 * (da.abs() + 1e-3 * math.sqrt(K) * 0.05) * (u.abs() + g.abs() + 1) + 1e-3
+        assert not bool((err > bound).any()), f"{form} {what}: {int((err > bound).sum())} out of tolerance, max err {float(err.max()):.4g}"
+
+
+def test_gemm_tn_strip_13b_adapter_gradients():
+    """Adapter weight gradients at the 13B widths: dB^T = t^T . dy with dy [8728, 27648] (the fused w1|w3 group) and dA = dt^T . x with
+    x [8728, 13824] (w2's input), R = 48 / 16 real adapter columns inside the 64-wide K-extension block (model/peft.py:58-159)."""
+    for N, R, seed in ((2 * FFN, 32, 51), (FFN, 16, 52), (3 * DIM, 48, 53)):
+        t_full = gen(ROWS, 64, seed=seed).to(BF)
+        x = gen(ROWS, N, seed=seed + 10, scale=0.05).to(BF)
+        td, xd = t_full.to(DEV)[:, :R], x.to(DEV)
+        S = 16
+        out = torch.full((R, N), float("nan"), dtype=torch.float32, device=DEV)
+        ops.gemm_tn_strip(td, xd, out, torch.empty(S * R * N, dtype=torch.float32, device=DEV), S)
+        want = t_full[:, :R].float().t() @ x.float()
+        err = (out.cpu() - want).abs()
+        bound = 2 ** -7 * want.abs() + 2e-3 * math.sqrt(ROWS) * 0.05 + 1e-3
+        assert not bool((err > bound).any()), f"strip R={R} N={N}: max err {float(err.max()):.4g}"
