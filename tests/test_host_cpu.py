@@ -40,6 +40,19 @@ def test_ctypes_arity_matches_header(built):
         assert n == len(built.SIGNATURES[name][1]), name
 
 
+def test_epilogue_flags_match_the_header(built):
+    """The epilogue / tile flags of the Python host are the header's enum values (A3V_EPI_SWIGLU_BWD was added in round 3)."""
+    src = open(os.path.join(ROOT, "include", "a3vlm_hip.h")).read()
+    enum = {}
+    for name, val in re.findall(r"\b(A3V_EPI_\w+)\s*=\s*([^,/\n]+)", src):
+        enum[name] = int(eval(val.strip(), {"__builtins__": {}}))
+    for name, val in enum.items():
+        py = name[len("A3V_"):]
+        assert hasattr(built, py), f"{name} has no counterpart in a3vlm_amd.lib"
+        assert getattr(built, py) == val, (name, val, getattr(built, py))
+    assert enum["A3V_EPI_SWIGLU_BWD"] == 128
+
+
 def test_host_side_pure_functions(built):
     lib = built.load()
     assert lib.a3v_gemm_skinny_split(8, 4096, 4096) == 8
