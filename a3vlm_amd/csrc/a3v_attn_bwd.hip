@@ -545,6 +545,505 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs p) {
   }
 }
 
+// ------------------------------------------------------------------ dK + dV in ONE pass (round 4)
+// The two kernels above run two waves per SIMD at 254 VGPRs: no room to hold a fragment ahead of its MFMA, so hipcc emits
+// `ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma` 48 times per query tile and the matrix pipe waits out an LDS round trip per MFMA
+// (the partner wave of an unrelated block is the only cover): 0.14 of the MFMA peak, and S^T is recomputed in each of them.
+// Here a block is still 4 waves x 32 keys, but ONE wave per SIMD with the whole 512-register file, both accumulator sets
+// (dV^T, dK^T: 128 registers), K and V of the wave's keys (64) and a software pipeline over 32-query UNITS u = (pair, half):
+//     step u:   A(u+1)  S = Q K^T, dP = dO V^T of the NEXT unit      16 MFMAs, fragments fetched one step ahead
+//             ∥ B(u)    P = exp2(S sl2 - lse), dS = P o (dP - D)      ~100 VALU in the shadow of A's MFMAs
+//               C(u)    dV^T += dO^T P, dK^T += Q^T dS                16 MFMAs, transpose-read fragments fetched at the top of the step
+//             ∥ fetch the row fragments of A(u+2)
+// so every MFMA finds its operands in registers and the only synchronisation is one block barrier per pair (64 queries).
+// (Q, dO) pairs stream through a ring of FOUR LDS buffers by LDS-DMA, issued two iterations ahead of their first read.  4 tile products per
+// (query, key) tile pair instead of the 5 of the two-launch form; same fragment helpers, same arithmetic per element, same
+// per-accumulator MFMA order: the results are bit-identical to attn_bwd_dkv_kernel<.., 0 / 1, ..>.
+//
+// Register plan.  hipcc places the A / B operands of an MFMA builtin in arch VGPRs only and has no pressure-aware scheduling: with the
+// loop-invariant K / V fragments there the loop wants ~300 arch VGPRs, the invariants are spilled (a scratch reload + vmcnt(0) in front of
+// every MFMA), and two inlined copies of the step disagree on where the accumulators live (128 v_accvgpr_mov per step).  So the
+// accumulator file is OWNED BY HAND, as in the one-wave-per-SIMD attention forward of the programming guide: every MFMA of the loop is an
+// asm statement on literal AGPRs
+//     a[0:63] dV^T   a[64:127] dK^T   a[128:159] K fragments   a[160:191] V fragments   a[192:223] S, dP of even units   a[224:255] of odd units
+// with its A operand (and P / dS) in compiler-allocated VGPRs; S / dP are read back by asm v_accvgpr_read at the top of a step (the
+// MFMAs that wrote them are a whole C phase = 16 MFMAs back, far beyond the 18 wait states an XDL result needs) and the compiler never
+// sees an AGPR: tests/test_kernel_budget_cpu.py checks that the kernel has no scratch and no compiler-generated v_accvgpr_* (a compiler
+// spill into the owned range would be silent corruption).
+template <int I, int N, typename F>
+__device__ __forceinline__ void sfor(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); sfor<I + 1, N>(f); }
+}
+#define A3V_A16(b) "a" #b
+// every owned AGPR, as clobbers of the statement that initialises them (this is also what makes the kernel descriptor allocate them)
+#define A3V_CL8(p) "a" #p "0", "a" #p "1", "a" #p "2", "a" #p "3", "a" #p "4", "a" #p "5", "a" #p "6", "a" #p "7", "a" #p "8", "a" #p "9"
+#define A3V_AGPR_0_255 "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", A3V_CL8(1), A3V_CL8(2), A3V_CL8(3), A3V_CL8(4), A3V_CL8(5), A3V_CL8(6), \
+    A3V_CL8(7), A3V_CL8(8), A3V_CL8(9), A3V_CL8(10), A3V_CL8(11), A3V_CL8(12), A3V_CL8(13), A3V_CL8(14), A3V_CL8(15), A3V_CL8(16), A3V_CL8(17), \
+    A3V_CL8(18), A3V_CL8(19), A3V_CL8(20), A3V_CL8(21), A3V_CL8(22), A3V_CL8(23), A3V_CL8(24), "a250", "a251", "a252", "a253", "a254", "a255"
+// acc a[ACC:ACC+15] (+)= A (VGPRs) x B (VGPRs); the s_nop covers a VALU write of A / B right in front (hipcc pads nothing inside asm)
+template <int ACC>
+__device__ __forceinline__ void mfma_vv(const bf16x8& a, const bf16x8& b) {
+  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(a), "v"(b), "i"(ACC), "i"(ACC + 15) : A3V_AGPR_0_255);
+}
+// acc a[ACC:ACC+15] (ZERO ? = : +=) A (VGPRs) x a[BR:BR+3]
+template <int ACC, int BR, bool ZERO>
+__device__ __forceinline__ void mfma_va(const bf16x8& a) {
+  if constexpr (ZERO)
+    asm volatile("v_mfma_f32_32x32x16_bf16 a[%c1:%c2], %0, a[%c3:%c4], 0" ::"v"(a), "i"(ACC), "i"(ACC + 15), "i"(BR), "i"(BR + 3) : A3V_AGPR_0_255);
+  else
+    asm volatile("v_mfma_f32_32x32x16_bf16 a[%c1:%c2], %0, a[%c3:%c4], a[%c1:%c2]" ::"v"(a), "i"(ACC), "i"(ACC + 15), "i"(BR), "i"(BR + 3) : A3V_AGPR_0_255);
+}
+template <int R>
+__device__ __forceinline__ float agpr_read() {
+  float v;
+  asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(v) : "i"(R) : A3V_AGPR_0_255);
+  return v;
+}
+template <int R>
+__device__ __forceinline__ void agpr_write(unsigned v) {
+  asm volatile("v_accvgpr_write_b32 a[%c1], %0" ::"v"(v), "i"(R) : A3V_AGPR_0_255);
+}
+template <int R0>
+__device__ __forceinline__ f32x16 agpr_read16() {
+  f32x16 v;
+  sfor<0, 16>([&](auto i) { v[decltype(i)::value] = agpr_read<R0 + decltype(i)::value>(); });
+  return v;
+}
+
+// LDS-DMA as asm statements: hipcc orders every LDS read it cannot prove disjoint from an outstanding `buffer_load .. lds` BUILTIN behind
+// `s_waitcnt vmcnt(0)` -- with a ring buffer chosen at run time that is a full memory round trip in front of the first fragment read of every
+// step.  The asm form is invisible to that bookkeeping (completion = this kernel's own `s_waitcnt vmcnt` + barrier); M0 (the LDS destination)
+// is written in the statement that reads it; `s_nop 4` in front covers descriptor words fresh from a v_readfirstlane.
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+__device__ __forceinline__ void dma16_asm(i32x4_t rs, unsigned lds_addr, unsigned voff) {
+  asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs) : "memory", A3V_AGPR_0_255);
+}
+__device__ __forceinline__ void dma4_asm(i32x4_t rs, unsigned lds_addr, unsigned voff) {
+  asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs) : "memory", A3V_AGPR_0_255);
+}
+__device__ __forceinline__ i32x4_t make_rsrc(const void* base, int bytes) {
+  const uint64_t a = (uint64_t)base;
+  i32x4_t r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+  r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32) & 0xffff);
+  r[2] = __builtin_amdgcn_readfirstlane(bytes);
+  r[3] = 0x00020000;
+  return r;
+}
+template <int HD>
+__device__ __forceinline__ void stage_rows_dma_asm(const bf16_t* base, int64_t row_stride, int row0, int nrows, unsigned lds_addr, unsigned voff0, int wave) {
+  int64_t left = ((int64_t)(nrows - 1 - row0) * row_stride + HD) * 2;                // bytes from the tile's first row to the end of the last valid row
+  if (left < 0) left = 0;                                                            // the whole tile lies past the last row: zeros, no access
+  const i32x4_t rs = make_rsrc(base + (int64_t)(left ? row0 : 0) * row_stride, (int)(left < 0x7fffffff ? left : 0x7fffffff));
+  const unsigned step = dma_step<HD>(row_stride);
+#pragma unroll
+  for (int i = 0; i < 64 * (HD / 8) / 256; ++i) dma16_asm(rs, lds_addr + (wave * 64 + i * 256) * 16, voff0 + i * step);
+}
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+template <int HD>
+__device__ __forceinline__ bf16x8 frag_rows_tr2(const char* lds, TrBase tb0, int db, int tb, int c) {
+  const char* blk = lds + (32 * tb + 16 * c) * (HD * 2);
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(blk + (tb0.lo ^ (db << 6))));
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(blk + (tb0.hi ^ (db << 6))));
+  const s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int HD, bool PACKED>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(BwdArgs p) {
+  constexpr int TILE = 64 * HD * 2;
+  constexpr int BUFB = 2 * TILE + 1024;            // [Q rows | dO rows | lse[64] D[64] ...]
+  constexpr int NKS = HD / 16, NDB = HD / 32;
+  constexpr int RV = 0, RK = 64, RKF = 128, RVF = 160, RS = 192, RDP = 208;      // the owned AGPR ranges (see above); S / dP: set (unit & 1) at + 32
+  constexpr int NB = 4;                            // ring depth: pairs are issued two iterations ahead of their use
+  __shared__ __attribute__((aligned(1024))) char lds[NB * BUFB + 4096];    // + a 1-KiB landing patch per wave for the pieces of an iteration that has no pair to fetch
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef AB_STAMP
+  unsigned long long* tl = (p.stamps && tid == 0) ? p.stamps + 4096 + 8 * blockIdx.x : nullptr;
+  if (tl) { tl[0] = __builtin_amdgcn_s_memrealtime(); tl[4] = __builtin_amdgcn_s_getreg(0x0004 | (0 << 6) | (31 << 11)); tl[5] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)); }
+#endif
+  int head_slot, kt_;
+  xcd_head_tile((p.S + 127) / 128, head_slot, kt_, p.group_kv);
+  const int b = head_slot / p.Hkv, hk = head_slot - b * p.Hkv;
+  const int nrep = p.H / p.Hkv;
+  const int kl = lane & 31, hh = lane >> 5;
+  const int kv_lo = kt_ * 128 + wave * 32;         // wave-uniform: first key of this wave
+  const int kvrow = kv_lo + kl;
+  const int kc = kvrow < p.S ? kvrow : p.S - 1;
+  asm volatile("" ::: A3V_AGPR_0_255);
+  const float sl2 = p.scale * 1.4426950408889634f;
+  const int q_begin = p.causal ? kt_ * 2 : 0;      // first 64-query tile that can see this block's keys
+  const int n_qt = (p.S + 63) / 64;
+  const int n_it = n_qt - q_begin, total = nrep * n_it;
+  const unsigned qoff = dma_lane_offset0<HD>((int64_t)p.H * HD, tid);
+  const int fbase = frag_rows_base<HD>(kl, hh);
+  const TrBase trb = tr_bases<HD>(lane);
+
+  int rep_n = 0, qi_n = 0, buf_n = 0;              // (head repetition, query tile, ring buffer) of the next pair to issue
+  const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)lds);
+  // One pair = PP / 2 pieces of the Q tile + PP / 2 of the dO tile + one 256-byte piece (lse: wave 0, D: wave 1) per wave.  EVERY iteration
+  // issues exactly PP + 1 pieces per wave -- an iteration with no pair left to fetch sends them through a zero-length descriptor (no memory
+  // request, zeros) into the wave's landing patch -- so "pair i landed" is always "at most (PP + 1) x (pairs issued after i) outstanding", and
+  // the pieces are issued ONE PER K-STEP between the MFMAs of an iteration's first step (a burst of nine costs the lone wave ~800 cycles).
+  constexpr int PP = HD / 16;
+  i32x4_t rsQ, rsO, rsX;
+  unsigned dmaQ, dmaO, dmaX, dma_step_i, voffX;
+  const unsigned qstep = dma_step<HD>((int64_t)p.H * HD);
+  // descriptor state of the next pair to issue, advanced incrementally (the from-scratch form cost ~500 cycles of 64-bit scalar multiplies per pair)
+  const int64_t rstride = (int64_t)p.H * HD;
+  const uint64_t pairB = (uint64_t)(64 * rstride * 2);                                      // bytes from one 64-query tile to the next (Q, dO)
+  uint64_t aQ = (uint64_t)(p.q + ((int64_t)b * p.S * p.H + hk * nrep) * HD + (int64_t)q_begin * 64 * rstride);
+  uint64_t aO = (uint64_t)(p.dout + ((int64_t)b * p.S * p.H + hk * nrep) * HD + (int64_t)q_begin * 64 * rstride);
+  uint64_t aL = (uint64_t)(p.lse + ((int64_t)b * p.H + hk * nrep) * p.S + q_begin * 64);
+  uint64_t aD = (uint64_t)(p.D + ((int64_t)b * p.S + q_begin * 64) * p.H + hk * nrep);
+  int64_t leftQ = ((int64_t)(p.S - 1 - q_begin * 64) * rstride + HD) * 2;                    // bytes from the tile's first row to the end of the last valid row
+  int rowsL = p.S - q_begin * 64;                                                            // query rows left from the tile's first row
+  voffX = (wave == 1) ? lane * p.H * 4 : lane * 4;
+  auto mk = [&](uint64_t a, int bytes) __attribute__((always_inline)) {
+    i32x4_t r;
+    r[0] = (int)(unsigned)a; r[1] = (int)(unsigned)(a >> 32) & 0xffff; r[2] = bytes; r[3] = 0x00020000;
+    return r;
+  };
+  auto prep_issue = [&](bool real) __attribute__((always_inline)) {
+    const unsigned buf = lds0 + buf_n * BUFB, patch = lds0 + NB * BUFB + wave * 1024;
+    const int nb = real ? (int)(leftQ < 0x7fffffff ? leftQ : 0x7fffffff) : 0;
+    rsQ = mk(aQ, nb);
+    rsO = mk(aO, nb);
+    dmaQ = real ? buf + wave * 1024 : patch;
+    dmaO = real ? buf + TILE + wave * 1024 : patch;
+    dma_step_i = real ? 4096u : 0u;
+    if (wave == 0) { rsX = mk(aL, real ? rowsL * 4 : 0); dmaX = real ? buf + 2 * TILE : patch; }
+    else if (wave == 1) { rsX = mk(aD, real ? ((rowsL - 1) * p.H + 1) * 4 : 0); dmaX = real ? buf + 2 * TILE + 256 : patch; }
+    else { rsX = mk(aL, 0); dmaX = patch; }
+    if (real) {
+      if (++buf_n == NB) buf_n = 0;
+      if (++qi_n == n_it) {                        // next head repetition of the group: back to the first query tile
+        qi_n = 0; ++rep_n;
+        const int64_t back = (int64_t)(n_it - 1) * 64;
+        aQ += (uint64_t)(HD * 2) - (uint64_t)(back * rstride * 2); aO += (uint64_t)(HD * 2) - (uint64_t)(back * rstride * 2);
+        aL += (uint64_t)((int64_t)p.S * 4) - (uint64_t)(back * 4); aD += 4 - (uint64_t)(back * p.H * 4);
+        leftQ += back * rstride * 2; rowsL += (int)back;
+      } else {
+        aQ += pairB; aO += pairB; aL += 256; aD += (uint64_t)(64 * p.H * 4);
+        leftQ -= (int64_t)pairB; rowsL -= 64;
+      }
+    }
+  };
+  auto piece = [&](auto i_) __attribute__((always_inline)) {
+    constexpr int i = decltype(i_)::value;
+    if constexpr (i < PP / 2) dma16_asm(rsQ, dmaQ + i * dma_step_i, qoff + i * qstep);
+    else if constexpr (i < PP) dma16_asm(rsO, dmaO + (i - PP / 2) * dma_step_i, qoff + (i - PP / 2) * qstep);
+    else dma4_asm(rsX, dmaX, voffX);
+  };
+  auto issue = [&](bool real) __attribute__((always_inline)) {            // the whole pair in one burst (prologue)
+    prep_issue(real);
+    sfor<0, PP + 1>([&](auto i_) { piece(i_); });
+  };
+
+  bf16x8 qa[NKS], da[NKS];                         // row fragments (A operands) of the NEXT unit's S / dP products
+  auto fetch = [&](const char* buf, int tb) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      qa[ks] = frag_rows<HD>(buf, fbase, tb, ks);
+      da[ks] = frag_rows<HD>(buf + TILE, fbase, tb, ks);
+    }
+  };
+  auto dead = [&](int qr0) { return qr0 >= p.S || (p.causal && qr0 + 31 < kv_lo); };        // no (query, key) of the unit is visible
+  auto interior = [&](int qr0) { return qr0 + 32 <= p.S && kv_lo + 31 < p.S && (!p.causal || qr0 >= kv_lo + 31); };
+
+#ifdef AB_STAMP
+  unsigned long long* stamps = (p.stamps && blockIdx.x == AB_STAMP && tid == 0) ? p.stamps : nullptr;
+  int cur_it = 0;
+#endif
+  // One pipeline step.  DA: run A (S, dP of the next unit, from qa / da).  DBC: run B and C of the current unit (its pair in `cb`, half
+  // `tbc`, first query row qr0).  MASK: the unit has invisible (query, key) pairs.  Then fetch the fragments of the unit after next.
+  // Instruction ORDER is the whole game for a lone wave: it issues in order, so an MFMA behind an MFMA stalls the wave until the pipe takes
+  // it (32 cycles) and nothing else issues meanwhile, and an LDS read costs its share of the CU's 256 B/clk while the other three waves read
+  // too (~16 cycles per b128, ~8 per transpose read).  Two MFMAs back to back + 16 other instructions per k-step measured 62 cycles per MFMA
+  // in A || B and 69 in C (tools/attn_bwd_stamps.py); the stream below alternates ONE MFMA with its share of the other work everywhere:
+  //   A || B, per k-step:  S MFMA | DMA piece, AGPR reads + fma + exp of element pair ks | dP MFMA | mul + cvt of pair ks - 1 (its
+  //                        exponentials were issued a whole MFMA earlier), one transpose-read pair of C's first half, lse / D of the next group
+  //   C, first half:       MFMA | 2 transpose reads of the second half + 1 row fragment of A(u + 2)      (x 2 NDB)
+  //   C, second half:      MFMA | 1 row fragment of A(u + 2)                                               (x 2 NDB)
+  // asm volatile statements (MFMAs, AGPR reads, DMA pieces, the empty `pin`s) keep their source order; pin(x) forces x to be computed in
+  // front of the next MFMA, a "memory" clobber keeps LDS reads on their side of it.
+  auto step = [&](auto DA_, auto DBC_, auto MASK_, auto TBC_, const char* cb, int qr0, const char* fb, int tbf) __attribute__((always_inline)) {
+    constexpr bool DA = decltype(DA_)::value, DBC = decltype(DBC_)::value, MASK = decltype(MASK_)::value;
+    constexpr int tbc = decltype(TBC_)::value;          // half of the current unit = its S / dP register set; A writes the other set
+    constexpr int RSC = RS + 32 * tbc, RDC = RDP + 32 * tbc, RSN = RS + 32 * (1 - tbc), RDN = RDP + 32 * (1 - tbc);
+    constexpr int EPK = 16 / NKS;                  // elements of B per k-step of A (2 at hd 128, 4 at hd 64)
+    bf16x8 trO[2][NDB], trQ[2][NDB], bP[2], bS[2];
+    f32x4 l4[4], d4[4];
+    float ex[EPK], dd[EPK];                        // exponentials and (dP - D) of the element group whose mul + cvt half is still to come
+    const float* sm = reinterpret_cast<const float*>(cb + 2 * TILE) + tbc * 32 + 4 * hh;
+    if constexpr (DBC) {                           // lse / D of query rows 8 g + 4 hh + 0..3 of the unit; group g + 1 is requested while group g is used
+      l4[0] = *reinterpret_cast<const f32x4*>(sm);
+      d4[0] = *reinterpret_cast<const f32x4*>(sm + 64);
+    }
+    auto finish = [&](auto kp_) __attribute__((always_inline)) {      // mul + cvt half of element group kp
+      constexpr int kp = decltype(kp_)::value;
+#pragma unroll
+      for (int j = 0; j < EPK; ++j) {
+        const int r = kp * EPK + j;
+        bP[r >> 3][r & 7] = f2bf(ex[j]);
+        bS[r >> 3][r & 7] = f2bf(ex[j] * dd[j]);
+      }
+      // the packed words of this group (EPK / 2 dwords of each operand) must exist in front of the next MFMA
+      u32x4 wP, wS;
+      __builtin_memcpy(&wP, &bP[(kp * EPK) >> 3], 16);
+      __builtin_memcpy(&wS, &bS[(kp * EPK) >> 3], 16);
+      constexpr int w0 = ((kp * EPK) & 7) / 2;
+      if constexpr (EPK == 2) asm volatile("" : "+v"(wP[w0]), "+v"(wS[w0]));
+      else asm volatile("" : "+v"(wP[w0]), "+v"(wP[w0 + 1]), "+v"(wS[w0]), "+v"(wS[w0 + 1]));
+      __builtin_memcpy(&bP[(kp * EPK) >> 3], &wP, 16);
+      __builtin_memcpy(&bS[(kp * EPK) >> 3], &wS, 16);
+    };
+    sfor<0, NKS>([&](auto ks_) {
+      constexpr int ks = decltype(ks_)::value;
+      if constexpr (DA) mfma_va<RSN, RKF + 4 * ks, ks == 0>(qa[ks]);
+      if constexpr (tbc == 0) piece(ks_);          // this iteration's DMA pieces: one per k-step of its first step (PP == NKS)
+      float en[EPK], dn[EPK];
+      if constexpr (DBC) {
+        constexpr int g4 = (ks * EPK) >> 2;
+        sfor<0, EPK>([&](auto j_) {
+          constexpr int j = decltype(j_)::value, r = ks * EPK + j, e = r & 3;
+          const float sv = agpr_read<RSC + r>();
+          const float dv = agpr_read<RDC + r>();
+          float a = fmaf(sv, sl2, -1.4426950408889634f * l4[g4][e]);
+          if constexpr (MASK) {
+            const int qg = qr0 + 8 * g4 + 4 * hh + e;
+            const bool ok = (qg < p.S) && (kvrow < p.S) && (!p.causal || kvrow <= qg);
+            a = ok ? a : -INFINITY;                // exp2(-inf) = 0: the select sits in front of the exponential (no exec branch per element)
+          }
+          en[j] = __builtin_amdgcn_exp2f(a);
+          dn[j] = dv - d4[g4][e];
+        });
+        if constexpr (EPK == 2) asm volatile("" : "+v"(en[0]), "+v"(en[1]), "+v"(dn[0]), "+v"(dn[1]));
+        else asm volatile("" : "+v"(en[0]), "+v"(en[1]), "+v"(en[2]), "+v"(en[3]), "+v"(dn[0]), "+v"(dn[1]), "+v"(dn[2]), "+v"(dn[3]));
+      }
+      if constexpr (DA) mfma_va<RDN, RVF + 4 * ks, ks == 0>(da[ks]);
+      if constexpr (DBC) {
+        if constexpr (ks > 0) finish(std::integral_constant<int, ks - 1>{});
+#pragma unroll
+        for (int j = 0; j < EPK; ++j) { ex[j] = en[j]; dd[j] = dn[j]; }
+        if constexpr (ks < NDB) {                  // the transpose-read fragments of C's first half (query rows 0-15 of the unit), one (dO^T, Q^T) pair per k-step
+          trO[0][ks] = frag_rows_tr2<HD>(cb + TILE, trb, ks, tbc, 0);
+          trQ[0][ks] = frag_rows_tr2<HD>(cb, trb, ks, tbc, 0);
+        }
+        constexpr int gn = ((ks * EPK) >> 2) + 1;  // lse / D of the next group, requested when the current group's first elements are read
+        if constexpr (((ks * EPK) & 3) == 0 && gn < 4) {
+          l4[gn] = *reinterpret_cast<const f32x4*>(sm + 8 * gn);
+          d4[gn] = *reinterpret_cast<const f32x4*>(sm + 64 + 8 * gn);
+        }
+        asm volatile("" ::: "memory");             // pins the LDS reads above to this k-step (hipcc would hoist them all to the top: +60 VGPRs)
+      }
+    });
+    if constexpr (tbc == 0) piece(std::integral_constant<int, PP>{});
+    if constexpr (DBC) finish(std::integral_constant<int, NKS - 1>{});
+    asm volatile("" ::: "memory");
+#ifdef AB_STAMP
+    if (stamps && cur_it < 64) stamps[(64 + cur_it) * 8 + 6 + tbc] = __builtin_amdgcn_s_memtime();
+#endif
+    // C: dV^T += dO^T P, dK^T += Q^T dS
+    constexpr int FPD = NKS / NDB;                 // row-fragment k-steps per d block (2)
+    sfor<0, NDB>([&](auto d_) {
+      constexpr int d = decltype(d_)::value;
+      if constexpr (DBC) {
+        mfma_vv<RV + 16 * d>(trO[0][d], bP[0]);
+        trO[1][d] = frag_rows_tr2<HD>(cb + TILE, trb, d, tbc, 1);
+      }
+      qa[d * FPD] = frag_rows<HD>(fb, fbase, tbf, d * FPD);
+      asm volatile("" ::: "memory");
+      if constexpr (DBC) {
+        mfma_vv<RK + 16 * d>(trQ[0][d], bS[0]);
+        trQ[1][d] = frag_rows_tr2<HD>(cb, trb, d, tbc, 1);
+      }
+      da[d * FPD] = frag_rows<HD>(fb + TILE, fbase, tbf, d * FPD);
+      asm volatile("" ::: "memory");
+    });
+    sfor<0, NDB>([&](auto d_) {
+      constexpr int d = decltype(d_)::value;
+      if constexpr (DBC) mfma_vv<RV + 16 * d>(trO[1][d], bP[1]);
+#pragma unroll
+      for (int ks = d * FPD + 1; ks < (d + 1) * FPD; ++ks) qa[ks] = frag_rows<HD>(fb, fbase, tbf, ks);
+      asm volatile("" ::: "memory");
+      if constexpr (DBC) mfma_vv<RK + 16 * d>(trQ[1][d], bS[1]);
+#pragma unroll
+      for (int ks = d * FPD + 1; ks < (d + 1) * FPD; ++ks) da[ks] = frag_rows<HD>(fb + TILE, fbase, tbf, ks);
+      asm volatile("" ::: "memory");
+    });
+    if constexpr (DA && !DBC) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory", A3V_AGPR_0_255);   // A's results -> the next step's AGPR reads with no C phase in between
+  };
+  using T_ = std::true_type; using F_ = std::false_type;
+  // cur live (+ next live or dead): the full step (A on a dead next unit multiplies fragments nobody reads: harmless, and only at the end of a
+  // block); cur dead + next live: A only (the first units of waves 1-3 of a causal block); both dead: fetch only.
+  auto run = [&](bool lc, bool ln, bool mk, auto tbc, const char* cb, int qr0, const char* fb, int tbf) __attribute__((always_inline)) {
+    if (lc) {
+      if (mk) step(T_{}, T_{}, T_{}, tbc, cb, qr0, fb, tbf);
+      else step(T_{}, T_{}, F_{}, tbc, cb, qr0, fb, tbf);
+    } else if (ln) {
+      step(T_{}, F_{}, F_{}, tbc, cb, qr0, fb, tbf);
+    } else {
+      step(F_{}, F_{}, F_{}, tbc, cb, qr0, fb, tbf);
+    }
+  };
+
+  // ---- prologue: pairs 0, 1, 2 in flight; A(0) and the fragments of A(1) from pair 0
+#ifdef AB_STAMP
+#define AB_PE(k) do { if (stamps) stamps[2 * 64 * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define AB_PE(k) do {} while (0)
+#endif
+  // K and V rows of the block's 128 keys go through LDS like every other tile -- ring buffers 2 and 3, free until pairs 2 / 3 are issued --
+  // by coalesced LDS-DMA, and each wave reads its keys' fragments (B operands of S = Q K^T and dP = dO V^T) back with ds_read_b128.  The
+  // first build loaded them straight into registers, 16 bytes per lane at a 256-byte stride: 1024 sector requests per wave, ~4 us per
+  // block of pure address-unit time in front of the first MFMA (tools/attn_bwd_timeline.py).  Pair 0 is issued first, pair 1 once the
+  // fragments sit in their AGPRs, pair 2 between the MFMAs of A(0).
+  AB_PE(0);
+#ifdef AB_STAMP
+  if (tl) tl[6] = __builtin_amdgcn_s_memrealtime();
+#endif
+  issue(true);
+#ifdef AB_STAMP
+  if (tl) tl[7] = __builtin_amdgcn_s_memrealtime();
+#endif
+  {
+    const bf16_t* Kb = p.k + b * p.k_sb + hk * p.k_sh;
+    const bf16_t* Vb = p.v + b * p.v_sb + hk * p.v_sh;
+    const unsigned kvoffK = dma_lane_offset0<HD>(HD, tid), kvoffV = dma_lane_offset0<HD>(p.v_ss, tid);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {                    // two 64-key tiles each
+      stage_rows_dma_asm<HD>(Kb, HD, kt_ * 128 + 64 * t, p.S, lds0 + 2 * BUFB + t * TILE, kvoffK, wave);
+      stage_rows_dma_asm<HD>(Vb, p.v_ss, kt_ * 128 + 64 * t, p.S, lds0 + 3 * BUFB + t * TILE, kvoffV, wave);
+    }
+    sfor<0, 128>([&](auto i) { agpr_write<decltype(i)::value>(0u); });       // dV^T / dK^T = 0 while the tiles fly
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory", A3V_AGPR_0_255);
+    __syncthreads();
+    const char* Kt = lds + 2 * BUFB + (wave >> 1) * TILE;                     // this wave's 32 keys: rows 32 (wave & 1) .. of tile wave >> 1
+    const char* Vt = lds + 3 * BUFB + (wave >> 1) * TILE;
+    sfor<0, NKS>([&](auto ks_) {
+      constexpr int ks = decltype(ks_)::value;
+      const bf16x8 kq = frag_rows<HD>(Kt, fbase, wave & 1, ks), vq = frag_rows<HD>(Vt, fbase, wave & 1, ks);
+      u32x4 ku, vu;
+      __builtin_memcpy(&ku, &kq, 16);
+      __builtin_memcpy(&vu, &vq, 16);
+      sfor<0, 4>([&](auto j) {
+        agpr_write<RKF + 4 * ks + decltype(j)::value>(ku[decltype(j)::value]);
+        agpr_write<RVF + 4 * ks + decltype(j)::value>(vu[decltype(j)::value]);
+      });
+    });
+    __syncthreads();                                  // every wave has its fragments: buffers 2 / 3 may take pairs 2 / 3
+  }
+  AB_PE(1);
+  // (pair 0 landed with the K / V tiles: one wait above)
+  AB_PE(2);
+  issue(total > 1);
+  AB_PE(3);
+  fetch(lds, 0);
+  prep_issue(total > 2);
+  sfor<0, NKS>([&](auto ks_) {
+    constexpr int ks = decltype(ks_)::value;
+    mfma_va<RS, RKF + 4 * ks, ks == 0>(qa[ks]);
+    piece(ks_);
+    mfma_va<RDP, RVF + 4 * ks, ks == 0>(da[ks]);
+  });
+  piece(std::integral_constant<int, PP>{});
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory", A3V_AGPR_0_255);
+  fetch(lds, 1);
+  AB_PE(4);
+  int qi_c = 0, buf_c = 0;
+#ifdef AB_STAMP
+  if (tl) tl[1] = __builtin_amdgcn_s_memrealtime();
+#endif
+  for (int it = 0; it < total; ++it) {
+    const int q0 = (q_begin + qi_c) * 64;
+    if (++qi_c == n_it) qi_c = 0;
+    const int q0x = (q_begin + qi_c) * 64;                        // first query row of the next pair (if there is one)
+    const char* cb = lds + buf_c * BUFB;
+    if (++buf_c == NB) buf_c = 0;
+    const char* xb = lds + buf_c * BUFB;                          // the next pair's buffer
+    const bool more = it + 1 < total;
+#ifdef AB_STAMP
+    cur_it = it;
+#endif
+    AB_ST(1, it, 0);
+    // pair it + 1 (issued two iterations ago) has landed -- the pieces of pair it + 2 may still be in flight; every wave is done with pair
+    // it - 1, whose buffer pair it + 3 goes to (its pieces ride between the MFMAs of the step below)
+    if constexpr (PP == 8) asm volatile("s_waitcnt vmcnt(9)" ::: "memory", A3V_AGPR_0_255); else asm volatile("s_waitcnt vmcnt(5)" ::: "memory", A3V_AGPR_0_255);
+    AB_ST(1, it, 1);
+    __syncthreads();
+    AB_ST(1, it, 2);
+    prep_issue(it + 3 < total);
+    AB_ST(1, it, 3);
+    const bool l0 = !dead(q0), l1 = !dead(q0 + 32), lx = more && !dead(q0x);
+    run(l0, l1, !interior(q0), std::integral_constant<int, 0>{}, cb, q0, xb, 0);
+    AB_ST(1, it, 4);
+    run(l1, lx, !interior(q0 + 32), std::integral_constant<int, 1>{}, cb, q0 + 32, xb, 1);
+    AB_ST(1, it, 5);
+  }
+#ifdef AB_STAMP
+  if (tl) tl[2] = __builtin_amdgcn_s_memrealtime();
+#endif
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory", A3V_AGPR_0_255);               // the last MFMAs -> the AGPR reads below
+  AB_PE(5);
+  // Epilogue: both 32 x HD tiles of the wave leave through private LDS patches (the ring is free after one more barrier) as whole rows, 16
+  // bytes per lane (per-lane row stores put 16 bytes into each of 32 rows per instruction: ~7 B/clk/CU, 4.6 us per block in the first
+  // build); packed mode: dK rotated back by -theta (LLM/llama_ens5.py:123-135 backward), its cos / sin rows requested before anything else
+  const float* CS = PACKED ? p.cos_sin + (int64_t)(p.rope_pos0 + kc) * HD : nullptr;
+  f32x4 cs[NDB][4];
+  if constexpr (PACKED) {
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) cs[d][g4] = *reinterpret_cast<const f32x4*>(CS + d * 32 + g4 * 8 + hh * 4);
+  }
+  __syncthreads();
+  AB_PE(6);
+  char* patchV = lds + wave * (32 * HD * 2);
+  char* patchK = lds + 4 * (32 * HD * 2) + wave * (32 * HD * 2);
+  const int wx = (kl & (HD / 8 - 1)) << 1;
+  sfor<0, NDB>([&](auto d_) {
+    constexpr int d = decltype(d_)::value;
+    const f32x16 av = agpr_read16<RV + 16 * d>();
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      bf16x4 ov;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ov[e] = f2bf(av[g4 * 4 + e]);
+      *reinterpret_cast<bf16x4*>(patchV + kl * (HD * 2) + (((d * 8 + g4 * 2 + hh) ^ wx) << 3)) = ov;
+    }
+  });
+  bf16_t* baseV = PACKED ? p.dqkv + (int64_t)b * p.S * p.ld_qkv + (int64_t)(p.H + p.Hkv + hk) * HD : p.dv + ((int64_t)b * p.Hkv + hk) * p.S * HD;
+  bf16_t* baseK = PACKED ? p.dqkv + (int64_t)b * p.S * p.ld_qkv + (int64_t)(p.H + hk) * HD : p.dk + ((int64_t)b * p.Hkv + hk) * p.S * HD;
+  const int64_t ldo = PACKED ? p.ld_qkv : HD;
+  store_patch_rows<HD>(patchV, baseV, ldo, kv_lo, p.S, lane);
+  AB_PE(7);
+  sfor<0, NDB>([&](auto d_) {
+    constexpr int d = decltype(d_)::value;
+    f32x16 ak = agpr_read16<RK + 16 * d>();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ak[r] *= p.scale;          // dS was formed without the 1 / sqrt(hd) factor (see the dQ kernel)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      float v0 = ak[g4 * 4 + 0], v1 = ak[g4 * 4 + 1], v2 = ak[g4 * 4 + 2], v3 = ak[g4 * 4 + 3];
+      bf16x4 ok;
+      if constexpr (PACKED) {
+        const f32x4 c4 = cs[d][g4];
+        ok[0] = f2bf(v0 * c4[0] + v1 * c4[1]); ok[1] = f2bf(-v0 * c4[1] + v1 * c4[0]);
+        ok[2] = f2bf(v2 * c4[2] + v3 * c4[3]); ok[3] = f2bf(-v2 * c4[3] + v3 * c4[2]);
+      } else {
+        ok[0] = f2bf(v0); ok[1] = f2bf(v1); ok[2] = f2bf(v2); ok[3] = f2bf(v3);
+      }
+      *reinterpret_cast<bf16x4*>(patchK + kl * (HD * 2) + (((d * 8 + g4 * 2 + hh) ^ wx) << 3)) = ok;
+    }
+  });
+  store_patch_rows<HD>(patchK, baseK, ldo, kv_lo, p.S, lane);
+  AB_PE(8);
+#ifdef AB_STAMP
+  if (tl) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tl[3] = __builtin_amdgcn_s_memrealtime(); }
+#endif
+}
+
 }  // namespace
 
 // declared in a3v_train.hip
@@ -597,11 +1096,17 @@ static int attention_bwd_mfma_impl(const void* q, const void* k, int64_t k_sb, i
   };
   p.group_q = group_of(B * H, gq.x);
   p.group_kv = group_of(B * Hkv, gk.x);
+  // A3V_ATTN_BWD_V2 (default 1): dK and dV by the one-pass, one-wave-per-SIMD kernel (0: the two round-1 launches; A/B and equality tests)
+  const int v2 = A3V_ENV_INT("A3V_ATTN_BWD_V2", 1);
 #define A3V_BWD_LAUNCH(HDV, PK)                                                                  \
   do {                                                                                           \
     hipLaunchKernelGGL((attn_bwd_dq_kernel<HDV, PK>), gq, dim3(256), 0, st, p);                  \
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDV, 0, PK>), gk, dim3(256), 0, st, p);              \
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDV, 1, PK>), gk, dim3(256), 0, st, p);              \
+    if (v2 & 1) {                                                                                \
+      hipLaunchKernelGGL((attn_bwd_dkv2_kernel<HDV, PK>), gk, dim3(256), 0, st, p);              \
+    } else {                                                                                     \
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDV, 0, PK>), gk, dim3(256), 0, st, p);            \
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDV, 1, PK>), gk, dim3(256), 0, st, p);            \
+    }                                                                                            \
   } while (0)
   if (hd == 128) {
     if (dqkv) A3V_BWD_LAUNCH(128, true); else A3V_BWD_LAUNCH(128, false);

@@ -28,6 +28,21 @@ __global__ __launch_bounds__(256) void rows_ssq_kernel(const bf16_t* __restrict_
 }
 }  // namespace
 
+// Which form a3v_llama_decode_step takes for a geometry, decided BEFORE anything is launched: 2 = the fused five-launch form, 1 = the
+// per-kernel form (<= 16 rows, bf16 weights), 0 = not taken (A3V_ERR_SHAPE up front; the host runs its general path on untouched state).
+static int decode_step_form(int B, int dim, int H, int Hkv, int hd, int ffn, int w8) {
+  if (B <= 0 || B > 32) return 0;
+  const int64_t ldq = (int64_t)(H + 2 * Hkv) * hd;
+  const int Bc = B > 16 ? (B + 1) / 2 : B;
+  const bool fused = (hd == 64 || hd == 128) && dim % 16 == 0 && dim / 16 * 16 * 4 <= A3V_WS_PARTIALS - A3V_WS_SSQ &&
+                     a3v_gemv_supported(Bc, (int)ldq, dim, 0, w8) && a3v_gemv_supported(Bc, dim, H * hd, A3V_EPI_RESIDUAL, w8) &&
+                     a3v_gemv_supported(Bc, 2 * ffn, dim, A3V_EPI_SWIGLU, w8) && a3v_gemv_supported(Bc, dim, ffn, A3V_EPI_RESIDUAL, w8) &&
+                     ldq % 16 == 0 && (2 * ffn) % 32 == 0 && Bc * H * (int)sizeof(int) <= A3V_WS_SSQ - A3V_WS_ATTN_COUNTERS;
+  if (fused) return 2;
+  return (w8 || B > 16) ? 0 : 1;
+}
+extern "C" int a3v_llama_decode_step_form(int B, int dim, int H, int Hkv, int hd, int ffn, int w8) { return decode_step_form(B, dim, H, Hkv, hd, ffn, w8); }
+
 extern "C" int a3v_llama_decode_step(const a3v_llama_layer* layers, int n_layers, void* h, void* xn, void* qkv, void* att,
                                      void* act, float* attn_scratch, void* skinny_ws, const float* cos_sin, int B, int dim, int H, int Hkv,
                                      int hd, int ffn, int Smax, int pos, float eps, void* stream) {
@@ -49,16 +64,12 @@ extern "C" int a3v_llama_decode_step(const a3v_llama_layer* layers, int n_layers
   // cache rows), so a batch of 17..32 runs as two row chunks through the same fused launches: the weights are streamed once per
   // chunk (a 32-row batch costs two 16-row steps, i.e. the 16-row tok/s), every buffer is addressed at its row offset.
   const int Bc = B > 16 ? (B + 1) / 2 : B;
-  const bool fused = (hd == 64 || hd == 128) && dim % 16 == 0 && dim / 16 * 16 * 4 <= A3V_WS_PARTIALS - A3V_WS_SSQ &&
-                     a3v_gemv_supported(Bc, (int)ldq, dim, 0, w8) && a3v_gemv_supported(Bc, dim, H * hd, A3V_EPI_RESIDUAL, w8) &&
-                     a3v_gemv_supported(Bc, 2 * ffn, dim, A3V_EPI_SWIGLU, w8) && a3v_gemv_supported(Bc, dim, ffn, A3V_EPI_RESIDUAL, w8) &&
-                     ldq % 16 == 0 && (2 * ffn) % 32 == 0;
-  if (w8 && !fused) return A3V_ERR_SHAPE;          // the fp8 images exist only for the fused form
-  if (B > 16 && !fused) return A3V_ERR_SHAPE;      // the per-kernel form below is for <= 16 rows (the host takes its general path)
+  const int form = decode_step_form(B, dim, H, Hkv, hd, ffn, w8);
+  if (!form) return A3V_ERR_SHAPE;                 // fp8 images / 17..32 rows exist only in the fused form (the host takes its general path)
+  const bool fused = form == 2;
   if (fused) {
     float* ssq = (float*)((char*)skinny_ws + A3V_WS_SSQ);
     int* actr = (int*)((char*)skinny_ws + A3V_WS_ATTN_COUNTERS);
-    if (Bc * H * (int)sizeof(int) > A3V_WS_SSQ - A3V_WS_ATTN_COUNTERS) return A3V_ERR_SHAPE;
     const int64_t kv_b = (int64_t)Hkv * Smax * hd;       // elements per batch row of a K / V^T cache
     for (int b0 = 0; b0 < B; b0 += Bc) {
       const int nb = B - b0 < Bc ? B - b0 : Bc;

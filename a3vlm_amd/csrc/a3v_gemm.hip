@@ -2954,13 +2954,51 @@ extern "C" int a3v_build_flags(void) {
 #endif
 }
 
-// Optional scratch for the split-K form of the hybrid dispatch's tail rows (a3v_gemm_set_workspace): the library never
-// allocates, so without it the tail runs as a plain 128x128 launch.
-static float* g_gemm_ws = nullptr;
-static int64_t g_gemm_ws_bytes = 0;
+// Optional scratch for the split-K forms of the hybrid dispatch (tail rows, few-tile problems): the library never allocates, so without
+// it those rows run as plain launches.  Registrations are keyed by (device, stream): two streams that run GEMMs concurrently must not
+// share split-K planes (round 3 kept ONE process-global pointer: a second stream, model or device raced through it silently).
+//   a3v_gemm_set_workspace_for(stream, ptr, bytes)   the scratch of GEMM calls issued on `stream` of the current device
+//   a3v_gemm_set_workspace(ptr, bytes)               legacy form: a scratch for callers that never name a stream; it is BOUND to the
+//                                                    first (device, stream) that uses it -- any other stream without a registration
+//                                                    of its own gets none (plain launches), never somebody else's planes
+#include <mutex>
+#include <vector>
+namespace {
+struct GemmWs { float* p; int64_t bytes; };
+struct GemmWsEntry { int dev; hipStream_t st; float* p; int64_t bytes; };
+std::mutex g_ws_mu;
+std::vector<GemmWsEntry> g_ws_tab;
+GemmWsEntry g_ws_legacy = {-1, nullptr, nullptr, 0};
+bool g_ws_legacy_bound = false;
+GemmWs gemm_ws_for(hipStream_t st) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  for (const GemmWsEntry& e : g_ws_tab)
+    if (e.dev == dev && e.st == st) return {e.p, e.bytes};
+  if (g_ws_legacy.p) {
+    if (!g_ws_legacy_bound) { g_ws_legacy.dev = dev; g_ws_legacy.st = st; g_ws_legacy_bound = true; }
+    if (g_ws_legacy.dev == dev && g_ws_legacy.st == st) return {g_ws_legacy.p, g_ws_legacy.bytes};
+  }
+  return {nullptr, 0};
+}
+}  // namespace
+extern "C" int a3v_gemm_set_workspace_for(void* stream, void* ptr, int64_t bytes) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  for (size_t i = 0; i < g_ws_tab.size(); ++i)
+    if (g_ws_tab[i].dev == dev && g_ws_tab[i].st == (hipStream_t)stream) {
+      if (ptr) { g_ws_tab[i].p = (float*)ptr; g_ws_tab[i].bytes = bytes; } else g_ws_tab.erase(g_ws_tab.begin() + i);
+      return A3V_OK;
+    }
+  if (ptr) g_ws_tab.push_back({dev, (hipStream_t)stream, (float*)ptr, bytes});
+  return A3V_OK;
+}
 extern "C" int a3v_gemm_set_workspace(void* ptr, int64_t bytes) {
-  g_gemm_ws = (float*)ptr;
-  g_gemm_ws_bytes = ptr ? bytes : 0;
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  g_ws_legacy = {-1, nullptr, (float*)ptr, ptr ? bytes : 0};
+  g_ws_legacy_bound = false;
   return A3V_OK;
 }
 
@@ -3069,6 +3107,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
     if ((N % 8) || (ldr % 4) || ldr < 2 * (int64_t)N || ldc < 2 * (int64_t)N) return A3V_ERR_SHAPE;
   }
   hipStream_t st = (hipStream_t)stream;
+  const GemmWs gws = gemm_ws_for(st);
   if (dtype == A3V_F32) {
     if (K % 16 || lda % 4 || ldw % 4) return A3V_ERR_SHAPE;
     if ((epilogue & A3V_EPI_SWIGLU) && (N % 32)) return A3V_ERR_SHAPE;
@@ -3196,7 +3235,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
       int S2 = tail_tiles > 0 ? (int)(cu_count() / tail_tiles) : 0;
       if (S2 > 8) S2 = 8;
       while (S2 > 1 && K / 64 < 8 * S2) --S2;
-      const bool simple_epi = !(p.epi & ~(A3V_EPI_RESIDUAL | A3V_EPI_RES_F32 | A3V_EPI_OUT_F32)) && g_gemm_ws && N % 4 == 0;
+      const bool simple_epi = !(p.epi & ~(A3V_EPI_RESIDUAL | A3V_EPI_RES_F32 | A3V_EPI_OUT_F32)) && gws.p && N % 4 == 0;
       const double tail = (S2 >= 3 && simple_epi && pp_ring() && pp_persistent()) ? 1.0 / S2 + 0.2 : small_cost(tail_rows) + 0.25;
       c_hyb = (double)((mt_h * tn256 + 255) / 256) + tail;
     }
@@ -3210,13 +3249,13 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
       while (S3 > 1 && K / 64 < 8 * S3) --S3;
       const int okbits = A3V_EPI_BIAS | A3V_EPI_RESIDUAL | A3V_EPI_RES_F32 | A3V_EPI_OUT_F32;
       const bool on = A3V_ENV_INT("A3V_GEMM_RING_SPLIT", 1) != 0;
-      if (on && eligible && S3 >= 3 && !(p.epi & ~okbits) && pp_ring() && pp_persistent() && g_gemm_ws && N % 4 == 0 &&
-          (int64_t)S3 * M * N * 4 <= g_gemm_ws_bytes && (!(p.epi & A3V_EPI_BIAS) || !(reinterpret_cast<uintptr_t>(bias) & 7)))
+      if (on && eligible && S3 >= 3 && !(p.epi & ~okbits) && pp_ring() && pp_persistent() && gws.p && N % 4 == 0 &&
+          (int64_t)S3 * M * N * 4 <= gws.bytes && (!(p.epi & A3V_EPI_BIAS) || !(reinterpret_cast<uintptr_t>(bias) & 7)))
         c_spl = 1.0 / S3 + 0.2;
     }
     if (c_spl < c_small && c_spl < c_big && c_spl < c_hyb) {
       GemmArgs t = p;
-      t.C = g_gemm_ws; t.ldc = N; t.res = nullptr; t.bias = nullptr;
+      t.C = gws.p; t.ldc = N; t.res = nullptr; t.bias = nullptr;
       t.epi = A3V_EPI_OUT_F32 | GEMM_EPI_RAW;
       t.tiles_m = (M + 255) / 256; t.tiles_n = (int)tn256;
       t.c_split = (int64_t)M * N * 4;
@@ -3224,7 +3263,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
       hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0>), dim3(t.tiles_m * t.tiles_n, S3), dim3(512), 0, st, t);
       const int64_t n4 = (int64_t)M * (N / 4);
       const int rb = (int)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256);
-      hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(rb), dim3(256), 0, st, g_gemm_ws, S3, (int64_t)M * N, M, N, p.C, p.ldc, p.res, p.ldr,
+      hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(rb), dim3(256), 0, st, gws.p, S3, (int64_t)M * N, M, N, p.C, p.ldc, p.res, p.ldr,
                          p.epi & ~A3V_EPI_BIAS, (p.epi & A3V_EPI_BIAS) ? (const bf16_t*)p.bias : nullptr);
     } else if (c_big <= c_small && c_big <= c_hyb) {
       launch(257, p);
@@ -3254,9 +3293,9 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
       if (S2 > 8) S2 = 8;
       while (S2 > 1 && K / 64 < 8 * S2) --S2;
       const bool ring_tail = A3V_ENV_INT("A3V_GEMM_RING_TAIL", 1) != 0;
-      if (ring_tail && pp_ring() && pp_persistent() && S2 >= 3 && !(p.epi & ~simple) && g_gemm_ws && (int64_t)S2 * r.M * N * 4 <= g_gemm_ws_bytes && N % 4 == 0) {
+      if (ring_tail && pp_ring() && pp_persistent() && S2 >= 3 && !(p.epi & ~simple) && gws.p && (int64_t)S2 * r.M * N * 4 <= gws.bytes && N % 4 == 0) {
         GemmArgs t = r;
-        t.C = g_gemm_ws; t.ldc = N; t.res = nullptr; t.bias = nullptr;
+        t.C = gws.p; t.ldc = N; t.res = nullptr; t.bias = nullptr;
         t.epi = A3V_EPI_OUT_F32 | GEMM_EPI_RAW;
         t.tiles_m = (t.M + 255) / 256; t.tiles_n = (int)tn256;
         t.c_split = (int64_t)t.M * N * 4;
@@ -3265,10 +3304,10 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
         hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0>), dim3(big_tiles, S2), dim3(512), 0, st, t);
         const int64_t n4 = (int64_t)r.M * (N / 4);
         const int rb = (int)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256);
-        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(rb), dim3(256), 0, st, g_gemm_ws, S2, (int64_t)r.M * N, r.M, N, r.C, r.ldc, r.res, r.ldr, p.epi);
-      } else if (S > 1 && !(p.epi & ~simple) && g_gemm_ws && (int64_t)S * r.M * N * 4 <= g_gemm_ws_bytes && N % 4 == 0) {
+        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(rb), dim3(256), 0, st, gws.p, S2, (int64_t)r.M * N, r.M, N, r.C, r.ldc, r.res, r.ldr, p.epi);
+      } else if (S > 1 && !(p.epi & ~simple) && gws.p && (int64_t)S * r.M * N * 4 <= gws.bytes && N % 4 == 0) {
         GemmArgs t = r;
-        t.C = g_gemm_ws; t.ldc = N; t.res = nullptr; t.bias = nullptr;
+        t.C = gws.p; t.ldc = N; t.res = nullptr; t.bias = nullptr;
         t.epi = A3V_EPI_OUT_F32 | GEMM_EPI_RAW;
         t.tiles_m = (t.M + 127) / 128; t.tiles_n = (N + 127) / 128;
         t.c_split = (int64_t)t.M * N * 4;
@@ -3276,7 +3315,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
         hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 128, 2, 2>), dim3(t.tiles_m * t.tiles_n, S), dim3(256), 0, st, t);
         const int64_t n4 = (int64_t)r.M * (N / 4);
         const int rb = (int)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256);
-        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(rb), dim3(256), 0, st, g_gemm_ws, S, (int64_t)r.M * N, r.M, N, r.C, r.ldc, r.res, r.ldr, p.epi);
+        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(rb), dim3(256), 0, st, gws.p, S, (int64_t)r.M * N, r.M, N, r.C, r.ldc, r.res, r.ldr, p.epi);
       } else {
         launch(128, r);
       }
@@ -3550,6 +3589,7 @@ static int gemm_tn_impl(const void* At, int64_t lda, const void* Wt, int64_t ldw
   p.tiles_n = (N + 255) / 256;
   p.sumsq = sumsq;
   hipStream_t st = (hipStream_t)stream;
+  const GemmWs gws = gemm_ws_for(st);
   // rows of C beyond whole tile rounds (e.g. dW of w1|w3: 86 x 16 tiles = 5.4 rounds): split over the contracted index into fp32
   // planes + the reduce epilogue, as in a3v_gemm_nn / a3v_gemm_nt (needs the registered workspace; otherwise one plain launch)
   const int ncu = cu_count();
@@ -3565,14 +3605,14 @@ static int gemm_tn_impl(const void* At, int64_t lda, const void* Wt, int64_t ldw
   if (S < 1) S = 1;
   const int m_big = (int)(mt_h * 256);
   const bool tail_on = A3V_ENV_INT("A3V_TN_TAIL", 1) != 0;
-  if (tail_on && mt_h >= 1 && m_big < M && S > 1 && rem_tiles * 4 < 3 * ncu && g_gemm_ws && (int64_t)S * (M - m_big) * N * 4 <= g_gemm_ws_bytes) {
+  if (tail_on && mt_h >= 1 && m_big < M && S > 1 && rem_tiles * 4 < 3 * ncu && gws.p && (int64_t)S * (M - m_big) * N * 4 <= gws.bytes) {
     GemmArgs q = p;
     q.M = m_big; q.tiles_m = (int)mt_h;
     launch_tn<false>(dim3(q.tiles_m * q.tiles_n), st, q);
     GemmArgs t = p;
     t.M = M - m_big;
     t.A = p.A + m_big;                      // At is [K][lda] with the C-row index contiguous: the tail rows of C are columns m_big.. of At
-    t.C = g_gemm_ws; t.ldc = N; t.res = nullptr; t.sumsq = nullptr;      // (raw planes: the reduce pass below adds up the final values)
+    t.C = gws.p; t.ldc = N; t.res = nullptr; t.sumsq = nullptr;      // (raw planes: the reduce pass below adds up the final values)
     t.epi = A3V_EPI_OUT_F32 | GEMM_EPI_RAW;
     t.tiles_m = (t.M + 255) / 256;
     t.c_split = (int64_t)t.M * N * 4;
@@ -3582,7 +3622,7 @@ static int gemm_tn_impl(const void* At, int64_t lda, const void* Wt, int64_t ldw
     const void* Rt = residual ? (const char*)residual + (int64_t)m_big * ldr * ((epilogue & A3V_EPI_RES_F32) ? 4 : 2) : nullptr;
     const int64_t n4 = (int64_t)t.M * (N / 4);
     const int rb = (int)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256);
-    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(rb), dim3(256), 0, st, g_gemm_ws, S, (int64_t)t.M * N, t.M, N, Ct, ldc, Rt, ldr, epilogue,
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(rb), dim3(256), 0, st, gws.p, S, (int64_t)t.M * N, t.M, N, Ct, ldc, Rt, ldr, epilogue,
                        (const bf16_t*)nullptr, sumsq ? sumsq + (int64_t)tm_all * p.tiles_n * 8 : nullptr);
     A3V_LAUNCH_CHECK();
     return A3V_OK;
@@ -3645,6 +3685,7 @@ static int gemm_nt_fp8_impl(const void* Aq, int64_t lda, const float* sa, const 
   if (rk) { p.rk = *rk; p.epi |= GEMM_EPI_ROPEKV; }
   p.tiles_n = (N + 255) / 256;
   hipStream_t st = (hipStream_t)stream;
+  const GemmWs gws = gemm_ws_for(st);
   // Tile rounds: tiles_m x tiles_n blocks over the CUs.  When the last round would be mostly empty (e.g. 35 x 16 = 560 tiles on 256
   // CUs: a third round at 19 %), the tile rows that fill whole rounds run as usual and the remaining rows (< one round of tiles)
   // are split over K into raw fp32 planes -- S times the blocks at 1/S the length -- which a reduce pass rounds and stores with
@@ -3658,8 +3699,8 @@ static int gemm_nt_fp8_impl(const void* Aq, int64_t lda, const float* sa, const 
   int S = 1;
   while (rem_tiles * S * 2 <= ncu && S < 8 && (K / 128) >= 8 * S) S *= 2;   // measured on wo / w2 of 7B: S = 2 (96 blocks) beat S = 8 (384 blocks)
   const int m_big = (int)(mt_h * 256);
-  if (!rk && !(epilogue & ~simple) && mt_h >= 1 && m_big < M && S > 1 && rem_tiles * 4 < 3 * ncu && g_gemm_ws &&
-      (int64_t)S * (M - m_big) * N * 4 <= g_gemm_ws_bytes) {
+  if (!rk && !(epilogue & ~simple) && mt_h >= 1 && m_big < M && S > 1 && rem_tiles * 4 < 3 * ncu && gws.p &&
+      (int64_t)S * (M - m_big) * N * 4 <= gws.bytes) {
     GemmArgs q = p;
     q.M = m_big; q.tiles_m = (int)mt_h;
     hipLaunchKernelGGL(gemm_nt_fp8_pp_kernel, dim3(q.tiles_m * q.tiles_n), dim3(512), 0, st, q);
@@ -3667,7 +3708,7 @@ static int gemm_nt_fp8_impl(const void* Aq, int64_t lda, const float* sa, const 
     t.M = M - m_big;
     t.A = (const bf16_t*)((const char*)Aq + (int64_t)m_big * lda);
     t.sa = sa + m_big;
-    t.C = g_gemm_ws; t.ldc = N; t.res = nullptr; t.bias = nullptr;
+    t.C = gws.p; t.ldc = N; t.res = nullptr; t.bias = nullptr;
     t.epi = A3V_EPI_OUT_F32 | GEMM_EPI_RAW | GEMM_EPI_SCALE;
     t.tiles_m = (t.M + 255) / 256;
     t.c_split = (int64_t)t.M * N * 4;
@@ -3677,7 +3718,7 @@ static int gemm_nt_fp8_impl(const void* Aq, int64_t lda, const float* sa, const 
     const void* Rt = residual ? (const char*)residual + (int64_t)m_big * ldr * ((epilogue & A3V_EPI_RES_F32) ? 4 : 2) : nullptr;
     const int64_t n4 = (int64_t)t.M * (N / 4);
     const int rb = (int)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256);
-    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(rb), dim3(256), 0, st, g_gemm_ws, S, (int64_t)t.M * N, t.M, N, Ct, ldc, Rt, ldr, epilogue);
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(rb), dim3(256), 0, st, gws.p, S, (int64_t)t.M * N, t.M, N, Ct, ldc, Rt, ldr, epilogue);
     A3V_LAUNCH_CHECK();
     return A3V_OK;
   }
@@ -3723,6 +3764,7 @@ extern "C" int a3v_gemm_nn(const void* A, int64_t lda, const void* Wt, int64_t l
   if ((epilogue & (A3V_EPI_RESIDUAL | A3V_EPI_RES_F32)) && (!residual || ldr % 4)) return A3V_ERR_ARG;
   if (((int64_t)(M - 1) * lda + K) * 2 >= (1LL << 31) || ((int64_t)(K - 1) * ldw + N) * 2 >= (1LL << 31)) return A3V_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
+  const GemmWs gws = gemm_ws_for(st);
   GemmArgs p{};
   p.A = (const bf16_t*)A; p.W = (const bf16_t*)Wt; p.C = C; p.bias = nullptr; p.res = residual;
   p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr;
@@ -3738,14 +3780,14 @@ extern "C" int a3v_gemm_nn(const void* A, int64_t lda, const void* Wt, int64_t l
   while (S > 1 && (K / 64) < 16 * S) --S;
   if (S < 1) S = 1;
   const int m_big = (int)(mt_h * 256);
-  if (!swb && mt_h >= 1 && m_big < M && S > 1 && rem_tiles * 4 < 3 * ncu && g_gemm_ws && (int64_t)S * (M - m_big) * N * 4 <= g_gemm_ws_bytes) {
+  if (!swb && mt_h >= 1 && m_big < M && S > 1 && rem_tiles * 4 < 3 * ncu && gws.p && (int64_t)S * (M - m_big) * N * 4 <= gws.bytes) {
     GemmArgs q = p;
     q.M = m_big; q.tiles_m = (int)mt_h;
     launch_tn<true>(dim3(q.tiles_m * q.tiles_n), st, q);
     GemmArgs t = p;
     t.M = M - m_big;
     t.A = p.A + (int64_t)m_big * lda;
-    t.C = g_gemm_ws; t.ldc = N; t.res = nullptr;
+    t.C = gws.p; t.ldc = N; t.res = nullptr;
     t.epi = A3V_EPI_OUT_F32 | GEMM_EPI_RAW;
     t.tiles_m = (t.M + 255) / 256;
     t.c_split = (int64_t)t.M * N * 4;
@@ -3755,7 +3797,7 @@ extern "C" int a3v_gemm_nn(const void* A, int64_t lda, const void* Wt, int64_t l
     const void* Rt = residual ? (const char*)residual + (int64_t)m_big * ldr * ((epilogue & A3V_EPI_RES_F32) ? 4 : 2) : nullptr;
     const int64_t n4 = (int64_t)t.M * (N / 4);
     const int rb = (int)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256);
-    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(rb), dim3(256), 0, st, g_gemm_ws, S, (int64_t)t.M * N, t.M, N, Ct, ldc, Rt, ldr, epilogue);
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(rb), dim3(256), 0, st, gws.p, S, (int64_t)t.M * N, t.M, N, Ct, ldc, Rt, ldr, epilogue);
     A3V_LAUNCH_CHECK();
     return A3V_OK;
   }

@@ -10,7 +10,8 @@ import os
 from ctypes import c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liba3vlm_hip.so")
+# A3V_LIB_PATH: another build of the SAME library (tools/: cycle-stamp and ablation builds); never a different implementation
+LIB_PATH = os.environ.get("A3V_LIB_PATH") or os.path.join(_HERE, "liba3vlm_hip.so")
 
 BF16, F32 = 0, 1
 EPI_NONE, EPI_BIAS, EPI_GELU, EPI_QUICKGELU, EPI_RESIDUAL, EPI_SWIGLU, EPI_OUT_F32, EPI_RES_F32 = 0, 1, 2, 4, 8, 16, 32, 64
@@ -47,6 +48,7 @@ SIGNATURES = {
     "a3v_gemm_tn_sumsq": (I, [P, L, P, L, P, L, I, I, I, P, L, I, P, L, P]),
     "a3v_gemm_tn_sumsq_slots": (L, [I, I]),
     "a3v_gemm_set_workspace": (I, [P, L]),
+    "a3v_gemm_set_workspace_for": (I, [P, P, L]),
     "a3v_gemm_nt_splitk": (I, [P, L, P, L, P, I, I, I, I, P]),
     "a3v_splitk_reduce": (I, [P, I, I, I, P, L, I, I, P]),
     "a3v_gemm_skinny_split": (I, [I, I, I]),
@@ -105,6 +107,7 @@ class ImageDesc(ctypes.Structure):
 
 
 SIGNATURES["a3v_llama_decode_step"] = (I, [ctypes.POINTER(LlamaLayer), I, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, F, P])
+SIGNATURES["a3v_llama_decode_step_form"] = (I, [I, I, I, I, I, I, I])
 
 _lib = None
 

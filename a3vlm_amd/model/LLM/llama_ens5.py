@@ -723,12 +723,13 @@ class Transformer(nn.Module):
         if (S == 1 and (B <= 16 or (B <= 32 and a.dim % 128 == 0 and self.ffn % 128 == 0)) and self._dtype == torch.bfloat16
                 and self.head_dim in (64, 128) and a.dim % 32 == 0 and self.ffn % 32 == 0
                 and not getattr(self, "_per_kernel_decode", False)):     # test hook: run the step kernel by kernel
-            try:
+            # the C entry says up front which form it takes (a3v_llama_decode_step_form): 17..32 rows need the fused GEMV forms (two row
+            # chunks); a geometry they do not take goes through the general kernels -- decided BEFORE h or the KV cache are touched, an
+            # error from inside the step is never papered over
+            w8 = 1 if getattr(self, "_q8", None) is not None else 0
+            if _lib.load().a3v_llama_decode_step_form(B, a.dim, a.n_heads, self.n_kv_heads, self.head_dim, self.ffn, w8) or B <= 16:
                 self._decode_step(h, B, start_pos)
-            except _lib.A3VError:
-                if B <= 16:
-                    raise
-                # 17..32 rows need the fused GEMV forms (two row chunks); a geometry they do not take goes through the general kernels
+            else:
                 self._decoder_layers(h, B, S, start_pos, rope0, self._k_cache, self._vt_cache, True)
         else:
             self._decoder_layers(h, B, S, start_pos, rope0, self._k_cache, self._vt_cache, True)

@@ -338,7 +338,7 @@ class MetaModel(nn.Module):
                 logits = self.llma.forward_inference(tokens[:, prev_pos:cur_pos], prev_pos,
                                                      images if prev_pos == 0 else None)
             if temperature > 0:
-                ops.sample_top_p(logits, temperature, top_p, uni[cur_pos - start_pos], sampled)
+                self._sample_into(logits, temperature, top_p, uni[cur_pos - start_pos], sampled)
             ops.generate_step(logits, sampled, tokens, text_mask, cur_pos, stop_seq, stop_off, len(l_stop), stopped, stop_pos, live)
             if ((cur_pos - start_pos) % poll_every == poll_every - 1 or cur_pos == total_len - 1) and int(live.item()) == 0:
                 break
@@ -380,7 +380,7 @@ class MetaModel(nn.Module):
             logits = self.llma.forward_inference(tokens[None, prev_pos:cur_pos], prev_pos,
                                                  image if prev_pos == 0 else None)
             if temperature > 0:
-                nt = ops.sample_top_p(logits, temperature, top_p, torch.rand(1, device=dev), nt_buf)
+                nt = self._sample_into(logits, temperature, top_p, torch.rand(1, device=dev), nt_buf)
             else:
                 nt = ops.argmax(logits, nt_buf)
             nt = int(nt.reshape(-1)[0].item())
@@ -398,6 +398,15 @@ class MetaModel(nn.Module):
             yield {"text": generated, "end_of_content": False}
         generated = self.tokenizer.decode(tokens[start_pos:generate_until].tolist())
         yield {"text": generated, "end_of_content": True}
+
+    def _sample_into(self, logits: torch.Tensor, temperature: float, top_p: float, uniforms: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+        """One top-p draw per row into ``out``: the device kernel where it applies (V <= 65536, 0 < top_p), otherwise the reference's
+        sort / cumsum / multinomial recipe (meta.py:456-458, 568-583) -- larger vocabularies must keep working as they do there."""
+        if logits.shape[-1] <= 65536 and top_p > 0:
+            return ops.sample_top_p(logits, temperature, top_p, uniforms, out)
+        probs = torch.softmax(logits.float() / temperature, dim=-1)
+        out.copy_(self.sample_top_p(probs, top_p).reshape(-1))
+        return out
 
     def sample_top_p(self, probs: torch.Tensor, p: float) -> torch.Tensor:
         """meta.py:568-583, kept for callers of the reference's method (torch ops; ``generate`` itself draws on the device with

@@ -41,12 +41,16 @@ _gemm_ws = {}
 
 
 def _ensure_gemm_workspace(device) -> None:
-    """Register (once per process) the scratch a3v_gemm_nt may use for the split-K tail of its hybrid dispatch."""
-    if _gemm_ws:
+    """Register (once per device and stream) the scratch the GEMM entry points may use for the split-K planes of their hybrid dispatch
+    (a3v_gemm_set_workspace_for: keyed by stream, so concurrent streams never share planes)."""
+    st = _stream()
+    key = (torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device(), st)
+    if key in _gemm_ws:
         return
     ws = torch.empty(96 << 20, dtype=torch.uint8, device=device)
-    _gemm_ws[device] = ws
-    _l.check(_l.load().a3v_gemm_set_workspace(ws.data_ptr(), ws.numel()), "a3v_gemm_set_workspace")
+    _gemm_ws[key] = ws
+    with torch.cuda.device(key[0]):
+        _l.check(_l.load().a3v_gemm_set_workspace_for(st, ws.data_ptr(), ws.numel()), "a3v_gemm_set_workspace_for")
 
 
 def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, residual=None,

@@ -54,6 +54,18 @@ class FusedAdamW(torch.optim.Optimizer):
             self.engine.sync_optimizer()
         return super().state_dict()
 
+    def load_state_dict(self, state_dict):
+        """The device tables of the multi-tensor launch hold raw pointers of the moment tensors, which a load replaces."""
+        if self.engine is not None:
+            self.engine.sync_optimizer()
+        super().load_state_dict(state_dict)
+        self._tables.clear()
+
+    def add_param_group(self, param_group):
+        super().add_param_group(param_group)
+        if hasattr(self, "_tables"):
+            self._tables.clear()
+
     def _ordered(self):
         """[(bucket or None, group, parameter)] in forward order (parameters the engine does not know first)."""
         rank, name = {}, {}
@@ -119,12 +131,20 @@ class FusedAdamW(torch.optim.Optimizer):
                         sink = (img.data_ptr(), p.shape[-1] if p.dim() > 1 else p.numel(), 1, 0, 0, 0)
                     elif self.engine is not None and hasattr(self.engine, "adapter_sink"):
                         sink = self.engine.adapter_sink(p)          # (d1, s1r, s1c, d2, s2r, s2c) inside the fused LoRA group images
-                        if sink is not None:
-                            adapters.add(id(p))
+                    st = self.state[p]
+                    # a3v_adamw_multi does 16-byte vector accesses on p / g / m / v (and 8-byte ones on a contiguous image) through a table
+                    # the C entry cannot check: anything misaligned or non-contiguous takes the per-tensor launch, which checks for itself
+                    ok = all(t.is_contiguous() and t.data_ptr() % 16 == 0 for t in (p, p.grad, st["exp_avg"], st["exp_avg_sq"]))
+                    if img is not None and img.data_ptr() % 8:
+                        ok = False
+                    if not ok:
+                        continue
                     lst.append((p, sink, img is not None))
                 if len(lst) >= 2:
                     small[gi] = lst
         in_multi = {id(p) for lst in small.values() for p, _, _ in lst}
+        # only adapters whose bf16 values the multi launch really writes into the fused images count as adopted by the engine
+        adapters = {id(p) for lst in small.values() for p, sink, same in lst if sink is not None and not same}
         for bucket, group, p in order:
             if overlap and bucket != last:
                 if last is not None:
@@ -156,7 +176,9 @@ class FusedAdamW(torch.optim.Optimizer):
                 steps.add(int(st["step"].item()))
             if len(steps) != 1:
                 raise RuntimeError("FusedAdamW multi-tensor launch: the small tensors of a param group must share their step count")
-            key = tuple((p.data_ptr(), p.grad.data_ptr(), sink) for p, sink, _ in lst)
+            # the table holds raw pointers of the moments too: load_state_dict() replaces those tensors
+            key = tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr(), sink)
+                        for p, sink, _ in lst)
             ent = self._tables.get(gi)
             if ent is None or ent[0] != key:
                 rows = []

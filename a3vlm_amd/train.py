@@ -844,7 +844,8 @@ class TrainEngine:
         if self.stream == torch.bfloat16 and self.act == torch.bfloat16 and kx:
             # bf16 stream + adapters inside the GEMMs: dh IS the dy operand of the wo / w2 groups, so it lives in the first `dim`
             # columns of a buffer with room for dt = dy . B behind it (no copy of dh per layer)
-            self._dh_full = self._buf("dh.x", (rows, dim + self._kext()), self.stream, zero=True)
+            # (width of the wo / w2 groups' adapter block, pad64(r) -- NOT _kext(), the qkv group's pad64(3 r): the two differ from r = 22 on)
+            self._dh_full = self._buf("dh.x", (rows, dim + self._kext_cols("w2.0")), self.stream, zero=True)
             dh = self._dh_full[:, :dim]
         else:
             dh = self._buf("dh", (rows, dim), self.stream, zero=True)

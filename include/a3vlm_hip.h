@@ -14,7 +14,10 @@
  *  - `stream` is a hipStream_t passed as void* (NULL = the null stream); kernels are
  *    enqueued asynchronously on it and never synchronise.
  *  - never allocates; scratch is passed in by the caller.
- *  - no global mutable state; re-entrant from any host thread.
+ *  - re-entrant from any host thread.  The only process-wide state is (i) the table of scratch registrations of
+ *    a3v_gemm_set_workspace_for (mutex-protected, keyed by device and stream: two streams never share split-K planes) and (ii) the
+ *    cached values of the A3V_* environment switches (A/B runs only; a3v_reload_env re-reads them).  No kernel result depends on
+ *    state left by an earlier call on another stream.
  *  - return value: 0 on success, a hipError_t (>0) from the launch, or a negative
  *    A3V_ERR_* for argument errors.  The Python host raises RuntimeError on != 0.
  *  - dtype codes: A3V_BF16 activations/weights are bfloat16 with fp32 accumulation
@@ -137,9 +140,14 @@ int a3v_gemm_nn(const void* A, int64_t lda, const void* Wt, int64_t ldw, void* C
 int a3v_gemm_tn_splitk(const void* At, int64_t lda, const void* Wt, int64_t ldw, float* partial, int M, int N, int K,
                        int S, void* stream);
 
-/* Optional: register a scratch buffer (device memory, >= 32 MiB recommended; NULL unregisters) that a3v_gemm_nt may use
- * to split the K loop of the few-hundred-row tail of its hybrid tile dispatch.  The library itself never allocates.  One
- * buffer per process (one process per GPU); it must outlive every later a3v_gemm_nt call and is used on the call's stream. */
+/* Optional: register a scratch buffer (device memory, >= 32 MiB recommended; NULL unregisters) that a3v_gemm_nt / _nn / _tn /
+ * _nt_fp8 may use for the split-K planes of their hybrid tile dispatch (the few-hundred-row tail, few-tile problems).  The library
+ * itself never allocates.  Registrations are keyed by (current device, stream): GEMM calls issued on `stream` use that buffer and no
+ * other, so two streams (a second model, an optimizer stream, a second device of one process) never share planes.  The buffer must
+ * outlive every later GEMM call on that stream. */
+int a3v_gemm_set_workspace_for(void* stream, void* ptr, int64_t bytes);
+/* Legacy form for callers that do not name a stream: the buffer is bound to the FIRST (device, stream) whose GEMM call uses it; calls
+ * on any other stream without a registration of their own get no scratch (plain launches), never this buffer. */
 int a3v_gemm_set_workspace(void* ptr, int64_t bytes);
 
 /* Split-K form for skinny products with a long K (the LoRA adapter GEMMs of model/peft.py:84-99 and their gradients:
@@ -321,6 +329,10 @@ int a3v_llama_decode_step(const a3v_llama_layer* layers, int n_layers, void* h, 
                           void* att, void* act, float* attn_scratch, void* skinny_ws, const float* cos_sin, int B,
                           int dim, int H, int Hkv, int hd, int ffn, int Smax, int pos, float eps,
                           void* stream);
+/* Which form a3v_llama_decode_step takes for a geometry, decided before anything is launched: 2 = the fused five-launch form,
+ * 1 = the per-kernel form (<= 16 rows, bf16 weights), 0 = not taken (the call returns A3V_ERR_SHAPE with every buffer untouched and
+ * the host runs the general kernels: llama_ens5.py:490-531 has no batch limit below max_batch_size). */
+int a3v_llama_decode_step_form(int B, int dim, int H, int Hkv, int hd, int ffn, int w8);
 
 /* ---------------------------------------------------------------------------------------
  * Training (backward) entry points.  Reference: autograd through the same modules under

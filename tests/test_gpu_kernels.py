@@ -966,3 +966,40 @@ def test_gemm_tn_strip(Kt, R, N, S, ld_extra):
     of2 = torch.empty_like(of)
     ops.gemm_tn_strip(td, xd, of2, scratch, S)
     assert torch.equal(of, of2)
+
+
+def test_gemm_split_k_scratch_is_per_stream():
+    """Two streams run hybrid-tail GEMMs (big tiles + split-K tail through the registered scratch) concurrently, many times: each stream
+    has its own scratch (a3v_gemm_set_workspace_for keys registrations by device and stream; round 3 kept one process-global pointer
+    that both tails wrote), so both results equal the serial ones bit for bit."""
+    from a3vlm_amd import lib as _lib
+    g = torch.Generator().manual_seed(77)
+    M, N = 8 * 1091, 4096
+    shapes = [(4096, 1), (11008, 2)]                         # the wo / w2 shapes of the 7B step: 2.19 tile rounds -> split-K tail
+    data = []
+    for K, seed in shapes:
+        a = (torch.randn(M, K, generator=g)).to(BF).to(DEV)
+        w = (torch.randn(N, K, generator=g) * 0.05).to(BF).to(DEV)
+        r = torch.randn(M, N, generator=g).to(BF).to(DEV)
+        ref = torch.empty(M, N, dtype=BF, device=DEV)
+        ops.gemm_nt(a, w, ref, residual=r)
+        data.append((a, w, r, ref))
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = [torch.empty(M, N, dtype=BF, device=DEV) for _ in data]
+    for rep in range(6):
+        for o in outs:
+            o.fill_(float("nan"))
+        torch.cuda.synchronize()
+        for st, (a, w, r, _), o in zip((s1, s2), data, outs):
+            with torch.cuda.stream(st):
+                for _ in range(3):
+                    ops.gemm_nt(a, w, o, residual=r)
+        torch.cuda.synchronize()
+        for (_, _, _, ref), o in zip(data, outs):
+            assert torch.equal(o, ref), rep
+    # the legacy registration binds to the first stream that uses it and is never handed to another one
+    L = _lib.load()
+    ws = torch.empty(96 << 20, dtype=torch.uint8, device=DEV)
+    assert L.a3v_gemm_set_workspace(ws.data_ptr(), ws.numel()) == 0
+    assert L.a3v_gemm_set_workspace(None, 0) == 0

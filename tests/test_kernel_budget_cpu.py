@@ -52,3 +52,44 @@ def test_gemm_kernels_stay_inside_their_register_budget(tmp_path):
         assert hits, f"kernel {key} not found (renamed? update the budget table)"
         for n, v in hits.items():
             assert v <= limit, f"{n}: {v} B of scratch per lane (budget {limit})"
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_owned_agpr_kernels_are_never_touched_by_the_compiler(tmp_path):
+    """The one-pass dK + dV attention backward keeps its accumulators, the K / V fragments and S / dP in hand-owned AGPRs (every MFMA of
+    its loop is an asm statement on literal a[...] registers).  That is only sound while hipcc itself never allocates an AGPR in those
+    kernels -- a compiler spill into the owned range would be silent corruption -- so the generated code must contain NO v_accvgpr_* /
+    v_mfma instruction outside the asm statements and no scratch."""
+    src = os.path.join(ROOT, "a3vlm_amd", "csrc", "a3v_attn_bwd.hip")
+    out = tmp_path / "b.s"
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "--cuda-device-only", "-S", src, "-o", str(out)],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    kernels, cur, in_asm = {}, None, False
+    for line in open(out):
+        m = re.match(r"^(_ZN\S*attn_bwd_dkv2_kernel\S*):", line)
+        if m:
+            cur = m.group(1)
+            kernels[cur] = {"bad": [], "scratch": 0, "mfma": 0}
+            continue
+        if cur is None:
+            continue
+        if line.startswith(".Lfunc_end"):
+            cur = None
+            continue
+        if "#ASMSTART" in line:
+            in_asm = True
+        elif "#ASMEND" in line:
+            in_asm = False
+        elif re.search(r"\bv_accvgpr_|\bv_mfma_", line):
+            if in_asm:
+                kernels[cur]["mfma"] += "v_mfma" in line
+            else:
+                kernels[cur]["bad"].append(line.strip())
+        elif "scratch_" in line:
+            kernels[cur]["scratch"] += 1
+    assert len(kernels) == 4, list(kernels)          # hd 64 / 128 x packed / plain
+    for name, k in kernels.items():
+        assert not k["bad"], f"{name}: compiler-generated AGPR / MFMA instructions: {k['bad'][:3]}"
+        assert k["scratch"] == 0, f"{name}: {k['scratch']} scratch instructions"
+        assert k["mfma"] > 60, (name, k["mfma"])            # the loop really is the asm stream (hd 64: 88 MFMAs over its step variants)

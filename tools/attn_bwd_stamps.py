@@ -51,6 +51,12 @@ for kern, name in enumerate(("dQ", "dV", "dK")):
         for j in range(6):
             tot[j] += d[j]
         if i < 6 or i >= n - 2:
-            print(f"  it {i:2d}: vmcnt {d[0]:4d}  barrier {d[1]:4d}  issue {d[2]:4d}  s/dp+softmax {d[3]:4d}  acc-mfma {d[4]:4d}   total {d[5]:4d}")
+            extra = f"   [one-pass dK+dV: A||B of step 1 {int(r[i, 6] - r[i, 3])}, C {int(r[i, 4] - r[i, 6])}; step 2: {int(r[i, 7] - r[i, 4])}, {int(r[i, 5] - r[i, 7])}]" if int(r[i, 6]) else ""
+            print(f"  it {i:2d}: vmcnt {d[0]:4d}  barrier {d[1]:4d}  issue {d[2]:4d}  s/dp+softmax {d[3]:4d}  acc-mfma {d[4]:4d}   total {d[5]:4d}" + extra)
     if n:
         print("  mean:  vmcnt %.0f  barrier %.0f  issue %.0f  s/dp+softmax %.0f  acc-mfma %.0f   total %.0f  (shader cycles)" % tuple(x / n for x in tot))
+
+pe = t[2, 0:2].reshape(-1)[:9]
+if int(pe[0]):
+    names = ["issue 3 pairs", "K / V loads + AGPR init", "vmcnt(pair 0)", "barrier + A(0) + fetch", "(loop)", "AGPR reads + scale", "barrier", "patch writes", "row stores issued"]
+    print("one-pass dK+dV, block prologue / epilogue (shader cycles):", ", ".join(f"{n} {int(pe[i + 1] - pe[i])}" for i, n in enumerate(names[:8])))
