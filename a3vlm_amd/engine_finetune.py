@@ -58,7 +58,8 @@ def train_one_epoch(model, data_loader, optimizer, epoch: int, start_iter: int, 
     params = [p for p in model.parameters() if p.requires_grad]
     clip = getattr(args, "clip_grad", -1) or -1
     bad = torch.zeros((), dtype=torch.bool, device=dev)          # sticky: some loss / gradient norm of this epoch was not finite
-    takes_scale = hasattr(optimizer, "engine")                   # FusedAdamW: device-scalar coefficient, negative = skip
+    zero1 = bool(getattr(optimizer, "zero1", False))            # zero1.Zero1Optimizer: also the gradient exchange (pass it as `reducer`)
+    takes_scale = hasattr(optimizer, "engine") or zero1          # FusedAdamW / Zero1Optimizer: device-scalar coefficient, negative = skip
 
     def stop_if_bad(step: int) -> None:
         if bool(bad):                              # host read: only at logging / checkpoint / epoch boundaries
@@ -72,7 +73,7 @@ def train_one_epoch(model, data_loader, optimizer, epoch: int, start_iter: int, 
         engine.static_grad_scale = 1.0 / accum_iter
     # the clip's sums of squares ride the backward (side stream / behind each bucket's all-reduce) instead of one 27-GB pass after it
     sumsq = None
-    if engine is not None and clip > 0 and takes_scale and optimizer.engine is engine:
+    if engine is not None and clip > 0 and takes_scale and not zero1 and optimizer.engine is engine:
         sumsq = getattr(engine, "_grad_square_sums", None)
         if sumsq is None or sumsq.reducer is not reducer:       # bound to ONE reducer: another (or none) this epoch = a new object
             if sumsq is not None:
@@ -114,7 +115,10 @@ def train_one_epoch(model, data_loader, optimizer, epoch: int, start_iter: int, 
                         bad = reducer.any_rank(bad)
                 coef = None
                 if clip > 0:
-                    if takes_scale:
+                    if zero1:
+                        # the norm of the AVERAGED gradient from the ranks' slices (one tiny SUM all-reduce) + the replicated pieces
+                        stats["grad_norm"], coef = optimizer.clip_coef(clip)
+                    elif takes_scale:
                         # one norm over the engine's flat gradient buffer; the coefficient stays on the device and is applied by the
                         # optimizer kernel as it reads the gradients (a3v_adamw_scaled): no grad.mul_ pass, no host sync
                         eng = optimizer.engine

@@ -74,7 +74,28 @@ def get_args_parser():
     p.add_argument("--quant", action="store_true", default=False)
     p.add_argument("--synthetic", type=int, default=0, help="use a seeded synthetic dataset of this many items")
     p.add_argument("--max_seq_len", type=int, default=None)
+    p.add_argument("--zero1", action="store_true", default=False,
+                   help="shard the fp32 masters and the AdamW state of the big matrices over the DP ranks (reduce-scatter -> AdamW on 1/N -> "
+                        "all-gather of bf16 parameters): the reference's FSDP(SHARD_GRAD_OP) sizing for the 13B full fine-tune (configs[3])")
     return p
+
+
+class _OneRank:
+    """torch.distributed's surface for a single process (``--zero1`` without a launcher: one slice = everything)."""
+    class ReduceOp:
+        SUM, AVG, MAX = "sum", "avg", "max"
+
+    @staticmethod
+    def get_world_size(group=None):
+        return 1
+
+    @staticmethod
+    def get_rank(group=None):
+        return 0
+
+    @staticmethod
+    def get_backend(group=None):
+        return "none"
 
 
 class SyntheticDialogDataset(torch.utils.data.Dataset):
@@ -128,7 +149,7 @@ def main(args):
         model = MetaModel(args.llama_type, args.llama_config, args.tokenizer_path, with_visual=not args.no_visual,
                           max_seq_len=args.max_seq_len or args.max_words)
     torch.set_default_dtype(old)
-    promote_trainable_params_to_fp32(model)                              # :217
+    promote_trainable_params_to_fp32(model, keep_matrices_sharded=args.zero1)        # :217 (ZeRO-1: the big matrices' masters live in 1/N slices)
     if args.pretrained_path and rank == 0:
         print("load result:", load_tensor_parallel_model_list(model, args.pretrained_path))
     if distributed:                                                      # :237-239 (every parameter, trainable or frozen)
@@ -140,13 +161,26 @@ def main(args):
 
     # AdamW(0.9, 0.95) over the reference's two weight-decay groups; the HIP kernel streams each parameter's state once
     # (5.7 TB/s against 4.3 for torch's multi-tensor kernel); A3V_TORCH_ADAMW=1 selects torch.optim.AdamW (same state layout)
-    if os.environ.get("A3V_TORCH_ADAMW", "0") == "1":
+    reducer = None
+    if args.zero1:
+        from .optim import FusedAdamW
+        from .zero1 import Zero1Optimizer
+        if args.precision != "bf16":
+            raise SystemExit("--zero1 needs --precision bf16 (the sharded matrices are the bf16 compute parameters)")
+        eng = model.train_engine(zero1_world=world)
+        groups = [{**g, "params": [q for q in g["params"] if q.dtype == torch.float32]} for g in add_weight_decay(model, args.weight_decay)]
+        small = FusedAdamW([g for g in groups if g["params"]], lr=args.lr, betas=(0.9, 0.95), engine=eng)
+        zd = dist if distributed else _OneRank()
+        optimizer = reducer = Zero1Optimizer(eng, zd, lr=args.lr, betas=(0.9, 0.95), weight_decay=args.weight_decay,
+                                             reduce_dtype=torch.bfloat16, small=small)
+    elif os.environ.get("A3V_TORCH_ADAMW", "0") == "1":
         optimizer = torch.optim.AdamW(add_weight_decay(model, args.weight_decay), lr=args.lr, betas=(0.9, 0.95), fused=True)
     else:
         from .optim import FusedAdamW
         optimizer = FusedAdamW(add_weight_decay(model, args.weight_decay), lr=args.lr, betas=(0.9, 0.95), engine=model.train_engine())
     # gradient wire dtype = FSDP's MixedPrecision(reduce_dtype) of the reference (:251-255): bf16 under --precision bf16
-    reducer = GradReducer(model.train_engine(), dist, reduce_dtype=torch.bfloat16 if args.precision == "bf16" else None) if distributed else None
+    if reducer is None:
+        reducer = GradReducer(model.train_engine(), dist, reduce_dtype=torch.bfloat16 if args.precision == "bf16" else None) if distributed else None
 
     image_words = model.get_image_words()
     if args.synthetic:
@@ -178,7 +212,7 @@ def main(args):
         d = latest_checkpoint_dir(args.resume) or args.resume
         print("resume:", load_tensor_parallel_model_list(model, [d]))
         other = torch.load(os.path.join(d, "consolidated.00-of-01.other.pth"), weights_only=False)
-        opt_path = os.path.join(d, "consolidated.00-of-01.optimizer.pth")
+        opt_path = os.path.join(d, f"zero1-optimizer.{rank:05d}-of-{world:05d}.pth" if args.zero1 else "consolidated.00-of-01.optimizer.pth")
         if os.path.isfile(opt_path):
             optimizer.load_state_dict(torch.load(opt_path, weights_only=False)["optimizer"])
         if other.get("iter") is not None:

@@ -167,7 +167,7 @@ class MetaModel(nn.Module):
         # final scalar reduction of B*(T-1) fp32 values: plumbing, not the hot path
         return row_loss.sum() / n_valid.to(torch.float32)[0]
 
-    def train_engine(self, compute_dtype: torch.dtype = None):
+    def train_engine(self, compute_dtype: torch.dtype = None, zero1_world: int = 0):
         """The HIP forward/backward engine of the plugin (a3vlm_amd/train.py).  compute dtype: bf16
         ("autocast") unless the model is all-fp32 (parity path)."""
         from ..train import TrainEngine
@@ -177,7 +177,7 @@ class MetaModel(nn.Module):
                 compute_dtype = frozen[0].dtype if frozen else torch.bfloat16
                 if getattr(self, "train_compute_dtype", None) is not None:
                     compute_dtype = self.train_compute_dtype
-            self._engine = TrainEngine(self.llma, compute_dtype)
+            self._engine = TrainEngine(self.llma, compute_dtype, zero1_world=zero1_world)
             self._anchor = torch.zeros((), dtype=torch.float32, device=self._device, requires_grad=True)
         return self._engine
 

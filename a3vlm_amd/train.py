@@ -41,7 +41,7 @@ class TrainEngine:
     fuse_swiglu_bwd = os.environ.get("A3V_FUSE_SWIGLU_BWD", "1") != "0"   # LoRA: SwiGLU backward in the epilogue of w2's input-gradient GEMM (0: separate pass, A/B)
 
     def __init__(self, model, compute_dtype: torch.dtype = torch.bfloat16, recompute: Optional[bool] = None,
-                 stream_dtype: Optional[torch.dtype] = None):
+                 stream_dtype: Optional[torch.dtype] = None, zero1_world: int = 0):
         """``stream_dtype``: dtype of the residual stream h, of its per-layer checkpoints and of its gradient dh.  Default = the compute
         dtype: under ``--precision bf16`` the reference wraps the model in FSDP with MixedPrecision(param_dtype=bf16)
         (main_finetune.py:241-263) and runs it under autocast (engine_finetune.py:44-50), so the embeddings come out in bf16 and every
@@ -51,7 +51,12 @@ class TrainEngine:
         ``recompute``: True = keep only each block's input and re-run the block in backward (the reference's
         activation checkpointing, main_finetune.py:268-276); False = keep every block's intermediates (about
         1.15 GB per 7B layer at 8 x 1091 tokens -- affordable in 288 GB of HBM and ~1/4 fewer GEMM FLOPs per step).
-        None = decide from free HBM at the first step."""
+        None = decide from free HBM at the first step.
+        ``zero1_world`` = N > 0 (``a3vlm_amd.zero1``, the reference's FSDP(SHARD_GRAD_OP) sizing for configs[3]): trainable parameters left in
+        the compute dtype (the big matrices: not promoted to fp32) have NO fp32 replica here -- they become views of one flat buffer in the
+        compute dtype laid out like the flat gradient buffer (every bucket's sharded span padded to a multiple of 64 N elements, so that
+        reduce-scatter / all-gather work on it in place), the GEMM images are views of the same storage, and ``Zero1Optimizer`` owns the
+        fp32 master / AdamW state of 1/N of it.  fp32 parameters (norms, projector) stay replicated as before."""
         install_param_epoch_hook()     # weight-image caches must notice optimizers that do not bump Tensor._version
         self.m = model
         self.lora = int(getattr(model, "lora_rank", 0) or 0) > 0
@@ -72,6 +77,10 @@ class TrainEngine:
         self.static_grad_scale: Optional[float] = None      # set by a trainer that knows d(total)/d(loss) (1 / accum_iter)
         self._saved = None
         self._weights_ready: Dict[str, torch.cuda.Event] = {}   # bucket -> event of FusedAdamW.step(overlap=True), see await_weights
+        self.zero1_world = int(zero1_world or 0)
+        self._flat_params: Optional[torch.Tensor] = None    # zero1: the sharded parameters' storage (compute dtype, flat-gradient layout)
+        self._z1: List[tuple] = []                          # zero1: (bucket, start, end, shard_start, shard_end, [(seg_start, seg_end, name)])
+        self._z1_fresh = True                               # zero1: the sharded gradients restart (store / zero) at the next backward
 
     # ------------------------------------------------------------------ buffers
     def _buf(self, name, shape, dtype=None, zero=False):
@@ -145,7 +154,7 @@ class TrainEngine:
 
     def _check_dtypes(self):
         for n, p in self.m.get_trainable_params().items():
-            if p.requires_grad and p.dtype != torch.float32:
+            if p.requires_grad and p.dtype != torch.float32 and not (self.zero1_world and p.dtype == self.act):
                 raise TypeError(f"trainable parameter {n} must be fp32 (promote_trainable_params_to_fp32, "
                                 f"util/tensor_type.py:60-66); got {p.dtype}")
 
@@ -188,7 +197,10 @@ class TrainEngine:
                         ("qformer_proj.1.weight", q1.weight), ("qformer_proj.1.bias", q1.bias)]
             items.append(("vision_proj", vis))
         # frozen parameters get no gradient storage (LoRA / partial fine-tuning)
-        return [(b, [(n, q) for n, q in plist if q.requires_grad]) for b, plist in items]
+        lay = [(b, [(n, q) for n, q in plist if q.requires_grad]) for b, plist in items]
+        if self.zero1_world:           # sharded (compute-dtype) parameters first in every bucket: one contiguous span per bucket (stable order)
+            lay = [(b, [it for it in pl if it[1].dtype != torch.float32] + [it for it in pl if it[1].dtype == torch.float32]) for b, pl in lay]
+        return lay
 
     def ensure_grads(self):
         """Allocate the flat fp32 gradient buffer once; (re)attach zeroed views where .grad is None."""
@@ -197,11 +209,24 @@ class TrainEngine:
             total = 0
             offs = {}
             self._ranges = []
+            zw = self.zero1_world
             for bucket, plist in self._layout():
+                if zw:
+                    total = (total + 64 * zw - 1) // (64 * zw) * (64 * zw)              # a bucket's sharded span starts on a 64 N granule
                 start = total
+                segs = []
                 for name, p in plist:
+                    if zw and p.dtype == torch.float32 and segs and segs[-1] is not None:
+                        total = (total + 64 * zw - 1) // (64 * zw) * (64 * zw)          # end of the bucket's sharded span: whole 64 N granules
+                        self._z1.append((bucket, segs))
+                        segs = [None]                                                   # (closed)
                     offs[name] = (total, p)
+                    if zw and p.dtype != torch.float32:
+                        segs.append((total, total + p.numel(), name))
                     total += (p.numel() + 63) // 64 * 64
+                if zw and segs and segs[-1] is not None:
+                    total = (total + 64 * zw - 1) // (64 * zw) * (64 * zw)
+                    self._z1.append((bucket, segs))
                 self._ranges.append((bucket, start, total))
             self._flat = torch.zeros(total, dtype=torch.float32, device=m._device)
             for name, (o, p) in offs.items():
@@ -210,6 +235,28 @@ class TrainEngine:
             self._offs = {name: (o, (p.numel() + 63) // 64 * 64) for name, (o, p) in offs.items()}
             self._gemm_written = {n for n in self._params if n == "output.weight" or (n.startswith("layers.") and n.endswith(
                 ("wq.weight", "wk.weight", "wv.weight", "wo.weight", "w1.weight", "w2.weight", "w3.weight")) and "lora_" not in n)}
+            if zw:
+                # the sharded parameters move into ONE flat buffer in the compute dtype with the gradient buffer's layout (their old
+                # storage is released): reduce-scatter / all-gather address it by the same flat ranges as the gradients
+                rng = {b: (st, en) for b, st, en in self._ranges}
+                z1 = []
+                for bucket, segs in self._z1:
+                    segs = [x for x in segs if x is not None]
+                    ss = segs[0][0]
+                    se = (segs[-1][1] + 64 * zw - 1) // (64 * zw) * (64 * zw)
+                    assert (se - ss) % (64 * zw) == 0 and se <= rng[bucket][1], (bucket, ss, se, rng[bucket])
+                    z1.append((bucket, rng[bucket][0], rng[bucket][1], ss, se, segs))
+                self._z1 = z1
+                self._flat_params = torch.zeros(total, dtype=self.act, device=m._device)
+                with torch.no_grad():
+                    for _, _, _, _, _, segs in z1:
+                        for a, z, name in segs:
+                            q = self._params[name]
+                            dst = self._flat_params[a:z].view(q.shape)
+                            dst.copy_(q.data)
+                            q.data = dst
+                if hasattr(m, "invalidate_packed_weights"):
+                    m.invalidate_packed_weights()
         runs = []                     # [start, end) float ranges of the flat buffer to zero, adjacent ones merged (one fill per run)
         for name, p in self._params.items():
             if not p.requires_grad:
@@ -217,6 +264,19 @@ class TrainEngine:
                     p.grad = None
                 continue
             v = self._views[name]
+            if self.zero1_world and p.dtype != torch.float32:
+                # a sharded parameter: its gradient lives in the flat buffer only (torch refuses an fp32 .grad on a bf16 tensor); it
+                # restarts after every Zero1Optimizer.step (zero1_mark_fresh)
+                if self._z1_fresh:
+                    if name in self._gemm_written:
+                        self._fresh.add(name)
+                    else:
+                        o, n = self._offs[name]
+                        if runs and runs[-1][1] == o:
+                            runs[-1][1] = o + n
+                        else:
+                            runs.append([o, o + n])
+                continue
             if p.grad is None:
                 # big decoder / head matrices are written (not accumulated) by their first weight-gradient GEMM of the
                 # step: no 27 GB zero-fill and no read of the old value.  Everything else is zeroed here.
@@ -233,6 +293,43 @@ class TrainEngine:
                 raise RuntimeError(f"{name}.grad was replaced by a foreign tensor; use zero_grad(set_to_none=True) or keep the views")
         for o, e in runs:
             self._flat[o:e].zero_()
+        self._z1_fresh = False
+
+    # ------------------------------------------------------------------ ZeRO-1 (a3vlm_amd.zero1.Zero1Optimizer)
+    def flat_params(self) -> torch.Tensor:
+        if self._flat is None:
+            self.ensure_grads()
+        if self._flat_params is None:
+            raise RuntimeError("flat_params(): the engine was not built with zero1_world")
+        return self._flat_params
+
+    def zero1_buckets(self, weight_decay: float = 0.0):
+        """[(bucket, start, end, shard_start, shard_end, [(seg_start, seg_end, weight_decay)])]: per-parameter pieces of each bucket's sharded
+        span with the reference's decay rule (no decay for *.bias / *norm.weight, util/misc.py:586-599: none of the sharded matrices)."""
+        self.flat_params()
+        return [(b, s, e, ss, se, [(a, z, 0.0 if (n.endswith(".bias") or n.endswith("norm.weight")) else weight_decay) for a, z, n in segs])
+                for b, s, e, ss, se, segs in self._z1]
+
+    def zero1_mark_fresh(self) -> None:
+        """The sharded parameters were updated in place (all-gather into flat_params): their gradients restart at the next backward and
+        every cache keyed on parameter state (packed inference weights) is stale; the training images are views and need nothing."""
+        self._z1_fresh = True
+        for _, _, _, _, _, segs in self._z1:
+            for _, _, name in segs:
+                torch.autograd.graph.increment_version(self._params[name])
+
+    def _pview(self, ps) -> Optional[torch.Tensor]:
+        """[rows, cols] view of consecutive sharded parameters (wq|wk|wv, w1|w3, or one matrix) in the flat parameter buffer, or None."""
+        fp = self._flat_params
+        if fp is None or any(q.dtype != fp.dtype or q.untyped_storage().data_ptr() != fp.untyped_storage().data_ptr() for q in ps):
+            return None
+        es = fp.element_size()
+        o = (ps[0].data_ptr() - fp.data_ptr()) // es
+        n, cols = sum(q.numel() for q in ps), ps[0].shape[1]
+        for a, b2 in zip(ps, ps[1:]):
+            if b2.data_ptr() != a.data_ptr() + a.numel() * es or b2.shape[1] != cols:
+                return None
+        return fp[o:o + n].view(n // cols, cols)
 
     def grad_ranges(self):
         return list(self._ranges)
@@ -971,6 +1068,14 @@ class _Images:
             return "L" + key.split(".")[1]
         return "vp" if key.startswith(("vp", "vq")) else "out"
 
+    def _fused(self, ps):
+        """The fused matrix of consecutive parameters: a VIEW of the flat parameter buffer under ZeRO-1 (always current, no copy: the
+        image IS the parameter storage), else their concatenation."""
+        v = self.eng._pview(list(ps)) if self.eng.zero1_world and not self.eng.lora else None
+        if v is not None:
+            return v
+        return torch.cat(list(ps), dim=0) if len(ps) > 1 else ps[0]
+
     def _both(self, key, w):      # forward image W [N,K] now; W^T [K, N padded to 64] only when somebody asks for key + ".t"
         ext = self.eng._kext_cols(key)
         if ext:                   # LoRA inside the GEMMs: one [N + Rp, K + Rp] image = [[W, B], [A, 0]]; forward reads [W | B] (rows 0..N),
@@ -1068,12 +1173,12 @@ class _Images:
         if self.ver.get(g) != ver:
             with torch.no_grad():
                 if g.startswith("L"):
-                    self._both(f"qkv.{i}", torch.cat([ps[0], ps[1], ps[2]], dim=0))
-                    self._both(f"wo.{i}", ps[3])
-                    self._both(f"w13.{i}", torch.cat([ps[4], ps[5]], dim=0))
-                    self._both(f"w2.{i}", ps[6])
+                    self._both(f"qkv.{i}", self._fused(ps[0:3]))
+                    self._both(f"wo.{i}", self._fused(ps[3:4]))
+                    self._both(f"w13.{i}", self._fused(ps[4:6]))
+                    self._both(f"w2.{i}", self._fused(ps[6:7]))
                 elif g == "out":
-                    self._both("out", ps[0])
+                    self._both("out", self._fused(ps[0:1]))
                 else:
                     self._both("vp", ps[0])
                     self.store["vp.b"] = ps[1].to(eng.act)

@@ -7,11 +7,19 @@ import torch
 import torch.nn as nn
 
 
-def promote_trainable_params_to_fp32(model: nn.Module) -> None:
-    """util/tensor_type.py:60-66: trainables become fp32 masters, frozen params keep their dtype."""
-    for p in model.parameters():
-        if p.requires_grad:
-            p.data = p.data.float()
+def promote_trainable_params_to_fp32(model: nn.Module, keep_matrices_sharded: bool = False) -> None:
+    """util/tensor_type.py:60-66: trainables become fp32 masters, frozen params keep their dtype.
+    ``keep_matrices_sharded`` (ZeRO-1, ``--zero1``): the decoder's linears, the embeddings and the LM head stay in the compute dtype --
+    their fp32 masters exist only as 1/N slices inside ``zero1.Zero1Optimizer``, as FSDP(SHARD_GRAD_OP) shards them in the reference
+    (main_finetune.py:241-263); everything else (norms, projector, tags, adapters) is promoted as usual."""
+    big = (".wq.weight", ".wk.weight", ".wv.weight", ".wo.weight", ".w1.weight", ".w2.weight", ".w3.weight")
+    for n, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        if keep_matrices_sharded and "lora_" not in n and (n.endswith(big) and ".layers." in "." + n or n.endswith(("tok_embeddings.weight", "output.weight"))) \
+                and "clip." not in n and "visual" not in n:
+            continue
+        p.data = p.data.float()
 
 
 def adjust_learning_rate_epoch(optimizer, epoch: float, *, lr: float, min_lr: float, warmup_epochs: float, epochs: float) -> float:

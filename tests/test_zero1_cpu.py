@@ -1,0 +1,200 @@
+"""CPU (-m "not gpu"): ZeRO-1 (a3vlm_amd/zero1.py) with world_size 2 over gloo -- reduce-scatter of every gradient bucket, AdamW on each
+rank's slice of the fp32 masters / moments, all-gather of the updated parameters -- equals the replicated DP step (all-reduce + AdamW on
+everything, dp.GradReducer) BIT FOR BIT in fp32; and the flat parameter layout TrainEngine(zero1_world=N) builds.
+
+The AdamW arithmetic of the test is passed in (``update=``): the product updates on the device only (a3v_adamw_scaled)."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from a3vlm_amd.dp import GradReducer
+from a3vlm_amd.zero1 import Zero1Optimizer
+
+
+def adamw_ref(master, grad, m, v, out, lr, b1, b2, eps, wd, step, grad_scale):
+    """torch.optim.AdamW's update (decoupled decay, bias correction) on flat fp32 slices, in place."""
+    g = grad * (grad_scale if grad_scale is not None else 1.0)
+    master.mul_(1.0 - lr * wd)
+    m.mul_(b1).add_(g, alpha=1.0 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1.0 - b2)
+    denom = (v / (1.0 - b2 ** step)).sqrt_().add_(eps)
+    master.addcdiv_(m / (1.0 - b1 ** step), denom, value=-lr)
+    out.copy_(master)
+
+
+class FakeZ1Engine:
+    """A flat fp32 gradient buffer and a flat parameter buffer with TrainEngine(zero1_world=N)'s layout: per bucket a sharded span
+    (several parameters, padded to 64 N) followed by small replicated parameters."""
+
+    def __init__(self, world, spec):
+        self.world, self._z1, self._ranges, total = world, [], [], 0
+        g = 64 * world
+        for i, (sharded, small) in enumerate(spec):
+            total = (total + g - 1) // g * g
+            start, segs = total, []
+            for n in sharded:
+                segs.append((total, total + n, 0.1 if n % 2 == 0 else 0.0))
+                total += (n + 63) // 64 * 64
+            total = (total + g - 1) // g * g
+            ss, se = start, total
+            total += sum((n + 63) // 64 * 64 for n in small)
+            self._ranges.append((f"layer{i}", start, total))
+            self._z1.append((f"layer{i}", start, total, ss, se, segs))
+        self._flat = torch.zeros(total)
+        self._params = torch.zeros(total)
+        self.on_layer_grads_ready = None
+        self.fresh = 0
+
+    def flat_grads(self):
+        return self._flat
+
+    def flat_params(self):
+        return self._params
+
+    def grad_ranges(self):
+        return list(self._ranges)
+
+    def zero1_buckets(self, weight_decay=0.0):
+        return [(b, s, e, ss, se, [(a, z, wd) for a, z, wd in segs]) for b, s, e, ss, se, segs in self._z1]
+
+    def zero1_mark_fresh(self):
+        self.fresh += 1
+
+
+SPEC = [([1000, 300], [64]), ([4096], [10, 10]), ([130, 70, 257], [])]
+
+
+def _worker(rank, world, port, outdir, wire):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        eng = FakeZ1Engine(world, SPEC)
+        n = eng.flat_params().numel()
+        init = torch.randn(n, generator=torch.Generator().manual_seed(7))
+        eng.flat_params().copy_(init)
+        opt = Zero1Optimizer(eng, dist, lr=1e-2, betas=(0.9, 0.95), eps=1e-8, reduce_dtype=wire, update=adamw_ref)
+        # the replicated reference on the same rank: GradReducer's all-reduce + the same AdamW on every element of the sharded spans
+        ref_eng = FakeZ1Engine(world, SPEC)
+        red = GradReducer(ref_eng, dist, reduce_dtype=wire)
+        ref_p, ref_m, ref_v = init.clone(), torch.zeros(n), torch.zeros(n)
+        for step in range(1, 4):
+            local = torch.randn(n, generator=torch.Generator().manual_seed(100 * step + rank))
+            inside = torch.zeros(n, dtype=torch.bool)
+            for _, s0, e0 in eng.grad_ranges():
+                inside[s0:e0] = True
+            local[~inside] = 0.0                      # (alignment gaps between buckets carry no gradient in the engine either)
+            coef = torch.tensor([0.5 if step == 2 else 1.0])
+            # accumulation window of two micro-steps: the first is a no_sync step
+            for micro, e_on in ((0, False), (1, True)):
+                for e, hooked in ((eng, opt), (ref_eng, red)):
+                    hooked.enabled = e_on
+                    e.flat_grads().add_(local if micro else 0.5 * local)
+                    for nme, s, en in reversed(e.grad_ranges()):
+                        e.on_layer_grads_ready(nme, s, en)
+            opt.finish()
+            red.finish()
+            norm = opt.grad_norm()
+            sharded = torch.zeros(n, dtype=torch.bool)
+            for _, _, _, ss, se, _ in eng.zero1_buckets():
+                sharded[ss:se] = True
+            want_norm = torch.linalg.vector_norm(ref_eng.flat_grads())
+            assert torch.allclose(norm, want_norm, rtol=1e-5), (float(norm), float(want_norm))
+            opt.step(grad_scale=coef)
+            for _, _, _, ss, se, segs in ref_eng.zero1_buckets():
+                for a, z, wd in segs:
+                    adamw_ref(ref_p[a:z], ref_eng.flat_grads()[a:z], ref_m[a:z], ref_v[a:z], ref_p[a:z].clone(), 1e-2, 0.9, 0.95, 1e-8, wd, step, coef)
+            eng.flat_grads().zero_()
+            ref_eng.flat_grads().zero_()
+            assert eng.fresh == step
+        torch.save((eng.flat_params().clone(), ref_p, sharded, opt.state_dict()), os.path.join(outdir, f"z{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("wire", [None, torch.bfloat16])
+def test_zero1_step_equals_replicated_step_world2_gloo(wire, tmp_path):
+    world, port = 2, 29400 + (os.getpid() % 200) * 2 + (0 if wire is None else 1)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), wire), nprocs=world, join=True)
+    res = [torch.load(os.path.join(str(tmp_path), f"z{r}.pt"), weights_only=False) for r in range(world)]
+    p0, ref0, sharded, sd0 = res[0]
+    p1, ref1, _, sd1 = res[1]
+    assert torch.equal(p0, p1), "every rank holds the same parameters after the all-gather"
+    assert torch.equal(ref0, ref1)
+    # the sharded spans: bit for bit the replicated step (fp32 wire and bf16 wire alike: same cast, same sum, same update per element)
+    assert torch.equal(p0[sharded], ref0[sharded])
+    assert float((p0[sharded] - torch.randn(p0.numel(), generator=torch.Generator().manual_seed(7))[sharded]).abs().max()) > 1e-3
+    # each rank's state = its slice only: 1 / world of the sharded elements (masters + two moments)
+    n_sh = int(sharded.sum())
+    for sd in (sd0, sd1):
+        held = sum(b["master"].numel() for b in sd["zero1"]["buckets"].values())
+        assert held * world == n_sh
+
+
+def test_zero1_state_round_trip_single_rank():
+    class One:
+        class ReduceOp:
+            SUM, AVG, MAX = "sum", "avg", "max"
+        get_world_size = staticmethod(lambda group=None: 1)
+        get_rank = staticmethod(lambda group=None: 0)
+        get_backend = staticmethod(lambda group=None: "none")
+    eng = FakeZ1Engine(1, SPEC)
+    eng.flat_params().copy_(torch.randn(eng.flat_params().numel(), generator=torch.Generator().manual_seed(1)))
+    opt = Zero1Optimizer(eng, One, lr=1e-2, reduce_dtype=None, update=adamw_ref)
+    eng.flat_grads().copy_(torch.randn(eng.flat_grads().numel(), generator=torch.Generator().manual_seed(2)))
+    for nme, s, e in eng.grad_ranges():
+        eng.on_layer_grads_ready(nme, s, e)
+    opt.finish()
+    opt.step()
+    sd = opt.state_dict()
+    after = eng.flat_params().clone()
+    eng2 = FakeZ1Engine(1, SPEC)
+    opt2 = Zero1Optimizer(eng2, One, lr=1e-2, reduce_dtype=None, update=adamw_ref)
+    opt2.load_state_dict(sd)
+    sharded = torch.zeros(after.numel(), dtype=torch.bool)
+    for _, _, _, ss, se, _ in eng.zero1_buckets():
+        sharded[ss:se] = True
+    assert torch.equal(eng2.flat_params()[sharded], after[sharded]) and opt2.step_count == 1
+    with pytest.raises(RuntimeError):
+        sd["zero1"]["rank"] = 1
+        opt2.load_state_dict(sd)
+
+
+def test_train_engine_zero1_layout_on_cpu():
+    """TrainEngine(zero1_world=N): the big matrices move into one flat buffer in the compute dtype with the gradient buffer's layout, every
+    bucket's sharded span is a whole number of 64 N granules, the fused GEMM images are views of that storage, small parameters stay fp32."""
+    from a3vlm_amd.model.LLM import llama_ens5 as plugin
+    from a3vlm_amd.train import TrainEngine
+    from a3vlm_amd.util import promote_trainable_params_to_fp32
+    m = plugin.Transformer(plugin.ModelArgs(dim=128, n_layers=2, n_heads=2, vocab_size=200, multiple_of=64, max_seq_len=64))
+    for p in m.parameters():
+        p.requires_grad = True
+    m.to(torch.bfloat16)
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    promote_trainable_params_to_fp32(m, keep_matrices_sharded=True)
+    assert m.layers[0].attention.wq.weight.dtype == torch.bfloat16 and m.layers[0].attention_norm.weight.dtype == torch.float32
+    assert m.tok_embeddings.weight.dtype == torch.bfloat16 and m.norm.weight.dtype == torch.float32
+    W = 8
+    eng = TrainEngine(m, torch.bfloat16, zero1_world=W)
+    fp = eng.flat_params()
+    assert fp.dtype == torch.bfloat16 and fp.numel() == eng.flat_grads().numel()
+    for name, s, e, ss, se, segs in eng.zero1_buckets(0.02):
+        assert (se - ss) % (64 * W) == 0 and ss % (64 * W) == 0 and s <= ss < se <= e
+        for a, z, wd in segs:
+            assert ss <= a < z <= se and wd == 0.02
+    for n, p in m.named_parameters():
+        assert torch.equal(p.detach().float(), before[n].float()), n
+        inside = p.untyped_storage().data_ptr() == fp.untyped_storage().data_ptr()
+        assert inside == (p.dtype == torch.bfloat16), n
+        if inside:        # gradient view and parameter view address the same flat range
+            off = (p.data_ptr() - fp.data_ptr()) // 2
+            assert eng._views[n].data_ptr() == eng.flat_grads().data_ptr() + 4 * off
+    a = m.layers[1].attention
+    qkv = eng._pview([a.wq.weight, a.wk.weight, a.wv.weight])
+    assert qkv is not None and qkv.shape == (3 * 128, 128) and qkv.data_ptr() == a.wq.weight.data_ptr()
+    assert torch.equal(qkv, torch.cat([a.wq.weight, a.wk.weight, a.wv.weight]).detach())
+    eng.zero1_mark_fresh()
+    assert eng._z1_fresh
