@@ -1214,7 +1214,7 @@ def step_loss(engine: TrainEngine, anchor: torch.Tensor, examples, labels, image
 
 def hbm_budget(dim: int, n_layers: int, n_heads: int, ffn: int, vocab: int, batch: int, seq: int, text: int, n_kv_heads: Optional[int] = None,
                vit_params: int = 304_000_000, proj_in: int = 1024, world: int = 1, wire_bytes: int = 2, recompute: bool = False,
-               stream_bytes: int = 2) -> Dict[str, int]:
+               stream_bytes: int = 2, zero1: bool = False) -> Dict[str, int]:
     """Bytes of one pure-DP replica of the FULL fine-tune (every rank of a DP job holds exactly this; SURVEY 7 "13B full fine-tune
     memory", main_finetune.py:241-276): what ``TrainEngine`` + ``FusedAdamW`` + ``dp.GradReducer`` allocate, from their own layouts.
     fp32 masters / flat gradient buffer / two AdamW moments of every trainable parameter, the bf16 GEMM images of the decoder and
@@ -1234,14 +1234,27 @@ def hbm_budget(dim: int, n_layers: int, n_heads: int, ffn: int, vocab: int, batc
     sb = stream_bytes
     block = rows * (2 * dim * 2 + qkv * 2 + 2 * n_heads * hd * 2 + 3 * ffn * 2 + dim * sb) + batch * hkv * spad * hd * 2 + batch * n_heads * seq * 4
     bwd_ws = rows * ((dim * 2 if sb == 4 else 0) + ffn * 2 + 2 * ffn * 2 + dim * 2 + n_heads * hd * 2 + qkv * 2 + dim * sb) + batch * hkv * hd * spad * 2
-    out = {
-        "masters_fp32": 4 * p_train, "grads_fp32": 4 * p_train, "adamw_moments_fp32": 8 * p_train, "images_bf16": 2 * p_mat,
-        "vit_bf16": 2 * vit_params,
-        "wire_buckets": wire_bytes * p_train if world > 1 and wire_bytes != 4 else 0,
+    if zero1:
+        # ZeRO-1 (zero1.Zero1Optimizer, TrainEngine(zero1_world=world)): the big matrices (decoder linears, embeddings, head) exist once in
+        # bf16 (parameters = GEMM images = all-gather destination), their fp32 masters, both moments, the fp32 gradient slice and the bf16
+        # output slice only for 1 / world of them; ONE wire bucket of the largest layer instead of persistent buckets for all
+        p_big = p_mat + dim * vocab
+        p_small = p_train - p_big
+        layer_big = p_layer if n_layers else 0
+        out = {"masters_fp32": 4 * p_small + 4 * p_big // world, "grads_fp32": 4 * p_train + 4 * p_big // world,
+               "adamw_moments_fp32": 8 * p_small + 8 * p_big // world, "images_bf16": 2 * p_big + 2 * p_big // world,
+               "vit_bf16": 2 * vit_params,
+               "wire_buckets": (wire_bytes * max(layer_big, dim * vocab) + wire_bytes * max(layer_big, dim * vocab) // world) if wire_bytes != 4 else 0}
+    else:
+        out = {
+            "masters_fp32": 4 * p_train, "grads_fp32": 4 * p_train, "adamw_moments_fp32": 8 * p_train, "images_bf16": 2 * p_mat,
+            "vit_bf16": 2 * vit_params,
+            "wire_buckets": wire_bytes * p_train if world > 1 and wire_bytes != 4 else 0}
+    out.update({
         "stream_checkpoints": (n_layers + 1) * rows * dim * sb + rows * dim * sb,
         "block_activations": block * (1 if recompute else n_layers),
         "backward_workspace": bwd_ws,
         "ce_buffers": batch * text * vocab * 2 * 2 + batch * text * dim * 2 * 2,
-    }
+    })
     out["total"] = sum(out.values())
     return out

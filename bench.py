@@ -385,6 +385,77 @@ def train_leg(m, B, T, image, tokens, steps, warmup, timer, recompute=None):
 train_leg.exposed = None
 
 
+class _ShardOf:
+    """torch.distributed's surface of rank 0 of an N-rank job for ``Zero1Optimizer(stub_collective=True)``: on ONE GPU this allocates and
+    updates exactly what rank 0 of a DP-N ZeRO-1 job holds (1/N of the masters and moments), with the collectives replaced by the local
+    slice copies -- the memory and the compute of one DP-N shard, not its wire time."""
+    class ReduceOp:
+        SUM, AVG, MAX = "sum", "avg", "max"
+
+    def __init__(self, world):
+        self.world = world
+
+    def get_world_size(self, group=None):
+        return self.world
+
+    def get_rank(self, group=None):
+        return 0
+
+    def get_backend(self, group=None):
+        return "stub"
+
+
+def zero1_leg(m, B, T, image, tokens, steps, warmup, timer, shard_of=8, recompute=False):
+    """configs[3] under ZeRO-1 (a3vlm_amd/zero1.py = the reference's FSDP(SHARD_GRAD_OP) sizing): full fine-tune step of this rank's
+    micro-batch with the big matrices kept only in bf16 (flat buffer = parameters = GEMM images), fp32 masters + AdamW moments of 1/N of
+    them.  With a real process group (N = world > 1) the collectives run; on one GPU (``shard_of`` = 8) rank 0's shard of a DP-8 job is
+    emulated: same allocations, same kernels, collectives stubbed.  DESTRUCTIVE for ``m`` (small parameters become fp32, the big ones move
+    into the engine's flat buffer)."""
+    from a3vlm_amd.train import TrainEngine
+    from a3vlm_amd.util import promote_trainable_params_to_fp32, add_weight_decay
+    from a3vlm_amd.optim import FusedAdamW
+    from a3vlm_amd.zero1 import Zero1Optimizer
+    for n, p in m.named_parameters():
+        p.requires_grad = not n.startswith("clip.")
+    m._ws.clear(); m._packed.clear(); m._packed_version = None; m._destroy_kv_cache()
+    gc.collect()
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
+    promote_trainable_params_to_fp32(m, keep_matrices_sharded=True)
+    real = timer.dist is not None
+    zd = timer.dist if real else _ShardOf(shard_of)
+    world = zd.get_world_size()
+    eng = TrainEngine(m, torch.bfloat16, recompute=recompute, zero1_world=world)
+    groups = [{**g, "params": [q for q in g["params"] if q.dtype == torch.float32]} for g in add_weight_decay(m, 0.0)]
+    small = FusedAdamW([g for g in groups if g["params"]], lr=2e-5, betas=(0.9, 0.95), engine=eng)
+    opt = Zero1Optimizer(eng, zd, lr=2e-5, betas=(0.9, 0.95), reduce_dtype=torch.bfloat16, small=small)
+    opt.stub_collective = not real
+    labels = tokens.clone()
+    labels[:, :T // 2] = 0
+
+    def one():
+        loss = eng.forward_loss(tokens, labels, image)
+        eng.backward(1.0)
+        opt.finish()
+        _, coef = opt.clip_coef(8.0)
+        opt.step(grad_scale=coef.reshape(1))
+        m.zero_grad(set_to_none=True)
+        one.loss = loss
+    try:
+        sec = timer(one, steps, max(1, warmup))
+    finally:
+        for p in m.parameters():               # whatever happens, the legs that follow start from parameters without gradient views
+            p.grad = None
+    mem = torch.cuda.max_memory_allocated() / 2 ** 30
+    n_big = sum(b["shard"][1] - b["shard"][0] for b in opt.buckets)
+    out = {"sec": sec, "loss": float(one.loss), "hbm_gib": mem, "sharded_params": n_big, "shard_state_gib": opt.shard_bytes() / 2 ** 30,
+           "world": world, "emulated": not real, "recompute": bool(eng.recompute), "wire_bytes_per_step": int(opt.wire_bytes_last_step)}
+    del eng, opt, small, one
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
 def lora_leg(m, args, B, T, image, tokens, steps, warmup, timer, dev, rank=16):
     """configs[2]: LoRA fine-tune step (rank-16 adapters on the seven decoder linears of every block + norms + projector
     trainable, base matrices frozen in bf16) on this rank's micro-batch; adapter plugin built around the SAME base parameters."""
@@ -575,6 +646,18 @@ def m13b_leg(B, T, steps, warmup, timer, dev):
     res = {"forward_samples_s": round(B * world / sec, 2), "forward_ms": round(sec * 1e3, 1), "forward_mfma_frac": round(fl["total"] / sec / MFMA_PEAK_BF16, 4),
            "decode_tok_s": round(B * world / dsec, 1), "decode_ms_per_step": round(dsec * 1e3, 3),
            "decode_hbm_frac": round(bytes_decode_step(args, B, T + W + 10) / dsec / HBM_PEAK, 4)}
+    # configs[3] under ZeRO-1: rank 0's shard of a DP-8 job (or the real N ranks), micro-batch 8, block activations kept (no recompute)
+    try:
+        z = zero1_leg(m, B, T, img, tok, 2, 1, timer, shard_of=8, recompute=False)
+        flz = flops_forward(args, B, T, W)
+        res["train_zero1"] = {"micro_batch": B, "samples_s": round(B * world / z["sec"], 2), "ms_per_step": round(z["sec"] * 1e3, 1), "loss": round(z["loss"], 4),
+                              "hbm_gib": round(z["hbm_gib"], 1), "shard_of": z["world"], "collectives": "stubbed (one-GPU emulation of rank 0 of DP-8)" if z["emulated"] else "RCCL",
+                              "optimizer_state_gib_per_rank": round(z["shard_state_gib"], 1), "sharded_params": z["sharded_params"], "recompute": z["recompute"],
+                              "wire_bytes_per_step": z["wire_bytes_per_step"], "mfma_frac_3x": round(3 * flz["total"] / z["sec"] / MFMA_PEAK_BF16, 4),
+                              "note": "ZeRO-1 (main_finetune --zero1; the reference's FSDP(SHARD_GRAD_OP), main_finetune.py:241-263): bf16 parameters = GEMM "
+                                      "images in one flat buffer, reduce-scatter -> AdamW on 1/N of the fp32 masters + moments -> all-gather"}
+    except Exception as e:
+        res["train_zero1"] = {"samples_s": None, "error": repr(e)[:300]}
     mb = 4
     try:
         tsec, loss, mem, ntr, rec = train_leg(m, mb, T, img[:mb].contiguous(), tok[:mb].contiguous(), 2, 1, timer, recompute=True)
@@ -727,6 +810,26 @@ def pmc_traffic():
         return None
 
 
+def in_step_ring_ms(headline):
+    """ms per step of the ring GEMM kernels INSIDE the headline step, from the newest step-alone rocprofv3 table under profiles/
+    (tools/round_evidence.sh; `roofline.gemm_ms_per_step` is each shape timed alone): the two should agree to a few per cent."""
+    import glob
+    name = {"lora": "lora_step", "train": "train_step", "forward": "forward_step"}[headline]
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r*_kernel_stats_{name}.txt")))
+    if not files:
+        return None
+    tot, calls = 0.0, 0.0
+    for line in open(files[-1]):
+        if "gemm_nt_bf16_ring_kernel" in line or (headline == "train" and "gemm_tn_bf16_pp_kernel" in line):
+            parts = line.rsplit(None, 6)
+            try:
+                calls += float(parts[-6]); tot += float(parts[-5])
+            except (ValueError, IndexError):
+                pass
+    return {"ms_per_step": round(tot, 2), "calls_per_step": int(calls), "file": os.path.basename(files[-1]),
+            "kernels": "gemm_nt_bf16_ring_kernel<...>" + (" + gemm_tn_bf16_pp_kernel<...>" if headline == "train" else "")}
+
+
 def launch_only(a, rank, world):
     """A3V_BENCH_LAUNCH_ONLY=1 (CPU test of the launch contract, no GPU work): every rank joins a gloo group, one all-reduce
     counts them, rank 0 prints the line's launch fields."""
@@ -768,6 +871,18 @@ def main():
         dist = None
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local if world > 1 else 0)
+    # the SCALE run must prove itself: the number of ranks comes OUT OF THE COMMUNICATOR (an all-reduce of ones on the device the rank
+    # computes on), and every rank reports the device it sits on
+    rccl_ranks, rank_devices = 1, None
+    if dist is not None:
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        rccl_ranks = int(ones.item())
+        props = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "local_rank": local, "device": int(dev.index), "name": props.name, "uuid": str(getattr(props, "uuid", "")),
+                "backend": dist.get_backend()}
+        rank_devices = [None] * world
+        dist.all_gather_object(rank_devices, mine)
     timer = Timer(dist, dev)
     legs = set((a.legs.split(",") if a.legs else (ALL_LEGS if world == 1 else CORE_LEGS)))
     if a.model != "7b":
@@ -889,6 +1004,7 @@ def main():
                     "frac_full_fine_tune_mix": round(all_f / all_t / MFMA_PEAK_BF16, 4),
                     "families": {k: {"tflops": round(v[0] / v[1] / 1e12, 1), "frac": round(v[0] / v[1] / MFMA_PEAK_BF16, 4), "ms_per_step": round(v[1] * 1e3, 2)}
                                  for k, v in fam.items() if v[1] > 0},
+                    "in_step": in_step_ring_ms(headline),
                     "gemm_ms_per_step": round(tot_t * 1e3, 2), "gemm_calls_per_step": sum(r["count"] for r in table if r["kind"] in use),
                     "note": "achieved = algorithmic 2MNK of every GEMM call of one headline step / its HIP-event duration on the launch stream "
                             "(FLOP-weighted over the step's shapes = total GEMM FLOP / total GEMM time), each shape timed alone after a clock "
@@ -932,7 +1048,8 @@ def main():
                        "geometry": "S (single 336x336 crop); geometry R (W=1455) in `geometry_R`",
                        "global_batch": B * world, "seq_len": S,
                        "parallelism": f"dp{world}" + (" (bucketed RCCL gradient all-reduce overlapped with backward)" if world > 1 else "")},
-            "rccl_ranks": world,
+            "rccl_ranks": rccl_ranks,                  # counted by an all-reduce of ones through the process group, not copied from WORLD_SIZE
+            "rank_devices": rank_devices,
             "exposed_allreduce_ms": exposed["exposed_allreduce_ms"] if exposed else None,
             "allreduce": exposed,
             "decode_tok_s": res.get("decode", {}).get("tok_s"),

@@ -202,6 +202,11 @@ def test_dp_replica_fits_288_gib():
     # an fp32 wire needs no extra buckets (reduced in place); 13B with stored activations at micro-batch 8 does NOT fit -> recompute
     assert hbm_budget(5120, 40, 40, 13824, 32000, 4, 1091, 512, recompute=True, world=8, wire_bytes=4)["wire_buckets"] == 0
     assert hbm_budget(5120, 40, 40, 13824, 32000, 8, 1091, 512, recompute=False, world=8)["total"] > 288 * G
+    # ZeRO-1 (--zero1) at DP 8: the sharded masters / moments free ~130 GB per GPU -- 13B runs at micro-batch 8 WITHOUT recompute
+    z13 = hbm_budget(5120, 40, 40, 13824, 32000, 8, 1091, 512, recompute=False, world=8, zero1=True)
+    assert z13["total"] < 288 * G * 0.90, z13["total"] / G
+    assert d13["masters_fp32"] + d13["adamw_moments_fp32"] - z13["masters_fp32"] - z13["adamw_moments_fp32"] > 125 * G
+    assert z13["wire_buckets"] < 2 * G
 
 
 # ------------------------------------------------------------------ the non-finite flag is global under DP
