@@ -593,6 +593,14 @@ __device__ __forceinline__ void mfma_va(const bf16x8& a) {
   else
     asm volatile("v_mfma_f32_32x32x16_bf16 a[%c1:%c2], %0, a[%c3:%c4], a[%c1:%c2]" ::"v"(a), "i"(ACC), "i"(ACC + 15), "i"(BR), "i"(BR + 3) : A3V_AGPR_0_255);
 }
+// VGPR accumulator (+)= A (VGPRs) x a[BR:BR+3]: for dP, which the VALU reads element by element (no v_accvgpr_read per element)
+template <int BR, bool ZERO>
+__device__ __forceinline__ void mfma_va_v(f32x16& acc, const bf16x8& a) {
+  if constexpr (ZERO)
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], 0" : "=&v"(acc) : "v"(a), "i"(BR), "i"(BR + 3) : A3V_AGPR_0_255);
+  else
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(acc) : "v"(a), "i"(BR), "i"(BR + 3) : A3V_AGPR_0_255);
+}
 template <int R>
 __device__ __forceinline__ float agpr_read() {
   float v;
@@ -767,10 +775,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(BwdArgs p) {
   //   C, second half:      MFMA | 1 row fragment of A(u + 2)                                               (x 2 NDB)
   // asm volatile statements (MFMAs, AGPR reads, DMA pieces, the empty `pin`s) keep their source order; pin(x) forces x to be computed in
   // front of the next MFMA, a "memory" clobber keeps LDS reads on their side of it.
+  f32x16 dpv[2];                                   // dP of the even / odd units: VGPR accumulators (B reads them directly)
   auto step = [&](auto DA_, auto DBC_, auto MASK_, auto TBC_, const char* cb, int qr0, const char* fb, int tbf) __attribute__((always_inline)) {
     constexpr bool DA = decltype(DA_)::value, DBC = decltype(DBC_)::value, MASK = decltype(MASK_)::value;
     constexpr int tbc = decltype(TBC_)::value;          // half of the current unit = its S / dP register set; A writes the other set
-    constexpr int RSC = RS + 32 * tbc, RDC = RDP + 32 * tbc, RSN = RS + 32 * (1 - tbc), RDN = RDP + 32 * (1 - tbc);
+    constexpr int RSC = RS + 16 * tbc, RSN = RS + 16 * (1 - tbc);
     constexpr int EPK = 16 / NKS;                  // elements of B per k-step of A (2 at hd 128, 4 at hd 64)
     bf16x8 trO[2][NDB], trQ[2][NDB], bP[2], bS[2];
     f32x4 l4[4], d4[4];
@@ -808,8 +817,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(BwdArgs p) {
         sfor<0, EPK>([&](auto j_) {
           constexpr int j = decltype(j_)::value, r = ks * EPK + j, e = r & 3;
           const float sv = agpr_read<RSC + r>();
-          const float dv = agpr_read<RDC + r>();
-          float a = fmaf(sv, sl2, -1.4426950408889634f * l4[g4][e]);
+          const float dv = dpv[tbc][r];
+          float a = fmaf(sv, sl2, l4[g4][e]);        // l4 = -lse log2(e): pre-scaled in LDS by wave 3 one iteration ahead
           if constexpr (MASK) {
             const int qg = qr0 + 8 * g4 + 4 * hh + e;
             const bool ok = (qg < p.S) && (kvrow < p.S) && (!p.causal || kvrow <= qg);
@@ -821,7 +830,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(BwdArgs p) {
         if constexpr (EPK == 2) asm volatile("" : "+v"(en[0]), "+v"(en[1]), "+v"(dn[0]), "+v"(dn[1]));
         else asm volatile("" : "+v"(en[0]), "+v"(en[1]), "+v"(en[2]), "+v"(en[3]), "+v"(dn[0]), "+v"(dn[1]), "+v"(dn[2]), "+v"(dn[3]));
       }
-      if constexpr (DA) mfma_va<RDN, RVF + 4 * ks, ks == 0>(da[ks]);
+      if constexpr (DA) mfma_va_v<RVF + 4 * ks, ks == 0>(dpv[1 - tbc], da[ks]);
       if constexpr (DBC) {
         if constexpr (ks > 0) finish(std::integral_constant<int, ks - 1>{});
 #pragma unroll
@@ -888,6 +897,14 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(BwdArgs p) {
     }
   };
 
+  // lse of a landed pair -> -lse log2(e) in place (64 floats, wave 3, one iteration before the pair's units read it: the barrier in
+  // between publishes it): one multiply per query row instead of one per (query, key) element
+  auto prescale_lse = [&](const char* buf) __attribute__((always_inline)) {
+    if (wave == 3) {
+      float* sm = const_cast<float*>(reinterpret_cast<const float*>(buf + 2 * TILE));
+      sm[lane] = -1.4426950408889634f * sm[lane];
+    }
+  };
   // ---- prologue: pairs 0, 1, 2 in flight; A(0) and the fragments of A(1) from pair 0
 #ifdef AB_STAMP
 #define AB_PE(k) do { if (stamps) stamps[2 * 64 * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -919,6 +936,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(BwdArgs p) {
     sfor<0, 128>([&](auto i) { agpr_write<decltype(i)::value>(0u); });       // dV^T / dK^T = 0 while the tiles fly
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory", A3V_AGPR_0_255);
     __syncthreads();
+    prescale_lse(lds);                                                        // pair 0 (published by the barrier below)
     const char* Kt = lds + 2 * BUFB + (wave >> 1) * TILE;                     // this wave's 32 keys: rows 32 (wave & 1) .. of tile wave >> 1
     const char* Vt = lds + 3 * BUFB + (wave >> 1) * TILE;
     sfor<0, NKS>([&](auto ks_) {
@@ -945,7 +963,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(BwdArgs p) {
     constexpr int ks = decltype(ks_)::value;
     mfma_va<RS, RKF + 4 * ks, ks == 0>(qa[ks]);
     piece(ks_);
-    mfma_va<RDP, RVF + 4 * ks, ks == 0>(da[ks]);
+    mfma_va_v<RVF + 4 * ks, ks == 0>(dpv[0], da[ks]);
   });
   piece(std::integral_constant<int, PP>{});
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory", A3V_AGPR_0_255);
@@ -974,6 +992,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(BwdArgs p) {
     __syncthreads();
     AB_ST(1, it, 2);
     prep_issue(it + 3 < total);
+    if (more) prescale_lse(xb);                                   // pair it + 1 has landed; its units run after the next barrier
     AB_ST(1, it, 3);
     const bool l0 = !dead(q0), l1 = !dead(q0 + 32), lx = more && !dead(q0x);
     run(l0, l1, !interior(q0), std::integral_constant<int, 0>{}, cb, q0, xb, 0);

@@ -44,7 +44,7 @@ MFMA_PEAK_BF16 = 2.5e15      # dense, /opt/skills/guides/MI355X_MICROARCH.md
 MFMA_PEAK_FP8 = 5.0e15
 HBM_PEAK = 8.0e12            # spec; 6.3e12 achievable
 
-ALL_LEGS = ("forward", "decode", "generate", "fp8", "geometry_r", "config5", "lora", "train", "m13b", "cpu")
+ALL_LEGS = ("forward", "decode", "generate", "fp8", "geometry_r", "config5", "lora", "loader", "train", "m13b", "cpu")
 CORE_LEGS = ("forward", "decode", "lora", "train")
 
 
@@ -494,6 +494,111 @@ def lora_leg(m, args, B, T, image, tokens, steps, warmup, timer, dev, rank=16):
 lora_leg.exposed = None
 
 
+def loader_leg(m, args, B, T, steps, warmup, timer, dev, rank=16, workers=4):
+    """The headline step with the trainer's REAL input pipeline in the loop (reference: engine_finetune.py:13-105 over
+    data/conversation/dataset.py:210-273 + data/transform.py:59-68): PNG files on disk -> FinetuneDialogDataset (render the conversation,
+    tokenise, label the answers) and PIL decode in DataLoader worker processes -> FinetuneDistSampler -> pinned uint8 batch ->
+    a3v_preprocess_batch (PadToSquare / bicubic 336 / normalise on the device) -> engine_finetune.train_one_epoch (LoRA r = 16 step with clip
+    and FusedAdamW, the host loop included).  Same model, same step as `train_lora`; what is added is everything between the disk and
+    MetaModel.forward.  Synthetic 640 x 480 PNGs and conversations, padded to the same T text tokens."""
+    import argparse
+    import dataclasses
+    import json as _json
+    import tempfile
+    import numpy as np
+    from PIL import Image
+    from a3vlm_amd.data.conversation.dataset import FinetuneDialogDataset
+    from a3vlm_amd.data.transform import DevicePreprocessLoader, collate_raw_images, get_transform
+    from a3vlm_amd.dp import FinetuneDistSampler, GradReducer
+    from a3vlm_amd.engine_finetune import train_one_epoch
+    from a3vlm_amd.model.LLM import llama_ens5_peft as peft
+    from a3vlm_amd.model.meta import MetaModel
+    from a3vlm_amd.model.tokenizer import Tokenizer
+    from a3vlm_amd.optim import FusedAdamW
+    from a3vlm_amd.util import promote_trainable_params_to_fp32
+    tok_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "tokenizer.model")
+    world, rk = timer_world(timer), (timer.dist.get_rank() if timer.dist is not None else 0)
+    n_items = B * world * (steps + warmup)
+    tmp = tempfile.mkdtemp(prefix="a3v_loader_")
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:480, 0:640]
+    ann = []
+    for i in range(n_items):                      # smooth renders with a little noise: PNG sizes like a PartNet render, cheap to write
+        if rk == 0 or timer.dist is None:
+            base = np.stack([(xx * (1 + i % 3) + yy) % 256, (yy * 2 + 7 * i) % 256, (xx + yy * (1 + i % 5)) % 256], -1).astype(np.float32)
+            img = np.clip(base * 0.5 + 64 + rng.normal(0, 2, base.shape), 0, 255).astype(np.uint8)
+            Image.fromarray(img).save(os.path.join(tmp, f"r{i}.png"), compress_level=1)
+        box = ",".join(f"[{rng.random():.2f},{rng.random():.2f},{rng.random():.2f}]" for _ in range(8))
+        ann.append({"image": f"r{i}.png", "conversations": [
+            {"from": "human", "value": "<image>\nDetect all manipulable object parts and provide their 3D bounding boxes."},
+            # (six boxes: with the fixture tokenizer the conversation fills all T text tokens, labels to the end -- the same trimmed length
+            #  as the device-resident synthetic step)
+            {"from": "gpt", "value": "There are six manipulable object parts with their 3d bounding boxes: " + " ".join(f"<box>door</box>[{box}]" for _ in range(6))}]})
+    if timer.dist is not None:
+        timer.dist.barrier()
+    with open(os.path.join(tmp, "mm.json"), "w") as f:
+        _json.dump(ann, f)
+    with open(os.path.join(tmp, "data.yaml"), "w") as f:
+        f.write(f"META:\n  - path: '{tmp}/mm.json'\n    type: 'image_text'\n    root: '{tmp}'\n")
+    pm = share_into(peft.Transformer, peft.ModelArgs(**dataclasses.asdict(args), lora_rank=rank), m, dev)
+    train = pm.get_trainable_params()
+    for n, p in pm.named_parameters():
+        p.requires_grad = n in train
+    promote_trainable_params_to_fp32(pm)
+    mm = MetaModel.__new__(MetaModel)
+    torch.nn.Module.__init__(mm)
+    mm.llma, mm.tokenizer, mm.llama_type, mm.is_peft = pm, Tokenizer(tok_path), "llama_ens5_peft", True
+    eng = mm.train_engine(torch.bfloat16)
+    params = [p for p in mm.parameters() if p.requires_grad]
+    opt = FusedAdamW(params, lr=2e-5, betas=(0.9, 0.95), weight_decay=0.0, engine=eng)
+    red = GradReducer(eng, timer.dist, reduce_dtype=torch.bfloat16) if timer.dist is not None else None
+    W = pm.image_words
+    ds = FinetuneDialogDataset(os.path.join(tmp, "data.yaml"), get_transform("padded_resize", 336, on_device=True), max_words=T + W, image_words=W,
+                               tokenizer=mm.tokenizer, cache_on_disk=False, rank=rk)
+    sampler = FinetuneDistSampler(ds, num_replicas=world, rank=rk, shuffle=True, batch_size=B, acc_grad=1, seed=0)
+    inner = torch.utils.data.DataLoader(ds, batch_size=B, sampler=sampler, num_workers=workers, pin_memory=True, drop_last=True,
+                                        collate_fn=collate_raw_images, persistent_workers=False)
+    loader = DevicePreprocessLoader(inner, 336, dev, torch.float32)
+    marks = {}
+
+    class Timed:
+        """the epoch's loader with a timestamp in front of batch `warmup` (worker start-up and the first steps are not the steady state)"""
+        def __len__(self):
+            return len(loader)
+
+        def __iter__(self):
+            for i, b in enumerate(loader):
+                if i == warmup:
+                    torch.cuda.synchronize()
+                    if timer.dist is not None:
+                        timer.dist.barrier()
+                    marks["t0"] = time.perf_counter()
+                yield b
+    targs = argparse.Namespace(accum_iter=1, clip_grad=8, lr=2e-5, min_lr=0.0, warmup_epochs=0.0, epochs=1, print_freq=10 ** 6, save_iteration_interval=0)
+    torch.cuda.reset_peak_memory_stats()
+    try:
+        sampler.set_epoch(0, 0)
+        stats = train_one_epoch(mm, Timed(), opt, 0, 0, targs, reducer=red, log=lambda *_: None)
+        torch.cuda.synchronize()
+        if timer.dist is not None:
+            timer.dist.barrier()
+        t1 = time.perf_counter()
+    finally:
+        for p in m.parameters():
+            p.grad = None
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+    n_timed = len(loader) - warmup
+    sec = (t1 - marks["t0"]) / max(n_timed, 1)
+    del eng, opt, red, pm, mm, loader, inner
+    gc.collect()
+    torch.cuda.empty_cache()
+    return {"samples_s": round(B * world / sec, 3), "ms_per_step": round(sec * 1e3, 2), "steps_timed": n_timed, "workers": workers,
+            "closs": round(float(stats["closs"]), 4),
+            "pipeline": "640x480 PNG files -> FinetuneDialogDataset + PIL decode in DataLoader workers -> FinetuneDistSampler -> pinned uint8 batch -> "
+                        "a3v_preprocess_batch on the device -> engine_finetune.train_one_epoch (LoRA r=16, clip 8, FusedAdamW)"}
+
+
 # ---------------------------------------------------------------------------------------------------------------- inference legs
 def decode_leg(m, fwd_prefill, B, T, n_steps, timer, dev, image_words=None):
     """Greedy decode MODEL steps after a prefill (KV cache holds T + W positions): argmax + one-token forward_inference."""
@@ -888,7 +993,7 @@ def main():
     if a.model != "7b":
         legs -= {"m13b", "geometry_r", "config5"} if a.model == "13b" else {"m13b"}
     if a.no_train:
-        legs -= {"train", "lora", "m13b"}
+        legs -= {"train", "lora", "loader", "m13b"}
     if a.no_cpu_baseline:
         legs.discard("cpu")
 
@@ -967,6 +1072,14 @@ def main():
                     "config": f"configs[2]: LoRA r=16 on all 7 decoder linears + norms + projector trainable, base frozen bf16, bs={B}/GPU, dp{world}",
                     "flop_convention": "2 x forward FLOPs (forward + input-gradient GEMMs; no weight-gradient GEMMs for frozen matrices)"}
         res["train_lora"] = guarded("lora", _lora)
+    if "loader" in legs:
+        def _loader():
+            out = loader_leg(m, args, B, T, max(a.steps, 20) if a.model != "tiny" else a.steps, max(4, a.warmup) if a.model != "tiny" else a.warmup, timer, dev)
+            syn = (res.get("train_lora") or {}).get("samples_s")
+            if syn:
+                out["vs_device_resident_synthetic_step"] = round(out["samples_s"] / syn, 4)
+            return out
+        res["train_lora_with_loader"] = guarded("loader", _loader)
     train = None
     if "train" in legs:
         def _train():
