@@ -1,5 +1,5 @@
 // EXPERIMENT (round 4; built only with `make EXPERIMENTS=1`, not part of the C-ABI of include/a3vlm_hip.h; driver: tools/lora_stream_bench.py).
-// Outcome (profiles/r04d_lora_stream_experiments.txt): correct on the first run, NOT faster than the kernels it was meant to replace --
+// Outcome (profiles/r04d_stream_experiments.txt): correct on the first run, NOT faster than the kernels it was meant to replace --
 // the NT form 2.2 - 3.3 TB/s against 3.4 - 5.0 (a wave load in the MFMA operand layout = 16 rows x 64 B costs ~90 TA cycles instead of
 // 16, whether it hits L2 or not), the TN form 4.5 - 5.0 against 4.1 - 4.8 at its best slice count; ring depth (3 or 4 stages) and panel
 // width (256 or 512 B) change nothing.  A bare LDS-DMA stream with the same panel walk (tools/ubench/dmaread.hip) does 5.1 TB/s with the
