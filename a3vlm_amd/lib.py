@@ -42,6 +42,9 @@ SIGNATURES = {
     "a3v_scale_cast": (I, [P, I, P, I, L, F, P]),
     "a3v_sumsq_partials": (I, [P, L, P, P]),
     "a3v_grad_bucket_allreduce": (I, [P, P, L, P, I, P]),
+    "a3v_grad_bucket_reduce_scatter": (I, [P, P, L, P, P, P, I, P]),
+    "a3v_param_shard_all_gather": (I, [P, P, P, L, P]),
+    "a3v_rccl_comm_count": (I, [P]),
     "a3v_rccl_available": (I, []),
     "a3v_gemm_nn": (I, [P, L, P, L, P, L, I, I, I, P, L, I, P]),
     "a3v_gemm_tn": (I, [P, L, P, L, P, L, I, I, I, P, L, I, P]),

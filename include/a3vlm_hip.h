@@ -496,6 +496,19 @@ int a3v_scale_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int
  * is the caller's decision.  RCCL is not linked into the library: ncclAllReduce is resolved at run time from the librccl already
  * in the process (PyTorch-ROCm's), A3V_RCCL_LIB, or the loader path; A3V_ERR_ARG when none is found. */
 int a3v_grad_bucket_allreduce(void* comm, float* grad, int64_t n, void* wire_bf16, int average, void* stream);
+
+/* ZeRO-1 through the same boundary (round 4; the reference trains configs[3] under FSDP SHARD_GRAD_OP, main_finetune.py:241-263:
+ * gradients and AdamW state sharded over DP; the Python host drives these two collectives through torch.distributed,
+ * a3vlm_amd/zero1.py).  a3v_grad_bucket_reduce_scatter: `grad` = a bucket's sharded span, world * n_per_rank fp32 elements (world =
+ * ncclCommCount(comm)); rank r receives the average (or sum) of elements [r n_per_rank, (r + 1) n_per_rank) in `shard` (fp32).
+ * wire_bf16 (world * n_per_rank bf16) + wire_shard_bf16 (n_per_rank bf16), both or neither: the span crosses the wire in bf16.
+ * a3v_param_shard_all_gather: every rank's updated bf16 parameter slice (n_per_rank elements) gathered into the flat bf16 parameter
+ * buffer (world * n_per_rank elements; in place when shard_bf16 = flat_bf16 + rank * n_per_rank).  a3v_rccl_comm_count: the
+ * communicator's size (-1 without RCCL).  Same run-time RCCL resolution as a3v_grad_bucket_allreduce. */
+int a3v_grad_bucket_reduce_scatter(void* comm, const float* grad, int64_t n_per_rank, float* shard, void* wire_bf16, void* wire_shard_bf16,
+                                   int average, void* stream);
+int a3v_param_shard_all_gather(void* comm, const void* shard_bf16, void* flat_bf16, int64_t n_per_rank, void* stream);
+int a3v_rccl_comm_count(void* comm);
 int a3v_rccl_available(void);
 
 /* Partial sums of squares of an fp32 range: out[0 .. A3V_SUMSQ_SLOTS) (every slot written).  The global-norm gradient clip

@@ -166,6 +166,24 @@ def test_c_abi_bucket_allreduce_on_a_raw_rccl_communicator():
         st.synchronize()
         assert torch.equal(grad, want.to(torch.bfloat16).float()) and torch.equal(wire, want.to(torch.bfloat16))
         assert lib.a3v_grad_bucket_allreduce(None, grad.data_ptr(), n, None, 1, st.cuda_stream) != 0
+        # ZeRO-1's two collectives through the same boundary (one rank: the slice is the whole span)
+        assert lib.a3v_rccl_comm_count(comm) == 1 and lib.a3v_rccl_comm_count(None) == -1
+        src = torch.randn(n, device="cuda", generator=g)
+        shard = torch.zeros(n, device="cuda")
+        st.wait_stream(torch.cuda.current_stream())
+        _l.check(lib.a3v_grad_bucket_reduce_scatter(comm, src.data_ptr(), n, shard.data_ptr(), None, None, 1, st.cuda_stream), "a3v_grad_bucket_reduce_scatter")
+        st.synchronize()
+        assert torch.equal(shard, src)
+        wshard = torch.empty(n, dtype=torch.bfloat16, device="cuda")
+        _l.check(lib.a3v_grad_bucket_reduce_scatter(comm, src.data_ptr(), n, shard.data_ptr(), wire.data_ptr(), wshard.data_ptr(), 1, st.cuda_stream),
+                 "a3v_grad_bucket_reduce_scatter")
+        st.synchronize()
+        assert torch.equal(shard, src.to(torch.bfloat16).float())
+        assert lib.a3v_grad_bucket_reduce_scatter(comm, src.data_ptr(), n, shard.data_ptr(), wire.data_ptr(), None, 1, st.cuda_stream) != 0
+        flat = torch.zeros(n, dtype=torch.bfloat16, device="cuda")
+        _l.check(lib.a3v_param_shard_all_gather(comm, wshard.data_ptr(), flat.data_ptr(), n, st.cuda_stream), "a3v_param_shard_all_gather")
+        st.synchronize()
+        assert torch.equal(flat, wshard)
     finally:
         rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
         rccl.ncclCommDestroy(comm)
