@@ -411,6 +411,548 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_bf16_kernel(AttnArgs p) {
   }
 }
 
+#ifdef A3V_EXPERIMENTS   // measured and not dispatched (profiles/r04g_attn_w64_experiment.txt): built only with `make EXPERIMENTS=1`, A3V_ATTN_W64=1
+// ------------------------------------------------------------------------------------
+// attn_prefill_w64_kernel (round 4): hd = 128, ONE wave per SIMD, 64 query rows per wave.
+//   * the 32-row wave of the kernel above reads 1 KiB of LDS per MFMA (K / V^T fragments): at the MFMA rate that is the LDS
+//     bandwidth of the CU.  Here a wave owns TWO 32-row query blocks (A, B) and every K / V^T fragment feeds two MFMAs.
+//   * block = 128 query rows = 4 waves = (query half qw) x (key half kw): a step stages 128 keys, wave (qw, kw) takes the 64-key
+//     sub-tile kw of every step for its 64 rows -- the two waves of a query half do the same amount of work under the causal
+//     mask (the diagonal costs one sub-tile slot per block), and merge (O, m, l) through LDS at the end (flash-decoding inside
+//     the block).  Each wave finalises ONE of the two query blocks of its half.
+//   * software pipeline over 32-key UNITS u: phase(u) = { O += V^T(u-1) P(u-1) ; S(u+1) = K(u+1) Q^T } (32 MFMAs) beside the
+//     softmax algebra of S(u): one element (fma, exp, sum, max, cvt, lane swap) per MFMA, placed by hand between the MFMA
+//     statements.  The exponentials are taken SPECULATIVELY against the current reference of the row while the unit's maximum
+//     is reduced beside them; only when some row of the wave outgrows the lazy-rescale bound (2^8) is the unit redone after a
+//     rescale (wave-uniform, rare after a row's first unit): no decision sits between the maxima and the exponentials.
+//   * register file owned by hand (the idiom of attn_bwd_dkv2_kernel): a[0:63] O^T of block A, a[64:127] of block B,
+//     a[128:159] / a[160:191] the Q fragments of A / B; every MFMA is an asm statement on those literals; the scores land in
+//     VGPRs (the VALU reads every element), P^T operands are VGPRs.  hipcc's own allocation of the builtin form moved the
+//     accumulators between the two files around every branch (2000+ v_accvgpr moves, 1.6 KB of scratch).
+//   * K sub-tiles run one step ahead of V^T: at the single barrier of step s, K(s+2) and V^T(s+1) are issued by LDS-DMA (asm
+//     form: hipcc would put vmcnt(0) in front of every LDS read behind a builtin DMA) into the stages phase 1 of step s released.
+// Same values as attn_prefill_bf16_kernel up to the order of the fp32 sums (tests compare both with the oracle).
+// ------------------------------------------------------------------------------------
+#define W64_CL8(p) "a" #p "0", "a" #p "1", "a" #p "2", "a" #p "3", "a" #p "4", "a" #p "5", "a" #p "6", "a" #p "7", "a" #p "8", "a" #p "9"
+#define W64_AGPRS "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", W64_CL8(1), W64_CL8(2), W64_CL8(3), W64_CL8(4), W64_CL8(5), W64_CL8(6), \
+    W64_CL8(7), W64_CL8(8), W64_CL8(9), W64_CL8(10), W64_CL8(11), W64_CL8(12), W64_CL8(13), W64_CL8(14), W64_CL8(15), W64_CL8(16), W64_CL8(17), \
+    W64_CL8(18), "a190", "a191"
+typedef __attribute__((ext_vector_type(4))) int w64_i32x4;
+template <int I, int N, typename F>
+__device__ __forceinline__ void w64_sfor(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); w64_sfor<I + 1, N>(f); }
+}
+// a[ACC:ACC+15] += A (VGPRs) x B (VGPRs)
+template <int ACC>
+__device__ __forceinline__ void w64_mfma_o(const bf16x8& a, const bf16x8& b) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(a), "v"(b), "i"(ACC), "i"(ACC + 15) : W64_AGPRS);
+}
+// VGPR accumulator (ZERO ? = : +=) A (VGPRs) x a[BR:BR+3]
+template <int BR, bool ZERO>
+__device__ __forceinline__ void w64_mfma_s(f32x16& acc, const bf16x8& a) {
+  if constexpr (ZERO)
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], 0" : "=&v"(acc) : "v"(a), "i"(BR), "i"(BR + 3) : W64_AGPRS);
+  else
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(acc) : "v"(a), "i"(BR), "i"(BR + 3) : W64_AGPRS);
+}
+template <int R>
+__device__ __forceinline__ float w64_agpr_read() {
+  float v;
+  asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(v) : "i"(R) : W64_AGPRS);
+  return v;
+}
+template <int R>
+__device__ __forceinline__ void w64_agpr_write(unsigned v) {
+  asm volatile("v_accvgpr_write_b32 a[%c1], %0" ::"v"(v), "i"(R) : W64_AGPRS);
+}
+template <int R>
+__device__ __forceinline__ void w64_agpr_scale(float f) {
+  float t;
+  asm volatile("v_accvgpr_read_b32 %0, a[%c2]\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a[%c2], %0" : "=&v"(t) : "v"(f), "i"(R) : W64_AGPRS);
+}
+__device__ __forceinline__ void w64_dma16(w64_i32x4 rs, unsigned lds_addr, unsigned voff, unsigned soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+__device__ __forceinline__ float w64_max3(float a, float b, float c) {
+  float d;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ float w64_max(float a, float b) {
+  float d;
+  asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ unsigned w64_cvt_pk(float lo, float hi) {
+  unsigned d;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(d) : "v"(lo), "v"(hi));
+  return d;
+}
+
+// own value and the value of lane ^ 32 in (a, b) or (b, a).  Asm form: with both operands of the builtin holding the same value hipcc
+// uses ONE of the two results for both (v_max v, v, v in the ISA), i.e. the exchange silently disappears.
+__device__ __forceinline__ void w64_xchg32(float x, float& a, float& b) {
+  a = x; b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+
+template <bool CAUSAL>
+__global__ __launch_bounds__(256, 1) void attn_prefill_w64_kernel(AttnArgs p) {
+  constexpr int HD = 128, KROW = 256;
+  constexpr int SUB = 16384;          // one 64-key sub-tile: K 64 rows x 256 B, V^T 128 d-rows x 128 B
+  constexpr int STAGE = 2 * SUB;      // a step's two sub-tiles (key halves)
+  constexpr int RA = 0, RB = 64, QA = 128, QB = 160;     // owned AGPR ranges
+  extern __shared__ __attribute__((aligned(1024))) char w64_lds[];
+  char* const Kst = w64_lds;                  // [2 stages][2 subs][16 KB]
+  char* const Vst = w64_lds + 2 * STAGE;      // [2 stages][2 subs][16 KB]
+  const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)w64_lds);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qw = wave >> 1, kw = wave & 1;
+  const int nqt = (p.Sq + 127) / 128;
+  int vb;
+  {   // XCD-aware block order, as in attn_prefill_bf16_kernel
+    const int total = gridDim.x, id = blockIdx.x;
+    const int xcd = id & 7, q = total >> 3, r = total & 7;
+    vb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  }
+  int head_slot = vb / nqt;
+  int qt = nqt - 1 - (vb - head_slot * nqt);
+  if (CAUSAL && p.head_group > 1) {
+    const int G = p.head_group, per = G * nqt;
+    const int grp = vb / per, r = vb - grp * per;
+    head_slot = grp * G + r % G;
+    qt = nqt - 1 - r / G;
+  }
+  const int b = head_slot / p.H, h = head_slot - b * p.H;
+  const int hk = h / (p.H / p.Hkv);
+  const int q0 = qt * 128 + qw * 64;
+  const int off = p.Sk - p.Sq;
+
+  const bf16_t* Q = (const bf16_t*)p.q + b * p.q_sb + h * p.q_sh;
+  const bf16_t* K = (const bf16_t*)p.k + b * p.k_sb + hk * p.k_sh;
+  const bf16_t* VT = (const bf16_t*)p.vt + b * p.v_sb + hk * p.v_sh;
+
+  const int ql = lane & 31, hh = lane >> 5;
+  const int qrA = q0 + ql, qrB = q0 + 32 + ql;
+
+  // key range of the block / of this wave's 64 rows
+  int kv_end_blk = p.Sk, kv_end_w = p.Sk;
+  if (CAUSAL) {
+    kv_end_blk = min(p.Sk, min(qt * 128 + 127, p.Sq - 1) + off + 1);
+    kv_end_w = min(p.Sk, min(q0 + 63, p.Sq - 1) + off + 1);
+  }
+  if (q0 >= p.Sq) kv_end_w = 0;
+#ifdef W64_NO_LOOP      // timing experiment (wrong results): the per-block cost alone
+  kv_end_blk = 0; kv_end_w = 0;
+#endif
+  const int n_steps = __builtin_amdgcn_readfirstlane((kv_end_blk + 127) / 128);
+  const int n_my = __builtin_amdgcn_readfirstlane(kv_end_w > 64 * kw ? (kv_end_w - 64 * kw + 127) / 128 : 0);
+
+#ifdef W64_STAMP        // cycle stamps of one wave (block W64_STAMP, wave 0) into the lse buffer: tools/w64_stamps.py
+  unsigned long long* stamps = (vb == W64_STAMP && tid == 0) ? reinterpret_cast<unsigned long long*>(p.lse + (int64_t)p.B * p.H * p.Sq) : nullptr;   // behind the lse rows (the tool allocates the room)
+  int stamp_i = 0;
+#define W64_ST() do { if (stamps && stamp_i < 512) { stamps[stamp_i++] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define W64_ST() do {} while (0)
+#endif
+  // ---- staging: LDS-DMA for sub-tiles whose 64 keys exist, a register path (zero-filled V^T columns) for a ragged one ----
+  w64_i32x4 rsK, rsV;
+  {
+    const uint64_t ka = (uint64_t)K, va = (uint64_t)VT;
+    rsK[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)ka); rsK[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(ka >> 32) & 0xffff);
+    rsK[2] = 0x7fffffff; rsK[3] = 0x00020000;
+    rsV[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)va); rsV[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(va >> 32) & 0xffff);
+    rsV[2] = 0x7fffffff; rsV[3] = 0x00020000;
+  }
+  unsigned koff[4], voff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int id = tid + i * 256;
+    const int row = id >> 4, slot = id & 15;
+    koff[i] = (unsigned)((row * p.k_ss + (slot ^ (row & 15)) * 8) * 2);
+    const int d = id >> 3, vs = id & 7;
+    voff[i] = (unsigned)((d * p.v_sd + (vs ^ ((d >> 1) & 7)) * 8) * 2);
+  }
+  auto fetchK = [&](int s, int stg) __attribute__((always_inline)) {
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const int kv0 = s * 128 + sub * 64;
+      if (kv0 >= kv_end_blk) continue;
+      const int ko = stg * STAGE + sub * SUB;
+      if (kv0 + 64 <= p.Sk) {
+        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)(kv0 * p.k_ss * 2));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w64_dma16(rsK, lds0 + ko + (wave * 64 + i * 256) * 16, koff[i], so);
+      } else {
+        char* Ks = Kst + ko;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int id = tid + i * 256;
+          const int row = id >> 4, ch = id & 15;
+          int kr = kv0 + row;
+          kr = kr < p.Sk ? kr : p.Sk - 1;
+          const u32x4 v = *reinterpret_cast<const u32x4*>(K + (int64_t)kr * p.k_ss + ch * 8);
+          *reinterpret_cast<u32x4*>(Ks + row * KROW + ((ch ^ (row & 15)) << 4)) = v;
+        }
+      }
+    }
+  };
+  auto fetchV = [&](int s, int stg) __attribute__((always_inline)) {
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const int kv0 = s * 128 + sub * 64;
+      if (kv0 >= kv_end_blk) continue;
+      const int vo = 2 * STAGE + stg * STAGE + sub * SUB;
+      if (kv0 + 64 <= p.Sk) {
+        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(kv0 * 2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w64_dma16(rsV, lds0 + vo + (wave * 64 + i * 256) * 16, voff[i], so);
+      } else {
+        char* Vs = w64_lds + vo;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int id = tid + i * 256;
+          const int d = id >> 3, ch = id & 7;
+          const int kv = kv0 + ch * 8;
+          u32x4 v = {0u, 0u, 0u, 0u};
+          if (kv + 8 <= p.Sk) {
+            v = *reinterpret_cast<const u32x4*>(VT + (int64_t)d * p.v_sd + kv);
+          } else if (kv < p.Sk) {
+            const unsigned short* src = reinterpret_cast<const unsigned short*>(VT + (int64_t)d * p.v_sd + kv);
+            unsigned short e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) e[j] = (kv + j < p.Sk) ? src[j] : (unsigned short)0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (unsigned)e[2 * j] | ((unsigned)e[2 * j + 1] << 16);
+          }
+          *reinterpret_cast<u32x4*>(Vs + d * 128 + ((ch ^ ((d >> 1) & 7)) << 4)) = v;
+        }
+      }
+    }
+  };
+
+  W64_ST();
+  asm volatile("s_nop 4" ::: W64_AGPRS);      // descriptor words fresh from v_readfirstlane
+  if (n_steps > 0) { fetchK(0, 0); fetchV(0, 0); }
+  if (n_steps > 1) fetchK(1, 1);
+
+  // Q fragments (B operand of S^T = K Q^T): Q[row][16 ks + 8 hh + e] -> a[QA + 4 ks ..], a[QB + 4 ks ..]; O^T = 0
+  {
+    const int ra = qrA < p.Sq ? qrA : p.Sq - 1, rb = qrB < p.Sq ? qrB : p.Sq - 1;
+    u32x4 ta[HD / 16], tb[HD / 16];
+#pragma unroll
+    for (int ks = 0; ks < HD / 16; ++ks) {
+      ta[ks] = *reinterpret_cast<const u32x4*>(Q + (int64_t)ra * p.q_ss + ks * 16 + hh * 8);
+      tb[ks] = *reinterpret_cast<const u32x4*>(Q + (int64_t)rb * p.q_ss + ks * 16 + hh * 8);
+    }
+    w64_sfor<0, 128>([&](auto i) { w64_agpr_write<decltype(i)::value>(0u); });
+    w64_sfor<0, HD / 16>([&](auto ks) {
+      w64_sfor<0, 4>([&](auto j) {
+        w64_agpr_write<QA + 4 * decltype(ks)::value + decltype(j)::value>(ta[decltype(ks)::value][decltype(j)::value]);
+        w64_agpr_write<QB + 4 * decltype(ks)::value + decltype(j)::value>(tb[decltype(ks)::value][decltype(j)::value]);
+      });
+    });
+  }
+
+  float mA = -INFINITY, mB = -INFINITY, mbA = 0.f, mbB = 0.f, lA = 0.f, lB = 0.f;   // reference, reference * scale_log2 (0 while -inf), per-lane partial sums
+  f32x16 s0A, s0B, s1A, s1B;               // scores of the even / odd unit in flight
+  bf16x8 p0A[2], p0B[2], p1A[2], p1B[2];   // P^T operands of the even / odd unit
+  const float c = p.scale_log2;
+  const bool lazy = p.lazy_rescale != 0;
+
+  const int kfb = ql * KROW + ((hh ^ (ql & 15)) << 4);
+  const int vfb = ql * 128 + ((hh ^ ((ql >> 1) & 7)) << 4);
+
+  // causal / ragged mask of one unit (keys kb .. kb + 31); interior units skip it (wave-uniform)
+  auto mask_unit = [&](f32x16& sA, f32x16& sB, int kb) __attribute__((always_inline)) {
+    const bool need = (kb + 31 >= p.Sk) || (CAUSAL && kb + 31 > q0 + off);
+    if (!need) return;
+    const int limA = CAUSAL ? qrA + off : 0x7fffffff, limB = CAUSAL ? qrB + off : 0x7fffffff;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kv = kb + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      const bool in = kv < p.Sk;
+      sA[r] = (in && kv <= limA) ? sA[r] : -INFINITY;
+      sB[r] = (in && kv <= limB) ? sB[r] : -INFINITY;
+    }
+  };
+  // the unit again after a rescale (rare): new reference, O^T and l scaled, exponentials / sums / P^T operand from scratch
+  auto redo = [&](auto rc, const f32x16& s, float& m, float& mb, float& l, float mx, float (&t)[4], unsigned (&w)[8]) __attribute__((always_inline)) {
+    constexpr int R0 = decltype(rc)::value;
+    const float mn = fmaxf(m, mx);
+    const float mu = (mn == -INFINITY) ? 0.f : mn;
+    const float alpha = __builtin_amdgcn_exp2f((m - mu) * c);
+    m = mn; mb = mu * c;
+    l *= alpha;
+    asm volatile("s_nop 1" ::: W64_AGPRS);
+    w64_sfor<0, 64>([&](auto i) { w64_agpr_scale<R0 + decltype(i)::value>(alpha); });
+    float pv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pv[r] = __builtin_amdgcn_exp2f(fmaf(s[r], c, -mb));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t[r] = (pv[r] + pv[r + 4]) + (pv[r + 8] + pv[r + 12]);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) w[r] = w64_cvt_pk(pv[2 * r], pv[2 * r + 1]);
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(w[4 * cc + e], w[4 * cc + 2 + e], false, false);
+        w[4 * cc + e] = sw[0];
+        w[4 * cc + 2 + e] = sw[1];
+      }
+  };
+
+  // phase(u): PV: O += V^T(u-1) P(u-1) (Vs = that unit's sub-tile, TB = its 32-key half); QK: S(u+1) = K(u+1) Q^T (Ks likewise);
+  // softmax of the current unit's scores (cA, cB) -> P operands (pcA, pcB).  MFMA order per fragment pair g: O_A, O_B (V^T fragment g),
+  // S_A, S_B (K fragment g); one softmax element after every MFMA (two when the phase has only one of the products).
+  auto phase = [&](auto pvc, auto qkc, auto tbc, const char* Vs, const char* Ks, f32x16& cA, f32x16& cB, f32x16& nA, f32x16& nB,
+                   bf16x8 (&pcA)[2], bf16x8 (&pcB)[2], const bf16x8 (&ppA)[2], const bf16x8 (&ppB)[2]) __attribute__((always_inline)) {
+    constexpr bool PV = decltype(pvc)::value, QK = decltype(qkc)::value;
+    constexpr int TB = decltype(tbc)::value;
+    constexpr int SPM = (PV && QK) ? 1 : 2;       // softmax elements per MFMA
+    float tA[4], tB[4], mxA = 0.f, mxB = 0.f, sprev = 0.f, cs = c;
+    float ev[32];
+    unsigned wA[8], wB[8];
+    // slice(j): exponential of element j (and its place in the maximum chain), then the bookkeeping of element j - 1 (sum, bf16 pair,
+    // lane swap) -- one element behind, so that no instruction waits on the transcendental in front of it
+    auto tail = [&](auto jc) __attribute__((always_inline)) {
+      constexpr int j = decltype(jc)::value, r = j & 15;
+      constexpr bool isB = j >= 16;
+      float (&t)[4] = isB ? tB : tA;
+      unsigned (&w)[8] = isB ? wB : wA;
+      if constexpr (r < 4) t[r] = ev[j]; else t[r & 3] += ev[j];
+      if constexpr (r & 1) w[r >> 1] = w64_cvt_pk(ev[j - 1], ev[j]);
+      if constexpr ((r & 7) == 5 || (r & 7) == 7) {
+        constexpr int cc = r >> 3, e2 = ((r & 7) == 7) ? 1 : 0;
+        const auto sw = __builtin_amdgcn_permlane32_swap(w[4 * cc + e2], w[4 * cc + 2 + e2], false, false);
+        w[4 * cc + e2] = sw[0];
+        w[4 * cc + 2 + e2] = sw[1];
+        asm volatile("" : "+v"(w[4 * cc + e2]), "+v"(w[4 * cc + 2 + e2]));
+      } else if constexpr (r & 1) {
+        asm volatile("" : "+v"(w[r >> 1]));
+      }
+      asm volatile("" : "+v"(t[r & 3]));
+    };
+    auto slice = [&](auto jc) __attribute__((always_inline)) {
+      constexpr int j = decltype(jc)::value, r = j & 15;
+      constexpr bool isB = j >= 16;
+      f32x16& s = isB ? cB : cA;
+      float& mx = isB ? mxB : mxA;
+      asm volatile("" : "+s"(cs));           // a new name for the scale per slice: the slice's arithmetic cannot move above this point
+      const float sv = s[r];
+      ev[j] = __builtin_amdgcn_exp2f(fmaf(sv, cs, -(isB ? mbB : mbA)));
+      if constexpr (r == 0) mx = sv;
+      else if constexpr (r == 15) mx = w64_max(mx, sv);
+      else if constexpr ((r & 1) == 0) mx = w64_max3(mx, sprev, sv);
+      else sprev = sv;
+      asm volatile("" : "+v"(ev[j]), "+v"(mx));
+      if constexpr (j > 0) tail(std::integral_constant<int, j - 1>{});
+    };
+#ifdef W64_NO_SM        // timing experiment (wrong results): MFMAs and fragment reads only
+    auto slice_x = [&](auto jc) __attribute__((always_inline)) {};
+#define slice slice_x
+#endif
+    auto vfrag = [&](int g) __attribute__((always_inline)) {
+      return *reinterpret_cast<const bf16x8*>(Vs + (g & 3) * 4096 + (vfb ^ ((4 * TB + 2 * (g >> 2)) << 4)));
+    };
+    auto kfrag = [&](int g) __attribute__((always_inline)) { return *reinterpret_cast<const bf16x8*>(Ks + TB * 8192 + (kfb ^ (g << 5))); };
+    bf16x8 vf[2], kf[2];
+    if constexpr (PV) vf[0] = vfrag(0);
+    if constexpr (QK) kf[0] = kfrag(0);
+    asm volatile("" ::: "memory");
+    w64_sfor<0, 8>([&](auto gc) {
+      constexpr int g = decltype(gc)::value;
+      constexpr int NM = (PV ? 2 : 0) + (QK ? 2 : 0);          // MFMAs of this fragment pair
+#ifndef W64_NO_FRAG     // timing experiment (wrong results): one fragment pair per phase
+      if constexpr (g < 7) {
+        if constexpr (PV) vf[(g + 1) & 1] = vfrag(g + 1);
+        if constexpr (QK) kf[(g + 1) & 1] = kfrag(g + 1);
+        asm volatile("" ::: "memory");
+      }
+#else
+      if constexpr (g == 0) { if constexpr (PV) vf[1] = vf[0]; if constexpr (QK) kf[1] = kf[0]; }
+#endif
+      int k = 0;
+      // S first, O last: the scores' last writers are two MFMAs away from the end of the phase (an XDL result needs ~19 wait states
+      // before a VALU may read it; hipcc knows nothing about the asm statements)
+      if constexpr (QK) {
+        w64_mfma_s<QA + 4 * g, g == 0>(nA, kf[g & 1]);
+        w64_sfor<0, SPM>([&](auto q) { slice(std::integral_constant<int, (g * NM + 0) * SPM + decltype(q)::value>{}); });
+        w64_mfma_s<QB + 4 * g, g == 0>(nB, kf[g & 1]);
+        w64_sfor<0, SPM>([&](auto q) { slice(std::integral_constant<int, (g * NM + 1) * SPM + decltype(q)::value>{}); });
+      }
+      if constexpr (PV) {
+        constexpr int o = QK ? 2 : 0;
+        w64_mfma_o<RA + 16 * (g & 3)>(vf[g & 1], ppA[g >> 2]);
+        w64_sfor<0, SPM>([&](auto q) { slice(std::integral_constant<int, (g * NM + o) * SPM + decltype(q)::value>{}); });
+        w64_mfma_o<RB + 16 * (g & 3)>(vf[g & 1], ppB[g >> 2]);
+        w64_sfor<0, SPM>([&](auto q) { slice(std::integral_constant<int, (g * NM + o + 1) * SPM + decltype(q)::value>{}); });
+      }
+      (void)k;
+#ifdef W64_STAMP_FINE
+      if constexpr ((g & 1) == 1) W64_ST();
+#endif
+    });
+#ifdef W64_NO_SM
+#undef slice
+    w64_sfor<0, 4>([&](auto i) { tA[decltype(i)::value] = 0.f; tB[decltype(i)::value] = 0.f; });
+    w64_sfor<0, 8>([&](auto i) { wA[decltype(i)::value] = 0x3c003c00u; wB[decltype(i)::value] = 0x3c003c00u; });
+#else
+    tail(std::integral_constant<int, 31>{});
+#endif
+    if constexpr (!PV) asm volatile("s_nop 15\n\ts_nop 3" ::: W64_AGPRS);     // scores of a phase without O MFMAs -> their first VALU reader
+    {
+      float x0, x1;
+      w64_xchg32(mxA, x0, x1); mxA = w64_max(x0, x1);
+      w64_xchg32(mxB, x0, x1); mxB = w64_max(x0, x1);
+    }
+    const bool gA = lazy ? (mxA > -INFINITY && (mA == -INFINITY || (mxA - mA) * c > 8.f)) : (mxA > mA);
+    const bool gB = lazy ? (mxB > -INFINITY && (mB == -INFINITY || (mxB - mB) * c > 8.f)) : (mxB > mB);
+    if (__builtin_amdgcn_ballot_w64(gA || gB) != 0) {
+      asm volatile("s_nop 15\n\ts_nop 15" ::: W64_AGPRS);       // the phase's last O MFMAs -> the AGPR reads of the rescale
+      redo(std::integral_constant<int, RA>{}, cA, mA, mbA, lA, mxA, tA, wA);
+      redo(std::integral_constant<int, RB>{}, cB, mB, mbB, lB, mxB, tB, wB);
+      asm volatile("s_nop 4" ::: W64_AGPRS);
+    }
+#ifdef W64_STAMP_FINE
+    W64_ST();
+#endif
+    lA += (tA[0] + tA[1]) + (tA[2] + tA[3]);
+    lB += (tB[0] + tB[1]) + (tB[2] + tB[3]);
+    __builtin_memcpy(&pcA[0], &wA[0], 16); __builtin_memcpy(&pcA[1], &wA[4], 16);
+    __builtin_memcpy(&pcB[0], &wB[0], 16); __builtin_memcpy(&pcB[1], &wB[4], 16);
+  };
+  // O += V^T(u) P(u) of a wave's LAST unit (second half of sub-tile Vs)
+  auto pv_tail = [&](const char* Vs, const bf16x8 (&ppA)[2], const bf16x8 (&ppB)[2]) __attribute__((always_inline)) {
+    w64_sfor<0, 8>([&](auto gc) {
+      constexpr int g = decltype(gc)::value;
+      const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vs + (g & 3) * 4096 + (vfb ^ ((4 + 2 * (g >> 2)) << 4)));
+      w64_mfma_o<RA + 16 * (g & 3)>(vf, ppA[g >> 2]);
+      w64_mfma_o<RB + 16 * (g & 3)>(vf, ppB[g >> 2]);
+    });
+  };
+  using T_ = std::true_type; using F_ = std::false_type;
+  using TB0 = std::integral_constant<int, 0>; using TB1 = std::integral_constant<int, 1>;
+
+  W64_ST();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  W64_ST();
+  if (n_my > 0) {   // S(0): unit 0 = step 0, first half of the wave's sub-tile
+    const char* Ks = Kst + kw * SUB;
+    w64_sfor<0, 8>([&](auto gc) {
+      constexpr int g = decltype(gc)::value;
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kfb ^ (g << 5)));
+      w64_mfma_s<QA + 4 * g, g == 0>(s0A, kf);
+      w64_mfma_s<QB + 4 * g, g == 0>(s0B, kf);
+    });
+    asm volatile("s_nop 15\n\ts_nop 3" ::: W64_AGPRS);         // S(0) -> its first VALU reader
+  }
+  auto step = [&](int s, auto stc) __attribute__((always_inline)) {
+    constexpr int SG = decltype(stc)::value;            // stage of step s (K(s), V^T(s)); the other one holds K(s+1) / V^T(s-1)
+    const char* Kcur = Kst + SG * STAGE + kw * SUB;
+    const char* Knxt = Kst + (1 - SG) * STAGE + kw * SUB;
+    const char* Vcur = Vst + SG * STAGE + kw * SUB;
+    const char* Vprv = Vst + (1 - SG) * STAGE + kw * SUB;
+    const int kb = s * 128 + kw * 64;
+    W64_ST();
+    // phase 1: unit 2s (scores s0) beside PV of unit 2s-1 (V^T(s-1), second half) and QK of unit 2s+1 (K(s), second half -> s1)
+    if (s < n_my) {
+      mask_unit(s0A, s0B, kb);
+      if (s > 0) phase(T_{}, T_{}, TB1{}, Vprv, Kcur, s0A, s0B, s1A, s1B, p0A, p0B, p1A, p1B);
+      else phase(F_{}, T_{}, TB1{}, Vprv, Kcur, s0A, s0B, s1A, s1B, p0A, p0B, p1A, p1B);
+    } else if (s == n_my && n_my > 0) {
+      pv_tail(Vprv, p1A, p1B);
+    }
+    W64_ST();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    W64_ST();
+    __syncthreads();
+    W64_ST();
+#ifndef W64_NO_DMA      // timing experiment (wrong results): no staging inside the loop
+    if (s + 2 < n_steps) fetchK(s + 2, SG);
+    if (s + 1 < n_steps) fetchV(s + 1, 1 - SG);
+#endif
+    W64_ST();
+    // phase 2: unit 2s+1 (scores s1) beside PV of unit 2s (V^T(s), first half) and QK of unit 2s+2 (K(s+1), first half -> s0)
+    if (s < n_my) {
+      mask_unit(s1A, s1B, kb + 32);
+      if (s + 1 < n_my) phase(T_{}, T_{}, TB0{}, Vcur, Knxt, s1A, s1B, s0A, s0B, p1A, p1B, p0A, p0B);
+      else phase(T_{}, F_{}, TB0{}, Vcur, Knxt, s1A, s1B, s0A, s0B, p1A, p1B, p0A, p0B);
+    }
+  };
+  {
+    int s = 0;
+    for (; s + 1 < n_steps; s += 2) {
+      step(s, std::integral_constant<int, 0>{});
+      step(s + 1, std::integral_constant<int, 1>{});
+    }
+    if (s < n_steps) step(s, std::integral_constant<int, 0>{});
+  }
+  if (n_my == n_steps && n_my > 0) pv_tail(Vst + ((n_steps - 1) & 1) * STAGE + kw * SUB, p1A, p1B);
+  asm volatile("s_nop 15\n\ts_nop 15" ::: W64_AGPRS);           // the last MFMAs -> the AGPR reads below
+
+  W64_ST();
+#ifdef W64_STAMP
+  if (stamps) return;
+#endif
+  // ---- merge the two key halves: wave (qw, kw) finalises query block kw of its half and hands the other block's partial over ----
+  __syncthreads();
+  constexpr int XSZ = 66 * 64 * 4;                     // 64 accumulator values + reference + partial sum per lane
+  float* xo = reinterpret_cast<float*>(w64_lds + wave * XSZ) + lane;
+  const float* xi = reinterpret_cast<const float*>(w64_lds + (wave ^ 1) * XSZ) + lane;
+  auto send = [&](auto rc, float m, float l) __attribute__((always_inline)) {
+    w64_sfor<0, 64>([&](auto i) { xo[decltype(i)::value * 64] = w64_agpr_read<decltype(rc)::value + decltype(i)::value>(); });
+    xo[64 * 64] = m;
+    xo[65 * 64] = l;
+  };
+  auto finish = [&](auto rc, float m, float l, int qrow, int qbase) __attribute__((always_inline)) {
+    constexpr int R0 = decltype(rc)::value;
+    const float m2 = xi[64 * 64], l2 = xi[65 * 64];
+    const float mn = fmaxf(m, m2);
+    const float mu = (mn == -INFINITY) ? 0.f : mn;
+    const float a1 = __builtin_amdgcn_exp2f((m - mu) * c), a2 = __builtin_amdgcn_exp2f((m2 - mu) * c);
+    const float lp = l * a1 + l2 * a2;
+    float x0, x1;
+    w64_xchg32(lp, x0, x1);
+    const float l_tot = x0 + x1;
+    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+    if (p.lse && qrow < p.Sq && hh == 0) p.lse[((int64_t)b * p.H + h) * p.Sq + qrow] = mn * p.scale + __logf(l_tot);
+    const float f1 = a1 * inv, f2 = a2 * inv;
+    // whole-row stores through a private LDS patch (see attn_prefill_bf16_kernel)
+    constexpr int ROWB = HD * 2, NPAIR = HD / 8, RPI = 64 / NPAIR;
+    char* patch = w64_lds + 4 * XSZ + 1024 + wave * (32 * ROWB);
+    char* wrow = patch + ql * ROWB;
+    const int wx = (ql & (NPAIR - 1)) << 1;
+    w64_sfor<0, 16>([&](auto qc) {                     // 4 accumulator values -> one 8-byte slot
+      constexpr int d = decltype(qc)::value >> 2, g4 = decltype(qc)::value & 3;
+      bf16x4 ov;
+      w64_sfor<0, 4>([&](auto ec) {
+        constexpr int e = decltype(ec)::value, i = d * 16 + g4 * 4 + e;
+        ov[e] = f2bf(w64_agpr_read<R0 + i>() * f1 + xi[i * 64] * f2);
+      });
+      *reinterpret_cast<bf16x4*>(wrow + (((d * 8 + g4 * 2 + hh) ^ wx) << 3)) = ov;
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int pr = lane % NPAIR, rr = lane / NPAIR;
+    bf16_t* Ob = (bf16_t*)p.out + b * p.o_sb + h * p.o_sh + pr * 8;
+#pragma unroll
+    for (int it = 0; it < 32 / RPI; ++it) {
+      const int r = it * RPI + rr;
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(patch + r * ROWB + ((pr ^ (r & (NPAIR - 1))) << 4));
+      if (qbase + r < p.Sq) *reinterpret_cast<bf16x8*>(Ob + (int64_t)(qbase + r) * p.o_ss) = v;
+    }
+  };
+  if (kw == 0) send(std::integral_constant<int, RB>{}, mB, lB); else send(std::integral_constant<int, RA>{}, mA, lA);
+  __syncthreads();
+  if (kw == 0) finish(std::integral_constant<int, RA>{}, mA, lA, qrA, q0); else finish(std::integral_constant<int, RB>{}, mB, lB, qrB, q0 + 32);
+}
+
+#endif  // A3V_EXPERIMENTS (attn_prefill_w64_kernel)
+
 #ifdef A3V_EXPERIMENTS
 // ------------------------------------------------------------------------------------
 // Ping-pong prefill kernel (hd = 128; round 3) -- EXPERIMENT, built only with `make EXPERIMENTS=1` and selected by A3V_ATTN_PP=1: correct
@@ -1281,6 +1823,13 @@ static int attention_impl(const void* q, const void* k, const void* vt, void* ou
   }
 #endif
   dim3 grid(((Sq + 127) / 128) * H * B);
+#ifdef A3V_EXPERIMENTS
+  // hd 128: the one-wave-per-SIMD kernel with 64 query rows per wave (experiment, A3V_ATTN_W64=1)
+  const bool w64 = hd == 128 && A3V_ENV_INT("A3V_ATTN_W64", 0) != 0 && !(strides[9] % 8) && !(strides[10] % 8) && !(strides[11] % 8) &&
+                   !(reinterpret_cast<uintptr_t>(out) & 15) && (int64_t)Sk * strides[5] * 2 < (1LL << 31) && (int64_t)hd * strides[8] * 2 < (1LL << 31);
+#else
+  const bool w64 = false;
+#endif
   if (causal && (grid.x & 7) == 0 && ((B * H) & 7) == 0) {
     // default: the largest power of two (<= 16) whose K + V^T fit ~9 MB (measured best: 16 heads at S = 1091, 8 at S ~ 2000 --
     // twice the 4-MB L2, the Infinity Cache absorbs the rest; tools/ab_attn_order.py): 160.8 -> 142.3 us at S = 1091
@@ -1292,7 +1841,18 @@ static int attention_impl(const void* q, const void* k, const void* vt, void* ou
     while (G > 1 && ((B * H) / 8) % G) G >>= 1;            // groups must not straddle an XCD's range of heads
     p.head_group = G;
   }
-  if (hd == 128) {
+  if (w64) {
+#ifdef A3V_EXPERIMENTS
+    static bool attr_done = false;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute((const void*)attn_prefill_w64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      (void)hipFuncSetAttribute((const void*)attn_prefill_w64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      attr_done = true;
+    }
+    if (causal) hipLaunchKernelGGL(attn_prefill_w64_kernel<true>, grid, dim3(256), 128 * 1024, st, p);
+    else hipLaunchKernelGGL(attn_prefill_w64_kernel<false>, grid, dim3(256), 128 * 1024, st, p);
+#endif
+  } else if (hd == 128) {
     const bool ps = A3V_ENV_INT("A3V_ATTN_PSWAP", 1) != 0;          // A3V_ATTN_PSWAP=0: the 8-B-half V^T reads (A/B runs)
     if (causal) {
       if (ps) hipLaunchKernelGGL((attn_prefill_bf16_kernel<128, true, true>), grid, dim3(256), 0, st, p);
