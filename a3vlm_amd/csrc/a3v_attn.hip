@@ -41,6 +41,13 @@ __device__ __forceinline__ void buf_dma16(__amdgpu_buffer_rsrc_t rs, char* lds_d
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
 }
 
+// own value and the value of lane ^ 32 in (a, b) (lanes < 32) / (b, a) (lanes >= 32).  Asm form: with the same value in both operands
+// of __builtin_amdgcn_permlane32_swap hipcc uses ONE of the two results for both (v_max v, v, v in the ISA) and the exchange disappears.
+__device__ __forceinline__ void xchg32(float x, float& a, float& b) {
+  a = x; b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+
 // PSWAP: the P^T operand is regrouped so that a lane half holds 8 CONSECUTIVE keys (two v_permlane32_swap per 16 keys exchange the
 // {4 hh .. 4 hh + 3} quarters between lanes l and l + 32), and the V^T fragment becomes ONE 16-B chunk per lane (ds_read_b128,
 // lanes 0-31 chunk c, lanes 32-63 chunk c + 1: the 16 lanes of a read group cover 16 distinct bank slots) instead of two 8-B
@@ -234,16 +241,44 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_bf16_kernel(AttnArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[tb][r] = 0.f;
     // the two key blocks' accumulation chains alternate (back-to-back MFMAs on ONE accumulator issue at ~72 cycles, not 32)
-#pragma unroll
-    for (int ks = 0; ks < HD / 16; ++ks)
-#pragma unroll
-      for (int tb = 0; tb < 2; ++tb) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + tb * 32 * KROW + (kfb ^ (ks << 5)));
-#ifdef AP_NO_QK
-        if (ks == 0)
+#ifdef AP_FRAG_NEAR      // fragments read right in front of their MFMA (the round-1..3 form; A/B builds)
+    constexpr bool FRAG_AHEAD = false;
+#else
+    constexpr bool FRAG_AHEAD = HD == 128;      // hd 64 (the ViT) measured 15 % slower with the reads ahead: 34.5-36.0 against 29.8-30.6 us
 #endif
-        s[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[tb], 0, 0, 0);
+    if constexpr (!FRAG_AHEAD) {
+#pragma unroll
+      for (int ks = 0; ks < HD / 16; ++ks)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + tb * 32 * KROW + (kfb ^ (ks << 5)));
+          s[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[tb], 0, 0, 0);
+        }
+    } else {
+      // fragment reads TWO k-steps (4 MFMAs, >= 128 cycles) ahead of their MFMAs: hipcc reuses one register pair and issues every read
+      // right in front of its consumer (ds_read, s_waitcnt lgkmcnt, v_mfma: the LDS latency of every pair is exposed)
+      bf16x8 kr[3][2];
+#pragma unroll
+      for (int pre = 0; pre < 2; ++pre)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) kr[pre][tb] = *reinterpret_cast<const bf16x8*>(Ks + tb * 32 * KROW + (kfb ^ (pre << 5)));
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int ks = 0; ks < HD / 16; ++ks) {
+        if (ks + 2 < HD / 16) {
+#pragma unroll
+          for (int tb = 0; tb < 2; ++tb) kr[(ks + 2) % 3][tb] = *reinterpret_cast<const bf16x8*>(Ks + tb * 32 * KROW + (kfb ^ ((ks + 2) << 5)));
+          asm volatile("" : "+v"(qf[ks]) :: "memory");      // the k-step's MFMAs (they read qf[ks]) stay BEHIND the reads issued above
+        }
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) {
+#ifdef AP_NO_QK
+          if (ks == 0)
+#endif
+          s[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[ks % 3][tb], qf[ks], s[tb], 0, 0, 0);
+        }
       }
+    }
     AP_ST(t, 2);
     // ---- mask + online softmax (lane owns query column ql; kv = 32tb + (r&3)+8(r>>2)+4hh) ----
     const int qlim = CAUSAL ? (qrow + off) : 0x7fffffff;
@@ -264,13 +299,16 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_bf16_kernel(AttnArgs p) {
     for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[tb][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    // lane <-> lane + 32 by v_permlane32_swap (VALU) instead of __shfl_xor (ds_bpermute_b32: an LDS-pipe round trip + lgkmcnt(0) in the
+    // max -> reference -> exponentials chain of every tile); asm form, see xchg32
+    if (p.lazy_rescale & 2) mx = fmaxf(mx, __shfl_xor(mx, 32, 64));      // (A3V_ATTN_LAZY=3: the ds_bpermute form, A/B runs)
+    else { float x0, x1; xchg32(mx, x0, x1); mx = fmaxf(x0, x1); }
     const float m_new = fmaxf(m_run, mx);
     // Lazy rescale: m_run is the REFERENCE the exponentials are taken against, not necessarily the running maximum.  It only moves
     // when some row of the wave would otherwise see exp2 arguments above +LAZY (2^8: P <= 256 in bf16, the sums in fp32) -- after the
     // first tiles of a row that is rare, and the 64 multiplies of the O rescale + the l update (a quarter of the tile's VALU work,
     // which is what bounds this kernel) are skipped by a wave-uniform branch.  O / l and the LSE are unchanged in exact arithmetic.
-    const bool grow = p.lazy_rescale ? ((m_new - m_run) * p.scale_log2 > 8.f || m_run == -INFINITY) : true;
+    const bool grow = (p.lazy_rescale & 1) ? ((m_new - m_run) * p.scale_log2 > 8.f || m_run == -INFINITY) : true;
     const bool resc = __builtin_amdgcn_ballot_w64(grow && m_new != m_run) != 0;
     // rows past Sq (clamped duplicates) and fully-masked tiles keep m finite once any tile was seen
     const float m_tgt = resc ? m_new : m_run;
@@ -320,6 +358,31 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_bf16_kernel(AttnArgs p) {
     }
     AP_ST(t, 3);
     // ---- O^T += V^T . P^T ----
+    if constexpr (PSWAP && FRAG_AHEAD) {
+      // the four V^T fragments of the next (key block, 16-key chunk) group are read while the current group's four MFMAs run
+      constexpr int ND = HD / 32;
+      bf16x8 vr[2][ND];
+#pragma unroll
+      for (int d = 0; d < ND; ++d) vr[0][d] = *reinterpret_cast<const bf16x8*>(Vs + d * 32 * 128 + (vfb ^ (0 << 4)));
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int gI = 0; gI < 4; ++gI) {
+        const int tb = gI >> 1, c = gI & 1;
+        if (gI + 1 < 4) {
+          const int c16n = 4 * ((gI + 1) >> 1) + 2 * ((gI + 1) & 1);
+#pragma unroll
+          for (int d = 0; d < ND; ++d) vr[(gI + 1) & 1][d] = *reinterpret_cast<const bf16x8*>(Vs + d * 32 * 128 + (vfb ^ (c16n << 4)));
+          asm volatile("" : "+v"(pf[tb][c]) :: "memory");   // the group's MFMAs (they read pf[tb][c]) stay BEHIND the reads issued above
+        }
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+#ifdef AP_NO_PV
+          if (gI == 0)
+#endif
+          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vr[gI & 1][d], pf[tb][c], o[d], 0, 0, 0);
+        }
+      }
+    } else {
 #pragma unroll
     for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
@@ -339,11 +402,9 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_bf16_kernel(AttnArgs p) {
             const u32x4 av = {a0[0], a0[1], a1[0], a1[1]};
             __builtin_memcpy(&vf, &av, 16);
           }
-#ifdef AP_NO_PV
-          if (tb == 0 && c == 0)
-#endif
           o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[tb][c], o[d], 0, 0, 0);
         }
+    }
     AP_ST(t, 4);
   };
   {
@@ -660,7 +721,7 @@ __global__ __launch_bounds__(256, 1) void attn_prefill_w64_kernel(AttnArgs p) {
   f32x16 s0A, s0B, s1A, s1B;               // scores of the even / odd unit in flight
   bf16x8 p0A[2], p0B[2], p1A[2], p1B[2];   // P^T operands of the even / odd unit
   const float c = p.scale_log2;
-  const bool lazy = p.lazy_rescale != 0;
+  const bool lazy = (p.lazy_rescale & 1) != 0;
 
   const int kfb = ql * KROW + ((hh ^ (ql & 15)) << 4);
   const int vfb = ql * 128 + ((hh ^ ((ql >> 1) & 7)) << 4);
@@ -1135,7 +1196,7 @@ __global__ __launch_bounds__(512) void attn_prefill_pp_kernel(AttnArgs p) {
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[tb][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
-    const bool grow = p.lazy_rescale ? ((m_new - m_run) * p.scale_log2 > 8.f || m_run == -INFINITY) : true;
+    const bool grow = (p.lazy_rescale & 1) ? ((m_new - m_run) * p.scale_log2 > 8.f || m_run == -INFINITY) : true;
     const bool resc = __builtin_amdgcn_ballot_w64(grow && m_new != m_run) != 0;
     const float m_tgt = resc ? m_new : m_run;
     const float m_use = (m_tgt == -INFINITY) ? 0.f : m_tgt;
@@ -1751,7 +1812,7 @@ static int attention_impl(const void* q, const void* k, const void* vt, void* ou
   p.lse = lse;
   p.head_group = 1;
   p.staged_o = A3V_ENV_INT("A3V_ATTN_STAGED_O", 1) != 0;
-  p.lazy_rescale = A3V_ENV_INT("A3V_ATTN_LAZY", 1) != 0;
+  p.lazy_rescale = A3V_ENV_INT("A3V_ATTN_LAZY", 1);     // bit 0: lazy rescale; bit 1: ds_bpermute form of the row-maximum exchange (A/B)
   if (lse && Sq == 1 && dtype == A3V_BF16 && (hd == 64 || hd == 128)) return A3V_ERR_ARG;  // decode kernel has no LSE output
   if (dtype == A3V_F32) {
     if (hd > 256) return A3V_ERR_SHAPE;
