@@ -1110,6 +1110,15 @@ def main():
             ft = ("nt", "nn", "tn")
             all_f = sum(fam[k][0] for k in ft)
             all_t = sum(fam[k][1] for k in ft)
+            try:      # what the matrix pipe delivers on this box under its power limit (bare MFMA stream; context, not the price)
+                from a3vlm_amd import ops as _ops
+                pc, pr = _ops.probe_mfma_tflops(20000)
+                pipe = {"constant_operands_tflops": round(pc, 1), "random_operands_tflops": round(pr, 1),
+                        "frac_of_random_operand_rate": round(tot_f / tot_t / 1e12 / pr, 4) if pr > 0 else None,
+                        "note": "bare v_mfma_f32_16x16x32_bf16 stream on every CU, HIP events (a3v_probe_mfma_tflops): the chip clocks to its power "
+                                "budget, so random operands run slower than constants; `frac` above stays priced against the nominal 2.5 PF/s"}
+            except Exception as e:
+                pipe = {"error": repr(e)}
             return {"kernel": "MFMA GEMM family of the step: gemm_nt_bf16_ring_kernel (256x256x64 ping-pong over a 160-KiB LDS ring; forward linears), "
                               "gemm_tn_bf16_pp_kernel<A_ROWS> (NN input gradients / TN weight gradients), gemm_nt_bf16_kernel<128,128> on tail rows and small shapes",
                     "bound": "mfma", "achieved": round(tot_f / tot_t / 1e12, 1), "peak": MFMA_PEAK_BF16 / 1e12, "unit": "TFLOP/s",
@@ -1117,7 +1126,7 @@ def main():
                     "frac_full_fine_tune_mix": round(all_f / all_t / MFMA_PEAK_BF16, 4),
                     "families": {k: {"tflops": round(v[0] / v[1] / 1e12, 1), "frac": round(v[0] / v[1] / MFMA_PEAK_BF16, 4), "ms_per_step": round(v[1] * 1e3, 2)}
                                  for k, v in fam.items() if v[1] > 0},
-                    "in_step": in_step_ring_ms(headline),
+                    "in_step": in_step_ring_ms(headline), "mfma_pipe_measured": pipe,
                     "gemm_ms_per_step": round(tot_t * 1e3, 2), "gemm_calls_per_step": sum(r["count"] for r in table if r["kind"] in use),
                     "note": "achieved = algorithmic 2MNK of every GEMM call of one headline step / its HIP-event duration on the launch stream "
                             "(FLOP-weighted over the step's shapes = total GEMM FLOP / total GEMM time), each shape timed alone after a clock "

@@ -1003,3 +1003,11 @@ def test_gemm_split_k_scratch_is_per_stream():
     ws = torch.empty(96 << 20, dtype=torch.uint8, device=DEV)
     assert L.a3v_gemm_set_workspace(ws.data_ptr(), ws.numel()) == 0
     assert L.a3v_gemm_set_workspace(None, 0) == 0
+
+
+def test_mfma_probe_reports_a_plausible_pipe_rate():
+    """a3v_probe_mfma_tflops (bench.py `roofline.mfma_pipe_measured`): a bare MFMA stream lands between a third of and just above the
+    nominal 2.5 PF/s, and random operands are never faster than constants by more than the run-to-run spread."""
+    const, rand = ops.probe_mfma_tflops(4000)
+    assert 800.0 < rand < 2700.0 and 800.0 < const < 2700.0, (const, rand)
+    assert rand < const * 1.05, (const, rand)
