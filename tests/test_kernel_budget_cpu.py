@@ -93,3 +93,29 @@ def test_owned_agpr_kernels_are_never_touched_by_the_compiler(tmp_path):
         assert not k["bad"], f"{name}: compiler-generated AGPR / MFMA instructions: {k['bad'][:3]}"
         assert k["scratch"] == 0, f"{name}: {k['scratch']} scratch instructions"
         assert k["mfma"] > 60, (name, k["mfma"])            # the loop really is the asm stream (hd 64: 88 MFMAs over its step variants)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_prefill_attention_kernels_keep_two_waves_per_simd_and_no_scratch(tmp_path):
+    """The product prefill kernels run two blocks per CU (__launch_bounds__(256, 2)): <= 256 registers and no scratch.  The hd-128 form
+    reads its K / V^T fragments ahead of their MFMAs since round 4 (244 registers): a few more and hipcc spills into the tile loop.
+    The one-wave-per-SIMD experiment kernel (attn_prefill_w64_kernel) must not be in the product object, and the row-maximum exchange
+    must be the asm v_permlane32_swap (the builtin with one value in both operands silently loses the exchange)."""
+    src = os.path.join(ROOT, "a3vlm_amd", "csrc", "a3v_attn.hip")
+    out = tmp_path / "a.s"
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "--cuda-device-only", "-S", src, "-o", str(out)],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = open(out).read()
+    assert "attn_prefill_w64_kernel" not in text, "the experiment kernel is compiled into the product object"
+    found = 0
+    for m in re.finditer(r"^(_ZN\S*attn_prefill_bf16_kernel\S*):[^\n]*\n(.*?)\.end_amdhsa_kernel", text, flags=re.S | re.M):
+        name, body = m.group(1), m.group(2)
+        tail = text[m.start():]
+        vg = int(re.search(r"\.amdhsa_next_free_vgpr\s+(\d+)", tail).group(1))
+        sc = int(re.search(r"\.amdhsa_private_segment_fixed_size\s+(\d+)", tail).group(1))
+        assert vg <= 256, (name, vg)
+        assert sc == 0, (name, sc)
+        assert "v_permlane32_swap_b32 v" in body, name
+        found += 1
+    assert found >= 4, found
