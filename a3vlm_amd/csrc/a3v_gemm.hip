@@ -445,7 +445,12 @@ __device__ __forceinline__ bool gemm_epilogue_fast(f32x4 (&acc)[TM][TN], const G
             asm volatile("" : "+v"(sqr));
             const float* csr = csb + (((int64_t)(k.rope_pos0 + sqr)) << k.hd_shift);      // (pos << (hd_shift - 1)) * 2 floats
 #pragma unroll
+#ifdef ROPE_NO_CS      // timing build (wrong results): no cos / sin loads -- they are 21 of the epilogue's 28 us per launch (r04g_decode_fixup_and_rope_epilogue.txt)
+            for (int j = 0; j < 4; ++j) cs[ii][j] = f32x4{1.f, 0.f, 1.f, 0.f};
+            (void)csr;
+#else
             for (int j = 0; j < 4; ++j) cs[ii][j] = *reinterpret_cast<const f32x4*>(csr + j * 16);
+#endif
             sqr += 16;
             if (sqr >= S_) sqr -= S_;
           }
@@ -2735,6 +2740,9 @@ __global__ __launch_bounds__(256) void gemv_dma_bf16_kernel(GemvArgs p) {
     // access, no cache-wide write-back / invalidate), waits for the acknowledge, then bumps the arrival counter of its
     // tile (of its gate/up tile PAIR with SwiGLU).  The wave that arrives last reloads all partials in one round trip,
     // sums them in slice order (bit-identical whichever wave is last), resets the counter and runs the epilogue.
+#ifdef GEMV_NO_FIXUP   // timing build (wrong results): slice 0 finishes on its own partial, nobody stores or waits: 3.85 -> 3.43 ms per decode step
+    if (sl != 0) return;
+#else
     float* mine = p.part + (((int64_t)(tg * p.S + sl) * 4 + wave) * 64 + lane) * 4;
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(mine), "v"(v) : "memory");   // (s_nop: the store's data registers, see the V^T store of the fused-qkv epilogue)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2774,6 +2782,7 @@ __global__ __launch_bounds__(256) void gemv_dma_bf16_kernel(GemvArgs p) {
           for (int r = 0; r < 4; ++r) u[r] += y[s8][r];
         }
       }
+#endif
   }
   if (W8) {                 // per-row dequantisation scale on the summed accumulator (rows clamp: the stores are masked)
     const int nr = nt0 + (lane >> 4) * 4;
