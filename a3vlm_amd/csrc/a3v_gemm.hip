@@ -2548,6 +2548,76 @@ struct GemvArgs {
 constexpr int GEMV_EPI_ROPEKV = 1 << 24;
 constexpr int GEMV_EPI_SSQ = 1 << 25;
 
+// Epilogue of the decode GEMVs for one finished 16-row tile (SwiGLU: one gate / up tile pair): v[r] = D[n = nt0 + 4 (lane>>4) + r][m = lane & 15]
+// (u: the matching up-projection rows).  Shared by the split-K-across-blocks kernel above and the split-K-inside-the-block kernel below.
+__device__ __forceinline__ void gemv_finish(const GemvArgs& p, f32x4 v, f32x4 u, int nt0, int lane, bool swiglu) {
+  const int m = lane & 15;
+  if (swiglu) {
+    if (m >= p.M || nt0 >= p.N) return;
+    const int oc = (nt0 >> 1) + (lane >> 4) * 4;
+    bf16x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = f2bf(rbf(silu(rbf(v[r]))) * rbf(u[r]));
+    *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + oc) = o;
+    return;
+  }
+  const int n = nt0 + (lane >> 4) * 4;
+  float o4[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) o4[r] = rbf(v[r]);
+  if (p.epi & GEMV_EPI_ROPEKV) {
+    // fused apply_rotary_emb + KV-cache write of the decode step (llama_ens5.py:118,124-129; a3v_rope_kvcache at S == 1):
+    // rows n are [q heads | k heads | v heads] x hd; a lane holds two interleaved pairs of one head, batch row m.
+    if (m >= p.M || n >= p.N) return;
+    const int slot = n / p.hd, d = n % p.hd, half = p.hd >> 1;
+    if (slot < p.H + p.Hkv) {
+      const float* cs = p.cos_sin + ((int64_t)p.pos * half + (d >> 1)) * 2;
+      const f32x4 t = *reinterpret_cast<const f32x4*>(cs);          // (cos, sin) of the two pairs
+      bf16x4 o;
+      o[0] = f2bf(o4[0] * t[0] - o4[1] * t[1]);
+      o[1] = f2bf(o4[0] * t[1] + o4[1] * t[0]);
+      o[2] = f2bf(o4[2] * t[2] - o4[3] * t[3]);
+      o[3] = f2bf(o4[2] * t[3] + o4[3] * t[2]);
+      bf16_t* dst = slot < p.H ? reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + n
+                               : p.k_cache + (((int64_t)m * p.Hkv + (slot - p.H)) * p.Smax + p.pos) * p.hd + d;
+      *reinterpret_cast<bf16x4*>(dst) = o;
+    } else {
+      bf16_t* dst = p.vt_cache + (((int64_t)m * p.Hkv + (slot - p.H - p.Hkv)) * p.hd + d) * (int64_t)p.Smax + p.pos;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst[(int64_t)r * p.Smax] = f2bf(o4[r]);
+    }
+    return;
+  }
+  const bool live = m < p.M && n < p.N;
+  if (live && (p.epi & A3V_EPI_RESIDUAL)) {
+    const bf16x4 rr = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(p.res) + (int64_t)m * p.ldr + n);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o4[r] += bf2f(rr[r]);
+  }
+  if (p.epi & GEMV_EPI_SSQ) {
+    // sum of squares of the 16 bf16 values this tile contributes to row m (consumed by the next GEMV's RMSNorm prologue)
+    float sq = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const float hb = rbf(o4[r]); sq = fmaf(hb, hb, sq); }
+    if (!live) sq = 0.f;
+    sq += __shfl_xor(sq, 16, 64);
+    sq += __shfl_xor(sq, 32, 64);
+    if (lane < 16 && nt0 < p.N) p.ssq_out[(nt0 >> 4) * 16 + lane] = sq;
+  }
+  if (!live) return;
+  if (p.epi & A3V_EPI_OUT_F32) {
+    f32x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = o4[r];
+    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n) = o;
+  } else {
+    bf16x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = f2bf(o4[r]);
+    *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + n) = o;
+  }
+}
+
 // W8: the weight rows are OCP fp8 e4m3fn (weight-only quantisation, one fp32 scale per row applied to the summed
 // accumulator).  A ring stage is still 16 rows x 256 B, i.e. 256 k instead of 128; fragments are read 8 B per lane and
 // widened fp8 -> f32 -> bf16 in registers (exact), so the arithmetic is the bf16 MFMA on dequantised weights.
@@ -2795,72 +2865,156 @@ __global__ __launch_bounds__(256) void gemv_dma_bf16_kernel(GemvArgs p) {
       for (int r = 0; r < 4; ++r) u[r] *= su[r];
     }
   }
-  // v[r] = D[n = nt0 + 4 (lane>>4) + r][m = lane & 15]   (u: the matching up-projection rows with SwiGLU)
-  const int m = lane & 15;
-  if (swiglu) {
-    if (m >= p.M || nt0 >= p.N) return;
-    const int oc = (nt0 >> 1) + (lane >> 4) * 4;
-    bf16x4 o;
+  gemv_finish(p, v, u, nt0, lane, swiglu);
+}
+
+// ------------------------------------------------------------------------------------
+// Decode GEMV with the K split INSIDE the block (round 4; M <= 8, bf16 weights): the block owns ONE 16-row tile of W (with SwiGLU a
+// gate / up tile pair) and its waves are the K slices -- the same number of waves streaming the same 16 rows x (K / slices) through
+// the same private 2-stage rings as gemv_dma_bf16_kernel, but the partial accumulators meet in LDS behind one block barrier instead
+// of in HBM behind store -> acknowledge -> arrival counter -> reload (three dependent memory round trips per launch: 0.42 ms of the
+// 3.85-ms decode step, profiles/r04g_decode_fixup_and_rope_epilogue.txt).  What the shared LDS slice of A gave up for that: a wave
+// reads ITS K slice of the 8 activation rows straight from L2 into registers in MFMA operand layout (4 x 16 B per lane and stage,
+// two stages ahead; with the RMSNorm prologue the norm weights the same way and the normalisation in registers), so a block needs
+// only its rings + a 1-KiB reduce patch per wave and 5-6 blocks fit a CU.
+// ------------------------------------------------------------------------------------
+template <bool PRO>
+__global__ __launch_bounds__(768) void gemv_kq_bf16_kernel(GemvArgs p) {
+  extern __shared__ __attribute__((aligned(1024))) char kq_lds[];
+  __shared__ float rinv_s[8];
+  __shared__ float ssq_w[12][8];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nw = __builtin_amdgcn_readfirstlane((int)(blockDim.x >> 6));
+  const bool swiglu = (p.epi & A3V_EPI_SWIGLU) != 0;
+  // tile and K slice of this wave
+  const int tiles_pb = swiglu ? 2 : 1;
+  const int slices = nw / tiles_pb;
+  const int tile = blockIdx.x * tiles_pb + (swiglu ? (wave & 1) : 0);
+  const int sl = swiglu ? (wave >> 1) : wave;
+  const int n0 = tile * 16;
+  const int st0 = (int)(((int64_t)sl * p.nkb) / slices), st1 = (int)(((int64_t)(sl + 1) * p.nkb) / slices);
+  const int nst = st1 - st0;
+  char* Wring = kq_lds + wave * 2 * 4096;
+  float* red = reinterpret_cast<float*>(kq_lds + nw * 2 * 4096);          // [nw][64 lanes][4] partial accumulators
+  const int dr = lane >> 4, dslot = lane & 15;
+  const char* wrow[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) o[r] = f2bf(rbf(silu(rbf(v[r]))) * rbf(u[r]));
-    *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + oc) = o;
-    return;
+  for (int i = 0; i < 4; ++i) {
+    const int row = 4 * i + dr;
+    int wr = n0 + row;
+    wr = wr < p.N ? wr : p.N - 1;
+    wrow[i] = reinterpret_cast<const char*>(p.W) + (int64_t)wr * p.ldw * 2 + (int64_t)st0 * 256 + ((dslot ^ row) & 15) * 16;
   }
-  const int n = nt0 + (lane >> 4) * 4;
-  float o4[4];
+  auto dma_stage = [&](int st, int slot) {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) o4[r] = rbf(v[r]);
-  if (p.epi & GEMV_EPI_ROPEKV) {
-    // fused apply_rotary_emb + KV-cache write of the decode step (llama_ens5.py:118,124-129; a3v_rope_kvcache at S == 1):
-    // rows n are [q heads | k heads | v heads] x hd; a lane holds two interleaved pairs of one head, batch row m.
-    if (m >= p.M || n >= p.N) return;
-    const int slot = n / p.hd, d = n % p.hd, half = p.hd >> 1;
-    if (slot < p.H + p.Hkv) {
-      const float* cs = p.cos_sin + ((int64_t)p.pos * half + (d >> 1)) * 2;
-      const f32x4 t = *reinterpret_cast<const f32x4*>(cs);          // (cos, sin) of the two pairs
-      bf16x4 o;
-      o[0] = f2bf(o4[0] * t[0] - o4[1] * t[1]);
-      o[1] = f2bf(o4[0] * t[1] + o4[1] * t[0]);
-      o[2] = f2bf(o4[2] * t[2] - o4[3] * t[3]);
-      o[3] = f2bf(o4[2] * t[3] + o4[3] * t[2]);
-      bf16_t* dst = slot < p.H ? reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + n
-                               : p.k_cache + (((int64_t)m * p.Hkv + (slot - p.H)) * p.Smax + p.pos) * p.hd + d;
-      *reinterpret_cast<bf16x4*>(dst) = o;
-    } else {
-      bf16_t* dst = p.vt_cache + (((int64_t)m * p.Hkv + (slot - p.H - p.Hkv)) * p.hd + d) * (int64_t)p.Smax + p.pos;
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wrow[i] + st * 256),
+                                       (__attribute__((address_space(3))) void*)(Wring + slot * 4096 + i * 1024), 16, 0, 2);
+  };
+  // A fragments (B operand): lane (fr = lane & 15 -> activation row fr & 7, fg = lane >> 4): k = 128 stage + 32 s4 + 8 fg + 0..7
+  const int fr = lane & 15, fg = lane >> 4;
+  const int arow = (fr & 7) < p.M ? (fr & 7) : p.M - 1;
+  const bf16_t* arp = p.A + (int64_t)arow * p.lda + (int64_t)st0 * 128 + fg * 8;
+  const bf16_t* gp = PRO ? p.norm_w + (int64_t)st0 * 128 + fg * 8 : nullptr;
+  bf16x8 ax[2][4], ag[2][4];
+  auto load_a = [&](int st, int set) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) dst[(int64_t)r * p.Smax] = f2bf(o4[r]);
+    for (int s4 = 0; s4 < 4; ++s4) {
+      ax[set][s4] = *reinterpret_cast<const bf16x8*>(arp + st * 128 + s4 * 32);
+      if (PRO) ag[set][s4] = *reinterpret_cast<const bf16x8*>(gp + st * 128 + s4 * 32);
     }
-    return;
-  }
-  const bool live = m < p.M && n < p.N;
-  if (live && (p.epi & A3V_EPI_RESIDUAL)) {
-    const bf16x4 rr = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(p.res) + (int64_t)m * p.ldr + n);
+  };
+  if (nst > 0) { load_a(0, 0); dma_stage(0, 0); }
+  if (nst > 1) { load_a(1, 1); dma_stage(1, 1); }
+  float ri = 1.f;
+  if (PRO) {
+    // 1/rms of the 8 rows from the producer's per-16-column sums of squares (model/components.py:39,52-53); issued behind the first
+    // stages, so the reduction runs while they are in flight
+    f32x4 sq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    for (int t = threadIdx.x; t < p.ssq_tiles; t += blockDim.x) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) o4[r] += bf2f(rr[r]);
-  }
-  if (p.epi & GEMV_EPI_SSQ) {
-    // sum of squares of the 16 bf16 values this tile contributes to row m (consumed by the next GEMV's RMSNorm prologue)
-    float sq = 0.f;
+      for (int q = 0; q < 2; ++q) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(p.ssq_in + t * 16 + q * 4);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { const float hb = rbf(o4[r]); sq = fmaf(hb, hb, sq); }
-    if (!live) sq = 0.f;
-    sq += __shfl_xor(sq, 16, 64);
-    sq += __shfl_xor(sq, 32, 64);
-    if (lane < 16 && nt0 < p.N) p.ssq_out[(nt0 >> 4) * 16 + lane] = sq;
-  }
-  if (!live) return;
-  if (p.epi & A3V_EPI_OUT_F32) {
-    f32x4 o;
+        for (int r = 0; r < 4; ++r) sq[q][r] += x[r];
+      }
+    }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) o[r] = o4[r];
-    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n) = o;
-  } else {
-    bf16x4 o;
+    for (int q = 0; q < 2; ++q)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) o[r] = f2bf(o4[r]);
-    *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + n) = o;
+      for (int r = 0; r < 4; ++r) {
+        const float t = wave_sum(sq[q][r]);
+        if (lane == 0) ssq_w[wave][q * 4 + r] = t;
+      }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+      float t = 0.f;
+      for (int w = 0; w < nw; ++w) t += ssq_w[w][threadIdx.x];
+      rinv_s[threadIdx.x] = rsqrtf(t / (float)p.K + p.eps);
+    }
+    __syncthreads();
+    ri = rinv_s[fr & 7];
   }
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  int foff[4];
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) foff[s4] = (((4 * s4 + fg) ^ fr) & 15) * 16;
+  auto stage_body = [&](int st, auto setc) {
+    constexpr int SET = decltype(setc)::value;
+    // W(st) and A(st) have landed when at most the next stage's pieces are outstanding (in-order completion)
+    if (st + 1 < nst) { if (PRO) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const char* Ws = Wring + SET * 4096 + fr * 256;
+    bf16x8 wf[4], af[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) wf[s4] = *reinterpret_cast<const bf16x8*>(Ws + foff[s4]);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      if (PRO) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) af[s4][e] = f2bf(rbf((float)ax[SET][s4][e] * ri) * (float)ag[SET][s4][e]);
+      } else {
+        af[s4] = ax[SET][s4];
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragments are in registers: the slot may be overwritten
+    if (st + 2 < nst) { load_a(st + 2, SET); dma_stage(st + 2, SET); }
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      if (s4 & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s4], af[s4], acc1, 0, 0, 0);
+      else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s4], af[s4], acc0, 0, 0, 0);
+    }
+  };
+  {
+    int st = 0;
+    for (; st + 1 < nst; st += 2) {
+      stage_body(st, std::integral_constant<int, 0>{});
+      stage_body(st + 1, std::integral_constant<int, 1>{});
+    }
+    if (st < nst) stage_body(st, std::integral_constant<int, 0>{});
+  }
+  f32x4 v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = acc0[r] + acc1[r];
+  f32x4 u = {0.f, 0.f, 0.f, 0.f};
+  if (nw > 1) {
+    // the K slices meet in LDS: the tile's first wave sums them in slice order (deterministic) and finishes the tile
+    *reinterpret_cast<f32x4*>(red + (wave * 64 + lane) * 4) = v;
+    __syncthreads();
+    if (wave != 0) return;
+    v = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s8 = 0; s8 < slices; ++s8) {
+      const f32x4 x = *reinterpret_cast<const f32x4*>(red + ((s8 * tiles_pb) * 64 + lane) * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] += x[r];
+      if (swiglu) {
+        const f32x4 y = *reinterpret_cast<const f32x4*>(red + ((s8 * 2 + 1) * 64 + lane) * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) u[r] += y[r];
+      }
+    }
+  }
+  gemv_finish(p, v, u, blockIdx.x * tiles_pb * 16, lane, swiglu);
 }
 
 // ------------------------------------------------------------------------------------
@@ -3399,6 +3553,30 @@ static bool gemv_launch(GemvArgs& g, void* ws, hipStream_t st) {
   const size_t ldsb = (size_t)g.maxkb * arows * 256 + 4 * 2 * 4096;
   const int blocks = ((g.tgs + 7) / 8) * 8 * g.S;
   const bool pro = g.norm_w != nullptr;
+  // M <= 8, bf16 weights: the K slices as the waves of ONE block per 16-row tile (gemv_kq_bf16_kernel: the partials meet in LDS,
+  // no split-K fix-up through HBM); same slice count as the across-blocks plan.  A3V_GEMV_KQ=0: the across-blocks kernel (A/B runs)
+  const int kq_mode = A3V_ENV_INT("A3V_GEMV_KQ", 1);     // 1: the GEMVs without an RMSNorm prologue (wo, w2, LM head); 2: all; 0: none
+  if (!w8 && arows == 8 && (kq_mode == 2 || (kq_mode == 1 && !pro)) && g.N % 16 == 0 && (reinterpret_cast<uintptr_t>(g.A) & 15) == 0 && g.lda % 8 == 0 &&
+      (!pro || (reinterpret_cast<uintptr_t>(g.norm_w) & 15) == 0)) {
+    const bool sw = (g.epi & A3V_EPI_SWIGLU) != 0;
+    int slices = g.S;
+    if (sw && slices > 6) slices = 6;
+#ifdef A3V_ABLATION
+    { const int e = A3V_ENV_INT("A3V_GEMV_KQ_SLICES", 0); if (e > 0) slices = sw && e > 6 ? 6 : (e > 12 ? 12 : e); }     // sweeps (tools/ab_gemv_kq.py)
+#endif
+    while (slices > 1 && g.nkb < 2 * slices) --slices;
+    const int nw = slices * (sw ? 2 : 1);
+    const int tiles = g.N / 16;
+    if (!sw || tiles % 2 == 0) {
+      const int kq_blocks = sw ? tiles / 2 : tiles;
+      const size_t kq_lds = (size_t)nw * (2 * 4096 + 1024);
+      void (*kq)(GemvArgs) = pro ? gemv_kq_bf16_kernel<true> : gemv_kq_bf16_kernel<false>;
+      static bool kq_attr[2] = {};
+      if (!kq_attr[pro ? 1 : 0]) { (void)hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); kq_attr[pro ? 1 : 0] = true; }
+      hipLaunchKernelGGL(kq, dim3(kq_blocks), dim3(nw * 64), kq_lds, st, g);
+      return true;
+    }
+  }
   void (*kern)(GemvArgs);
   // weights are streamed once per step by ONE CU each: non-temporal policy on their LDS-DMA (A3V_GEMV_NT=0: default policy, A/B)
   const bool nt = A3V_ENV_INT("A3V_GEMV_NT", 1) != 0;
