@@ -1011,3 +1011,45 @@ def test_mfma_probe_reports_a_plausible_pipe_rate():
     const, rand = ops.probe_mfma_tflops(4000)
     assert 800.0 < rand < 2700.0 and 800.0 < const < 2700.0, (const, rand)
     assert rand < const * 1.05, (const, rand)
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(8, 4096, 4096, "res"), (8, 4096, 11008, "res"), (8, 32000, 4096, "f32"), (3, 1024, 512, ""), (8, 22016, 4096, "swiglu"),
+                                       (5, 10240, 5120, "swiglu"), (1, 64, 256, ""), (8, 12288, 4096, "")])
+def test_gemv_k_slices_inside_the_block_equal_the_across_blocks_form(M, N, K, epi):
+    """Round 4: the decode GEMVs without an RMSNorm prologue put the K slices of a 16-row tile into ONE block (gemv_kq_bf16_kernel: the partial
+    accumulators meet in LDS, no split-K fix-up through HBM).  Same slice order => the same bits as the across-blocks kernel
+    (A3V_GEMV_KQ=0) whenever the slice counts agree, and both within bf16 rounding of the fp32 product."""
+    from a3vlm_amd import lib as _l2
+    g = torch.Generator().manual_seed(N + K + M)
+    a = torch.randn(M, K, generator=g).to(BF).to(DEV)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(BF).to(DEV)
+    flags = {"res": ops.EPI_RESIDUAL, "f32": ops.EPI_OUT_F32, "swiglu": ops.EPI_SWIGLU, "": 0}[epi]
+    No = N // 2 if epi == "swiglu" else N
+    res = torch.randn(M, No, generator=g).to(BF).to(DEV) if epi == "res" else None
+    ws = ops.gemm_skinny_workspace(M, N, K, DEV)
+    outs = {}
+    for mode in ("2", "0"):
+        with _l2.env(A3V_GEMV_KQ=mode):
+            out = torch.zeros(M, No, device=DEV, dtype=torch.float32 if epi == "f32" else BF)
+            ops.gemm_skinny(a, w, out, ws, residual=res, epilogue=flags)
+            torch.cuda.synchronize()
+            outs[mode] = out.float().cpu()
+    y = a.float().cpu() @ w.float().cpu().t()
+    if epi == "swiglu":
+        y = y.view(M, N // 32, 2, 16)
+        gq, uq = y[:, :, 0].to(BF).float(), y[:, :, 1].to(BF).float()
+        y = (torch.nn.functional.silu(gq).to(BF).float() * uq).reshape(M, N // 2)
+    if res is not None:
+        y = y.to(BF).float() + res.float().cpu()
+    for mode in ("2", "0"):
+        err = float((outs[mode] - y).abs().max() / y.abs().max())
+        assert err < 2e-2, (mode, err)
+    same_plan = not (epi == "swiglu" and L_skinny_split(M, N, K) > 6)
+    if same_plan:
+        assert torch.equal(outs["2"], outs["0"])
+    assert int((ws.view(torch.int32)[: 4096] != 0).sum()) == 0          # the arrival counters are left at zero by both forms
+
+
+def L_skinny_split(M, N, K):
+    from a3vlm_amd import lib as _l3
+    return int(_l3.load().a3v_gemm_skinny_split(M, N, K))
