@@ -1970,6 +1970,9 @@ int a3v_attention_decode_fused(const void* q, const void* k, const void* vt, voi
     // one block per (batch, head) when that alone covers the CUs, else the fewest splits that do (never more than the
     // two-phase plan: the scratch buffer is sized for that one)
     int ns2 = (256 + B * H - 1) / (B * H);
+#ifdef A3V_ABLATION
+    { const int e = A3V_ENV_INT("A3V_DECODE_WAVE_SPLITS", 0); if (e > 0) ns2 = e; }      // sweeps: splits of the wave-streaming form
+#endif
     if (ns2 > ns) ns2 = ns;
     int ch2 = (Sk + ns2 - 1) / ns2;
     ch2 = (ch2 + 63) & ~63;
