@@ -107,12 +107,57 @@ __device__ __forceinline__ void store8(float* p, const float* v) {
   *reinterpret_cast<f32x4*>(p + 4) = b;
 }
 
+// Wave-wide butterfly reductions WITHOUT the LDS pipe (round 4).  __shfl_xor compiles to ds_bpermute_b32: six LDS round trips of ~100+
+// cycles each per reduction, in front of every row's second pass and in the prologue of every decode GEMV.  The same butterfly
+// (partner lane ^ 32, ^ 16, ^ 8, ^ 4, ^ 2, ^ 1 in this order -- the same pairs, hence the same bits as the __shfl_xor form) on the VALU:
+//   ^ 32 / ^ 16 : v_permlane32_swap / v_permlane16_swap (asm: with one value in both operands of the builtins hipcc keeps ONE of the
+//                 two results for both and the exchange disappears);
+//   ^ 8  / ^ 4  : DPP row_ror:8 / row_ror:4 (after the ^ 8 level the lanes i and i ^ 8 of a row hold the same value, so lane i + 4
+//                 mod 16 holds what lane i ^ 4 holds);   ^ 2 / ^ 1 : DPP quad_perm [2,3,0,1] / [1,0,3,2].
+__device__ __forceinline__ void lane_xchg32(float x, float& a, float& b) {
+  a = x; b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void lane_xchg16(float x, float& a, float& b) {
+  a = x; b = x;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+#ifdef A3V_WAVE_SHFL      // A/B builds: the __shfl_xor (ds_bpermute) forms of rounds 1-3
+#define wave_sum wave_sum_shfl
+#define wave_max wave_max_shfl
+#else
 __device__ __forceinline__ float wave_sum(float v) {
+  float a, b;
+  lane_xchg32(v, a, b); v = a + b;
+  lane_xchg16(v, a, b); v = a + b;
+  v += dpp_f<0x128>(v);
+  v += dpp_f<0x124>(v);
+  v += dpp_f<0x4E>(v);
+  v += dpp_f<0xB1>(v);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+  float a, b;
+  lane_xchg32(v, a, b); v = fmaxf(a, b);
+  lane_xchg16(v, a, b); v = fmaxf(a, b);
+  v = fmaxf(v, dpp_f<0x128>(v));
+  v = fmaxf(v, dpp_f<0x124>(v));
+  v = fmaxf(v, dpp_f<0x4E>(v));
+  v = fmaxf(v, dpp_f<0xB1>(v));
+  return v;
+}
+#endif
+// (the LDS-pipe forms, kept for the equality test of the two: a3v_probe_wave_reduce)
+__device__ __forceinline__ float wave_sum_shfl(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
+__device__ __forceinline__ float wave_max_shfl(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;

@@ -65,3 +65,24 @@ extern "C" int a3v_probe_mfma_tflops(int iters, float* scratch, float* tflops, v
   A3V_LAUNCH_CHECK();
   return A3V_OK;
 }
+
+// Self-check entry: the VALU butterfly reductions of a3v_common.h (v_permlane32/16_swap + DPP) against the __shfl_xor (ds_bpermute)
+// forms they replaced, on `n_waves` waves of values from `x` (64 floats per wave): *mismatches = lanes whose sum or max differs in
+// ANY bit.  The two butterflies pair the same lanes in the same order, so the count must be zero.
+namespace {
+__global__ __launch_bounds__(256) void wave_reduce_probe_kernel(const float* __restrict__ x, int n_waves, int* __restrict__ bad) {
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= n_waves) return;                                   // (wave-uniform: whole waves leave)
+  const float v = x[(int64_t)w * 64 + (threadIdx.x & 63)];
+  const float s0 = wave_sum(v), s1 = wave_sum_shfl(v), m0 = wave_max(v), m1 = wave_max_shfl(v);
+  if (__builtin_bit_cast(unsigned, s0) != __builtin_bit_cast(unsigned, s1) || __builtin_bit_cast(unsigned, m0) != __builtin_bit_cast(unsigned, m1))
+    atomicAdd(bad, 1);
+}
+}  // namespace
+
+extern "C" int a3v_probe_wave_reduce(const float* x, int n_waves, int* mismatches, void* stream) {
+  if (!x || n_waves <= 0 || !mismatches) return A3V_ERR_ARG;
+  hipLaunchKernelGGL(wave_reduce_probe_kernel, dim3((n_waves + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, n_waves, mismatches);
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}

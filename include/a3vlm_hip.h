@@ -79,6 +79,10 @@ int a3v_build_flags(void);
  * chip clocks to its power budget, so the second number is what the matrix pipe can deliver on real data (the nominal 2.5 PF/s is the
  * price the roofline fractions are quoted against).  `scratch`: device memory, 8 * CUs * 256 floats.  Synchronises `stream`. */
 int a3v_probe_mfma_tflops(int iters, float* scratch, float* tflops, void* stream);
+/* Self-check of the wave-wide reductions every row kernel uses (csrc/a3v_common.h: v_permlane32_swap / v_permlane16_swap + DPP butterfly)
+ * against the __shfl_xor forms they replaced in round 4: x = n_waves x 64 floats (device), *mismatches (device int, zeroed by the caller)
+ * += lanes whose sum or maximum differs in any bit.  Must stay 0: both butterflies pair the same lanes in the same order. */
+int a3v_probe_wave_reduce(const float* x, int n_waves, int* mismatches, void* stream);
 
 /* C[M,N] = epilogue(A[M,K] @ W[N,K]^T).  Replaces every F.linear on the path:
  * wq/wk/wv/wo (LLM/llama_ens5.py:63-90,112,169), w1/w2/w3 (:202-217), output (:267-269,

@@ -1053,3 +1053,23 @@ def test_gemv_k_slices_inside_the_block_equal_the_across_blocks_form(M, N, K, ep
 def L_skinny_split(M, N, K):
     from a3vlm_amd import lib as _l3
     return int(_l3.load().a3v_gemm_skinny_split(M, N, K))
+
+
+def test_wave_reductions_on_the_valu_equal_the_shuffle_forms_bit_for_bit():
+    """csrc/a3v_common.h wave_sum / wave_max (round 4: v_permlane32_swap, v_permlane16_swap, DPP row_ror / quad_perm -- no LDS round
+    trips) pair the same lanes in the same order as the __shfl_xor butterflies they replaced: identical bits on random data, on data
+    with infinities / huge dynamic range, and on denormals."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(4096, 64, generator=g)
+    x[100:200] *= torch.logspace(-30, 30, 100)[:, None]
+    x[300:310, ::7] = float("inf")
+    x[320:330, 3] = float("-inf")
+    x[400:420] *= 1e-41
+    xd = x.to(DEV).contiguous()
+    bad = torch.zeros(1, dtype=torch.int32, device=DEV)
+    from a3vlm_amd import lib as _lib
+    L = _lib.load()
+    rc = L.a3v_probe_wave_reduce(xd.data_ptr(), x.shape[0], bad.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert int(bad.item()) == 0
