@@ -146,17 +146,43 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_vec_kernel(const TS* __restri
     dwp[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const int row0 = blockIdx.x * RPB;
+  // bf16 stream: the NEXT row's x, dy and dh vectors (2 registers each) are requested before the current row's reductions and barrier,
+  // so the row loop no longer pays a memory round trip per row behind its barrier (round 4, rows wider than 4096; A/B macro RMSB_NO_PREFETCH)
+#ifdef RMSB_NO_PREFETCH
+  constexpr bool PF = false;
+#else
+  constexpr bool PF = sizeof(TS) == 2 && sizeof(TA) == 2 && MAXV > 4;     // dim 5120 (13B): 115 -> 82 us; dim 4096: 53 -> 55 us, kept off (tools/rmsnorm_bwd_bf16_bench.py)
+#endif
+  bf16x4 nx[MAXV], ng[MAXV], nh[MAXV];
+  auto fetch = [&](int row) {
+    if constexpr (PF) {
+      const int rc = row < rows ? row : rows - 1;
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i) {
+        const int c = tid + i * 256;
+        const int cc = c < nv ? c : 0;
+        nx[i] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(x) + (int64_t)rc * ldx + 4 * cc);
+        ng[i] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(dy) + (int64_t)rc * lddy + 4 * cc);
+        nh[i] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(dh) + (int64_t)rc * lddh + 4 * cc);
+      }
+    }
+  };
+  fetch(row0);
   for (int rr = 0; rr < RPB; ++rr) {
     const int row = row0 + rr;
     if (row >= rows) break;
     const TS* xr = x + (int64_t)row * ldx;
     const TA* dyr = dy + (int64_t)row * lddy;
-    f32x4 xv[MAXV], gv[MAXV];
+    f32x4 xv[MAXV], gv[MAXV], hv[MAXV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
       const int c = tid + i * 256;
       if (c < nv) {
+        if constexpr (PF) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { xv[i][e] = (float)nx[i][e]; gv[i][e] = (float)ng[i][e]; hv[i][e] = (float)nh[i][e]; }
+        } else {
         if constexpr (sizeof(TS) == 2) {
           const bf16x4 xb = *reinterpret_cast<const bf16x4*>(xr + 4 * c);
 #pragma unroll
@@ -171,6 +197,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_vec_kernel(const TS* __restri
         } else {
           gv[i] = *reinterpret_cast<const f32x4*>(dyr + 4 * c);
         }
+        }
       } else {
         xv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         gv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -181,6 +208,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_vec_kernel(const TS* __restri
         s2 = fmaf(gv[i][e] * wv[i][e], xv[i][e], s2);
       }
     }
+    if (rr + 1 < RPB) fetch(row + 1);
     s1 = wave_sum(s1); s2 = wave_sum(s2);
     const int pb = rr & 1;                    // double-buffered: one barrier per row
     if ((tid & 63) == 0) { red[pb][tid >> 6] = s1; red[pb][4 + (tid >> 6)] = s2; }
@@ -195,7 +223,9 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_vec_kernel(const TS* __restri
       const int c = tid + i * 256;
       if (c < nv) {
         f32x4 o;
-        if constexpr (sizeof(TS) == 2) {
+        if constexpr (PF) {
+          o = hv[i];
+        } else if constexpr (sizeof(TS) == 2) {
           const bf16x4 ob0 = *reinterpret_cast<const bf16x4*>(dhr + 4 * c);
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = (float)ob0[e];
