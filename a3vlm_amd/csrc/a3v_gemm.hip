@@ -3555,8 +3555,14 @@ static bool gemv_launch(GemvArgs& g, void* ws, hipStream_t st) {
   const bool pro = g.norm_w != nullptr;
   // M <= 8, bf16 weights: the K slices as the waves of ONE block per 16-row tile (gemv_kq_bf16_kernel: the partials meet in LDS,
   // no split-K fix-up through HBM); same slice count as the across-blocks plan.  A3V_GEMV_KQ=0: the across-blocks kernel (A/B runs)
-  const int kq_mode = A3V_ENV_INT("A3V_GEMV_KQ", 1);     // 1: the GEMVs without an RMSNorm prologue (wo, w2, LM head); 2: all; 0: none
-  if (!w8 && arows == 8 && (kq_mode == 2 || (kq_mode == 1 && !pro)) && g.N % 16 == 0 && (reinterpret_cast<uintptr_t>(g.A) & 15) == 0 && g.lda % 8 == 0 &&
+  // A3V_GEMV_KQ: 1 (default) = where it was measured to win: no RMSNorm prologue, no SwiGLU, and the 16-row tiles spread EVENLY over the
+  // CUs (one or two blocks each: 7B wo / w2 = 256 tiles: 11.5 -> 10.4 us, 19.4 -> 19.6) -- a block of 8 waves is a coarse unit, 320
+  // tiles (13B wo / w2) leave a quarter of the CUs with twice the work (15.1 -> 18.0 us, 32.0 -> 38.8: tools/ab_gemv_kq.py);
+  // 2 = every bf16 GEMV with M <= 8 (A/B runs); 0 = none
+  const int kq_mode = A3V_ENV_INT("A3V_GEMV_KQ", 1);
+  const int kq_tiles = g.N / 16, kq_cus = cu_count();
+  const bool kq_even = !pro && !(g.epi & A3V_EPI_SWIGLU) && kq_tiles % kq_cus == 0 && kq_tiles <= 2 * kq_cus;
+  if (!w8 && arows == 8 && (kq_mode == 2 || (kq_mode == 1 && kq_even)) && g.N % 16 == 0 && (reinterpret_cast<uintptr_t>(g.A) & 15) == 0 && g.lda % 8 == 0 &&
       (!pro || (reinterpret_cast<uintptr_t>(g.norm_w) & 15) == 0)) {
     const bool sw = (g.epi & A3V_EPI_SWIGLU) != 0;
     int slices = g.S;
