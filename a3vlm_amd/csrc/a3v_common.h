@@ -204,11 +204,12 @@ __device__ __forceinline__ float ld_agent(const float* p) {          // issue + 
 // caller; every kernel leaves the counter areas zero.
 //   [0, 16 KB)      GEMV split-K arrival counters (one per 16-row tile, N <= 65536)
 //   [16 KB, 32 KB)  decode-attention arrival counters (one per (batch, head))
-//   [32 KB, 48 KB)  per-tile sums of squares of the residual rows (RMSNorm fused into the consuming GEMV)
-//   [48 KB, ...)    split-K partial accumulators
+//   [32 KB, 64 KB)  per-tile sums of squares of the residual rows (RMSNorm fused into the consuming GEMV): dim / 16 tiles x 16 rows x 4 B,
+//                   i.e. dim <= 8192 (round 4: was 16 KB = dim <= 4096, which kept the 13B geometry, dim 5120, out of the fused decode step)
+//   [64 KB, ...)    split-K partial accumulators
 constexpr int A3V_WS_ATTN_COUNTERS = 16384;
 constexpr int A3V_WS_SSQ = 32768;
-constexpr int A3V_WS_PARTIALS = 49152;
+constexpr int A3V_WS_PARTIALS = 65536;
 int a3v_gemv_fused(const void* A, int64_t lda, const void* W, int64_t ldw, const float* wscale, void* C, int64_t ldc, int M, int N,
                    int K, const void* residual, int64_t ldr, int epilogue, const void* norm_w, const float* ssq_in, float eps,
                    float* ssq_out, int rope, const float* cos_sin, void* k_cache, void* vt_cache, int H, int Hkv, int hd,
