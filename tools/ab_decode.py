@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """A/B on one box: greedy decode model step (bs 8, 7B, context ~1100) with an environment switch of the library toggled per
-round inside ONE process (the switches are read per launch).  usage: ab_decode.py ENV_NAME [rounds]   e.g. ab_decode.py A3V_GEMV_NT"""
+round inside ONE process (the library caches its switches: every toggle goes through lib.env, which calls a3v_reload_env -- a bare
+os.environ write is NOT seen and both legs silently run the same kernels).  usage: ab_decode.py ENV_NAME [rounds]   e.g. ab_decode.py A3V_GEMV_NT"""
 import os
 import sys
 
@@ -8,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 import bench  # noqa: E402
-from a3vlm_amd import ops  # noqa: E402
+from a3vlm_amd import lib, ops  # noqa: E402
 
 name = sys.argv[1]
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 4
@@ -43,6 +44,6 @@ with torch.no_grad():
         m.quantize_decode_weights(mode)
         for _ in range(rounds):
             for val in ("1", "0"):
-                os.environ[name] = val
-                ms = run(32)
+                with lib.env(**{name: val}):
+                    ms = run(32)
                 print(f"weights={'bf16' if mode is None else mode} {name}={val}: {ms:.3f} ms/step  {B / ms * 1e3:.0f} tok/s", flush=True)
