@@ -882,6 +882,80 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_bf16_kernel(Ge
   gemm_epilogue<TM, TN, false, (TM > 4 ? EPI_SET_COMMON : EPI_SET_COMMON | EPI_SET_PRE)>(acc, p, m0 + wm * WTM, n0 + wn * WTN, lane, nk > 0 ? lds + wave * 4096 : nullptr);
 }
 
+// Adapter-sized products (N <= 64: t = x A^T, dt = dy B) stream one long operand once; what bounds them is how many of its bytes
+// the chip has outstanding, not MFMA.  The two-stage kernel above keeps ONE 8-KiB k-tile of the streamed operand in flight per
+// block (548 blocks x 8 KiB = 4.4 MB over the chip: 3.6 TB/s measured at 8728 x 64 x 22016).  Same 64 x 64 tile, same fragment
+// reads and MFMA order -- bit-identical planes -- with NST stages: NST - 1 k-tiles stay in flight across the block barrier
+// (counted waits: 4 LDS-DMA instructions per thread and stage), one barrier per k-tile.
+template <int N> __device__ __forceinline__ void vm_wait_imm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// TBM rows of the streamed operand per block (4 waves x TBM / 4 rows), NST stages of (TBM + 64) x 128 B.
+template <int TBM, int NST>
+__global__ __launch_bounds__(256) void gemm_nt_skinny_kernel(GemmArgs p) {
+  constexpr int TBN = 64, NW = 4, TN = 4, TM = TBM / 64, WTM = TBM / 4;
+  constexpr int STAGE = (TBM + TBN) * BK * 2;            // 16 / 24 / 40 KiB
+  constexpr int PER = TBM / 32 + 2;                      // LDS-DMA instructions per thread and stage
+  static_assert(PER * (NST - 2) <= 63, "vmcnt is a 6-bit counter");
+  extern __shared__ __attribute__((aligned(1024))) char lds_dyn[];
+  char* const lds = lds_dyn;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = blockIdx.x * TBM;
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int nk = p.K / BK;
+  {
+    const int z = blockIdx.y, S = gridDim.y;
+    const int t0 = (int)(((int64_t)z * nk) / S), t1 = (int)(((int64_t)(z + 1) * nk) / S);
+    p.A += (int64_t)t0 * BK;
+    p.W += (int64_t)t0 * BK;
+    p.C = reinterpret_cast<char*>(p.C) + (int64_t)z * p.c_split;
+    nk = t1 - t0;
+  }
+  auto stage = [&](int t) __attribute__((always_inline)) {
+    char* dst = lds + (t % NST) * STAGE;
+    stage_tile<TBM, NW>(p.A, p.lda, m0, p.M - 1, t * BK, dst, wave, lane);
+    stage_tile<TBN, NW>(p.W, p.ldw, 0, p.N - 1, t * BK, dst + TBM * BK * 2, wave, lane);
+  };
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (s < nk) stage(s);
+  const int frow = lane & 15, fsw = (lane >> 1) & 7, fks = lane >> 4;
+  for (int t = 0; t < nk; ++t) {
+    // k-tile t has landed when at most the pieces of the k-tiles issued after it are outstanding
+    const int ahead = min(NST - 2, nk - 1 - t);
+    if (ahead >= 3) vm_wait_imm<3 * PER>();
+    else if (ahead == 2) vm_wait_imm<2 * PER>();
+    else if (ahead == 1) vm_wait_imm<PER>();
+    else vm_wait_imm<0>();
+    // every wave's pieces of k-tile t are in, every wave is done with k-tile t - 1.  A bare s_barrier: __syncthreads() carries a fence
+    // that hipcc lowers to vmcnt(0), i.e. it would drain the k-tiles this loop exists to keep in flight
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (t + NST - 1 < nk) stage(t + NST - 1);            // into the buffer of k-tile t - 1
+    const char* cur = lds + (t % NST) * STAGE;
+    const char* At = cur + (wave * WTM + frow) * 128;
+    const char* Wt = cur + TBM * BK * 2 + frow * 128;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int off = ((kk * 4 + fks) ^ fsw) << 4;
+      bf16x8 af[TM], wf[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(Wt + j * 16 * 128 + off);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(At + i * 16 * 128 + off);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the epilogue's 4-KiB patches lie over the stage buffers
+  gemm_epilogue<TM, TN, false, EPI_SET_COMMON | EPI_SET_PRE>(acc, p, m0 + wave * WTM, 0, lane, nk > 0 ? lds + wave * 4096 : nullptr);
+}
+
 // Epilogue for v_mfma_f32_32x32x16 accumulators (D = W_frag x A_frag): for tile (i, j) the lane holds
 // C[m = mbase + 32 i + (lane&31)][n = nbase + 32 j + 8 g + 4 (lane>>5) + 0..3], g = reg/4.
 template <int TM, int TN>
@@ -3721,21 +3795,47 @@ extern "C" int a3v_gemm_nt_splitk(const void* A, int64_t lda, const void* W, int
   p.lda = lda; p.ldw = ldw; p.ldc = N; p.ldr = 0;
   p.M = M; p.N = N; p.K = K; p.epi = A3V_EPI_OUT_F32 | GEMM_EPI_RAW; p.dbg = 0;
   p.c_split = (int64_t)M * N * 4;
-  const int narrow = A3V_ENV_INT("A3V_SKINNY_NARROW", 3);   // 3: 64-row tiles (same-box sweep, tools/lora_skinny_bench.py: 20.5 / 42.8 / 41.9 / 111.5 us at S = 4 against 25.4 / 48.0 / 47.4 / 110.6 for the 256-row tile at its best S)
+  // Rows of the streamed operand per block and LDS stages (tools/skinny_stages_bench.py, operands rotating through 700 MB, us incl.
+  // the reduce pass at 8728 x 64 x K = 4096 / 11008 / 12288 / 22016):
+  //   64 rows, 2 stages, S = 4 (rounds 2-3)   24.0  54.5  60.0  112.1     half of the LDS-DMA traffic is the 64-row second operand
+  //   64 rows, 4 stages, S = 3                23.1  52.8  56.4   96.9     k-tiles in flight across the barrier: +2..14 %
+  //  256 rows, 3 stages, S = 7                23.5  46.3  49.0   82.9     35 row tiles x 7 slices = 245 blocks: ONE resident block per CU
+  //  256 rows, 3 stages, S = 8                31.2  63.0  66.1  114.0     280 blocks: the 24 that wait for a CU double the time
+  // so the 256-row form is taken when its blocks fill between half and all of the CUs (the caller picks S for that: train._skinny),
+  // the 64-row form otherwise.  A3V_SKINNY_NARROW = 1 / 2 / 3 forces 256 / 128 / 64 rows, A3V_SKINNY_STAGES = 2 the two-stage kernels.
+  const int narrow_env = A3V_ENV_INT("A3V_SKINNY_NARROW", 0);
+  const int nst_env = A3V_ENV_INT("A3V_SKINNY_STAGES", 0);
+  const int blocks256 = ((M + 255) / 256) * S;
+  const bool wide = narrow_env ? narrow_env == 1 : (blocks256 <= cu_count() && 2 * blocks256 > cu_count());
+  const int narrow = narrow_env ? narrow_env : (wide ? 1 : 3);
   if (N <= 64 && M >= 512 && narrow) {
-    // adapter-sized output (rank pad 64): 256 x 64 tiles -- 80 % of the LDS-DMA traffic is the streamed operand (50 % with the
-    // 128 x 128 tile, whose second operand tile is half padding)
-    // narrow = 2 / 3: 128- / 64-row tiles (48 / 32 KiB of LDS per block instead of 80: more blocks in flight per CU -- these
-    // launches are bound by how many k-tile loads the chip has outstanding, not by MFMA)
     p.tiles_n = 1;
-    if (narrow == 3) {
-      p.tiles_m = (M + 63) / 64;
+    const int nst = nst_env ? nst_env : (narrow == 1 ? 3 : 4);
+    const int rows = narrow == 3 ? 64 : narrow == 2 ? 128 : 256;
+    p.tiles_m = (M + rows - 1) / rows;
+    static bool attr[9] = {};
+    auto go = [&](auto kern, int bytes, int ai) {
+      if (!attr[ai]) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); attr[ai] = true; }
+      hipLaunchKernelGGL(kern, dim3(p.tiles_m, S), dim3(256), (size_t)bytes, (hipStream_t)stream, p);
+    };
+    // the product library carries the two forms the rule above picks; the other rows / stages of the sweep only in A3V_ABLATION builds
+    const int bytes = (rows + 64) * 128 * nst;
+    if (rows == 64 && nst == 4) go(gemm_nt_skinny_kernel<64, 4>, bytes, 1);
+    else if (rows == 256 && nst == 3) go(gemm_nt_skinny_kernel<256, 3>, bytes, 6);
+#ifdef A3V_ABLATION
+    else if (rows == 64 && nst == 3) go(gemm_nt_skinny_kernel<64, 3>, bytes, 0);
+    else if (rows == 64 && nst == 5) go(gemm_nt_skinny_kernel<64, 5>, bytes, 2);
+    else if (rows == 128 && nst == 3) go(gemm_nt_skinny_kernel<128, 3>, bytes, 3);
+    else if (rows == 128 && nst == 4) go(gemm_nt_skinny_kernel<128, 4>, bytes, 4);
+    else if (rows == 128 && nst == 5) go(gemm_nt_skinny_kernel<128, 5>, bytes, 5);
+    else if (rows == 256 && nst == 4) go(gemm_nt_skinny_kernel<256, 4>, bytes, 7);
+#endif
+    else if (nst != 2) return A3V_ERR_ARG;               // a rows / stages pair this build does not carry (sweeps only)
+    else if (narrow == 3) {
       hipLaunchKernelGGL((gemm_nt_bf16_kernel<64, 64, 4, 1>), dim3(p.tiles_m, S), dim3(256), 0, (hipStream_t)stream, p);
     } else if (narrow == 2) {
-      p.tiles_m = (M + 127) / 128;
       hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 64, 4, 1>), dim3(p.tiles_m, S), dim3(256), 0, (hipStream_t)stream, p);
     } else {
-      p.tiles_m = (M + 255) / 256;
       hipLaunchKernelGGL((gemm_nt_bf16_kernel<256, 64, 4, 1>), dim3(p.tiles_m, S), dim3(256), 0, (hipStream_t)stream, p);
     }
     A3V_LAUNCH_CHECK();

@@ -419,7 +419,11 @@ class TrainEngine:
         S = 1
         while blocks * S < 512 and S * 2 <= nk and S < 32:
             S *= 2
-        if N <= 64 and M >= 512 and S > 4:
+        if N <= 64 and M >= 2048 and a.is_cuda and os.environ.get("A3V_SKINNY_LEGACY", "0") != "1":   # =1 (with A3V_SKINNY_NARROW=3 A3V_SKINNY_STAGES=2): rounds 2-3
+            # 256-row blocks, one resident block per CU (a3v_gemm_nt_splitk takes that form when S x ceil(M / 256) fills between half and
+            # all of the CUs): 8728 rows -> 35 row tiles x 7 slices = 245 blocks; one slice more and the blocks that wait for a CU double the time
+            S = max(1, min(self._cus(a.device) // ((M + 255) // 256), nk // 2, 32))
+        elif N <= 64 and M >= 512 and S > 4:
             S = 4            # 64-row tiles (a3v_gemm_nt_splitk): M / 64 blocks per slice already fill the chip; more slices only add reduce work
         if S == 1 or self.act != torch.bfloat16 or K % 64:
             f32 = out.dtype == torch.float32 and self.act == torch.bfloat16
@@ -427,6 +431,12 @@ class TrainEngine:
                         epilogue=(ops.EPI_RES_F32 if accumulate else ops.EPI_OUT_F32) if f32 else 0)
             return
         ops.gemm_nt_splitk(a, w, out, self._buf("splitk", (S * M * N,), torch.float32), S, accumulate)
+
+    def _cus(self, dev) -> int:
+        n = getattr(self, "_cu_count", None)
+        if n is None:
+            n = self._cu_count = int(torch.cuda.get_device_properties(dev).multi_processor_count)
+        return n
 
     def _dgrad_w(self, dy: torch.Tensor, key: str, out: torch.Tensor):
         """out[M,K] = dy[M,N] @ W[N,K] for the weight image ``key``: the NN kernel on the forward image itself (the transposed

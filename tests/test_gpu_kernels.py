@@ -512,6 +512,30 @@ def test_gemm_nt_splitk(M, N, K, S):
     assert torch.equal(ob, ob2)
 
 
+@pytest.mark.parametrize("M,N,K,S", [(1000, 64, 22016, 4), (8728, 64, 4096, 3), (8728, 64, 4096, 7), (520, 48, 128, 2), (777, 64, 64, 1), (600, 64, 8768, 7),
+                                     (512, 64, 192, 1)])
+def test_skinny_nt_stages_write_the_planes_of_the_two_stage_kernel(M, N, K, S):
+    """gemm_nt_skinny_kernel<64, 4> / <256, 3> (k-tiles kept in flight across the block barrier) against the two-stage kernels they replace
+    for adapter-sized outputs: the split-K planes bit for bit (same fragments, same MFMA order per accumulator), ragged M, N < 64,
+    slices of one k-tile (fewer k-tiles than stages), uneven slices, the library's own pick of the form; and the reduced bf16 result
+    against the fp32 product."""
+    from a3vlm_amd import lib as _lib
+    a, w = rt(gen(M, K, seed=41)), rt(gen(N, K, seed=42, scale=0.05))
+    ad, wd = a.to(BF).to(DEV), w.to(BF).to(DEV)
+    planes, outs = {}, {}
+    for narrow, nst in ((3, 2), (3, 4), (1, 3), (1, 2), (0, 0)):       # narrow 3 / 1: 64 / 256 rows per block; (0, 0): the library's own choice
+        scratch = torch.full((S * M * N,), float("nan"), dtype=torch.float32, device=DEV)
+        ob = torch.empty(M, N, dtype=BF, device=DEV)
+        with _lib.env(A3V_SKINNY_STAGES=nst, A3V_SKINNY_NARROW=narrow):
+            ops.gemm_nt_splitk(ad, wd, ob, scratch, S)
+        torch.cuda.synchronize()
+        planes[narrow, nst], outs[narrow, nst] = scratch.clone(), ob
+    for key in planes:
+        assert torch.equal(planes[key], planes[3, 2]), f"rows / stages {key}: planes differ"
+        assert torch.equal(outs[key], outs[3, 2])
+    assert_close(outs[3, 4], a @ w.t(), rtol=2 ** -7, atol=2e-3 * math.sqrt(K) * 0.05 + 1e-3, what="skinny bf16")
+
+
 @pytest.mark.parametrize("M,N,K,lda,ldw", [(512, 512, 256, 512, 512), (4096, 1024, 1000, 4096, 1024), (264, 260, 70, 272, 264),
                                            (1024, 4096, 8728, 3 * 1024, 4096), (256, 256, 1, 256, 256)])
 def test_gemm_tn(M, N, K, lda, ldw):
