@@ -26,6 +26,24 @@ def _pad64(n: int) -> int:
     return (n + 63) // 64 * 64
 
 
+def skinny_slices(M: int, N: int, K: int, cus: int) -> int:
+    """Split-K slices for an adapter-sized product out[M, N] = a[M, K] @ w[N, K]^T (``TrainEngine._skinny``).  ``cus`` = compute units of
+    the device (0: not a GPU tensor).  N <= 64 and M >= 2048: 256-row blocks, ONE resident block per CU -- a3v_gemm_nt_splitk takes that form
+    when S x ceil(M / 256) fills between half and all of the CUs: 8728 rows -> 35 row tiles x 7 slices = 245 blocks; one slice more and the
+    blocks that wait for a CU double the time (profiles/r04k_skinny_stages_sweep.txt).  A3V_SKINNY_LEGACY=1 (with A3V_SKINNY_NARROW=3
+    A3V_SKINNY_STAGES=2): the slice count of rounds 2-3."""
+    blocks = ((M + 127) // 128) * ((N + 127) // 128)
+    nk = K // 64
+    S = 1
+    while blocks * S < 512 and S * 2 <= nk and S < 32:
+        S *= 2
+    if N <= 64 and M >= 2048 and cus > 0 and os.environ.get("A3V_SKINNY_LEGACY", "0") != "1":
+        S = max(1, min(cus // ((M + 255) // 256), nk // 2, 32))
+    elif N <= 64 and M >= 512 and S > 4:
+        S = 4            # 64-row tiles (a3v_gemm_nt_splitk): M / 64 blocks per slice already fill the chip; more slices only add reduce work
+    return S
+
+
 class TrainEngine:
     # A/B and test hooks (environment A3V_FUSE_QKV_ROPE=0 / A3V_TN_WGRAD=0 / A3V_NN_DGRAD=0 flips the default for a whole process)
     fuse_qkv_rope = os.environ.get("A3V_FUSE_QKV_ROPE", "1") != "0"   # qkv GEMM with the RoPE / cache-write epilogue
@@ -414,17 +432,7 @@ class TrainEngine:
         reduce pass; a plain launch would be a handful of blocks with a serial K loop (122 us instead of ~25 at 8728 x 64 x 4096)."""
         M, K = a.shape
         N = w.shape[0]
-        blocks = ((M + 127) // 128) * ((N + 127) // 128)
-        nk = K // 64
-        S = 1
-        while blocks * S < 512 and S * 2 <= nk and S < 32:
-            S *= 2
-        if N <= 64 and M >= 2048 and a.is_cuda and os.environ.get("A3V_SKINNY_LEGACY", "0") != "1":   # =1 (with A3V_SKINNY_NARROW=3 A3V_SKINNY_STAGES=2): rounds 2-3
-            # 256-row blocks, one resident block per CU (a3v_gemm_nt_splitk takes that form when S x ceil(M / 256) fills between half and
-            # all of the CUs): 8728 rows -> 35 row tiles x 7 slices = 245 blocks; one slice more and the blocks that wait for a CU double the time
-            S = max(1, min(self._cus(a.device) // ((M + 255) // 256), nk // 2, 32))
-        elif N <= 64 and M >= 512 and S > 4:
-            S = 4            # 64-row tiles (a3v_gemm_nt_splitk): M / 64 blocks per slice already fill the chip; more slices only add reduce work
+        S = skinny_slices(M, N, K, self._cus(a.device) if a.is_cuda else 0)
         if S == 1 or self.act != torch.bfloat16 or K % 64:
             f32 = out.dtype == torch.float32 and self.act == torch.bfloat16
             ops.gemm_nt(a, w, out, residual=out if accumulate else None,

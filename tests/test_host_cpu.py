@@ -148,3 +148,22 @@ def test_fused_adamw_refuses_cpu_parameters():
     p.grad = torch.ones(8)
     with pytest.raises(Exception):
         FusedAdamW([p], lr=1e-3).step()
+
+
+def test_adapter_product_slices_fill_one_block_per_cu():
+    """train.skinny_slices: the 256-row form of a3v_gemm_nt_splitk wants S x ceil(M / 256) blocks between half and all of the CUs (its own
+    dispatch rule, csrc/a3v_gemm.hip); never more slices than half the k-tiles; small M and non-GPU tensors keep the older rule."""
+    from a3vlm_amd.train import skinny_slices
+    for M in (2048, 4364, 8728, 8729, 17456, 40000):
+        for K in (4096, 11008, 12288, 22016):
+            S = skinny_slices(M, 64, K, 256)
+            blocks = -(-M // 256) * S
+            assert 1 <= S <= 32 and S <= K // 128
+            assert blocks <= 256, (M, K, S)
+            if S < min(32, K // 128):
+                assert 2 * blocks > 256, (M, K, S)      # one slice more would not fit
+    assert skinny_slices(8728, 64, 4096, 256) == 7
+    assert skinny_slices(8728, 64, 4096, 304) == 8      # another CU count, same rule
+    assert skinny_slices(1000, 64, 4096, 256) == 4      # below 2048 rows: 64-row tiles, four slices
+    assert skinny_slices(8728, 64, 4096, 0) == 4        # not on a GPU
+    assert skinny_slices(100000, 64, 4096, 256) == 1    # more row tiles than CUs: un-split
