@@ -161,7 +161,10 @@ int a3v_gemm_set_workspace(void* ptr, int64_t bytes);
 
 /* Split-K form for skinny products with a long K (the LoRA adapter GEMMs of model/peft.py:84-99 and their gradients:
  * N or M = 64, K = 4096 ... 22016): slice s of S writes the fp32 plane partial[s][M][N]; a3v_splitk_reduce sums the
- * planes in order, optionally accumulates into `out` (fp32 gradients) and rounds once to out_dtype. */
+ * planes in order, optionally accumulates into `out` (fp32 gradients) and rounds once to out_dtype.
+ * N <= 64, M >= 512: the streamed operand A goes through a multi-stage LDS ring (k-tiles stay in flight across the block barrier) as
+ * 256-row blocks when S * ceil(M / 256) fills between half and all of the CUs -- one resident block per CU, the caller picks S for that
+ * (S = CUs / ceil(M / 256)) -- else as 64-row blocks; every form writes the same planes bit for bit. */
 int a3v_gemm_nt_splitk(const void* A, int64_t lda, const void* W, int64_t ldw, float* partial, int M, int N,
                        int K, int S, void* stream);
 int a3v_splitk_reduce(const float* partial, int S, int M, int N, void* out, int64_t ldo, int out_dtype,
