@@ -3529,6 +3529,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
       int S2 = big_tiles > 0 ? cu_count() / big_tiles : 0;
       if (S2 > 8) S2 = 8;
       while (S2 > 1 && K / 64 < 8 * S2) --S2;
+      { const int e = A3V_ENV_INT("A3V_GEMM_TAIL_SLICES", 0); if (e >= 3 && e <= 16 && K / 64 >= 2 * e) S2 = e; }      // sweeps (tools/tail_cost.py)
       const bool ring_tail = A3V_ENV_INT("A3V_GEMM_RING_TAIL", 1) != 0;
       if (ring_tail && pp_ring() && pp_persistent() && S2 >= 3 && !(p.epi & ~simple) && gws.p && (int64_t)S2 * r.M * N * 4 <= gws.bytes && N % 4 == 0) {
         GemmArgs t = r;
