@@ -23,6 +23,8 @@ BUDGET = [   # (substring of the mangled kernel name, max scratch bytes per lane
     ("gemm_nt_bf16_ring_kernelILi0ELb0ELi0ELb1ELi4ELb0E", 96),     # fused-qkv form (its own instantiation: DESIGN.md section 4)
     ("gemm_nt_fp8_pp_kernel", 0),
     ("gemm_nt_bf16_kernelILi128ELi128ELi2ELi2E", 0),
+    ("gemm_nt_skinny_kernelILi256ELi3E", 0),                       # adapter-sized NT products, one resident 120-KiB block per CU
+    ("gemm_nt_skinny_kernelILi64ELi4E", 0),
 ]
 
 
@@ -47,6 +49,8 @@ def test_gemm_kernels_stay_inside_their_register_budget(tmp_path):
         assert not any(gone in n for n in scratch), f"{gone} is compiled into the product library"
     ring = [n for n in scratch if "gemm_nt_bf16_ring_kernel" in n]
     assert len(ring) == 3, ring          # common / +bias-activation / fused-qkv sets, nothing else
+    skinny = [n for n in scratch if "gemm_nt_skinny_kernel" in n]
+    assert len(skinny) == 2, skinny      # the two forms a3v_gemm_nt_splitk picks; the sweep's other rows / stages only with -DA3V_ABLATION
     for key, limit in BUDGET:
         hits = {n: v for n, v in scratch.items() if key in n}
         assert hits, f"kernel {key} not found (renamed? update the budget table)"
