@@ -62,13 +62,6 @@ struct GemmArgs {
   const float* sw;
   int xmap;          // ring kernel: 1 = every round of gridDim.x tiles is cut into eight runs, one per XCD (see tile_of)
   unsigned* xsync;   // ring kernel, A3V_GEMM_LOCKSTEP=1: eight zeroed counters; the blocks of an XCD start each tile round together
-  // ring kernel, TK instantiations (round 5): the tile rows beyond `tiles_m` (tk_tiles_m more rows of tiles, the rows up to M) are
-  // cut tk_S ways along K INSIDE the persistent launch -- one (tile, K-slice) unit per block BEFORE its whole tiles; fp32 planes in
-  // register-image order for these tiles only (tk_ws: [tile][slice][256 x 256]), arrival counters tk_ctr[tile] (zero before and after)
-  int tk_S, tk_tiles_m, tk_K;     // (tk_K = K: the kernel narrows its own K to the unit's slice and back)
-  int tk_wt;                      // 1: planes written through (sc0 sc1) + arrival right behind them; 0: through the L2, release + arrival after the whole tiles
-  float* tk_ws;
-  int* tk_ctr;
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
@@ -1334,7 +1327,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_pp_kernel(GemmArgs p) {
 // EARLY: the barrier that ends an MFMA interval is executed EARLY tile-rows before the interval's last MFMA.  Nothing after it
 // needs the barrier (the tail MFMAs read registers only), and the partner wave on the SIMD -- released by the same barrier --
 // starts its own MFMA stream while this wave is still feeding the pipe: no matrix-pipe bubble at the hand-over.
-template <int DBG, bool M32, int EARLY, bool STAGED = true, int SET = EPI_SET_COMMON, bool LW = false, bool LATEW = true, bool CONT = true, bool TK = false>   // CONT (product; r03): the DMA stream runs on ACROSS the block's tiles -- the last two LOAD intervals of a tile fetch K-tiles 0 / 1 of the block's next tile into the ring slots they would have used anyway, so there is no prologue burst, no pipeline drain / refill and no block-wide barrier between tiles (see the boundary notes in the body); LATEW (product; r03 A/B +1 % on every shape, bit-equal): group 0 waits for its W pieces of tile t+1 at the TOP of L(t+1) instead of between its last MFMA of M(t) and the barrier that hands the matrix pipe over; SET: which fast epilogue forms (gemm_epilogue_fast); M32: v_mfma_f32_32x32x16_bf16 (4x2 tiles per wave) instead of 16x16x32 (8x4)
+template <int DBG, bool M32, int EARLY, bool STAGED = true, int SET = EPI_SET_COMMON, bool LW = false, bool LATEW = true, bool CONT = true>   // CONT (product; r03): the DMA stream runs on ACROSS the block's tiles -- the last two LOAD intervals of a tile fetch K-tiles 0 / 1 of the block's next tile into the ring slots they would have used anyway, so there is no prologue burst, no pipeline drain / refill and no block-wide barrier between tiles (see the boundary notes in the body); LATEW (product; r03 A/B +1 % on every shape, bit-equal): group 0 waits for its W pieces of tile t+1 at the TOP of L(t+1) instead of between its last MFMA of M(t) and the barrier that hands the matrix pipe over; SET: which fast epilogue forms (gemm_epilogue_fast); M32: v_mfma_f32_32x32x16_bf16 (4x2 tiles per wave) instead of 16x16x32 (8x4)
 __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
   constexpr int TBM = 256, TBN = 256, WTM = 128, WTN = 64, TM = M32 ? 4 : 8, TN = M32 ? 2 : 4;
   constexpr int AH = 128 * BK * 2;                      // 16 KiB: one group's half of an A K-tile
@@ -1380,28 +1373,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
     tn0 = (((p.xmap & 2) && (group & 1)) ? p.tiles_n - 1 - tn : tn) * TBN;
   };
   int m0, n0, sm0, sn0;     // tile being computed / tile being staged
-  // TK (round 5): BEFORE its whole tiles the block takes ONE (tile, K-slice) unit of the tile rows beyond whole tile rounds.  Units
-  // are handed out from the last block down (where the whole tiles do not fill their last round, the blocks with one tile fewer
-  // come first); XCD x (= block & 7) gets a run of consecutive tiles with ALL their slices: the tiles of a column share their W
-  // panel, consecutive columns the A panels, in that XCD's L2.
-  const int tk_unit = (int)gridDim.x - 1 - (int)blockIdx.x;
-  const bool tk_mine = TK && gridDim.y == 1 && tk_unit < p.tk_S * p.tk_tiles_m * p.tiles_n;
-  int tk_t = 0, tk_z = 0, tk_k0 = 0;                     // the unit's tile (of the extra rows, column-major), slice, first K-tile
-  if (TK && tk_mine) {
-    const int T = p.tk_tiles_m * p.tiles_n;
-    if ((T & 7) == 0 && (gridDim.x & 7) == 0) {
-      const int x = tk_unit & 7, i = tk_unit >> 3, q = T >> 3;
-      tk_z = i / q;
-      tk_t = x * q + (i - tk_z * q);
-    } else {
-      tk_z = tk_unit / T;
-      tk_t = tk_unit - tk_z * T;
-    }
-    m0 = (p.tiles_m + tk_t % p.tk_tiles_m) * TBM;
-    n0 = (tk_t / p.tk_tiles_m) * TBN;
-  } else {
-    tile_of(blockIdx.x, m0, n0);
-  }
+  tile_of(blockIdx.x, m0, n0);
   sm0 = m0; sn0 = n0;
   typedef typename std::conditional<M32, f32x16, f32x4>::type acc_t;
   acc_t acc[TM][TN];
@@ -1416,18 +1388,9 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
     p.K = (t1 - t0) * BK;
     p.C = reinterpret_cast<char*>(p.C) + (int64_t)z * p.c_split;
   }
-  if (TK && tk_mine) {
-    // the operand windows start on the slice's K range; they move back to the whole K when the block leaves the unit
-    const int nk_all = p.K / BK;
-    const int t1 = (int)(((int64_t)(tk_z + 1) * nk_all) / p.tk_S);
-    tk_k0 = (int)(((int64_t)tk_z * nk_all) / p.tk_S);
-    p.A += (int64_t)tk_k0 * BK;
-    p.W += (int64_t)tk_k0 * BK;
-    p.K = (t1 - tk_k0) * BK;
-  }
-  int nk = p.K / BK;                                     // (TK: re-made once, when the block leaves its K-slice unit)
-  auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)(((int64_t)(p.M - 1) * p.lda + p.K) * 2), 0x00020000);
-  auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)(((int64_t)(p.N - 1) * p.ldw + p.K) * 2), 0x00020000);
+  const int nk = p.K / BK;
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)(((int64_t)(p.M - 1) * p.lda + p.K) * 2), 0x00020000);
+  const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)(((int64_t)(p.N - 1) * p.ldw + p.K) * 2), 0x00020000);
   // per-lane byte offset inside an 8-row chunk: row = lane/8, 16-B slot = (lane%8) ^ ((chunk*4 + lane/16) & 7)
   const unsigned lr = lane >> 3;
   unsigned voA[2], voW[2];
@@ -1532,8 +1495,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
   // Without CONT (and for nk == 1): prologue burst for the next tile before the epilogue, vmcnt(0) + block barrier at the k-loop entry.
   int wcur = 0, pa = 0;                                  // W ring slot / A parity of K-tile 0 of the current tile
   bool fresh = true;                                     // the tile's K-tiles 0 / 1 come from a prologue burst (first tile, or no CONT)
-  bool in_unit = TK && tk_mine;                          // the item being computed is the block's K-slice unit (always its first)
-  for (int vb = in_unit ? (int)blockIdx.x - (int)gridDim.x : (int)blockIdx.x;;) {
+  for (int vb = blockIdx.x;;) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1553,7 +1515,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
     }
     const int nb = vb + (int)gridDim.x;
     const bool more = nb < ntiles;
-    const bool cont = CONT && more && nk >= 2 && !(TK && in_unit);   // K-tiles nk, nk+1 of this k-loop are K-tiles 0, 1 of the block's next tile (the unit's K window differs: it is left through a prologue burst)
+    const bool cont = CONT && more && nk >= 2;           // K-tiles nk, nk+1 of this k-loop are K-tiles 0, 1 of the block's next tile
     if (cont) tile_of(nb, sm0, sn0);                     // (sm0, sn0): the tile being staged = the next one from here on
     if (fresh) {
       A3V_WAIT_VM0();
@@ -1675,42 +1637,11 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
     RG_TSTAMP(1);
     // every read of the rings is behind the last barrier.  No cont: stage the next tile now (prologue burst), store this one after.
     if (more && !cont) {
-      if (TK && in_unit) {
-        // leaving the unit: the operand windows go back to the whole K (the dump below reads none of them)
-        p.A -= (int64_t)tk_k0 * BK;
-        p.W -= (int64_t)tk_k0 * BK;
-        p.K = p.tk_K;
-        nk = p.K / BK;
-        rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)(((int64_t)(p.M - 1) * p.lda + p.K) * 2), 0x00020000);
-        rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)(((int64_t)(p.N - 1) * p.ldw + p.K) * 2), 0x00020000);
-      }
       tile_of(nb, sm0, sn0);
       prologue();
     }
     RG_TSTAMP(2);
-    if (TK && in_unit) {
-      // ---- K-slice unit: the S slices of a tile meet through fp32 planes in REGISTER-IMAGE order (per wave 32 x 1 KiB, lane-linear:
-      // every store / load instruction moves 1 KiB contiguous), written through (sc0 sc1) so that no cache-wide write-back or
-      // invalidate is needed between XCDs.  Every wave stores its whole accumulator, drains (the drain also keeps the k-loop's
-      // counted waits counting DMA pieces only) and bumps the tile's arrival counter; the tile is finished AFTER the block's whole
-      // tiles (below), by when every slice has long arrived.
-      const int S = p.tk_S;
-      const auto rsP = __builtin_amdgcn_make_buffer_rsrc((void*)(p.tk_ws + (int64_t)tk_t * S * 65536), 0, S * 262144, 0x00020000);
-      const unsigned own = (unsigned)(tk_z * 262144 + wave * 32768 + lane * 16);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          if constexpr (!M32) {
-            if (p.tk_wt) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rsP, own + (unsigned)((i * TN + j) * 1024), 0, 17);
-            else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rsP, own + (unsigned)((i * TN + j) * 1024), 0, 0);
-          }
-        }
-      if (p.tk_wt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(p.tk_ctr + tk_t * 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    } else {
+    {
       int lane_e = lane;
       asm volatile("" : "+v"(lane_e));
       // staging patches: the W slot of K-tile nk - 1 (cont: the one slot no piece of the next tile is in flight to); the slot behind the
@@ -1731,63 +1662,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
     } else {
       fresh = true;
     }
-    in_unit = false;
     vb = nb; m0 = sm0; n0 = sn0;
-  }
-  if (TK && tk_mine) {
-    // ---- finish the unit's tile: the first F = min(S, 4) slices share it -- slice z sums the planes of the 32-row groups g = z, z + F,
-    // ... of every wave's quarter IN SLICE ORDER (the sum the split-K reduce pass forms: same bits) and runs the general epilogue on
-    // them: every output kind, ragged rows included.  The last finisher re-zeroes the tile's counters for the next launch.
-    const int S = p.tk_S, F = S < 4 ? S : 4;
-    if (!p.tk_wt) {
-      // planes stored through the L2 (write-back): they have been draining to memory under the whole tiles; what is left goes out now
-      // (buffer_wbl2: the release every kernel end performs anyway), then the wave's arrival
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      if (lane == 0) __hip_atomic_fetch_add(p.tk_ctr + tk_t * 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (tk_z < F) {
-      int* ctr = p.tk_ctr + tk_t * 2;
-      const auto rsP = __builtin_amdgcn_make_buffer_rsrc((void*)(p.tk_ws + (int64_t)tk_t * S * 65536), 0, S * 262144, 0x00020000);
-      const int um0 = (p.tiles_m + tk_t % p.tk_tiles_m) * TBM, un0 = (tk_t / p.tk_tiles_m) * TBN;
-      if (lane == 0) {
-        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 8 * S) __builtin_amdgcn_s_sleep(4);
-      }
-      asm volatile("" ::: "memory");
-      for (int g = tk_z; g < 4; g += F) {
-        f32x4 sh[2][TN];
-#pragma unroll
-        for (int q = 0; q < 2 * TN; ++q) sh[q / TN][q % TN] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const unsigned src = (unsigned)(wave * 32768 + g * (2 * TN * 1024) + lane * 16);
-        for (int sb = 0; sb < S; sb += 4) {              // four planes (32 KiB per wave) in flight per round trip
-          u32x4 x[4][2 * TN];
-#pragma unroll
-          for (int s4 = 0; s4 < 4; ++s4) {
-            const int sp = sb + s4 < S ? sb + s4 : S - 1;
-#pragma unroll
-            for (int q = 0; q < 2 * TN; ++q) x[s4][q] = __builtin_amdgcn_raw_buffer_load_b128(rsP, src + (unsigned)(q * 1024), sp * 262144, 17);
-          }
-#pragma unroll
-          for (int s4 = 0; s4 < 4; ++s4)
-            if (sb + s4 < S) {
-#pragma unroll
-              for (int q = 0; q < 2 * TN; ++q) {
-                const f32x4 v = __builtin_bit_cast(f32x4, x[s4][q]);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) sh[q / TN][q % TN][r] += v[r];
-              }
-            }
-        }
-        if constexpr (!M32) gemm_epilogue<2, TN, false, SET>(sh, p, um0 + wr * WTM + g * 32, un0 + wc * WTN, lane, nullptr);
-      }
-      // the finishers' waves count themselves out; the last of the tile's 8 F waves leaves both counters zero for the next launch
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      int old = 0;
-      if (lane == 0) old = __hip_atomic_fetch_add(ctr + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (lane == 0 && old == 8 * F - 1) {
-        __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(ctr + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
   }
 #undef RG_TSTAMP
 #undef RG_STAMP
@@ -3326,10 +3201,7 @@ extern "C" int a3v_build_flags(void) {
 #include <mutex>
 #include <vector>
 namespace {
-// (round 5) the last A3V_WS_CTR_BYTES of a registered scratch hold the arrival counters of the in-launch K-slice units of the ring
-// kernel: zero-filled at registration, left zero by every launch; `bytes` is what remains for split-K planes
-constexpr int64_t A3V_WS_CTR_BYTES = 4096;
-struct GemmWs { float* p; int64_t bytes; int* ctr; };
+struct GemmWs { float* p; int64_t bytes; };
 struct GemmWsEntry { int dev; hipStream_t st; float* p; int64_t bytes; };
 std::mutex g_ws_mu;
 std::vector<GemmWsEntry> g_ws_tab;
@@ -3339,24 +3211,13 @@ GemmWs gemm_ws_for(hipStream_t st) {
   int dev = 0;
   (void)hipGetDevice(&dev);
   std::lock_guard<std::mutex> lk(g_ws_mu);
-  auto cut = [](float* p, int64_t bytes) -> GemmWs {
-    if (bytes < 2 * A3V_WS_CTR_BYTES) return {p, bytes, nullptr};
-    return {p, bytes - A3V_WS_CTR_BYTES, reinterpret_cast<int*>(reinterpret_cast<char*>(p) + bytes - A3V_WS_CTR_BYTES)};
-  };
   for (const GemmWsEntry& e : g_ws_tab)
-    if (e.dev == dev && e.st == st) return cut(e.p, e.bytes);
+    if (e.dev == dev && e.st == st) return {e.p, e.bytes};
   if (g_ws_legacy.p) {
     if (!g_ws_legacy_bound) { g_ws_legacy.dev = dev; g_ws_legacy.st = st; g_ws_legacy_bound = true; }
-    if (g_ws_legacy.dev == dev && g_ws_legacy.st == st) return cut(g_ws_legacy.p, g_ws_legacy.bytes);
+    if (g_ws_legacy.dev == dev && g_ws_legacy.st == st) return {g_ws_legacy.p, g_ws_legacy.bytes};
   }
-  return {nullptr, 0, nullptr};
-}
-// zero the counter area of a fresh registration (on the stream it is registered for; the legacy form has none: synchronous)
-int ws_zero_counters(void* ptr, int64_t bytes, hipStream_t st, bool async) {
-  if (!ptr || bytes < 2 * A3V_WS_CTR_BYTES) return A3V_OK;
-  char* c = reinterpret_cast<char*>(ptr) + bytes - A3V_WS_CTR_BYTES;
-  const hipError_t e = async ? hipMemsetAsync(c, 0, A3V_WS_CTR_BYTES, st) : hipMemset(c, 0, A3V_WS_CTR_BYTES);
-  return e == hipSuccess ? A3V_OK : (int)e;
+  return {nullptr, 0};
 }
 }  // namespace
 extern "C" int a3v_gemm_set_workspace_for(void* stream, void* ptr, int64_t bytes) {
@@ -3366,16 +3227,16 @@ extern "C" int a3v_gemm_set_workspace_for(void* stream, void* ptr, int64_t bytes
   for (size_t i = 0; i < g_ws_tab.size(); ++i)
     if (g_ws_tab[i].dev == dev && g_ws_tab[i].st == (hipStream_t)stream) {
       if (ptr) { g_ws_tab[i].p = (float*)ptr; g_ws_tab[i].bytes = bytes; } else g_ws_tab.erase(g_ws_tab.begin() + i);
-      return ws_zero_counters(ptr, bytes, (hipStream_t)stream, true);
+      return A3V_OK;
     }
   if (ptr) g_ws_tab.push_back({dev, (hipStream_t)stream, (float*)ptr, bytes});
-  return ws_zero_counters(ptr, bytes, (hipStream_t)stream, true);
+  return A3V_OK;
 }
 extern "C" int a3v_gemm_set_workspace(void* ptr, int64_t bytes) {
   std::lock_guard<std::mutex> lk(g_ws_mu);
   g_ws_legacy = {-1, nullptr, (float*)ptr, ptr ? bytes : 0};
   g_ws_legacy_bound = false;
-  return ws_zero_counters(ptr, ptr ? bytes : 0, nullptr, false);
+  return A3V_OK;
 }
 
 namespace {
@@ -3435,10 +3296,6 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
   }
 }
 }  // namespace
-
-#include <atomic>
-static std::atomic<int64_t> g_dispatch_count[2];
-extern "C" int64_t a3v_gemm_dispatch_count(int which) { return which >= 0 && which < 2 ? g_dispatch_count[which].load() : -1; }
 
 static int cu_count() {
   static int n = 0;
@@ -3524,7 +3381,6 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
       return;
     }
     q.tiles_m = (q.M + 255) / 256; q.tiles_n = (q.N + 255) / 256;
-    if (q.tk_S > 0) q.tiles_m -= q.tk_tiles_m;          // the whole tiles; the tile rows beyond them are the K-slice units' (TK)
     const int nt = q.tiles_m * q.tiles_n;
     // the ping-pong kernel is persistent: one block per CU walks its tiles (A3V_GEMM_PERSISTENT=0: one block per tile, for A/B runs)
     const dim3 g(cfg == 257 && pp_persistent() ? std::min(nt, cu_count()) : nt), b(512);
@@ -3580,14 +3436,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
       }
     }
 #endif
-    // the product path: the ring kernel, instantiated per set of fast epilogue forms (and, for the two sets whose shapes leave rows
-    // beyond whole tile rounds, with the in-launch K-slice units: TK)
-    if (q.tk_S > 0 && !(q.epi & GEMM_EPI_ROPEKV)) {
-      if (q.epi & (A3V_EPI_BIAS | A3V_EPI_GELU | A3V_EPI_QUICKGELU))
-        hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0, true, EPI_SET_COMMON | EPI_SET_PRE, false, true, true, true>), g, b, 0, st, q);
-      else hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0, true, EPI_SET_COMMON, false, true, true, true>), g, b, 0, st, q);
-      return;
-    }
+    // the product path: the ring kernel, instantiated per set of fast epilogue forms
     if (q.epi & GEMM_EPI_ROPEKV) hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0, true, EPI_SET_ROPE>), g, b, 0, st, q);
     else if (q.epi & (A3V_EPI_BIAS | A3V_EPI_GELU | A3V_EPI_QUICKGELU))
       hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0, true, EPI_SET_COMMON | EPI_SET_PRE>), g, b, 0, st, q);
@@ -3624,9 +3473,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
       if (S2 > 8) S2 = 8;
       while (S2 > 1 && K / 64 < 8 * S2) --S2;
       const bool simple_epi = !(p.epi & ~(A3V_EPI_RESIDUAL | A3V_EPI_RES_F32 | A3V_EPI_OUT_F32)) && gws.p && N % 4 == 0;
-      // (round 5) K-slice units inside the launch: any epilogue kind except the fused-qkv one, no second / third launch
-      const bool inl = A3V_ENV_INT("A3V_GEMM_TAIL_INLAUNCH", 1) != 0 && !rk && gws.ctr && (int64_t)S2 * tail_tiles * 262144 <= gws.bytes;
-      const double tail = (S2 >= 3 && (simple_epi || inl) && pp_ring() && pp_persistent()) ? 1.0 / S2 + (inl ? 0.12 : 0.2) : small_cost(tail_rows) + 0.25;
+      const double tail = (S2 >= 3 && simple_epi && pp_ring() && pp_persistent()) ? 1.0 / S2 + 0.2 : small_cost(tail_rows) + 0.25;
       c_hyb = (double)((mt_h * tn256 + 255) / 256) + tail;
     }
     // few big tiles (small N or M: the ViT's output projections, 76 tiles): the whole problem on the ring kernel split over K
@@ -3659,27 +3506,6 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
       launch(257, p);
     } else if (c_hyb < c_small) {
       const int m_big = (int)(mt_h * 256);
-      {
-        // (round 5) the rows beyond whole tile rounds as K-slice units INSIDE the persistent launch: one launch instead of three, no
-        // plane for the whole tiles, every epilogue kind (the finishing slices run the kernel's own epilogue).  A3V_GEMM_TAIL_INLAUNCH=0:
-        // the separate tail launch + reduce pass of rounds 2-4 (A/B runs, bit-equality tests).
-        const int tk_rows = (int)((M - m_big + 255) / 256), tk_tiles = tk_rows * (int)tn256;
-        int S2 = tk_tiles > 0 ? cu_count() / tk_tiles : 0;
-        if (S2 > 8) S2 = 8;
-        while (S2 > 1 && K / 64 < 8 * S2) --S2;
-        { const int e = A3V_ENV_INT("A3V_GEMM_TAIL_SLICES", 0); if (e >= 2 && e <= 8 && K / 64 >= 2 * e && e * tk_tiles <= cu_count()) S2 = e; }
-        const bool on = A3V_ENV_INT("A3V_GEMM_TAIL_INLAUNCH", 1) != 0 && A3V_ENV_INT("A3V_GEMM_RING_TAIL", 1) != 0;
-        if (on && pp_ring() && pp_persistent() && S2 >= 3 && !rk && gws.ctr && tk_tiles * 8 <= A3V_WS_CTR_BYTES &&
-            (int64_t)S2 * tk_tiles * 262144 <= gws.bytes && mt_h * tn256 >= cu_count() && S2 * tk_tiles <= cu_count()) {
-          GemmArgs q = p;
-          q.tk_S = S2; q.tk_tiles_m = tk_rows; q.tk_K = K; q.tk_ws = gws.p; q.tk_ctr = gws.ctr;
-          q.tk_wt = A3V_ENV_INT("A3V_GEMM_TAIL_WT", 0);
-          ++g_dispatch_count[0];
-          launch(257, q);
-          A3V_LAUNCH_CHECK();
-          return A3V_OK;
-        }
-      }
       GemmArgs q = p;
       q.M = m_big;
       launch(257, q);
@@ -3713,7 +3539,6 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
         t.c_split = (int64_t)t.M * N * 4;
         t.slow_epi = slow_epi_env(); t.nt_store = nt_store_env();
         t.skew = 0;
-        ++g_dispatch_count[1];
         hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0>), dim3(big_tiles, S2), dim3(512), 0, st, t);
         const int64_t n4 = (int64_t)r.M * (N / 4);
         const int rb = (int)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256);

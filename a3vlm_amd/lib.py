@@ -54,7 +54,6 @@ SIGNATURES = {
     "a3v_gemm_tn_sumsq_slots": (L, [I, I]),
     "a3v_gemm_set_workspace": (I, [P, L]),
     "a3v_gemm_set_workspace_for": (I, [P, P, L]),
-    "a3v_gemm_dispatch_count": (L, [I]),
     "a3v_gemm_nt_splitk": (I, [P, L, P, L, P, I, I, I, I, P]),
     "a3v_splitk_reduce": (I, [P, I, I, I, P, L, I, I, P]),
     "a3v_gemm_skinny_split": (I, [I, I, I]),

@@ -158,12 +158,6 @@ int a3v_gemm_set_workspace_for(void* stream, void* ptr, int64_t bytes);
 /* Legacy form for callers that do not name a stream: the buffer is bound to the FIRST (device, stream) whose GEMM call uses it; calls
  * on any other stream without a registration of their own get no scratch (plain launches), never this buffer. */
 int a3v_gemm_set_workspace(void* ptr, int64_t bytes);
-/* (round 5) The last 4 KiB of a registered scratch hold the arrival counters of the ring kernel's in-launch K-slice units (the rows
- * beyond whole tile rounds of a3v_gemm_nt: cut along K INSIDE the persistent launch); both registration
- * forms zero them (the _for form asynchronously on `stream`) and every launch leaves them zero.  a3v_gemm_dispatch_count(which)
- * returns how many a3v_gemm_nt calls of this process took a given form since load: 0 = rows beyond whole rounds inside the launch,
- * 1 = the same rows as a separate split-K launch + reduce pass (rounds 2-4; A3V_GEMM_TAIL_INLAUNCH=0).  Tests and tools only. */
-int64_t a3v_gemm_dispatch_count(int which);
 
 /* Split-K form for skinny products with a long K (the LoRA adapter GEMMs of model/peft.py:84-99 and their gradients:
  * N or M = 64, K = 4096 ... 22016): slice s of S writes the fp32 plane partial[s][M][N]; a3v_splitk_reduce sums the

@@ -992,53 +992,6 @@ def test_gemm_tn_strip(Kt, R, N, S, ld_extra):
     assert torch.equal(of, of2)
 
 
-@pytest.mark.parametrize("M,N,K", [(8728, 4096, 4096), (8728, 4096, 11008), (8728, 4096, 1600), (4616, 4096, 2048), (8448 + 3, 4096, 1536)])
-def test_gemm_ring_rows_beyond_whole_rounds_run_as_k_slice_units_inside_the_launch(M, N, K):
-    """Round 5: the tile rows beyond whole rounds of 256 tiles (M = 8728, N = 4096: 2.19 rounds) are cut along K INSIDE the persistent
-    ring launch -- one (tile, K-slice) unit per block after its whole tiles, fp32 planes for those tiles only, the first min(S, 4)
-    slices finish the tile with the kernel's own epilogue -- instead of a second split-K launch and a reduce pass.  Same K ranges
-    and the same slice-order sum as the separate tail (A3V_GEMM_TAIL_INLAUNCH=0): equal bit for bit for the output kinds both
-    handle; bias / GELU outputs (which the separate tail sent to the small-tile kernel) against the fp32 reference.  Three launches
-    in a row: the arrival counters are left zero."""
-    from a3vlm_amd import lib
-    L = lib.load()
-    a, w = gen(M, K, seed=70).to(BF).to(DEV), gen(N, K, seed=71, scale=0.05).to(BF).to(DEV)
-    res_b, res_f = gen(M, N, seed=72).to(BF).to(DEV), gen(M, N, seed=73).to(DEV)
-    bias = gen(N, seed=74).to(BF).to(DEV)
-
-    def run(kind):
-        if kind == "plain":
-            o = torch.full((M, N), 3.0, dtype=BF, device=DEV)
-            return ops.gemm_nt(a, w, o)
-        if kind == "residual":
-            o = torch.empty(M, N, dtype=BF, device=DEV)
-            return ops.gemm_nt(a, w, o, residual=res_b)
-        if kind == "res_f32":
-            o = res_f.clone()
-            return ops.gemm_nt(a, w, o, residual=o, epilogue=ops.EPI_RES_F32)
-        if kind == "out_f32":
-            o = torch.empty(M, N, dtype=torch.float32, device=DEV)
-            return ops.gemm_nt(a, w, o, epilogue=ops.EPI_OUT_F32)
-        o = torch.empty(M, N, dtype=BF, device=DEV)
-        return ops.gemm_nt(a, w, o, bias=bias, residual=res_b, epilogue=ops.EPI_GELU)
-
-    n0, n1 = L.a3v_gemm_dispatch_count(0), L.a3v_gemm_dispatch_count(1)
-    for kind in ("plain", "residual", "res_f32", "out_f32"):
-        with lib.env(A3V_GEMM_TAIL_INLAUNCH="0"):
-            want = run(kind)
-        for rep in range(3):
-            got = run(kind)
-            assert torch.equal(got, want), (kind, rep, int((got != want).sum()))
-    assert L.a3v_gemm_dispatch_count(0) - n0 == 12 and L.a3v_gemm_dispatch_count(1) - n1 == 4    # both forms really ran
-    ref = (a.float() @ w.float().t()).cpu()
-    assert_close(want, ref, rtol=2 ** -7, atol=1e-3 * math.sqrt(K) * 0.05 + 1e-3, what="out_f32 vs fp32 reference")
-    want = rt(res_b.float().cpu() + rt(F.gelu(rt(ref + bias.float().cpu()))))
-    for rep in range(2):
-        got = run("gelu")
-        assert_close(got, want, rtol=2 ** -6, atol=0.05, what="bias + GELU + residual through the finishing slices")
-    assert L.a3v_gemm_dispatch_count(0) - n0 == 14
-
-
 def test_gemm_split_k_scratch_is_per_stream():
     """Two streams run hybrid-tail GEMMs (big tiles + split-K tail through the registered scratch) concurrently, many times: each stream
     has its own scratch (a3v_gemm_set_workspace_for keys registrations by device and stream; round 3 kept one process-global pointer
