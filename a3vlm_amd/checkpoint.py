@@ -178,6 +178,10 @@ def save_checkpoint(output_dir: str, args, model, optimizer=None, loss_scaler=No
     name = f"epoch{epoch}" + (f"-iter{iteration}" if iteration is not None else "")
     save_dir = os.path.join(output_dir, name)
     os.makedirs(save_dir, exist_ok=True)
+    # ZeRO-1: the slices of the fp32 masters and moments are gathered bucket by bucket (COLLECTIVE: every rank calls this) and rank 0
+    # writes ONE world-size-independent ``consolidated.00-of-01.optimizer.pth``, as the reference does with
+    # ``FSDP.full_optim_state_dict`` on DP rank 0 (util/misc.py:395-403); any DP size -- and a resume at another one -- can load it
+    zero1_full = optimizer.full_state_dict() if optimizer is not None and getattr(optimizer, "zero1", False) else None
     if rank == 0:
         save_dtype = {"fp16": torch.float16, "bf16": torch.bfloat16, "tf32": torch.float}[getattr(args, "precision", "bf16")]
         sd = model.state_dict()
@@ -191,16 +195,13 @@ def save_checkpoint(output_dir: str, args, model, optimizer=None, loss_scaler=No
             json.dump(dataclasses.asdict(model.llma.args), f, indent=2)
         with open(os.path.join(save_dir, "meta.json"), "w") as f:
             json.dump({"llama_type": model.llama_type}, f, indent=2)
-        if optimizer is not None and not getattr(optimizer, "zero1", False):
-            torch.save({"optimizer": optimizer.state_dict()}, os.path.join(save_dir, "consolidated.00-of-01.optimizer.pth"))
+        if optimizer is not None:
+            torch.save({"optimizer": zero1_full if zero1_full is not None else optimizer.state_dict()},
+                       os.path.join(save_dir, "consolidated.00-of-01.optimizer.pth"))
         torch.save({"epoch": epoch, "iter": iteration,
                     "scaler": loss_scaler.state_dict() if hasattr(loss_scaler, "state_dict") else loss_scaler,
                     "args": vars(args) if hasattr(args, "__dict__") else args},
                    os.path.join(save_dir, "consolidated.00-of-01.other.pth"))
-    if optimizer is not None and getattr(optimizer, "zero1", False):
-        # ZeRO-1: every rank writes its own slice of the fp32 masters and moments (the model file holds the bf16 values all ranks compute
-        # with), as the reference's FSDP run keeps sharded optimizer state per rank
-        torch.save({"optimizer": optimizer.state_dict()}, os.path.join(save_dir, f"zero1-optimizer.{rank:05d}-of-{world_size:05d}.pth"))
     torch.save({"dataset_state": dataset_state}, os.path.join(save_dir, f"rank-specific-{rank:05d}-of-{world_size:05d}.pth"))
     return save_dir
 

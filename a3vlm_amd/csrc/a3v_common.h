@@ -178,6 +178,21 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return t;
 }
 
+// Opt a kernel into more than 64 KiB of dynamic LDS ONCE PER DEVICE (the attribute is per device; a process-wide "done" flag left a
+// second GPU of the process without it: launch failure).  `done`: a per-call-site table [A3V_MAX_DEV][slots]; the set is idempotent, so
+// two host threads racing through the flag at worst both make the call.  Returns the hipError_t of the set (0 = fine).
+constexpr int A3V_MAX_DEV = 16;
+template <int SLOTS>
+inline int a3v_dyn_lds_once(bool (&done)[A3V_MAX_DEV][SLOTS], int slot, const void* kern, int bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= A3V_MAX_DEV) dev = 0, done[0][slot] = false;
+  if (done[dev][slot]) return 0;
+  const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return (int)e;
+  done[dev][slot] = true;
+  return 0;
+}
+
 #define A3V_LAUNCH_CHECK()                         \
   do {                                             \
     hipError_t e_ = hipGetLastError();             \

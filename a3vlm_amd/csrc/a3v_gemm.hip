@@ -3652,8 +3652,8 @@ static bool gemv_launch(GemvArgs& g, void* ws, hipStream_t st) {
       const int kq_blocks = sw ? tiles / 2 : tiles;
       const size_t kq_lds = (size_t)nw * (2 * 4096 + 1024);
       void (*kq)(GemvArgs) = pro ? gemv_kq_bf16_kernel<true> : gemv_kq_bf16_kernel<false>;
-      static bool kq_attr[2] = {};
-      if (!kq_attr[pro ? 1 : 0]) { (void)hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); kq_attr[pro ? 1 : 0] = true; }
+      static bool kq_attr[A3V_MAX_DEV][2] = {};
+      if (a3v_dyn_lds_once(kq_attr, pro ? 1 : 0, (const void*)kq, 150 * 1024) != 0) return false;
       hipLaunchKernelGGL(kq, dim3(kq_blocks), dim3(nw * 64), kq_lds, st, g);
       return true;
     }
@@ -3668,9 +3668,9 @@ static bool gemv_launch(GemvArgs& g, void* ws, hipStream_t st) {
                     : (pro ? gemv_dma_bf16_kernel<16, true, false, AUX> : gemv_dma_bf16_kernel<16, false, false, AUX>)))
   kern = nt ? GEMV_PICK(2) : GEMV_PICK(0);
 #undef GEMV_PICK
-  static bool attr_done[16] = {};
+  static bool attr_done[A3V_MAX_DEV][16] = {};
   const int ki = (nt ? 8 : 0) + (w8 ? 4 : 0) + (arows == 16 ? 2 : 0) + (pro ? 1 : 0);
-  if (!attr_done[ki]) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_done[ki] = true; }
+  if (a3v_dyn_lds_once(attr_done, ki, (const void*)kern, 150 * 1024) != 0) return false;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), ldsb, st, g);
   return true;
 }
@@ -3814,10 +3814,11 @@ extern "C" int a3v_gemm_nt_splitk(const void* A, int64_t lda, const void* W, int
     const int nst = nst_env ? nst_env : (narrow == 1 ? 3 : 4);
     const int rows = narrow == 3 ? 64 : narrow == 2 ? 128 : 256;
     p.tiles_m = (M + rows - 1) / rows;
-    static bool attr[9] = {};
+    static bool attr[A3V_MAX_DEV][9] = {};
+    int attr_rc = 0;
     auto go = [&](auto kern, int bytes, int ai) {
-      if (!attr[ai]) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); attr[ai] = true; }
-      hipLaunchKernelGGL(kern, dim3(p.tiles_m, S), dim3(256), (size_t)bytes, (hipStream_t)stream, p);
+      attr_rc = a3v_dyn_lds_once(attr, ai, (const void*)kern, bytes);
+      if (attr_rc == 0) hipLaunchKernelGGL(kern, dim3(p.tiles_m, S), dim3(256), (size_t)bytes, (hipStream_t)stream, p);
     };
     // the product library carries the two forms the rule above picks; the other rows / stages of the sweep only in A3V_ABLATION builds
     const int bytes = (rows + 64) * 128 * nst;
@@ -3839,6 +3840,7 @@ extern "C" int a3v_gemm_nt_splitk(const void* A, int64_t lda, const void* W, int
     } else {
       hipLaunchKernelGGL((gemm_nt_bf16_kernel<256, 64, 4, 1>), dim3(p.tiles_m, S), dim3(256), 0, (hipStream_t)stream, p);
     }
+    if (attr_rc != 0) return attr_rc;
     A3V_LAUNCH_CHECK();
     return A3V_OK;
   }

@@ -82,6 +82,10 @@ def train_one_epoch(model, data_loader, optimizer, epoch: int, start_iter: int, 
         sumsq.attach()
     overlap = takes_scale and engine is not None and getattr(optimizer, "engine", None) is engine \
         and os.environ.get("A3V_ADAMW_OVERLAP", "0") == "1"
+    if zero1:
+        # ZeRO-1: bucket i's all-gather under the AdamW of buckets i+1.. and the next forward's first layers (on by default; a no-op
+        # at DP 1 and with stubbed collectives)
+        overlap = engine is not None and getattr(optimizer, "eng", None) is engine and os.environ.get("A3V_ZERO1_OVERLAP", "1") == "1"
     try:
         for step, batch in enumerate(data_loader, start=start_iter):
             examples, labels, imgs, depth = _unpack(batch)

@@ -212,9 +212,25 @@ def main(args):
         d = latest_checkpoint_dir(args.resume) or args.resume
         print("resume:", load_tensor_parallel_model_list(model, [d]))
         other = torch.load(os.path.join(d, "consolidated.00-of-01.other.pth"), weights_only=False)
-        opt_path = os.path.join(d, f"zero1-optimizer.{rank:05d}-of-{world:05d}.pth" if args.zero1 else "consolidated.00-of-01.optimizer.pth")
-        if os.path.isfile(opt_path):
-            optimizer.load_state_dict(torch.load(opt_path, weights_only=False)["optimizer"])
+        # optimizer state: one consolidated file for every mode (ZeRO-1 re-slices it for this run's DP size); the per-rank slice files of
+        # round 4 are still read when every rank has its own.  Whether a file is used is decided COLLECTIVELY (a rank that alone skipped the
+        # load would leave the others in a collective, or train on with different state).
+        opt_path = os.path.join(d, "consolidated.00-of-01.optimizer.pth")
+        legacy = os.path.join(d, f"zero1-optimizer.{rank:05d}-of-{world:05d}.pth")
+        have = torch.tensor([int(os.path.isfile(opt_path)), int(args.zero1 and os.path.isfile(legacy))], dtype=torch.int32)
+        if distributed:
+            have = have.to(dev)
+            dist.all_reduce(have, op=dist.ReduceOp.MIN)
+        have_full, have_legacy = (bool(x) for x in have.tolist())
+        if have_full:
+            optimizer.load_state_dict(torch.load(opt_path, weights_only=False, mmap=True)["optimizer"])
+        elif have_legacy:
+            optimizer.load_state_dict(torch.load(legacy, weights_only=False)["optimizer"])
+        else:
+            if rank == 0:
+                print(f"resume: no optimizer state under {d} on every rank -- AdamW moments start from zero")
+            if args.zero1:
+                optimizer.resync_from_params()       # the masters were snapshotted BEFORE the checkpoint's weights were loaded
         if other.get("iter") is not None:
             start_epoch, start_iter = other["epoch"], other["iter"] + 1
         else:

@@ -17,6 +17,16 @@ at micro-batch 4 with recompute.  Here (the ZeRO-1 fall-back it nam
   * small parameters (norm weights, projector, tags: fp32, replicated) keep the plain path: their gradient ranges are all-reduced and a
     ``FusedAdamW`` updates them identically on every rank.
 
+``step(overlap=True)`` (the trainer's default under DP): bucket i's all-gather is issued on a side stream the moment its AdamW launches
+are queued -- it runs under the AdamW of buckets i+1.. and, for the tail, under the next forward, which waits bucket by bucket on first
+use (``engine.await_weights``).  Same values as the serial step, bit for bit (``tests/test_zero1_cpu.py``).
+
+Checkpoints: ``state_dict()`` is the rank's slice (cheap, rank-local); ``full_state_dict()`` gathers the slices bucket by bucket to rank 0
+and is what ``checkpoint.save_checkpoint`` writes as ``consolidated.00-of-01.optimizer.pth`` -- one world-size-independent file, as the
+reference's ``FSDP.full_optim_state_dict`` path does (util/misc.py:395-403); ``load_state_dict`` takes either form and re-slices the full
+one for any world size.  A step skipped by a negative ``grad_scale`` still advances ``step_count`` (the bias correction), exactly as
+``FusedAdamW`` advances every parameter's ``step``: both counts are saved together, so they cannot disagree after a resume.
+
 The collective calls are ``torch.distributed`` (RCCL on the GPU; gloo in the CPU tests, which pass their own ``update`` function: there is
 no CPU AdamW in the product)."""
 from __future__ import annotations
@@ -72,6 +82,8 @@ class Zero1Optimizer:
         self._stream = None
         self._wire: Optional[torch.Tensor] = None
         self._reduced: set = set()
+        self._gather_stream = None
+        self._pending: Dict[str, object] = {}     # bucket -> all-gather still in flight (overlapped step): a CUDA event or a dist Work
         flat_p = engine.flat_params()
         dev = flat_p.device
         self.buckets: List[dict] = []
@@ -80,7 +92,8 @@ class Zero1Optimizer:
             assert n % (64 * self.world) == 0 and s <= ss <= se <= e, (name, s, e, ss, se)
             nb = n // self.world
             lo = ss + self.rank * nb
-            b = {"name": name, "range": (s, e), "shard": (ss, se), "mine": (lo, lo + nb), "segs": [], "n": nb}
+            b = {"name": name, "range": (s, e), "shard": (ss, se), "mine": (lo, lo + nb), "segs": [], "n": nb,
+                 "used": max([z for _, z, _ in segs], default=ss) - ss}       # parameters end here; the rest of the span is padding to 64 N
             if nb:
                 b["master"] = flat_p[lo:lo + nb].float()                       # fp32 masters start as the bf16 values (the reference promotes
                 b["m"] = torch.zeros(nb, dtype=torch.float32, device=dev)      # bf16-loaded weights the same way, util/tensor_type.py:60-66)
@@ -131,6 +144,7 @@ class Zero1Optimizer:
     def _exchange(self, name: str, start: int, end: int) -> None:
         dist, flat = self.dist, self.eng.flat_grads()
         b = self._by_name.get(name)
+        self._reduced.add(name)
         ss, se = (b["shard"] if b is not None else (start, start))
         # replicated pieces of the bucket (small fp32 parameters): plain average on every rank
         for a, z in ((start, ss), (se, end)):
@@ -167,13 +181,13 @@ class Zero1Optimizer:
             out.copy_(src[self.rank * b["n"]:(self.rank + 1) * b["n"]])
         if out is not b["g"]:
             _scale_cast(out, b["g"], 1.0)                                       # widen my slice of the averaged gradient
-        self._reduced.add(name)
 
     def finish(self) -> None:
         """Join the side stream; buckets the backward never announced (parameters without a gradient this step) are exchanged now."""
-        for b in self.buckets:
-            if b["n"] and b["name"] not in self._reduced and self.enabled:
-                self._on_ready(b["name"], *b["range"])
+        if self.enabled:
+            for name, s, e in self._ranges():      # replicated-only buckets (projector, tags) included: every rank hands over the same set
+                if name not in self._reduced:
+                    self._on_ready(name, s, e)
         if self._stream is not None:
             torch.cuda.current_stream().wait_stream(self._stream)
         self.wire_bytes_last_step, self._wire_bytes = self._wire_bytes, 0
@@ -195,7 +209,11 @@ class Zero1Optimizer:
         for b in self.buckets:
             if b["n"]:
                 loc = loc + torch.linalg.vector_norm(b["g"]) ** 2
-            (s, e), (ss, se) = b["range"], b["shard"]
+        # the replicated pieces: EVERY gradient range of the engine minus the sharded spans -- also the buckets that have no sharded
+        # span at all (vision_proj: projector matrices and image tags; round 4 left them out of the norm)
+        for name, s, e in self._ranges():
+            b = self._by_name.get(name)
+            ss, se = b["shard"] if b is not None and b["n"] else (s, s)
             for a, z in ((s, ss), (se, e)):
                 if z > a:
                     rep = rep + torch.linalg.vector_norm(flat[a:z]) ** 2
@@ -212,23 +230,69 @@ class Zero1Optimizer:
         return norm, torch.clamp(max_norm / (norm + 1e-6), max=1.0).to(torch.float32)
 
     # ------------------------------------------------------------------ update
+    def _ranges(self):
+        """(name, start, end) of every gradient bucket of the engine (sharded or not)."""
+        if hasattr(self.eng, "grad_ranges"):
+            return list(self.eng.grad_ranges())
+        return [(b["name"],) + tuple(b["range"]) for b in self.buckets]
+
+    def _order(self) -> List[dict]:
+        """Buckets in the order the next forward first touches them (the tail of the gathers hides under its first layers)."""
+        if hasattr(self.eng, "forward_order"):
+            rank = {it[0]: i for i, it in enumerate(self.eng.forward_order())}
+            return sorted(self.buckets, key=lambda b: rank.get(b["name"], len(rank)))
+        return list(self.buckets)
+
+    def await_params(self, name: str) -> None:
+        """The caller's stream (or the host, on CPU) waits for this bucket's all-gather of an overlapped step."""
+        h = self._pending.pop(name, None)
+        if h is None:
+            return
+        if isinstance(h, torch.cuda.Event):
+            torch.cuda.current_stream().wait_event(h)
+        else:
+            h.wait()
+
+    def sync_params(self) -> None:
+        for name in list(self._pending):
+            self.await_params(name)
+
     @torch.no_grad()
     def step(self, grad_scale: Optional[torch.Tensor] = None, overlap: bool = False) -> None:
+        self.sync_params()                               # gathers of a previous overlapped step nobody consumed
         self.step_count += 1
         g = self._group
         b1, b2 = g["betas"]
         flat_p = self.eng.flat_params()
-        for b in self.buckets:
+        real = self.world > 1 and not self.stub_collective
+        overlap = bool(overlap) and real
+        ready = getattr(self.eng, "_weights_ready", None)
+        for b in (self._order() if overlap else self.buckets):
             if not b["n"]:
                 continue
             for a, z, wd in b["segs"]:
                 self.update(b["master"][a:z], b["g"][a:z], b["m"][a:z], b["v"][a:z], b["out"][a:z], g["lr"], b1, b2, g["eps"], wd, self.step_count, grad_scale)
             ss, se = b["shard"]
-            if self.world > 1 and not self.stub_collective:
-                self.dist.all_gather_into_tensor(flat_p[ss:se], b["out"], group=self.group)
-            else:
+            if not real:
                 lo = b["mine"][0]
                 flat_p[lo:lo + b["n"]].copy_(b["out"])
+            elif not overlap:
+                self.dist.all_gather_into_tensor(flat_p[ss:se], b["out"], group=self.group)
+            elif flat_p.is_cuda:
+                # side stream: waits for this bucket's AdamW launches only; the compute stream goes on with the next bucket
+                if self._gather_stream is None:
+                    self._gather_stream = torch.cuda.Stream(device=flat_p.device)
+                gs = self._gather_stream
+                gs.wait_event(torch.cuda.current_stream().record_event())
+                with torch.cuda.stream(gs):
+                    self.dist.all_gather_into_tensor(flat_p[ss:se], b["out"], group=self.group)
+                    ev = gs.record_event()
+                if ready is not None:
+                    ready[b["name"]] = ev                # TrainEngine.await_weights / sync_optimizer wait on it
+                else:
+                    self._pending[b["name"]] = ev
+            else:
+                self._pending[b["name"]] = self.dist.all_gather_into_tensor(flat_p[ss:se], b["out"], group=self.group, async_op=True)
             self._wire_bytes += (se - ss) * b["out"].element_size()
         if self.small is not None:
             if grad_scale is not None and hasattr(self.small, "engine"):
@@ -238,30 +302,93 @@ class Zero1Optimizer:
         self._reduced.clear()
         self.eng.zero1_mark_fresh()                  # parameters changed in place: images are views, gradients restart from zero / store
 
-    # ------------------------------------------------------------------ state (per-rank shard files, like FSDP's sharded optimizer state)
+    def resync_from_params(self) -> None:
+        """Re-seed the fp32 masters (and the bf16 sink) from the CURRENT parameter values -- after model weights were loaded behind the
+        optimizer's back (a resume without optimizer state: the constructor's snapshot would otherwise overwrite the loaded weights at
+        the first all-gather).  Moments are kept."""
+        self.sync_params()
+        flat_p = self.eng.flat_params()
+        for b in self.buckets:
+            if b["n"]:
+                lo = b["mine"][0]
+                b["master"].copy_(flat_p[lo:lo + b["n"]])
+                b["out"].copy_(flat_p[lo:lo + b["n"]])
+
+    # ------------------------------------------------------------------ state
     def state_dict(self) -> Dict:
+        """This rank's slice (rank-local, no collective)."""
+        self.sync_params()
         return {"zero1": {"world": self.world, "rank": self.rank, "step": self.step_count,
                           "buckets": {b["name"]: {k: b[k].detach().cpu() for k in ("master", "m", "v")} for b in self.buckets if b["n"]}},
                 "small": self.small.state_dict() if self.small is not None else None}
 
-    def load_state_dict(self, sd: Dict) -> None:
-        z = sd["zero1"]
-        if z["world"] != self.world or z["rank"] != self.rank:
-            raise RuntimeError(f"ZeRO-1 state of rank {z['rank']}/{z['world']} loaded into rank {self.rank}/{self.world}")
-        self.step_count = int(z["step"])
-        flat_p = self.eng.flat_params()
+    def full_state_dict(self) -> Optional[Dict]:
+        """COLLECTIVE: the whole sharded state gathered bucket by bucket; rank 0 returns it (CPU tensors over each bucket's sharded span,
+        padding included), the other ranks return None.  World-size independent: any DP size can load it."""
+        self.sync_params()
+        full = {}
         for b in self.buckets:
             if not b["n"]:
                 continue
-            st = z["buckets"][b["name"]]
+            ent = {}
             for k in ("master", "m", "v"):
-                b[k].copy_(st[k])
-            b["out"].copy_(b["master"])
-            ss, se = b["shard"]
-            if self.world > 1:
-                self.dist.all_gather_into_tensor(flat_p[ss:se], b["out"], group=self.group)
-            else:
-                flat_p[b["mine"][0]:b["mine"][1]].copy_(b["out"])
+                if self.world > 1 and not self.stub_collective:
+                    buf = torch.empty(b["n"] * self.world, dtype=b[k].dtype, device=b[k].device)
+                    self.dist.all_gather_into_tensor(buf, b[k].contiguous(), group=self.group)
+                else:
+                    buf = b[k]
+                if self.rank == 0:
+                    ent[k] = buf.detach().cpu()
+                del buf
+            if self.rank == 0:
+                full[b["name"]] = ent
+        if self.rank != 0:
+            return None
+        # (a span is padded to a multiple of 64 x world at its END only: the first `used` elements have the same layout at every DP size)
+        return {"zero1_full": {"step": self.step_count, "world": self.world, "used": {b["name"]: b["used"] for b in self.buckets if b["n"]},
+                               "buckets": full},
+                "small": self.small.state_dict() if self.small is not None else None}
+
+    def load_state_dict(self, sd: Dict) -> None:
+        self.sync_params()
+        flat_p = self.eng.flat_params()
+        if "zero1_full" in sd:
+            # no collective: every rank reads the same file and keeps its slice; the parameters come from the masters everywhere
+            z = sd["zero1_full"]
+            self.step_count = int(z["step"])
+            for b in self.buckets:
+                if not b["n"]:
+                    continue
+                st, (ss, se) = z["buckets"][b["name"]], b["shard"]
+                n_st = st["master"].numel()
+                if z["used"][b["name"]] != b["used"] or n_st < b["used"]:
+                    raise RuntimeError(f"ZeRO-1 state of bucket {b['name']}: {z['used'][b['name']]} parameter elements saved, {b['used']} here")
+                lo = self.rank * b["n"]
+                hi = min(lo + b["n"], n_st)                 # the saving run's span may be shorter or longer: only padding differs
+                for k in ("master", "m", "v"):
+                    if hi > lo:
+                        b[k][:hi - lo].copy_(st[k][lo:hi])
+                b["out"].copy_(b["master"])
+                nc = min(n_st, se - ss)
+                flat_p[ss:ss + nc].copy_(st["master"][:nc])
+        else:
+            z = sd["zero1"]
+            if z["world"] != self.world or z["rank"] != self.rank:
+                raise RuntimeError(f"ZeRO-1 slice state of rank {z['rank']}/{z['world']} loaded into rank {self.rank}/{self.world} "
+                                   "(load the consolidated optimizer file to change the DP size)")
+            self.step_count = int(z["step"])
+            for b in self.buckets:
+                if not b["n"]:
+                    continue
+                st = z["buckets"][b["name"]]
+                for k in ("master", "m", "v"):
+                    b[k].copy_(st[k])
+                b["out"].copy_(b["master"])
+                ss, se = b["shard"]
+                if self.world > 1:
+                    self.dist.all_gather_into_tensor(flat_p[ss:se], b["out"], group=self.group)
+                else:
+                    flat_p[b["mine"][0]:b["mine"][1]].copy_(b["out"])
         if self.small is not None and sd.get("small") is not None:
             self.small.load_state_dict(sd["small"])
         self.eng.zero1_mark_fresh()

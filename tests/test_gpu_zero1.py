@@ -170,8 +170,9 @@ def test_zero1_two_ranks_track_the_replicated_step(tmp_path):
 
 
 def test_main_finetune_zero1_runs_and_resumes(tmp_path):
-    """The trainer entry point with --zero1 (one process): runs, logs a finite falling loss, writes the per-rank ZeRO state next to the
-    model file and resumes from it."""
+    """The trainer entry point with --zero1 (one process): runs, logs a finite falling loss, writes the CONSOLIDATED optimizer state (the
+    reference's consolidated.00-of-01.optimizer.pth: world-size independent) next to the model file and resumes from it; a resume from a
+    checkpoint WITHOUT optimizer state says so and re-seeds the fp32 masters from the loaded weights instead of reverting them."""
     gd = os.path.join(ROOT, "tests", "golden")
     extra = tmp_path / "vit.json"
     extra.write_text(json.dumps(dict(vit_width=64, vit_layers=2, vit_heads=4, vit_crop=112, n_views=1)))
@@ -191,6 +192,17 @@ def test_main_finetune_zero1_runs_and_resumes(tmp_path):
     assert "closs" in log
     lines = [json.loads(x) for x in open(out / "log.txt")]
     assert [ln["epoch"] for ln in lines] == [0, 1] and 0 < lines[1]["train_closs"] < lines[0]["train_closs"] + 0.5
-    assert os.path.isfile(out / "epoch1" / "zero1-optimizer.00000-of-00001.pth") and os.path.isfile(out / "epoch1" / "consolidated.00-of-01.model.pth")
+    assert os.path.isfile(out / "epoch1" / "consolidated.00-of-01.optimizer.pth") and os.path.isfile(out / "epoch1" / "consolidated.00-of-01.model.pth")
+    import torch
+    sd = torch.load(out / "epoch1" / "consolidated.00-of-01.optimizer.pth", weights_only=False)["optimizer"]
+    assert "zero1_full" in sd and sd["zero1_full"]["step"] > 0 and sd["small"] is not None
     log2 = run(["--epochs", "3", "--resume", str(out)])
-    assert "resume:" in log2 and os.path.isdir(out / "epoch2")
+    assert "resume:" in log2 and os.path.isdir(out / "epoch2") and "no optimizer state" not in log2
+    lines = [json.loads(x) for x in open(out / "log.txt")]
+    assert lines[-1]["epoch"] == 2 and 0 < lines[-1]["train_closs"] < lines[1]["train_closs"] + 0.5
+    # weights-only checkpoint: the loss continues from the loaded weights (stale masters would throw it back to the epoch-0 level)
+    os.remove(out / "epoch2" / "consolidated.00-of-01.optimizer.pth")
+    log3 = run(["--epochs", "4", "--resume", str(out)])
+    assert "no optimizer state" in log3
+    lines = [json.loads(x) for x in open(out / "log.txt")]
+    assert lines[-1]["epoch"] == 3 and 0 < lines[-1]["train_closs"] < lines[2]["train_closs"] + 0.5, lines
