@@ -6,7 +6,7 @@ decode step, and the training forward + backward of TrainEngine (full fine-tune 
 covered kernel by kernel; this file checks the composition at the size the driver times.  Same for one CLIP ViT block at width 1024.
 
 The oracle side is one layer at ~3.5 TFLOP per forward (a few seconds on the host's cores); it runs in fp32 on the bf16-rounded
-weights, the bound is the bf16 path's usual one (3e-2 of max |logit|, 1e-2 on the loss, cosine > 0.99 per gradient)."""
+weights, the bounds: 3e-2 of max |logit|, 1e-3 on the loss (north_star), relative L2 <= 2e-2 per gradient tensor."""
 import numpy as np
 import pytest
 import torch
@@ -34,9 +34,9 @@ def _weights(g, seed):
     return oargs, {k: v.to(BF).float() for k, v in sd.items()}              # the values the bf16 build multiplies with
 
 
-def _tokens(seed):
+def _tokens(seed, b=B, s=S):
     gen = torch.Generator().manual_seed(seed)
-    ex = torch.randint(3, V, (B, S), generator=gen)
+    ex = torch.randint(3, V, (b, s), generator=gen)
     ex[:, 0] = 1
     return ex
 
@@ -74,13 +74,21 @@ def test_block_forward_prefill_and_decode_at_full_width(g):
         assert float((lt - wt).abs().max()) / scale < 3e-2, t
 
 
-def _grad_check(tr, want, min_cos=0.99):
+LOSS_REL = 1e-3    # north_star: loss within 1e-3 relative of the reference's eager path
+REL_L2 = 2e-2      # per-tensor bound on |g - g_oracle|_2 / |g_oracle|_2 (round 5; was cosine > 0.99, i.e. a relative L2 of 0.14: a ragged
+                   # 24-row tile dropped from a weight gradient -- 0.3 % of the tokens, relative L2 ~ 5e-2 -- passed)
+
+
+def _grad_check(tr, want, bound=REL_L2, what=""):
+    worst = {}
     for name, p in tr.items():
         assert p.grad is not None, name
         a, b = p.grad.float().cpu().flatten(), want[name].float().flatten()
-        cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-20))
-        assert cos > min_cos, (name, cos)
-        assert 0.9 < float(a.norm() / (b.norm() + 1e-20)) < 1.1, name
+        worst[name] = float((a - b).norm() / (b.norm() + 1e-20))
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:4]
+    print(f"{what} gradient relative L2 vs oracle, worst: {[(n, round(v, 4)) for n, v in top]}")
+    bad = {n: v for n, v in worst.items() if not v < bound}
+    assert not bad, (what, bad)
 
 
 @pytest.mark.parametrize("g", ["7b", "13b"])
@@ -104,9 +112,10 @@ def test_block_full_fine_tune_step_at_full_width(g):
     want = {k: v.grad for k, v in osd.items()}
     eng = TrainEngine(m, BF)
     loss = eng.forward_loss(ex.to(DEV), lab.to(DEV), None)
-    assert abs(float(loss) - float(want_loss)) < 1e-2 * abs(float(want_loss))
+    print("full fine-tune", g, "loss", float(loss), "oracle", float(want_loss))
+    assert abs(float(loss) - float(want_loss)) < LOSS_REL * abs(float(want_loss))
     eng.backward(1.0)
-    _grad_check(m.get_trainable_params(), want)
+    _grad_check(m.get_trainable_params(), want, what=f"full fine-tune {g}")
 
 
 @pytest.mark.parametrize("g,rank", [("7b", 16), ("13b", 32)])
@@ -132,9 +141,40 @@ def test_block_lora_step_at_full_width(g, rank):
     want = {k: v.grad for k, v in osd.items() if v.requires_grad}
     eng = TrainEngine(m, BF)
     loss = eng.forward_loss(ex.to(DEV), lab.to(DEV), None)
-    assert abs(float(loss) - float(want_loss)) < 1e-2 * abs(float(want_loss))
+    print("lora", g, "loss", float(loss), "oracle", float(want_loss))
+    assert abs(float(loss) - float(want_loss)) < LOSS_REL * abs(float(want_loss))
     eng.backward(1.0)
-    _grad_check({k: v for k, v in tr.items() if v.requires_grad}, want, min_cos=0.985)
+    _grad_check({k: v for k, v in tr.items() if v.requires_grad}, want, what=f"LoRA r{rank} {g}")
+
+
+def test_block_lora_step_at_the_reference_recipe_length():
+    """The reference trains at max_words 2048 (scripts/a3vlm_train.sh:45-55: 448^2 input -> 1455 image words + text): one 7B-width LoRA
+    block step at S = 2048 (B = 4: 8192 rows; attention backward at 16 key blocks per query block instead of 9) against oracle autograd."""
+    g, rank, b, s_len = "7b", 16, 4, 2048
+    oargs, sd = _weights(g, 14)
+    lsd = {k: v.to(BF).float() for k, v in ref_cpu.make_lora_weights(oargs, rank, seed=6, std_a=0.02, std_b=0.02).items()}
+    m = peft.Transformer(peft.ModelArgs(**_args(g), lora_rank=rank))
+    m.load_state_dict({**sd, **lsd}, strict=True)
+    tr = m.get_trainable_params()
+    for n, p in m.named_parameters():
+        p.requires_grad = n in tr
+    m.to(BF).to(DEV)
+    promote_trainable_params_to_fp32(m)
+    tr = m.get_trainable_params()
+    ex = _tokens(4, b, s_len)
+    lab = ex.clone()
+    lab[:, :1455] = 0
+    lab[2, 1900:] = 0
+    osd = {k: v.clone().requires_grad_(k in tr) for k, v in {**sd, **lsd}.items()}
+    want_loss = ref_cpu.meta_forward_loss(ref_cpu.OracleDecoder(oargs, osd), ex, lab, None)
+    want_loss.backward()
+    want = {k: v.grad for k, v in osd.items() if v.requires_grad}
+    eng = TrainEngine(m, BF)
+    loss = eng.forward_loss(ex.to(DEV), lab.to(DEV), None)
+    print("lora S=2048 loss", float(loss), "oracle", float(want_loss))
+    assert abs(float(loss) - float(want_loss)) < LOSS_REL * abs(float(want_loss))
+    eng.backward(1.0)
+    _grad_check({k: v for k, v in tr.items() if v.requires_grad}, want, what="LoRA r16 7b S=2048")
 
 
 def test_vit_block_at_width_1024():

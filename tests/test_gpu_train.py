@@ -145,7 +145,11 @@ def test_rope_bwd_pack():
     (torch.float32, 2, 9, 4, 2, 16, True, False), (torch.float32, 1, 70, 2, 2, 64, False, False),
     (BF, 2, 40, 2, 1, 128, True, False), (torch.float32, 1, 33, 2, 2, 128, True, False),
     (BF, 2, 40, 2, 1, 128, True, True), (BF, 1, 300, 4, 2, 128, True, True), (BF, 2, 200, 2, 2, 64, False, True),
-    (BF, 1, 577, 2, 2, 64, False, True), (BF, 2, 129, 2, 2, 128, True, True)])
+    (BF, 1, 577, 2, 2, 64, False, True), (BF, 2, 129, 2, 2, 128, True, True),
+    # (round 5) the lengths of geometry R / the reference recipe / configs[4]: S = 1091, 1967, 2048 (GQA), 2182 -- the one-pass dK + dV
+    # kernel and the dQ kernel against oracle autograd at 9 ... 18 key blocks, not only against each other
+    (BF, 1, 1091, 2, 2, 128, True, True), (BF, 1, 1967, 2, 2, 128, True, True), (BF, 1, 2048, 4, 2, 128, True, True),
+    (BF, 1, 2182, 2, 2, 128, True, True)])
 def test_attention_lse_and_bwd(dtype, B, S, H, Hkv, hd, causal, mfma):
     q = gen(B, S, H, hd, seed=19).to(dtype).float().requires_grad_(True)
     k = gen(B, S, Hkv, hd, seed=20).to(dtype).float().requires_grad_(True)
