@@ -455,35 +455,65 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
 // of MASS restricted to the prefix chosen so far, then a scan from the heaviest bin down.  Ties (equal e_i; common in the bf16-
 // rounded tail, rare at the boundary) are ranked by token index.  Histograms are per wave and merged in wave order, so the sums
 // -- and the chosen token -- are reproducible run to run.
+// Round 5 (the eval recipe samples EVERY token: 203 us per step = 5 % of a decode step at bs 8): (i) e_i is computed ONCE and kept in LDS
+// (V <= 32768: 128 KiB beside the 30-KiB scratch; larger vocabularies recompute it per pass as before); (ii) the radix digits are taken
+// from key - min_key shifted so that the FIRST digit already spans the data's range: sharpened softmax values share their exponent,
+// so the plain bit pattern's top byte put every element into one or two bins -- 64 lanes of a wave on one LDS atomic, serialised,
+// 25 us per pass -- and spent a whole level on constant bits; now at most ceil(bits(max_key - min_key) / 8) levels run, each on
+// spread-out bins.
 struct TopPSel { unsigned key; float above; int rank; int id; };
 
-__device__ __forceinline__ float topp_e(const float* __restrict__ r, int i, float T, float xm) { return expf(r[i] / T - xm); }
+template <bool CACHE>
+__device__ __forceinline__ float topp_e(const float* __restrict__ r, const float* __restrict__ ec, int i, float T, float xm) {
+  if constexpr (CACHE) return ec[i];
+  else return expf(r[i] / T - xm);
+}
 
 // shared scratch of the selection (one block = one row)
 struct TopPShared {
   float hist[16][256];        // per-wave mass histograms of the current digit
   float bin[256];
+  float bin_top[256];         // the first digit's merged histogram: the same for both selections of a row (taken once)
   unsigned long long ball[64][16];   // tie ballots per (iteration, wave) of the last pass
   int wcnt[64][16];
   float red[16];
+  unsigned ured[2][16];
   unsigned sel_key; float sel_above; int sel_bin; int found;
   int tie_n;
 };
 
 // target in units of Z.  want_id: also locate the token (selection 2); else only (key, above, rank) are needed (selection 1).
-__device__ void topp_select(const float* __restrict__ r, int V, float T, float xm, float target, bool want_id, TopPShared& sh, TopPSel& out) {
+// kmin / levels / lsh: keys are ranked as (bits(e) - kmin) << lsh -- the left shift puts the range's top bit on the top bit of the
+// first of `levels` 8-bit digits (0 levels: every element has the same value), so the first histogram already spreads over 128+ bins.
+template <bool CACHE>
+__device__ void topp_select(const float* __restrict__ r, const float* __restrict__ ec, int V, float T, float xm, unsigned kmin, int levels, int lsh,
+                            float target, bool want_id, bool reuse_top, TopPShared& sh, TopPSel& out) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   unsigned prefix = 0;
   float above = 0.f;
   bool all_kept = false;
-  for (int level = 3; level >= 0; --level) {
+  for (int level = levels - 1; level >= 0; --level) {
+    const int shift = level * 8;
+    if (level == levels - 1 && reuse_top) {               // selection 2: the first digit's histogram of selection 1
+      if (tid < 256) sh.bin[tid] = sh.bin_top[tid];
+      if (tid == 0) sh.found = -1;
+      __syncthreads();
+    } else {
     for (int b = tid; b < 16 * 256; b += 1024) (&sh.hist[0][0])[b] = 0.f;
     __syncthreads();
-    const int shift = level * 8;
-    for (int i = tid; i < V; i += 1024) {
-      const float e = topp_e(r, i, T, xm);
-      const unsigned k = __float_as_uint(e);
-      if (level == 3 || (k >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&sh.hist[wave][(k >> shift) & 255], e);
+    // four elements per trip: the reads (LDS or expf) of a trip are in flight together; the adds keep the element order of the plain loop
+    for (int i0 = tid; i0 < V; i0 += 4096) {
+      float e4[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = i0 + q * 1024;
+        e4[q] = i < V ? topp_e<CACHE>(r, ec, i, T, xm) : -1.f;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const unsigned k = (__float_as_uint(e4[q]) - kmin) << lsh;
+        if (e4[q] >= 0.f && (level == levels - 1 || (k >> (shift + 8)) == (prefix >> (shift + 8)))) atomicAdd(&sh.hist[wave][(k >> shift) & 255], e4[q]);
+      }
     }
     __syncthreads();
     if (tid < 256) {
@@ -491,9 +521,11 @@ __device__ void topp_select(const float* __restrict__ r, int V, float T, float x
 #pragma unroll
       for (int w = 0; w < 16; ++w) m += sh.hist[w][tid];
       sh.bin[tid] = m;
+      if (level == levels - 1) sh.bin_top[tid] = m;
     }
     if (tid == 0) sh.found = -1;
     __syncthreads();
+    }
     if (wave == 0) {
       // lane l owns bins 4 l .. 4 l + 3; suffix sums from bin 255 down
       float b4[4];
@@ -527,7 +559,7 @@ __device__ void topp_select(const float* __restrict__ r, int V, float T, float x
       }
       // no bin passes: at the top level the target is beyond the total mass (cut: nothing is cut; draw: clamp onto the last
       // token); below it, the sub-bins' sum fell an ulp short of their parent's -- take the last non-empty one
-      const bool clamp_lo = best_hi < 0 && (level < 3 || want_id) && best_lo != 0x7fffffff;
+      const bool clamp_lo = best_hi < 0 && (level < levels - 1 || want_id) && best_lo != 0x7fffffff;
       if (best_hi >= 0 && best_hi == hi) { sh.found = hi; sh.sel_above = hi_excl; }
       if (clamp_lo && best_lo == lo) { sh.found = lo; sh.sel_above = lo_excl; }
     }
@@ -538,37 +570,48 @@ __device__ void topp_select(const float* __restrict__ r, int V, float T, float x
     __syncthreads();
   }
   if (all_kept) { out.key = 0u; out.above = -1.f; out.rank = 0; out.id = -1; return; }
-  const float ek = __uint_as_float(prefix);
+  const unsigned key = (prefix >> lsh) + kmin;           // (levels == 0: every element equals the smallest key)
+  const float ek = __uint_as_float(key);
   // ties on the selected value: rank inside them by token index
   int rank = ek > 0.f ? (int)floorf((target - above) / ek) : 0;
   if (rank < 0) rank = 0;
-  out.key = prefix; out.above = above; out.rank = rank; out.id = -1;
+  out.key = key; out.above = above; out.rank = rank; out.id = -1;
   const int iters = (V + 1023) / 1024;
   for (int k = 0; k < iters; ++k) {
     const int i = k * 1024 + tid;
-    const bool tie = i < V && __float_as_uint(topp_e(r, i, T, xm)) == prefix;
+    const bool tie = i < V && __float_as_uint(topp_e<CACHE>(r, ec, i, T, xm)) == key;
     const unsigned long long bl = __ballot(tie);
     if (lane == 0) { sh.ball[k][wave] = bl; sh.wcnt[k][wave] = __popcll(bl); }
   }
   __syncthreads();
-  if (tid == 0) {
-    int n = 0;
-    for (int k = 0; k < iters; ++k)
-      for (int w = 0; w < 16; ++w) n += sh.wcnt[k][w];
-    if (rank >= n) rank = n - 1;                         // float division landed past the last tied element
-    sh.tie_n = rank;
-    int id = -1, left = rank;
-    if (want_id) {
-      for (int k = 0; k < iters && id < 0; ++k)
-        for (int w = 0; w < 16 && id < 0; ++w) {
-          const int c = sh.wcnt[k][w];
-          if (left >= c) { left -= c; continue; }
-          unsigned long long bl = sh.ball[k][w];
-          for (int q = 0; q < left; ++q) bl &= bl - 1;   // drop the `left` lowest set bits
-          id = k * 1024 + w * 64 + __ffsll((long long)bl) - 1;
-        }
+  // (k, w) slots in token order = flat index t = k * 16 + w; thread t holds slot t's count: total and the slot the rank falls into by a
+  // block-wide scan over the <= 1024 slots (was: one thread walking 512 LDS words twice, ~10 us per selection)
+  {
+    const int c = tid < iters * 16 ? (&sh.wcnt[0][0])[tid] : 0;
+    int incl = c;                                        // inclusive scan inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += v;
     }
-    sh.sel_bin = id;
+    if (lane == 63) sh.ured[0][wave] = (unsigned)incl;
+    __syncthreads();
+    int base = 0, n = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      const int t = (int)sh.ured[0][w];
+      if (w < wave) base += t;
+      n += t;
+    }
+    if (rank >= n) rank = n - 1;                         // float division landed past the last tied element
+    if (tid == 0) { sh.tie_n = rank; sh.sel_bin = -1; }
+    __syncthreads();
+    const int before = base + incl - c;                  // ties in earlier slots
+    if (want_id && c > 0 && rank >= before && rank < before + c) {
+      unsigned long long bl = (&sh.ball[0][0])[tid];
+      for (int q = 0; q < rank - before; ++q) bl &= bl - 1;   // drop the lowest set bits
+      sh.sel_bin = (tid >> 4) * 1024 + (tid & 15) * 64 + __ffsll((long long)bl) - 1;
+    }
   }
   __syncthreads();
   out.rank = sh.tie_n;
@@ -576,9 +619,12 @@ __device__ void topp_select(const float* __restrict__ r, int V, float T, float x
   __syncthreads();
 }
 
+template <bool CACHE>
 __global__ __launch_bounds__(1024) void sample_top_p_kernel(const float* __restrict__ logits, int64_t ld, int V, float T, float top_p,
                                                             const float* __restrict__ u, int64_t* __restrict__ out) {
-  __shared__ TopPShared sh;
+  extern __shared__ __attribute__((aligned(16))) char topp_lds[];
+  TopPShared& sh = *reinterpret_cast<TopPShared*>(topp_lds);
+  float* ec = reinterpret_cast<float*>(topp_lds + ((sizeof(TopPShared) + 15) & ~(size_t)15));     // [V] when CACHE
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const float* r = logits + (int64_t)blockIdx.x * ld;
   // x_max and Z, fixed summation order (per thread, then lanes, then waves)
@@ -592,22 +638,42 @@ __global__ __launch_bounds__(1024) void sample_top_p_kernel(const float* __restr
   for (int w = 1; w < 16; ++w) xm = fmaxf(xm, sh.red[w]);
   __syncthreads();
   float z = 0.f;
-  for (int i = tid; i < V; i += 1024) z += topp_e(r, i, T, xm);
+  unsigned kmin = 0xffffffffu, kmax = 0u;
+  for (int i = tid; i < V; i += 1024) {
+    const float e = expf(r[i] / T - xm);
+    if constexpr (CACHE) ec[i] = e;
+    z += e;
+    const unsigned k = __float_as_uint(e);
+    kmin = min(kmin, k);
+    kmax = max(kmax, k);
+  }
   z = wave_sum(z);
-  if (lane == 0) sh.red[wave] = z;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    kmin = min(kmin, (unsigned)__shfl_xor((int)kmin, o, 64));
+    kmax = max(kmax, (unsigned)__shfl_xor((int)kmax, o, 64));
+  }
+  if (lane == 0) { sh.red[wave] = z; sh.ured[0][wave] = kmin; sh.ured[1][wave] = kmax; }
   __syncthreads();
   z = 0.f;
 #pragma unroll
-  for (int w = 0; w < 16; ++w) z += sh.red[w];
+  for (int w = 0; w < 16; ++w) {
+    z += sh.red[w];
+    kmin = min(kmin, sh.ured[0][w]);
+    kmax = max(kmax, sh.ured[1][w]);
+  }
   __syncthreads();
+  const unsigned range = kmax - kmin;
+  const int nbits = range == 0 ? 0 : 32 - __clz((int)range);
+  const int levels = (nbits + 7) / 8, lsh = levels * 8 - nbits;
   // 1. the nucleus: the last kept token is the one the cumulative mass passes top_p on (meta.py:571-573)
   TopPSel cut, pick;
-  topp_select(r, V, T, xm, top_p * z, false, sh, cut);
+  topp_select<CACHE>(r, ec, V, T, xm, kmin, levels, lsh, top_p * z, false, false, sh, cut);
   const float M = cut.above < 0.f ? z : cut.above + (float)(cut.rank + 1) * __uint_as_float(cut.key);
   // 2. one draw from the renormalised nucleus (meta.py:574-577): inverse CDF at u * M
   float uu = u[blockIdx.x];
   uu = uu < 0.f ? 0.f : (uu >= 1.f ? 0.99999994f : uu);
-  topp_select(r, V, T, xm, uu * M, true, sh, pick);
+  topp_select<CACHE>(r, ec, V, T, xm, kmin, levels, lsh, uu * M, true, true, sh, pick);
   if (tid == 0) {
     out[blockIdx.x] = pick.id < 0 ? 0 : pick.id;        // (id < 0 only for a row without any finite logit)
   }
@@ -1065,7 +1131,16 @@ extern "C" int a3v_sample_top_p(const float* logits, int64_t ld, int B, int V, f
                                 int64_t* out, void* stream) {
   if (!logits || !u || !out || B <= 0 || V <= 0) return A3V_ERR_ARG;
   if (V > 65536 || !(temperature > 0.f) || !(top_p > 0.f)) return A3V_ERR_SHAPE;
-  hipLaunchKernelGGL(sample_top_p_kernel, dim3(B), dim3(1024), 0, ST, logits, ld, V, temperature, top_p, u, out);
+  const size_t base = (sizeof(TopPShared) + 15) & ~(size_t)15;
+  if (V <= 32768 && A3V_ENV_INT("A3V_SAMPLER_CACHE", 1)) {     // e_i kept in LDS (A3V_SAMPLER_CACHE=0: recomputed per pass, A/B and equality tests)
+    static bool attr[A3V_MAX_DEV][1] = {};
+    const int bytes = (int)(base + (size_t)V * 4);
+    const int rc = a3v_dyn_lds_once(attr, 0, (const void*)sample_top_p_kernel<true>, 160 * 1024);
+    if (rc != 0) return rc;
+    hipLaunchKernelGGL(sample_top_p_kernel<true>, dim3(B), dim3(1024), (size_t)bytes, ST, logits, ld, V, temperature, top_p, u, out);
+  } else {
+    hipLaunchKernelGGL(sample_top_p_kernel<false>, dim3(B), dim3(1024), base, ST, logits, ld, V, temperature, top_p, u, out);
+  }
   A3V_LAUNCH_CHECK();
   return A3V_OK;
 }
