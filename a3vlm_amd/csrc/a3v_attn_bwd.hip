@@ -1149,7 +1149,7 @@ extern "C" int a3v_attention_bwd_mfma(const void* q, const void* k, int64_t k_sb
 
 // Packed form: the gradient of the fused qkv activation in one go (dq | dk | dv columns of [B*S, (H + 2 Hkv) * hd], q and k parts
 // rotated back), i.e. a3v_attention_bwd + a3v_rope_bwd_pack without the dq / dk / dv round trip.  D as above.
-extern "C" int a3v_attention_bwd_mfma_packed(const void* q, const void* k, int64_t k_sb, int64_t k_sh, const void* v, int64_t v_sb,
+extern "C" __attribute__((visibility("hidden"))) int a3v_attention_bwd_mfma_packed(const void* q, const void* k, int64_t k_sb, int64_t k_sh, const void* v, int64_t v_sb,
                                              int64_t v_ss, int64_t v_sh, const void* dout, const float* lse, const float* D, void* dqkv,
                                              int64_t ld_qkv, const float* cos_sin, int rope_pos0, int B, int S, int H, int Hkv, int hd,
                                              int causal, void* stream) {

@@ -934,7 +934,7 @@ extern "C" int a3v_attention_bwd(const void* q, const void* k, int64_t k_sb, int
   return A3V_OK;
 }
 
-extern "C" int a3v_attention_bwd_mfma_packed(const void* q, const void* k, int64_t k_sb, int64_t k_sh, const void* v, int64_t v_sb,
+extern "C" __attribute__((visibility("hidden"))) int a3v_attention_bwd_mfma_packed(const void* q, const void* k, int64_t k_sb, int64_t k_sh, const void* v, int64_t v_sb,
                                              int64_t v_ss, int64_t v_sh, const void* dout, const float* lse, const float* D, void* dqkv,
                                              int64_t ld_qkv, const float* cos_sin, int rope_pos0, int B, int S, int H, int Hkv, int hd,
                                              int causal, void* stream);

@@ -26,8 +26,6 @@ SIGNATURES = {
     "a3v_version": (I, []),
     "a3v_reload_env": (I, []),
     "a3v_build_flags": (I, []),
-    "a3v_probe_mfma_tflops": (I, [I, P, P, P]),
-    "a3v_probe_wave_reduce": (I, [P, I, P, P]),
     "a3v_gemm_nt": (I, [P, L, P, L, P, L, I, I, I, P, P, L, I, I, P]),
     "a3v_gemm_qkv_rope": (I, [P, L, P, L, I, P, L, P, P, P, L, P, L, P, I, I, I, I, I, I, I, I, P]),
     "a3v_gemm_nt_fp8": (I, [P, L, P, P, L, P, P, L, I, I, I, P, P, L, I, P]),

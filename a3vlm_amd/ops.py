@@ -572,17 +572,3 @@ def lora_refresh(wa, wb, A, At, B, Bt, col0: int, row0: int):
     rc = _l.load().a3v_lora_refresh(_p(wa), _p(wb), r, in_f, nj, _p(A), A.stride(0), _p(At), At.stride(0), _p(B), B.stride(0), _p(Bt),
                                     Bt.stride(0), col0, row0, _stream())
     _l.check(rc, "a3v_lora_refresh")
-
-
-
-def probe_mfma_tflops(iters: int = 20000):
-    """(constant operands, random operands) TFLOP/s of a bare v_mfma_f32_16x16x32_bf16 stream on the current device (a3v_probe_mfma_tflops):
-    what the matrix pipe delivers under the chip's power limit -- context for the roofline fractions, which are quoted against 2.5 PF/s."""
-    import torch
-    cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
-    scratch = torch.empty(8 * cus * 256, dtype=torch.float32, device="cuda")
-    import ctypes
-    res = (ctypes.c_float * 2)()
-    rc = _l.load().a3v_probe_mfma_tflops(int(iters), _p(scratch), ctypes.cast(res, ctypes.c_void_p), _stream())
-    _l.check(rc, "a3v_probe_mfma_tflops")
-    return float(res[0]), float(res[1])

@@ -1357,11 +1357,11 @@ def main():
             all_f = sum(fam[k][0] for k in ft)
             all_t = sum(fam[k][1] for k in ft)
             try:      # what the matrix pipe delivers on this box under its power limit (bare MFMA stream; context, not the price)
-                from a3vlm_amd import ops as _ops
-                pc, pr = _ops.probe_mfma_tflops(20000)
+                from tools.ubench.probe import probe_mfma_tflops
+                pc, pr = probe_mfma_tflops(20000)
                 pipe = {"constant_operands_tflops": round(pc, 1), "random_operands_tflops": round(pr, 1),
                         "frac_of_random_operand_rate": round(tot_f / tot_t / 1e12 / pr, 4) if pr > 0 else None,
-                        "note": "bare v_mfma_f32_16x16x32_bf16 stream on every CU, HIP events (a3v_probe_mfma_tflops): the chip clocks to its power "
+                        "note": "bare v_mfma_f32_16x16x32_bf16 stream on every CU, HIP events (tools/ubench/liba3v_probe.so): the chip clocks to its power "
                                 "budget, so random operands run slower than constants; `frac` above stays priced against the nominal 2.5 PF/s"}
             except Exception as e:
                 pipe = {"error": repr(e)}

@@ -74,16 +74,6 @@ int a3v_reload_env(void);
 /* bit 0: the library was built with -DA3V_EXPERIMENTS (`make EXPERIMENTS=1`): the measured-and-not-dispatched GEMM kernels
  * (two-stage ping-pong, one wave per SIMD, overlapped, 32x32x16 forms, stamped builds) and their switches exist. */
 int a3v_build_flags(void);
-/* Measurement entry (bench.py `roofline.mfma_pipe_measured`; no reference counterpart): TFLOP/s of a bare stream of
- * v_mfma_f32_16x16x32_bf16 on every CU of the current device, tflops[0] on constant operands, tflops[1] on random operands -- the
- * chip clocks to its power budget, so the second number is what the matrix pipe can deliver on real data (the nominal 2.5 PF/s is the
- * price the roofline fractions are quoted against).  `scratch`: device memory, 8 * CUs * 256 floats.  Synchronises `stream`. */
-int a3v_probe_mfma_tflops(int iters, float* scratch, float* tflops, void* stream);
-/* Self-check of the wave-wide reductions every row kernel uses (csrc/a3v_common.h: v_permlane32_swap / v_permlane16_swap + DPP butterfly)
- * against the __shfl_xor forms they replaced in round 4: x = n_waves x 64 floats (device), *mismatches (device int, zeroed by the caller)
- * += lanes whose sum or maximum differs in any bit.  Must stay 0: both butterflies pair the same lanes in the same order. */
-int a3v_probe_wave_reduce(const float* x, int n_waves, int* mismatches, void* stream);
-
 /* C[M,N] = epilogue(A[M,K] @ W[N,K]^T).  Replaces every F.linear on the path:
  * wq/wk/wv/wo (LLM/llama_ens5.py:63-90,112,169), w1/w2/w3 (:202-217), output (:267-269,
  * 486,530), visual_proj[0] (:330-333), the open_clip in_proj/out_proj/c_fc/c_proj, and

@@ -1030,9 +1030,10 @@ def test_gemm_split_k_scratch_is_per_stream():
 
 
 def test_mfma_probe_reports_a_plausible_pipe_rate():
-    """a3v_probe_mfma_tflops (bench.py `roofline.mfma_pipe_measured`): a bare MFMA stream lands between a third of and just above the
+    """tools/ubench/liba3v_probe.so (bench.py `roofline.mfma_pipe_measured`; not part of the product C-ABI): a bare MFMA stream lands between a third of and just above the
     nominal 2.5 PF/s, and random operands are never faster than constants by more than the run-to-run spread."""
-    const, rand = ops.probe_mfma_tflops(4000)
+    from tools.ubench.probe import probe_mfma_tflops
+    const, rand = probe_mfma_tflops(4000)
     assert 800.0 < rand < 2700.0 and 800.0 < const < 2700.0, (const, rand)
     assert rand < const * 1.05, (const, rand)
 
@@ -1089,11 +1090,5 @@ def test_wave_reductions_on_the_valu_equal_the_shuffle_forms_bit_for_bit():
     x[300:310, ::7] = float("inf")
     x[320:330, 3] = float("-inf")
     x[400:420] *= 1e-41
-    xd = x.to(DEV).contiguous()
-    bad = torch.zeros(1, dtype=torch.int32, device=DEV)
-    from a3vlm_amd import lib as _lib
-    L = _lib.load()
-    rc = L.a3v_probe_wave_reduce(xd.data_ptr(), x.shape[0], bad.data_ptr(), torch.cuda.current_stream().cuda_stream)
-    assert rc == 0
-    torch.cuda.synchronize()
-    assert int(bad.item()) == 0
+    from tools.ubench.probe import probe_wave_reduce
+    assert probe_wave_reduce(x.to(DEV).contiguous()) == 0

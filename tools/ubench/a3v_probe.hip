@@ -1,9 +1,12 @@
-// Measurement entry of the C-ABI (no reference counterpart): what the MFMA pipe of THIS device delivers on a bare stream of
+// Measurement / self-check entries, built into tools/ubench/liba3v_probe.so (NOT part of the product C-ABI; round 5 moved them out of
+// liba3vlm_hip.so): what the MFMA pipe of THIS device delivers on a bare stream of
 // v_mfma_f32_16x16x32_bf16 (the instruction of the GEMM kernels), once on constant operands and once on random operands.  The chip
 // clocks to its power budget: on random bf16 operands the same instruction stream runs 15-25 % slower than on constants
 // (tools/ubench/mfmarate.hip, profiles/r04g_mfma_rate.txt), so "fraction of 2.5 PF" and "fraction of what the pipe can deliver on
 // this data" are different numbers; bench.py prints both.
-#include "a3v_common.h"
+#include "../../a3vlm_amd/csrc/a3v_common.h"
+
+int a3v_env_generation() { return 0; }     // (a3v_common.h declares it for A3V_ENV_INT; unused here)
 
 namespace {
 __global__ __launch_bounds__(256) void mfma_probe_kernel(float* out, int iters, int random) {
