@@ -126,7 +126,7 @@ __device__ __forceinline__ void sumsq_flush(const GemmArgs& p, float ss, int mba
 constexpr int EPI_SET_COMMON = 1, EPI_SET_PRE = 2, EPI_SET_ROPE = 4, EPI_SET_SUMSQ = 8;   // SUMSQ: GemmArgs::sumsq honoured (weight-gradient kernels only)
 template <int TM, int TN, int SET>
 __device__ __forceinline__ bool gemm_epilogue_fast(f32x4 (&acc)[TM][TN], const GemmArgs& p, int mbase, int nbase, int lane, char* stage) {
-  if constexpr (TN != 4 || (TM % 4) != 0) {
+  if constexpr (TN != 4 || ((TM % 4) != 0 && TM != 6)) {          // (TM = 6: the 192-row ring tiles)
     return false;
   } else {
     // opaque copies: everything below is recomputed per tile AFTER the k-loop instead of being hoisted out of the persistent tile
@@ -246,14 +246,17 @@ __device__ __forceinline__ bool gemm_epilogue_fast(f32x4 (&acc)[TM][TN], const G
           const bf16_t* rp = reinterpret_cast<const bf16_t*>(r_) + (int64_t)(mbase + l3) * ldr_ + nbase + q * 8;
           const int64_t rstep = 8 * ldr_;
 #pragma unroll
-          for (int half = 0; half < TM / 4; ++half) {       // the loads of half a wave tile in flight at a time (32 VGPRs)
+          for (int half = 0; half < (TM + 2) / 4; ++half) { // the loads of two 32-row chunks in flight at a time (32 VGPRs); TM = 6: 2 + 1
             bf16x8 rr[2][4];
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
-              for (int it = 0; it < 4; ++it) { rr[c][it] = *reinterpret_cast<const bf16x8*>(rp); rp += rstep; }
+              for (int it = 0; it < 4; ++it) {
+                if (half * 2 + c < TM / 2) { rr[c][it] = *reinterpret_cast<const bf16x8*>(rp); rp += rstep; }
+              }
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
+              if (half * 2 + c >= TM / 2) continue;
               put(half * 2 + c);
 #pragma unroll
               for (int it = 0; it < 4; ++it) {
@@ -356,7 +359,7 @@ __device__ __forceinline__ bool gemm_epilogue_fast(f32x4 (&acc)[TM][TN], const G
       if constexpr ((SET & EPI_SET_SUMSQ) != 0) { if (p.sumsq) sumsq_flush(p, ss, mbase, nbase, lane); }
       return true;
     }
-    if (kind == A3V_EPI_SWIGLU) {
+    if (kind == A3V_EPI_SWIGLU && (TM % 4) == 0) {
       // 64 interleaved columns -> 32 output columns = 64 B per row.  chunk = four 16-row tiles = 64 rows x 64 B; 8-byte slot
       // s = 4 jp + g of row r at slot s ^ (((r >> 2) & 3) << 1) (rows r, r+4, r+8, r+12 share banks: the XOR separates them and keeps
       // 16-byte pairs together); read back as pairs, 16 rows x 64 B per store instruction
@@ -1327,13 +1330,16 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_pp_kernel(GemmArgs p) {
 // EARLY: the barrier that ends an MFMA interval is executed EARLY tile-rows before the interval's last MFMA.  Nothing after it
 // needs the barrier (the tail MFMAs read registers only), and the partner wave on the SIMD -- released by the same barrier --
 // starts its own MFMA stream while this wave is still feeding the pipe: no matrix-pipe bubble at the hand-over.
-template <int DBG, bool M32, int EARLY, bool STAGED = true, int SET = EPI_SET_COMMON, bool LW = false, bool LATEW = true, bool CONT = true>   // CONT (product; r03): the DMA stream runs on ACROSS the block's tiles -- the last two LOAD intervals of a tile fetch K-tiles 0 / 1 of the block's next tile into the ring slots they would have used anyway, so there is no prologue burst, no pipeline drain / refill and no block-wide barrier between tiles (see the boundary notes in the body); LATEW (product; r03 A/B +1 % on every shape, bit-equal): group 0 waits for its W pieces of tile t+1 at the TOP of L(t+1) instead of between its last MFMA of M(t) and the barrier that hands the matrix pipe over; SET: which fast epilogue forms (gemm_epilogue_fast); M32: v_mfma_f32_32x32x16_bf16 (4x2 tiles per wave) instead of 16x16x32 (8x4)
+template <int DBG, bool M32, int EARLY, bool STAGED = true, int SET = EPI_SET_COMMON, bool LW = false, bool LATEW = true, bool CONT = true, int TBM_ = 256>   // TBM_ (round 5): 192 = a 192 x 256 tile (six 16-row MFMA tiles per wave, 12-KiB A halves, 7 instead of 8 DMA pieces per wave and LOAD interval): M = 8728 x N = 4096 is 2.875 rounds of these instead of 2.19 rounds of 256 x 256 -- the rows beyond whole rounds cost no split-K planes; CONT (product; r03): the DMA stream runs on ACROSS the block's tiles -- the last two LOAD intervals of a tile fetch K-tiles 0 / 1 of the block's next tile into the ring slots they would have used anyway, so there is no prologue burst, no pipeline drain / refill and no block-wide barrier between tiles (see the boundary notes in the body); LATEW (product; r03 A/B +1 % on every shape, bit-equal): group 0 waits for its W pieces of tile t+1 at the TOP of L(t+1) instead of between its last MFMA of M(t) and the barrier that hands the matrix pipe over; SET: which fast epilogue forms (gemm_epilogue_fast); M32: v_mfma_f32_32x32x16_bf16 (4x2 tiles per wave) instead of 16x16x32 (8x4)
 __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
-  constexpr int TBM = 256, TBN = 256, WTM = 128, WTN = 64, TM = M32 ? 4 : 8, TN = M32 ? 2 : 4;
-  constexpr int AH = 128 * BK * 2;                      // 16 KiB: one group's half of an A K-tile
+  static_assert(TBM_ == 256 || (TBM_ == 192 && !M32 && LATEW && !LW), "the 192-row form exists for the product schedule only");
+  constexpr int TBM = TBM_, TBN = 256, WTM = TBM / 2, WTN = 64, TM = M32 ? 4 : WTM / 16, TN = M32 ? 2 : 4;
+  constexpr int AH = WTM * BK * 2;                      // 16 KiB (12 KiB): one group's half of an A K-tile
+  constexpr int APW = WTM / 32;                         // 1-KiB pieces (8 rows) of an A half per wave of a group: 4 (3)
+  constexpr int BURST = APW + 4;                        // pieces per wave and LOAD interval: A half + W half
   constexpr int WT = TBN * BK * 2;                      // 32 KiB: a W K-tile
   constexpr int ATOP = 0, ABOT = 2 * AH, WB = 4 * AH;   // ring bases
-  __shared__ __attribute__((aligned(1024))) char lds[4 * AH + 3 * WT];   // 163840 B = all of the CU's LDS
+  __shared__ __attribute__((aligned(1024))) char lds[4 * AH + 3 * WT];   // 163840 B = all of the CU's LDS (147456 B with 192-row tiles)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1413,15 +1419,23 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
   // tile prologue (all 8 waves, 14 pieces each): K-tile 0 whole, A_top and W of K-tile 1
   auto prologue = [&]() {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int ch = wave * 4 + c;                      // 32 chunks of A(0): waves 0-3 -> A_top, waves 4-7 -> A_bot
-      piece_a(sm0, ch * 8, 0, c & 1, lds + (wr ? ABOT : ATOP) + (ch & 15) * 1024);
+    for (int c = 0; c < APW; ++c) {
+      const int ch = (wave & 3) * APW + c;              // chunks of A(0): waves 0-3 -> A_top, waves 4-7 -> A_bot (chunk parity = swizzle key)
+      piece_a(sm0, wr * WTM + ch * 8, 0, ch & 1, lds + (wr ? ABOT : ATOP) + ch * 1024);
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) piece_w(sn0, (wave * 4 + c) * 8, 0, c & 1, lds + WB + (wave * 4 + c) * 1024);
     if (nk > 1) {
+      if constexpr (TBM == 256) {
 #pragma unroll
-      for (int c = 0; c < 2; ++c) piece_a(sm0, (wave * 2 + c) * 8, 1, c & 1, lds + ATOP + AH + (wave * 2 + c) * 1024);
+        for (int c = 0; c < 2; ++c) piece_a(sm0, (wave * 2 + c) * 8, 1, c & 1, lds + ATOP + AH + (wave * 2 + c) * 1024);
+      } else {                                          // 12 chunks over 8 waves: waves 0-3 two each, waves 4-7 one each
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const int ch = wave < 4 ? wave * 2 + c : 8 + (wave - 4);
+          if (c == 0 || wave < 4) piece_a(sm0, ch * 8, 1, ch & 1, lds + ATOP + AH + ch * 1024);
+        }
+      }
 #pragma unroll
       for (int c = 0; c < 4; ++c) piece_w(sn0, (wave * 4 + c) * 8, 1, c & 1, lds + WB + WT + (wave * 4 + c) * 1024);
     }
@@ -1535,7 +1549,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
           const bool nx = TAIL && t + 1 >= nk;
           const int tm = nx ? sm0 : m0, tk = nx ? t + 1 - nk : t + 1;
 #pragma unroll
-          for (int c = 0; c < 4; ++c) piece_a(tm, 128 + (g4 * 4 + c) * 8, tk, c & 1, lds + ABOT + ((pa ^ (t + 1)) & 1) * AH + (g4 * 4 + c) * 1024);
+          for (int c = 0; c < APW; ++c) piece_a(tm, WTM + (g4 * APW + c) * 8, tk, (g4 * APW + c) & 1, lds + ABOT + ((pa ^ (t + 1)) & 1) * AH + (g4 * APW + c) * 1024);
         }
         if (!TAIL || t + 2 < nk || cont) {
           const bool nx = TAIL && t + 2 >= nk;
@@ -1546,9 +1560,9 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
         if constexpr (LATEW) {
           // everything older than the bursts of L(t-1) and L(t) has landed: in particular this group's W half of tile t (the reads
           // below); in steady state 8 + 8 pieces may stay in flight, the last two tiles of the block's last k-loop issue shorter bursts
-          if (!TAIL || t + 2 < nk || cont) RG_VMCNT(16);
-          else if (t + 2 == nk) RG_VMCNT(12);
-          else RG_VMCNT(4);
+          if (!TAIL || t + 2 < nk || cont) vm_wait_imm<2 * BURST>();          // (16 with 256-row tiles)
+          else if (t + 2 == nk) vm_wait_imm<BURST + APW>();                      // L(t-1): A + W, L(t): A only (12)
+          else vm_wait_imm<APW>();                                                // only A_bot(nk-1) of L(nk-2) may be in flight (4)
         }
         RG_READ_FRAGS(lds + ATOP + ((pa ^ t) & 1) * AH, lds + WB + wcur * WT);
         A3V_WAIT_LGKM0();
@@ -1556,10 +1570,10 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
         if constexpr (LW) {                              // variant: W(t+1) is waited for HERE (one interval earlier), so nothing stands
           if (!TAIL || t + 2 < nk || cont) RG_VMCNT(8);  // between this group's last MFMA and the barrier that releases the other group
           else if (t + 2 == nk) RG_VMCNT(4);
-          else RG_VMCNT(0);
+          else RG_VMCNT(0);                               // (LW: 256-row tiles only)
         } else {
-          if (!TAIL || t + 2 < nk || cont) RG_VMCNT(12);
-          else if (t + 2 == nk) RG_VMCNT(8);
+          if (!TAIL || t + 2 < nk || cont) vm_wait_imm<BURST + 4>();              // this burst + the W half of the previous one (12)
+          else if (t + 2 == nk) vm_wait_imm<APW + 4>();                          // this burst (A only) + the W half of L(t-1) (8)
           else RG_VMCNT(0);
         }
         RG_STAMP(t, 2);
@@ -1600,14 +1614,14 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
           const bool nx = TAIL && t + 2 >= nk;
           const int tn = nx ? sn0 : n0, tm = nx ? sm0 : m0, tk = nx ? t + 2 - nk : t + 2;
 #pragma unroll
-          for (int c = 0; c < 4; ++c) piece_w(tn, 128 + (g4 * 4 + c) * 8, tk, c & 1, lds + WB + wn2 * WT + AH + (g4 * 4 + c) * 1024);
+          for (int c = 0; c < 4; ++c) piece_w(tn, 128 + (g4 * 4 + c) * 8, tk, c & 1, lds + WB + wn2 * WT + WT / 2 + (g4 * 4 + c) * 1024);
 #pragma unroll
-          for (int c = 0; c < 4; ++c) piece_a(tm, (g4 * 4 + c) * 8, tk, c & 1, lds + ATOP + ((pa ^ t) & 1) * AH + (g4 * 4 + c) * 1024);
+          for (int c = 0; c < APW; ++c) piece_a(tm, (g4 * APW + c) * 8, tk, (g4 * APW + c) & 1, lds + ATOP + ((pa ^ t) & 1) * AH + (g4 * APW + c) * 1024);
         }
         RG_READ_FRAGS(lds + ABOT + ((pa ^ t) & 1) * AH, lds + WB + wcur * WT);
         A3V_WAIT_LGKM0();
         RG_STAMP(t, 1);
-        if (!TAIL || t + 2 < nk || cont) RG_VMCNT(8);
+        if (!TAIL || t + 2 < nk || cont) vm_wait_imm<BURST>();                   // its previous burst (W half + A_top of tile t+1) has landed (8)
         else RG_VMCNT(0);
         RG_STAMP(t, 2);
         A3V_BARRIER();
@@ -3380,10 +3394,11 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
       hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 128, 2, 2>), dim3(q.tiles_m * q.tiles_n), dim3(256), 0, st, q);
       return;
     }
-    q.tiles_m = (q.M + 255) / 256; q.tiles_n = (q.N + 255) / 256;
+    const int tbm = cfg == 259 ? 192 : 256;
+    q.tiles_m = (q.M + tbm - 1) / tbm; q.tiles_n = (q.N + 255) / 256;
     const int nt = q.tiles_m * q.tiles_n;
     // the ping-pong kernel is persistent: one block per CU walks its tiles (A3V_GEMM_PERSISTENT=0: one block per tile, for A/B runs)
-    const dim3 g(cfg == 257 && pp_persistent() ? std::min(nt, cu_count()) : nt), b(512);
+    const dim3 g((cfg == 257 || cfg == 259) && pp_persistent() ? std::min(nt, cu_count()) : nt), b(512);
     if (cfg == 256) { hipLaunchKernelGGL((gemm_nt_bf16_kernel<256, 256, 2, 4>), g, b, 0, st, q); return; }
     q.xmap = (g.x & 63) ? 0 : A3V_ENV_INT("A3V_GEMM_XMAP", 1);   // =0: one contiguous run of tiles per XCD (A/B)
     if (!((q.xmap & 4) && g.x == 256 && (q.tiles_m & 15) == 0 && (q.tiles_n & 15) == 0)) q.xmap &= ~4;
@@ -3437,6 +3452,12 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
     }
 #endif
     // the product path: the ring kernel, instantiated per set of fast epilogue forms
+    if (cfg == 259) {                                    // 192 x 256 tiles (the fused-qkv form has no instantiation: general epilogue there)
+      if (q.epi & (A3V_EPI_BIAS | A3V_EPI_GELU | A3V_EPI_QUICKGELU))
+        hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0, true, EPI_SET_COMMON | EPI_SET_PRE, false, true, true, 192>), g, b, 0, st, q);
+      else hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0, true, EPI_SET_COMMON, false, true, true, 192>), g, b, 0, st, q);
+      return;
+    }
     if (q.epi & GEMM_EPI_ROPEKV) hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0, true, EPI_SET_ROPE>), g, b, 0, st, q);
     else if (q.epi & (A3V_EPI_BIAS | A3V_EPI_GELU | A3V_EPI_QUICKGELU))
       hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0, true, EPI_SET_COMMON | EPI_SET_PRE>), g, b, 0, st, q);
@@ -3444,9 +3465,10 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
   };
   const int64_t bytesA = ((int64_t)(M - 1) * lda + K) * 2, bytesW = ((int64_t)(N - 1) * ldw + K) * 2;
   const bool desc_ok = bytesA < (1LL << 31) && bytesW < (1LL << 31);   // buffer descriptors: 32-bit offsets
-  if (epilogue & (A3V_EPI_TILE_256PP32 | A3V_EPI_TILE_256PP | A3V_EPI_TILE_256 | A3V_EPI_TILE_128)) {
+  if (epilogue & (A3V_EPI_TILE_256PP32 | A3V_EPI_TILE_256PP | A3V_EPI_TILE_256 | A3V_EPI_TILE_128 | A3V_EPI_TILE_192PP)) {
     int cfg = 128;
-    if (epilogue & A3V_EPI_TILE_256PP32) cfg = 258;
+    if (epilogue & A3V_EPI_TILE_192PP) cfg = 259;
+    else if (epilogue & A3V_EPI_TILE_256PP32) cfg = 258;
     else if (epilogue & A3V_EPI_TILE_256PP) cfg = 257;
     else if (epilogue & A3V_EPI_TILE_256) cfg = 256;
     if (cfg > 256 && !desc_ok) return A3V_ERR_SHAPE;
@@ -3462,6 +3484,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
     // of 512 small tiles costs ~1.15 T256, and a split-K tail adds its reduce pass: the 7B qkv shape (6.56 rounds) went to the
     // hybrid under the old 0.65 and lost 11 % to the all-ring launch)
     auto small_cost = [&](long rows) { return rows <= 0 ? 0.0 : 1.15 * std::max(0.5, (double)((rows + 127) / 128) * tn128 / 512.0); };
+    const double round_us = 12.0 + 0.0206 * K;          // one round of 256 tiles of 256 x 256 on the ring kernel (M = 8192, N = 4096: 98 us at K = 4096, 476 at 22016)
     const double c_small = small_cost(M);
     const double c_big = eligible ? (double)((((long)(M + 255) / 256) * tn256 + 255) / 256) : 1e30;
     long mt_h = ((long)(M / 256) * tn256 / 256) * 256 / tn256;          // M-tile rows that make whole rounds
@@ -3473,9 +3496,16 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
       if (S2 > 8) S2 = 8;
       while (S2 > 1 && K / 64 < 8 * S2) --S2;
       const bool simple_epi = !(p.epi & ~(A3V_EPI_RESIDUAL | A3V_EPI_RES_F32 | A3V_EPI_OUT_F32)) && gws.p && N % 4 == 0;
-      const double tail = (S2 >= 3 && simple_epi && pp_ring() && pp_persistent()) ? 1.0 / S2 + 0.2 : small_cost(tail_rows) + 0.25;
+      // (round 5 recalibration, tools/ring192_ab.py) the split-K tail costs its 1 / S of a tile time plus ~32 us that do not depend on K
+      // (plane traffic + two launches): 0.30 of a round at K = 4096, 0.07 at K = 22016, where a round of 256 tiles takes ~12 + 0.0206 K us
+      const double tail = (S2 >= 3 && simple_epi && pp_ring() && pp_persistent()) ? 1.0 / S2 + 32.0 / round_us : small_cost(tail_rows) + 0.25;
       c_hyb = (double)((mt_h * tn256 + 255) / 256) + tail;
     }
+    // (round 5) the whole problem on 192 x 256 ring tiles: a round of them takes 0.79 of a 256 x 256 round (48 instead of 64 MFMAs per
+    // wave and K-tile on 7 / 8 of the LDS-DMA pieces); 8728 x 4096 is 2.875 rounds of these against 2 rounds + a split-K tail
+    double c_192 = 1e30;
+    if (eligible && !rk && pp_ring() && pp_persistent() && A3V_ENV_INT("A3V_GEMM_RING_192", 1) != 0 && !(p.epi & A3V_EPI_SWIGLU))
+      c_192 = 0.79 * (double)((((long)(M + 191) / 192) * tn256 + 255) / 256) + 0.02;
     // few big tiles (small N or M: the ViT's output projections, 76 tiles): the whole problem on the ring kernel split over K
     double c_spl = 1e30;
     int S3 = 0;
@@ -3490,7 +3520,9 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, 
           (int64_t)S3 * M * N * 4 <= gws.bytes && (!(p.epi & A3V_EPI_BIAS) || !(reinterpret_cast<uintptr_t>(bias) & 7)))
         c_spl = 1.0 / S3 + 0.2;
     }
-    if (c_spl < c_small && c_spl < c_big && c_spl < c_hyb) {
+    if (c_192 < c_spl && c_192 < c_small && c_192 < c_big && c_192 < c_hyb) {
+      launch(259, p);
+    } else if (c_spl < c_small && c_spl < c_big && c_spl < c_hyb) {
       GemmArgs t = p;
       t.C = gws.p; t.ldc = N; t.res = nullptr; t.bias = nullptr;
       t.epi = A3V_EPI_OUT_F32 | GEMM_EPI_RAW;

@@ -18,6 +18,7 @@ EPI_NONE, EPI_BIAS, EPI_GELU, EPI_QUICKGELU, EPI_RESIDUAL, EPI_SWIGLU, EPI_OUT_F
 EPI_SWIGLU_BWD = 128
 
 EPI_TILE_128, EPI_TILE_256, EPI_TILE_256PP, EPI_TILE_256PP32 = 1 << 16, 1 << 17, 1 << 18, 1 << 19
+EPI_TILE_192PP = 1 << 23
 
 P, I, L, F = c_void_p, c_int, c_int64, c_float
 

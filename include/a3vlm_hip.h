@@ -62,7 +62,8 @@ enum {
   A3V_EPI_TILE_128 = 1 << 16,  /* force the 128x128 tile kernel (tuning / tests)       */
   A3V_EPI_TILE_256 = 1 << 17,  /* force the 256x256 tile kernel (tuning / tests)       */
   A3V_EPI_TILE_256PP = 1 << 18,/* force the 256x256 ping-pong kernel (tuning / tests)  */
-  A3V_EPI_TILE_256PP32 = 1 << 19 /* ... its 32x32x16-MFMA form                         */
+  A3V_EPI_TILE_256PP32 = 1 << 19, /* ... its 32x32x16-MFMA form                        */
+  A3V_EPI_TILE_192PP = 1 << 23  /* force the ring kernel's 192 x 256 tile form (round 5; tuning / tests) */
 };
 
 int a3v_version(void);

@@ -827,6 +827,47 @@ def test_gemm_ring_stream_runs_on_across_the_tiles_of_a_block(M, N, K):
             assert torch.equal(got, want), (kind, rep, int((got != want).sum()))
 
 
+@pytest.mark.parametrize("M,N,K", [(8728, 4096, 320), (8728, 4096, 128), (4616, 1024, 192), (1000, 520, 704), (8728, 1280, 64), (192 * 40 + 5, 4096, 256)])
+def test_gemm_ring_192_row_tiles_equal_the_small_tile_kernel(M, N, K):
+    """Round 5: the ring kernel's 192 x 256 tile form (six 16-row MFMA tiles per wave, 12-KiB A halves, 7 DMA pieces per wave and LOAD
+    interval with their own counted waits) -- M = 8728 x N = 4096 is 2.875 rounds of these, no split-K planes for the rows beyond whole
+    rounds of 256 x 256.  Same MFMA and K order as the 128 x 128 kernel: equal bit for bit for every output kind of the fast epilogue
+    (plain / bf16 residual incl. its 2 + 1 chunk split at six row tiles / fp32 stream / fp32 out / SwiGLU backward) and through the
+    general epilogue (bias + GELU), over several tiles per block, short and odd K loops (nk = 1 ... 11), ragged rows and columns,
+    twice in a row."""
+    from a3vlm_amd import lib
+    a, w = gen(M, K, seed=60).to(BF).to(DEV), gen(N, K, seed=61, scale=0.05).to(BF).to(DEV)
+    res_b, res_f = gen(M, N, seed=62).to(BF).to(DEV), gen(M, N, seed=63).to(DEV)
+    bias = gen(N, seed=64).to(BF).to(DEV)
+    gu = gen(M, 2 * N, seed=65).to(BF).to(DEV)
+
+    def run(tile, kind):
+        if kind == "plain":
+            o = torch.full((M, N), 3.0, dtype=BF, device=DEV)
+            return ops.gemm_nt(a, w, o, epilogue=tile)
+        if kind == "residual":
+            o = torch.empty(M, N, dtype=BF, device=DEV)
+            return ops.gemm_nt(a, w, o, residual=res_b, epilogue=tile | ops.EPI_RESIDUAL)
+        if kind == "res_f32":
+            o = res_f.clone()
+            return ops.gemm_nt(a, w, o, residual=o, epilogue=tile | ops.EPI_RES_F32)
+        if kind == "out_f32":
+            o = torch.empty(M, N, dtype=torch.float32, device=DEV)
+            return ops.gemm_nt(a, w, o, epilogue=tile | ops.EPI_OUT_F32)
+        if kind == "swiglu_bwd":
+            o = torch.full((M, 2 * N), 5.0, dtype=BF, device=DEV)
+            return ops.gemm_nt(a, w, o, residual=gu, epilogue=tile | lib.EPI_SWIGLU_BWD)
+        o = torch.empty(M, N, dtype=BF, device=DEV)
+        return ops.gemm_nt(a, w, o, bias=bias, residual=res_b, epilogue=tile | ops.EPI_GELU)
+
+    kinds = ["plain", "residual", "res_f32", "out_f32", "gelu"] + (["swiglu_bwd"] if N % 8 == 0 else [])
+    for kind in kinds:
+        want = run(lib.EPI_TILE_128, kind)
+        for rep in range(2):
+            got = run(lib.EPI_TILE_192PP, kind)
+            assert torch.equal(got, want), (kind, rep, int((got != want).sum()))
+
+
 @pytest.mark.parametrize("M,F,K,tile", [(600, 1024, 256, "auto"), (600, 1024, 256, "pp"), (8728, 1280, 192, "auto"), (8728, 1280, 192, "pp"),
                                           (300, 528, 128, "t128"), (4608, 2816, 4160, "auto")])
 def test_gemm_swiglu_backward_epilogue_equals_gemm_then_swiglu_bwd(M, F, K, tile):
