@@ -37,16 +37,27 @@ def _dev(*ts):
             raise RuntimeError("a3vlm_amd ops need device tensors (no CPU fallback exists)")
 
 
-_gemm_ws = {}
+_gemm_ws = {}                 # (device, stream) -> scratch tensor, in order of last use (dicts keep insertion order)
+GEMM_WS_MAX_STREAMS = 8       # per process: a stream that has not run a GEMM while eight others did loses its 96-MiB scratch (it gets a new one
+                              # on its next GEMM); before round 5 every stream that ever ran a GEMM kept one for the life of the process
 
 
 def _ensure_gemm_workspace(device) -> None:
     """Register (once per device and stream) the scratch the GEMM entry points may use for the split-K planes of their hybrid dispatch
-    (a3v_gemm_set_workspace_for: keyed by stream, so concurrent streams never share planes)."""
+    (a3v_gemm_set_workspace_for: keyed by stream, so concurrent streams never share planes).  The scratch is allocated while its stream is
+    current and only ever used by launches on that stream, so dropping it (least recently used first, beyond GEMM_WS_MAX_STREAMS) is
+    ordered like any other free on that stream by the caching allocator; the registration is removed first."""
     st = _stream()
     key = (torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device(), st)
-    if key in _gemm_ws:
+    ws = _gemm_ws.pop(key, None)
+    if ws is not None:
+        _gemm_ws[key] = ws            # most recently used last
         return
+    while len(_gemm_ws) >= GEMM_WS_MAX_STREAMS:
+        (odev, ost), old = next(iter(_gemm_ws.items()))
+        with torch.cuda.device(odev):
+            _l.check(_l.load().a3v_gemm_set_workspace_for(ost, None, 0), "a3v_gemm_set_workspace_for(unregister)")
+        del _gemm_ws[(odev, ost)], old
     ws = torch.empty(96 << 20, dtype=torch.uint8, device=device)
     _gemm_ws[key] = ws
     with torch.cuda.device(key[0]):

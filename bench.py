@@ -1376,7 +1376,7 @@ def main():
                     "gemm_ms_per_step": round(tot_t * 1e3, 2), "gemm_calls_per_step": sum(r["count"] for r in table if r["kind"] in use),
                     "note": "achieved = algorithmic 2MNK of every GEMM call of one headline step / its HIP-event duration on the launch stream "
                             "(FLOP-weighted over the step's shapes = total GEMM FLOP / total GEMM time), each shape timed alone after a clock "
-                            "warm-up; the in-step kernel table of the same command is profiles/r03*_kernel_stats_*; traffic = rocprofv3 PMC bytes "
+                            "warm-up; the in-step kernel table of the same command is the newest profiles/r*_kernel_stats_*_step.txt (`in_step`); traffic = rocprofv3 PMC bytes "
                             "per launch of the dominant w1|w3 forward shape (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch "
                             "correction), newest summary under profiles/",
                     "shapes": table}

@@ -1063,6 +1063,18 @@ def test_gemm_split_k_scratch_is_per_stream():
         torch.cuda.synchronize()
         for (_, _, _, ref), o in zip(data, outs):
             assert torch.equal(o, ref), rep
+    # a process that runs GEMMs on many streams keeps at most GEMM_WS_MAX_STREAMS scratch buffers (least recently used dropped first,
+    # its registration removed before the memory goes back to the allocator); an evicted stream simply gets a new one
+    many = [torch.cuda.Stream() for _ in range(ops.GEMM_WS_MAX_STREAMS + 3)]
+    (a, w, r, ref) = data[0]
+    for rep in range(2):
+        for st in many:
+            o = torch.empty(M, N, dtype=BF, device=DEV)
+            with torch.cuda.stream(st):
+                ops.gemm_nt(a, w, o, residual=r)
+            st.synchronize()
+            assert torch.equal(o, ref)
+            assert len(ops._gemm_ws) <= ops.GEMM_WS_MAX_STREAMS
     # the legacy registration binds to the first stream that uses it and is never handed to another one
     L = _lib.load()
     ws = torch.empty(96 << 20, dtype=torch.uint8, device=DEV)
