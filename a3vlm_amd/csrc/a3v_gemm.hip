@@ -1303,6 +1303,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_pp_kernel(GemmArgs p) {
 }
 #endif  // A3V_EXPERIMENTS
 
+typedef __attribute__((ext_vector_type(4))) int i32x4r;
 // ------------------------------------------------------------------------------------
 // "Ring" form of the ping-pong kernel: the same tile, fragments, MFMA stream and epilogue, but the LDS is cut into three
 // rings that together use all 160 KiB of the CU, so every LDS-DMA piece has THREE OR FOUR intervals (1.5 - 2 K-tile periods)
@@ -1330,9 +1331,12 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_pp_kernel(GemmArgs p) {
 // EARLY: the barrier that ends an MFMA interval is executed EARLY tile-rows before the interval's last MFMA.  Nothing after it
 // needs the barrier (the tail MFMAs read registers only), and the partner wave on the SIMD -- released by the same barrier --
 // starts its own MFMA stream while this wave is still feeding the pipe: no matrix-pipe bubble at the hand-over.
-template <int DBG, bool M32, int EARLY, bool STAGED = true, int SET = EPI_SET_COMMON, bool LW = false, bool LATEW = true, bool CONT = true, int TBM_ = 256>   // TBM_ (round 5): 192 = a 192 x 256 tile (six 16-row MFMA tiles per wave, 12-KiB A halves, 7 instead of 8 DMA pieces per wave and LOAD interval): M = 8728 x N = 4096 is 2.875 rounds of these instead of 2.19 rounds of 256 x 256 -- the rows beyond whole rounds cost no split-K planes; CONT (product; r03): the DMA stream runs on ACROSS the block's tiles -- the last two LOAD intervals of a tile fetch K-tiles 0 / 1 of the block's next tile into the ring slots they would have used anyway, so there is no prologue burst, no pipeline drain / refill and no block-wide barrier between tiles (see the boundary notes in the body); LATEW (product; r03 A/B +1 % on every shape, bit-equal): group 0 waits for its W pieces of tile t+1 at the TOP of L(t+1) instead of between its last MFMA of M(t) and the barrier that hands the matrix pipe over; SET: which fast epilogue forms (gemm_epilogue_fast); M32: v_mfma_f32_32x32x16_bf16 (4x2 tiles per wave) instead of 16x16x32 (8x4)
+template <int DBG, bool M32, int EARLY, bool STAGED = true, int SET = EPI_SET_COMMON, bool LW = false, bool LATEW = true, bool CONT = true, int TBM_ = 256, bool F8 = false>   // F8 (round 5): OCP e4m3fn operands (the W8A8 prefill): a K-tile is still 128 BYTES per row -- 128 elements -- so rings, DMA pieces, swizzle and fragment reads are the bf16 kernel's; the two 16-byte fragments of a lane feed ONE v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales) instead of two 16x16x32 bf16 MFMAs, and the per-row scales sa[m] sw[n] are applied to the accumulators in front of the SAME staged epilogues (the two-stage fp8 kernel it replaces was one tile per block with the general epilogue: 21-25 k cycles of an 83 k-cycle tile); TBM_ (round 5): 192 = a 192 x 256 tile (six 16-row MFMA tiles per wave, 12-KiB A halves, 7 instead of 8 DMA pieces per wave and LOAD interval): M = 8728 x N = 4096 is 2.875 rounds of these instead of 2.19 rounds of 256 x 256 -- the rows beyond whole rounds cost no split-K planes; CONT (product; r03): the DMA stream runs on ACROSS the block's tiles -- the last two LOAD intervals of a tile fetch K-tiles 0 / 1 of the block's next tile into the ring slots they would have used anyway, so there is no prologue burst, no pipeline drain / refill and no block-wide barrier between tiles (see the boundary notes in the body); LATEW (product; r03 A/B +1 % on every shape, bit-equal): group 0 waits for its W pieces of tile t+1 at the TOP of L(t+1) instead of between its last MFMA of M(t) and the barrier that hands the matrix pipe over; SET: which fast epilogue forms (gemm_epilogue_fast); M32: v_mfma_f32_32x32x16_bf16 (4x2 tiles per wave) instead of 16x16x32 (8x4)
 __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
   static_assert(TBM_ == 256 || (TBM_ == 192 && !M32 && LATEW && !LW), "the 192-row form exists for the product schedule only");
+  static_assert(!F8 || (!M32 && EARLY == 0 && DBG == 0), "fp8 operands: 16x16x128 MFMA, product schedule");
+  constexpr int EB = F8 ? 1 : 2;                        // bytes per operand element
+  constexpr int BKE = 128 / EB;                         // elements per K-tile (128 bytes per row either way)
   constexpr int TBM = TBM_, TBN = 256, WTM = TBM / 2, WTN = 64, TM = M32 ? 4 : WTM / 16, TN = M32 ? 2 : 4;
   constexpr int AH = WTM * BK * 2;                      // 16 KiB (12 KiB): one group's half of an A K-tile
   constexpr int APW = WTM / 32;                         // 1-KiB pieces (8 rows) of an A half per wave of a group: 4 (3)
@@ -1387,33 +1391,33 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
   // split-K (gridDim.y slices; the tail rows of the hybrid dispatch): slice z takes the k-tiles [z nk/S, (z+1) nk/S) and writes
   // its own raw fp32 plane (summed, rounded and finished by splitk_epilogue_kernel)
   if (gridDim.y > 1) {
-    const int nk_all = p.K / BK, z = blockIdx.y, S = gridDim.y;
+    const int nk_all = p.K / BKE, z = blockIdx.y, S = gridDim.y;
     const int t0 = (int)(((int64_t)z * nk_all) / S), t1 = (int)(((int64_t)(z + 1) * nk_all) / S);
-    p.A += (int64_t)t0 * BK;
-    p.W += (int64_t)t0 * BK;
-    p.K = (t1 - t0) * BK;
+    p.A = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(p.A) + (int64_t)t0 * 128);
+    p.W = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(p.W) + (int64_t)t0 * 128);
+    p.K = (t1 - t0) * BKE;
     p.C = reinterpret_cast<char*>(p.C) + (int64_t)z * p.c_split;
   }
-  const int nk = p.K / BK;
-  const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)(((int64_t)(p.M - 1) * p.lda + p.K) * 2), 0x00020000);
-  const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)(((int64_t)(p.N - 1) * p.ldw + p.K) * 2), 0x00020000);
+  const int nk = p.K / BKE;
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)(((int64_t)(p.M - 1) * p.lda + p.K) * EB), 0x00020000);
+  const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)(((int64_t)(p.N - 1) * p.ldw + p.K) * EB), 0x00020000);
   // per-lane byte offset inside an 8-row chunk: row = lane/8, 16-B slot = (lane%8) ^ ((chunk*4 + lane/16) & 7)
   const unsigned lr = lane >> 3;
   unsigned voA[2], voW[2];
 #pragma unroll
   for (int par = 0; par < 2; ++par) {
     const unsigned sl = (lane & 7) ^ ((par * 4 + (lane >> 4)) & 7);
-    voA[par] = (unsigned)((lr * p.lda + sl * 8) * 2);
-    voW[par] = (unsigned)((lr * p.ldw + sl * 8) * 2);
+    voA[par] = (unsigned)(lr * p.lda * EB + sl * 16);
+    voW[par] = (unsigned)(lr * p.ldw * EB + sl * 16);
   }
   // one 1-KiB piece = 8 rows x 128 B; `row` = first row inside the A (W) tile, `par` = its chunk index & 1 (swizzle key)
   // (`tm0` / `tn0`: first row of the tile the K-tile belongs to -- the tile being computed, or with CONT the block's next one)
   auto piece_a = [&](int tm0, int row, int t, int par, char* dst) {
-    const unsigned so = (unsigned)(((int64_t)(tm0 + row) * p.lda + (DBG == 7 ? (t & 3) : t) * BK) * 2);   // DBG 7 (timing experiment): the same four K-tiles over and over = cache-resident operands
+    const unsigned so = (unsigned)((int64_t)(tm0 + row) * p.lda * EB + (DBG == 7 ? (t & 3) : t) * 128);   // DBG 7 (timing experiment): the same four K-tiles over and over = cache-resident operands
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)dst, 16, voA[par] + so, 0, 0, 0);
   };
   auto piece_w = [&](int tn0, int row, int t, int par, char* dst) {
-    const unsigned so = (unsigned)(((int64_t)(tn0 + row) * p.ldw + (DBG == 7 ? (t & 3) : t) * BK) * 2);
+    const unsigned so = (unsigned)((int64_t)(tn0 + row) * p.ldw * EB + (DBG == 7 ? (t & 3) : t) * 128);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)dst, 16, voW[par] + so, 0, 0, 0);
   };
   // tile prologue (all 8 waves, 14 pieces each): K-tile 0 whole, A_top and W of K-tile 1
@@ -1472,6 +1476,16 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
 
 #define RG_MFMA_PART(tail)                                                                           \
   do {                                                                                               \
+    if constexpr (F8) {                                                                              \
+      if (!(tail)) {                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                               \
+          _Pragma("unroll") for (int j = 0; j < TN; ++j)                                             \
+            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(                            \
+                __builtin_shufflevector(__builtin_bit_cast(i32x4r, wf[0][j]), __builtin_bit_cast(i32x4r, wf[1][j]), 0, 1, 2, 3, 4, 5, 6, 7), \
+                __builtin_shufflevector(__builtin_bit_cast(i32x4r, af[0][i]), __builtin_bit_cast(i32x4r, af[1][i]), 0, 1, 2, 3, 4, 5, 6, 7), \
+                acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);                                      \
+      }                                                                                              \
+    } else                                                                                           \
     _Pragma("unroll") for (int kk = 0; kk < NKK; ++kk)                                               \
       _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                               \
         const bool in_tail = (kk == NKK - 1) && (i >= TM - EARLY);                                   \
@@ -1661,6 +1675,22 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(GemmArgs p) {
       // staging patches: the W slot of K-tile nk - 1 (cont: the one slot no piece of the next tile is in flight to); the slot behind the
       // prologue's two otherwise
       const int wst = cont ? (wcur == 0 ? 2 : wcur - 1) : 2;
+      if constexpr (F8) {
+        // acc = sum_k qa[m][k] qw[n][k]: the product's value is that times sa[m] sw[n] (what the general epilogue's F8 form applies);
+        // done here so that the staged forms run on fp8 tiles too (the host leaves GEMM_EPI_SCALE out of p.epi for this kernel)
+        const int mr_ = m0 + wr * WTM + (lane_e & 15), nc_ = n0 + wc * WTN + (lane_e >> 4) * 4;
+        f32x4 swv[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) swv[j] = nc_ + j * 16 < p.N ? *reinterpret_cast<const f32x4*>(p.sw + nc_ + j * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const float sam = mr_ + i * 16 < p.M ? p.sa[mr_ + i * 16] : 0.f;
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] *= sam * swv[j][r];
+        }
+      }
       if constexpr (M32) gemm_epilogue32<TM, TN>(acc, p, m0 + wr * WTM, n0 + wc * WTN, lane_e);
       else gemm_epilogue<TM, TN, false, SET>(acc, p, m0 + wr * WTM, n0 + wc * WTN, lane_e, STAGED ? lds + WB + wst * WT + wave * 4096 : nullptr);
     }
@@ -3993,6 +4023,24 @@ extern "C" int a3v_gemm_tn_splitk(const void* At, int64_t lda, const void* Wt, i
   return A3V_OK;
 }
 
+// (round 5) the fp8 product on the ring kernel: persistent tile walk, three LDS rings, staged epilogues.  `grid_y` > 1: split-K planes.
+// Bias / activation kinds keep the two-stage kernel (no fp8 instantiation of that epilogue set).  A3V_GEMM_FP8_RING=0: the two-stage
+// kernel for everything (A/B runs, equality tests).
+static bool launch_ring_fp8(GemmArgs q, int grid_y, hipStream_t st) {
+  if (A3V_ENV_INT("A3V_GEMM_FP8_RING", 1) == 0 || !pp_persistent()) return false;
+  if (q.epi & (A3V_EPI_BIAS | A3V_EPI_GELU | A3V_EPI_QUICKGELU)) return false;
+  q.epi &= ~GEMM_EPI_SCALE;                              // the kernel scales its accumulators itself, in front of the staged epilogues
+  q.slow_epi = slow_epi_env(); q.nt_store = nt_store_env();
+  q.skew = 0; q.xsync = nullptr;
+  const int nt = q.tiles_m * q.tiles_n;
+  const dim3 g(grid_y > 1 ? nt : std::min(nt, cu_count()), grid_y), b(512);
+  q.xmap = (g.x & 63) || grid_y > 1 ? 0 : A3V_ENV_INT("A3V_GEMM_XMAP", 1);
+  if (!((q.xmap & 4) && g.x == 256 && (q.tiles_m & 15) == 0 && (q.tiles_n & 15) == 0)) q.xmap &= ~4;
+  if (q.epi & GEMM_EPI_ROPEKV) hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0, true, EPI_SET_ROPE, false, true, true, 256, true>), g, b, 0, st, q);
+  else hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0, true, EPI_SET_COMMON, false, true, true, 256, true>), g, b, 0, st, q);
+  return true;
+}
+
 // C = epilogue((Aq . Wq^T) * sa[m] * sw[n]): fp8 (OCP e4m3fn) activations and weights with per-row fp32 scales, MX-scaled
 // MFMA at twice the bf16 rate.  K % 128 == 0; 256 x 256 tiles for the whole problem; epilogues as a3v_gemm_nt (bf16 C).
 static int gemm_nt_fp8_impl(const void* Aq, int64_t lda, const float* sa, const void* Wq, int64_t ldw, const float* sw, void* C,
@@ -4031,7 +4079,7 @@ static int gemm_nt_fp8_impl(const void* Aq, int64_t lda, const float* sa, const 
       (int64_t)S * (M - m_big) * N * 4 <= gws.bytes) {
     GemmArgs q = p;
     q.M = m_big; q.tiles_m = (int)mt_h;
-    hipLaunchKernelGGL(gemm_nt_fp8_pp_kernel, dim3(q.tiles_m * q.tiles_n), dim3(512), 0, st, q);
+    if (!launch_ring_fp8(q, 1, st)) hipLaunchKernelGGL(gemm_nt_fp8_pp_kernel, dim3(q.tiles_m * q.tiles_n), dim3(512), 0, st, q);
     GemmArgs t = p;
     t.M = M - m_big;
     t.A = (const bf16_t*)((const char*)Aq + (int64_t)m_big * lda);
@@ -4040,7 +4088,7 @@ static int gemm_nt_fp8_impl(const void* Aq, int64_t lda, const float* sa, const 
     t.epi = A3V_EPI_OUT_F32 | GEMM_EPI_RAW | GEMM_EPI_SCALE;
     t.tiles_m = (t.M + 255) / 256;
     t.c_split = (int64_t)t.M * N * 4;
-    hipLaunchKernelGGL(gemm_nt_fp8_pp_kernel, dim3(t.tiles_m * t.tiles_n, S), dim3(512), 0, st, t);
+    if (!launch_ring_fp8(t, S, st)) hipLaunchKernelGGL(gemm_nt_fp8_pp_kernel, dim3(t.tiles_m * t.tiles_n, S), dim3(512), 0, st, t);
     const int esz = (epilogue & (A3V_EPI_OUT_F32 | A3V_EPI_RES_F32)) ? 4 : 2;
     void* Ct = (char*)C + (int64_t)m_big * ldc * esz;
     const void* Rt = residual ? (const char*)residual + (int64_t)m_big * ldr * ((epilogue & A3V_EPI_RES_F32) ? 4 : 2) : nullptr;
@@ -4051,7 +4099,7 @@ static int gemm_nt_fp8_impl(const void* Aq, int64_t lda, const float* sa, const 
     return A3V_OK;
   }
   p.tiles_m = tm_all;
-  hipLaunchKernelGGL(gemm_nt_fp8_pp_kernel, dim3(p.tiles_m * p.tiles_n), dim3(512), 0, st, p);
+  if (!launch_ring_fp8(p, 1, st)) hipLaunchKernelGGL(gemm_nt_fp8_pp_kernel, dim3(p.tiles_m * p.tiles_n), dim3(512), 0, st, p);
   A3V_LAUNCH_CHECK();
   return A3V_OK;
 }
