@@ -4026,7 +4026,7 @@ extern "C" int a3v_gemm_tn_splitk(const void* At, int64_t lda, const void* Wt, i
 // (round 5) the fp8 product on the ring kernel: persistent tile walk, three LDS rings, staged epilogues.  `grid_y` > 1: split-K planes.
 // Bias / activation kinds keep the two-stage kernel (no fp8 instantiation of that epilogue set).  A3V_GEMM_FP8_RING=0: the two-stage
 // kernel for everything (A/B runs, equality tests).
-static bool launch_ring_fp8(GemmArgs q, int grid_y, hipStream_t st) {
+static bool launch_ring_fp8(GemmArgs q, int grid_y, hipStream_t st, int tbm = 256) {
   if (A3V_ENV_INT("A3V_GEMM_FP8_RING", 1) == 0 || !pp_persistent()) return false;
   if (q.epi & (A3V_EPI_BIAS | A3V_EPI_GELU | A3V_EPI_QUICKGELU)) return false;
   q.epi &= ~GEMM_EPI_SCALE;                              // the kernel scales its accumulators itself, in front of the staged epilogues
@@ -4036,7 +4036,8 @@ static bool launch_ring_fp8(GemmArgs q, int grid_y, hipStream_t st) {
   const dim3 g(grid_y > 1 ? nt : std::min(nt, cu_count()), grid_y), b(512);
   q.xmap = (g.x & 63) || grid_y > 1 ? 0 : A3V_ENV_INT("A3V_GEMM_XMAP", 1);
   if (!((q.xmap & 4) && g.x == 256 && (q.tiles_m & 15) == 0 && (q.tiles_n & 15) == 0)) q.xmap &= ~4;
-  if (q.epi & GEMM_EPI_ROPEKV) hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0, true, EPI_SET_ROPE, false, true, true, 256, true>), g, b, 0, st, q);
+  if (tbm == 192) hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0, true, EPI_SET_COMMON, false, true, true, 192, true>), g, b, 0, st, q);
+  else if (q.epi & GEMM_EPI_ROPEKV) hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0, true, EPI_SET_ROPE, false, true, true, 256, true>), g, b, 0, st, q);
   else hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<0, false, 0, true, EPI_SET_COMMON, false, true, true, 256, true>), g, b, 0, st, q);
   return true;
 }
@@ -4075,6 +4076,21 @@ static int gemm_nt_fp8_impl(const void* Aq, int64_t lda, const float* sa, const 
   int S = 1;
   while (rem_tiles * S * 2 <= ncu && S < 8 && (K / 128) >= 8 * S) S *= 2;   // measured on wo / w2 of 7B: S = 2 (96 blocks) beat S = 8 (384 blocks)
   const int m_big = (int)(mt_h * 256);
+  // (round 5) 192 x 256 ring tiles where they cost fewer rounds than whole 256-row rounds + a split-K tail (a round of them is 0.79 of a
+  // 256-row round; the tail's ~32 us do not shrink with the fp8 round time ~12 + 0.0103 K us): A3V_GEMM_FP8_192 = 0 never, 2 always
+  {
+    const int e192 = A3V_ENV_INT("A3V_GEMM_FP8_192", 1);
+    const bool tail_form = !rk && !(epilogue & ~simple) && mt_h >= 1 && m_big < M && S > 1 && rem_tiles * 4 < 3 * ncu;
+    const double round_us = 12.0 + 0.0103 * K;
+    const double c_now = tail_form ? (double)(mt_h * p.tiles_n / ncu) + 1.0 / S + 32.0 / round_us : (double)((total + ncu - 1) / ncu);
+    const long t192 = (long)((M + 191) / 192) * p.tiles_n;
+    const double c_192 = 0.79 * (double)((t192 + ncu - 1) / ncu) + 0.02;
+    if (e192 && !rk && !(epilogue & (A3V_EPI_SWIGLU | A3V_EPI_BIAS | A3V_EPI_GELU | A3V_EPI_QUICKGELU)) && M >= 512 && N >= 512 && (e192 == 2 || c_192 < c_now)) {
+      GemmArgs q = p;
+      q.tiles_m = (M + 191) / 192;
+      if (launch_ring_fp8(q, 1, st, 192)) { A3V_LAUNCH_CHECK(); return A3V_OK; }
+    }
+  }
   if (!rk && !(epilogue & ~simple) && mt_h >= 1 && m_big < M && S > 1 && rem_tiles * 4 < 3 * ncu && gws.p &&
       (int64_t)S * (M - m_big) * N * 4 <= gws.bytes) {
     GemmArgs q = p;
