@@ -2908,9 +2908,17 @@ __global__ __launch_bounds__(256) void gemv_dma_bf16_kernel(GemvArgs p) {
         bf16x8 wf;
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
+          // (round 5) v_cvt_scalef32_pk_bf16_fp8 (gfx950): two e4m3 bytes -> two bf16 in ONE VALU op (scale 1: exact, as the fp8 -> f32
+          // -> bf16 pair of ops it replaces; A3V_W8_CVT_F32 builds keep those for the A/B)
+#ifdef A3V_W8_CVT_F32
           const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)wq[s8][h2], false);
           const f32x2 hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)wq[s8][h2], true);
           wf[4 * h2 + 0] = f2bf(lo[0]); wf[4 * h2 + 1] = f2bf(lo[1]); wf[4 * h2 + 2] = f2bf(hi[0]); wf[4 * h2 + 3] = f2bf(hi[1]);
+#else
+          const bf16x2 lo = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(wq[s8][h2], 1.0f, false);
+          const bf16x2 hi = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(wq[s8][h2], 1.0f, true);
+          wf[4 * h2 + 0] = lo[0]; wf[4 * h2 + 1] = lo[1]; wf[4 * h2 + 2] = hi[0]; wf[4 * h2 + 3] = hi[1];
+#endif
         }
         if (s8 & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[s8], acc1, 0, 0, 0);
         else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[s8], acc0, 0, 0, 0);
