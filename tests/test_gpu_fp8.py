@@ -271,6 +271,58 @@ def test_gemm_nt_fp8_split_tail(M, N, K, mode):
         assert_close(out.cpu() - res, want, rtol=2 ** -7, atol=atol, what="fp8 f32 residual split tail")
 
 
+@pytest.mark.parametrize("M,N,K,exact", [(8728, 4096, 4096, False), (8728, 4096, 11008, False), (8728, 1280, 384, True), (4452, 4096, 2048, False),
+                                         (1000, 776, 1152, True), (2048, 2048, 640, True)])
+def test_gemm_nt_fp8_ring_forms_equal_the_two_stage_kernel(M, N, K, exact):
+    """Round 5: the fp8 product runs on the ring kernel (persistent tile walk, three LDS rings, DMA stream across tiles, scales applied in
+    front of the staged epilogues) on 256 x 256 tiles or, where whole rounds + a split-K tail cost more, on 192 x 256 tiles.  Same MFMA,
+    same K order, same scale expression, epilogues that round identically: where the two-stage kernel runs un-split (`exact`: at most one
+    round of tiles) the ring forms equal it BIT FOR BIT for plain / residual / fp32-stream / SwiGLU outputs, twice in a row; where it takes
+    its split-K tail (another summation order) they stay within one bf16 step of it."""
+    from a3vlm_amd import lib
+    g = torch.Generator(device=DEV).manual_seed(9)
+    aq = torch.randint(0, 256, (M, K), device=DEV, generator=g, dtype=torch.uint8)
+    wq = torch.randint(0, 256, (N, K), device=DEV, generator=g, dtype=torch.uint8)
+    aq[(aq & 0x7f) >= 0x60] &= 0x9f      # |x| < 2: no NaN encodings, sums stay small
+    wq[(wq & 0x7f) >= 0x60] &= 0x9f
+    sa = torch.rand(M, device=DEV, generator=g) * 1e-2 + 1e-3
+    sw = torch.rand(N, device=DEV, generator=g) * 1e-2 + 1e-3
+    res_b = (torch.randn(M, N, device=DEV, generator=g)).to(BF)
+    res_f = torch.randn(M, N, device=DEV, generator=g)
+
+    def run(kind):
+        if kind == "plain":
+            o = torch.full((M, N), 3.0, dtype=BF, device=DEV)
+            return ops.gemm_nt_fp8(aq, sa, wq, sw, o)
+        if kind == "residual":
+            o = res_b.clone()
+            return ops.gemm_nt_fp8(aq, sa, wq, sw, o, residual=o)
+        if kind == "res_f32":
+            o = res_f.clone()
+            return ops.gemm_nt_fp8(aq, sa, wq, sw, o, residual=o, epilogue=ops.EPI_RES_F32)
+        o = torch.empty(M, N // 2, dtype=BF, device=DEV)
+        return ops.gemm_nt_fp8(aq, sa, wq, sw, o, epilogue=ops.EPI_SWIGLU)
+
+    kinds = ["plain", "residual", "res_f32"] + (["swiglu"] if N % 32 == 0 else [])
+    for kind in kinds:
+        res = {"residual": res_b, "res_f32": res_f}.get(kind)
+        with lib.env(A3V_GEMM_FP8_RING="0"):
+            want = run(kind)                                   # the two-stage kernel
+        with lib.env(A3V_GEMM_FP8_192="2"):
+            for rep in range(2):
+                got = run(kind)
+                assert (torch.equal(got, want) if exact else _within_tail_noise(got, want, res)), (kind, rep, int((got != want).sum()))
+        got = run(kind)                                        # the default dispatch
+        assert (torch.equal(got, want) if exact else _within_tail_noise(got, want, res)), kind
+
+
+def _within_tail_noise(got, want, res=None):
+    """one bf16 step of the PRODUCT (the residual is added after the product is rounded: |product| <= |sum| + |residual|)"""
+    d = (got.float() - want.float()).abs()
+    mag = want.float().abs() + (res.float().abs() if res is not None else 0.0)
+    return bool((d <= 2 ** -7 * mag + 1e-6 * float(want.float().abs().max()) + 1e-30).all())
+
+
 def test_gemm_nt_fp8_7b_size_scale_homogeneity():
     """BASELINE-size property (wo of Llama-2-7B at 8728 tokens: rows in rounds + split-K tail): doubling the activation scales
     doubles every output exactly (the scales enter once, in the epilogue, before the single bf16 rounding)."""
