@@ -96,6 +96,35 @@ def test_device_sampler_full_vocabulary_with_ties(T, p):
         assert torch.equal(ops.sample_top_p(ld, T, p, u, out), a)
 
 
+def test_device_sampler_lds_cached_and_recomputing_forms_agree_and_large_vocabularies_work():
+    """Round 5: e_i is kept in LDS for V <= 32768 (one expf per element instead of one per pass); larger vocabularies (and
+    A3V_SAMPLER_CACHE=0) recompute it per pass with the same expression, the same keys and the same summation order: identical ids.
+    V = 50000 (no cache possible) against the oracle's inverse CDF."""
+    from a3vlm_amd import lib
+    g = torch.Generator().manual_seed(21)
+    B = 8
+    for V, T, p in ((32000, 0.1, 0.75), (32768, 1.0, 0.9), (1003, 0.7, 0.5)):
+        logits = (torch.randn(B, V, generator=g) * 2.0).bfloat16().float().to(DEV)
+        out = torch.empty(B, dtype=torch.long, device=DEV)
+        for _ in range(6):
+            u = torch.rand(B, generator=g).to(DEV)
+            a = ops.sample_top_p(logits, T, p, u, out).clone()
+            with lib.env(A3V_SAMPLER_CACHE="0"):
+                b = ops.sample_top_p(logits, T, p, u, out).clone()
+            assert torch.equal(a, b), (V, a.tolist(), b.tolist())
+    V, T, p = 50000, 0.8, 0.9
+    logits = torch.randn(B, V, generator=g) * 2.0
+    probs = torch.softmax(logits / T, dim=-1)
+    ld = logits.to(DEV)
+    out = torch.empty(B, dtype=torch.long, device=DEV)
+    for _ in range(8):
+        u = torch.rand(B, generator=g)
+        got = ops.sample_top_p(ld, T, p, u.to(DEV), out).cpu().tolist()
+        want = ref_cpu.sample_top_p_at(probs, p, u).tolist()
+        for r in range(B):
+            assert _boundary_ok(probs[r], p, float(u[r]), got[r], want[r], eps=4e-5), (r, float(u[r]), got[r], want[r])
+
+
 def test_device_sampler_follows_the_renormalised_distribution():
     """4000 draws of one row at T = 1, top-p 0.9 over a 50-token head: empirical frequencies match the renormalised nucleus."""
     g = torch.Generator().manual_seed(3)
