@@ -254,8 +254,11 @@ class Zero1Optimizer:
             h.wait()
 
     def sync_params(self) -> None:
+        """Every all-gather of an overlapped step has landed (the optimizer's own handles and the events handed to the engine)."""
         for name in list(self._pending):
             self.await_params(name)
+        if hasattr(self.eng, "sync_optimizer"):
+            self.eng.sync_optimizer()
 
     @torch.no_grad()
     def step(self, grad_scale: Optional[torch.Tensor] = None, overlap: bool = False) -> None:

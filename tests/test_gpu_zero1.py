@@ -120,8 +120,11 @@ def _two_rank_worker(rank, world, port, outdir):
             eng.backward(1.0)
             opt.finish()
             norm, coef = opt.clip_coef(1.0)
-            opt.step(grad_scale=coef.reshape(1))
+            # (round 5) the trainer's default: every bucket's all-gather on the side stream behind its AdamW launches; the next forward
+            # waits bucket by bucket (engine.await_weights), the last step's gathers are joined by sync_params below
+            opt.step(grad_scale=coef.reshape(1), overlap=True)
             m.zero_grad(set_to_none=True)
+        opt.sync_params()
         torch.cuda.synchronize()
         held = sum(b["master"].numel() for b in opt.buckets if b["n"])
         torch.save({"params": {n: p.detach().float().cpu() for n, p in m.named_parameters()}, "losses": losses, "held": held,
