@@ -741,6 +741,7 @@ def recipe_leg(m, args, B, timer, dev, gen_long=1024):
     rk = {**dataclasses.asdict(args), "vit_crop": 224, "n_views": 5, "extra_feat_dim": 3072 + 1536, "qformer_tokens": 32, "max_seq_len": 4096}
     g = torch.Generator(device=dev).manual_seed(9)
     out = {}
+    part = os.environ.get("A3V_RECIPE_PART", "all")          # "train" / "eval": one half only (step-alone kernel tables: tools/prof_leg.sh)
     # ---------------- eval recipe
     mr = share_into(plugin.Transformer, plugin.ModelArgs(**rk), m, dev)
     W = mr.image_words
@@ -753,7 +754,7 @@ def recipe_leg(m, args, B, timer, dev, gen_long=1024):
     torch.nn.Module.__init__(mm)
     mm.llma, mm.llama_type = mr, "llama_ens5"
     ev = {"image_words": W, "temperature": 0.1, "top_p": 0.75, "batch": B, "max_seq_len": 4096}
-    for ctx in (1500, 2500, 3500):
+    for ctx in ((1500, 2500, 3500) if part != "train" else ()):
         Tp = ctx - W
         mm.tokenizer = _SynthTokenizer(Tp)
         prompts = [f"eval prompt {i} {ctx}" for i in range(B)]
@@ -778,8 +779,9 @@ def recipe_leg(m, args, B, timer, dev, gen_long=1024):
     def long_one():
         _, ids = mm.generate(prompts, img, max_gen_len=gen_long, temperature=0.1, top_p=0.75, additional_stop_symbols=["###"], return_ids=True)
         cnt["n"] = sum(len(t) for t in ids)
-    sec = timer(long_one, 1, 0)
-    ev["long_run"] = {"from_ctx": 1500, "new_tokens": cnt["n"], "seconds": round(sec, 3), "tok_s_end_to_end": round(cnt["n"] * world / sec, 1)}
+    if part != "train":
+        sec = timer(long_one, 1, 0)
+        ev["long_run"] = {"from_ctx": 1500, "new_tokens": cnt["n"], "seconds": round(sec, 3), "tok_s_end_to_end": round(cnt["n"] * world / sec, 1)}
     ev["note"] = ("MetaModel.generate(temperature=0.1, top_p=0.75) end to end on geometry R (448^2 -> 5 x 224 crops, W = 1455; Q-Former / ConvNeXt / DINOv2 "
                   "features synthetic through the plugin hooks): a3v_sample_top_p + a3v_generate_step per token; hbm_frac = bf16 weights + KV of all "
                   "sequences at the run's middle context / 8 TB/s")
@@ -788,6 +790,8 @@ def recipe_leg(m, args, B, timer, dev, gen_long=1024):
     mr._ws.clear(); mr._destroy_kv_cache()
     del mr, mm
     gc.collect(); torch.cuda.empty_cache()
+    if part == "eval":
+        return out
     # ---------------- training recipe
     mb, accum, S = 4, 2, 2048
     Tt = S - W
