@@ -67,7 +67,16 @@ def test_committed_bench_lines_follow_the_contract():
             assert leg in d and "error" not in d[leg], leg
         assert d["geometry_R"]["image_words"] == 1455 and d["config5"]["seq_len"] == 1024 + 2 * 579
         assert d["m13b"]["train_replica"]["hbm_gib"] < 288 and d["m13b"]["train_replica"]["trainable_params"] > 13e9
-        assert {"nt", "nn", "tn"} <= set(r["families"]) and r["traffic"]["file"][:3] in ("r02", "r03")
+        assert {"nt", "nn", "tn"} <= set(r["families"]) and r["traffic"]["file"][:3] in ("r02", "r03", "r04", "r05")
+        if os.path.basename(files[-1]) >= "r05":
+            # round 5: the reference's own recipes, the full-depth parity field and the stated DP-8 wire expectation ride the line
+            rc = d["recipe"]
+            assert "error" not in rc and rc["train_lora"]["seq_len"] == 2048 and 0 < rc["train_lora"]["attention_share"] < 0.5
+            assert all(rc["eval"][f"ctx_{x}"]["tok_s_after_prefill"] > 0 for x in (1500, 2500, 3500)) and rc["eval"]["top_p"] == 0.75
+            assert c["parity_full_depth"]["layers"] == 32 and c["parity_full_depth_rel_err"] < 5e-2 and c["parity_full_depth"]["argmax_equal"]
+            w3 = d["wire_prediction_dp8"]["configs3_zero1"]
+            assert w3["wire_ms_one_link_ring"] > w3["wire_ms_all_7_links"] > 0
+            assert d["m13b"]["train_zero1_recipe"]["seq_len"] == 2048
         assert c["c1"]["ids_equal"] is True and c["decode_tok_s"] > 0
         assert d["generate"]["tok_s_end_to_end"] > 0 and d["decode"]["roofline"]["bound"] == "hbm"
 
