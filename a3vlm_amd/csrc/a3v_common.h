@@ -232,9 +232,6 @@ int a3v_gemv_fused(const void* A, int64_t lda, const void* W, int64_t ldw, const
 bool a3v_gemv_supported(int M, int N, int K, int epilogue, int w8);
 int a3v_attention_decode_fused(const void* q, const void* k, const void* vt, void* out, int B, int Sk, int H, int Hkv, int hd,
                                const int64_t* strides, float* scratch, int* counters, void* stream);
-// internal (a3v_chain.hip): one layer's GEMV chain of the decode step as one persistent launch (A3V_ERR_SHAPE: geometry not taken)
-int a3v_decode_chain(const a3v_llama_layer* L, const a3v_llama_layer* Lnext, void* h, void* qkv, void* att, void* act, float* ssq, void* ws,
-                     const float* cos_sin, int B, int dim, int H, int Hkv, int hd, int ffn, int Smax, int pos, float eps, void* stream);
 // internal (a3v_train.hip): bf16 transposes of n_out x n_in matrices [R, C] -> [C, Rpad] in one launch
 int a3v_transpose_2level(const bf16_t* src, int64_t ld_src, int64_t bs_in, int64_t bs_out, bf16_t* dst, int64_t ld_dst, int64_t bsd_in,
                          int64_t bsd_out, int R, int C, int Rpad, int n_in, int n_out, void* stream);

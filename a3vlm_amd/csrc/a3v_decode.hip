@@ -79,21 +79,10 @@ extern "C" int a3v_llama_decode_step(const a3v_llama_layer* layers, int n_layers
       bf16_t* fc = (bf16_t*)act + (int64_t)b0 * ffn;
       hipLaunchKernelGGL(rows_ssq_kernel, dim3((dim / 16 * 16 + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)hc, (int64_t)dim, nb, dim, ssq);
       A3V_LAUNCH_CHECK();
-      // (round 5) A3V_DECODE_CHAIN=1: the four GEMVs between two attentions (wo, w1|w3, w2 and the NEXT layer's qkv) as ONE persistent
-      // launch per layer (a3v_chain.hip): bf16 weights, <= 8 rows, one row chunk
-      const bool chain = A3V_ENV_INT("A3V_DECODE_CHAIN", 0) != 0 && !w8 && B <= 8 && dim % 128 == 0 && (H * hd) % 128 == 0 && ffn % 128 == 0;
       for (int i = 0; i < n_layers; ++i) {
         const a3v_llama_layer& L = layers[i];
         bf16_t* kc = (bf16_t*)L.k_cache + b0 * kv_b;
         bf16_t* vc = (bf16_t*)L.vt_cache + b0 * kv_b;
-        if (chain) {
-          if (i == 0 && (rc = a3v_gemv_fused(hc, dim, L.wqkv, dim, nullptr, qc, ldq, nb, (int)ldq, dim, nullptr, 0, 0, L.attn_norm_w, ssq, eps, nullptr, 1,
-                                             cos_sin, kc, vc, H, Hkv, hd, Smax, pos, skinny_ws, stream))) return rc;
-          if ((rc = a3v_attention_decode_fused(qc, kc, vc, ac, nb, pos + 1, H, Hkv, hd, strides, attn_scratch, actr, stream))) return rc;
-          if ((rc = a3v_decode_chain(&L, i + 1 < n_layers ? &layers[i + 1] : nullptr, hc, qc, ac, fc, ssq, skinny_ws, cos_sin, nb, dim, H, Hkv, hd, ffn,
-                                     Smax, pos, eps, stream))) return rc;
-          continue;
-        }
         if ((rc = a3v_gemv_fused(hc, dim, w8 ? L.wqkv_q : L.wqkv, dim, L.wqkv_s, qc, ldq, nb, (int)ldq, dim, nullptr, 0, 0, L.attn_norm_w, ssq, eps,
                                  nullptr, 1, cos_sin, kc, vc, H, Hkv, hd, Smax, pos, skinny_ws, stream))) return rc;
         if ((rc = a3v_attention_decode_fused(qc, kc, vc, ac, nb, pos + 1, H, Hkv, hd, strides, attn_scratch, actr, stream))) return rc;
