@@ -1212,6 +1212,9 @@ def main():
         print(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks; reporting n_gpus={world}", file=sys.stderr)
     if os.environ.get("A3V_BENCH_LAUNCH_ONLY") == "1":
         return launch_only(a, rank, world)
+    # stdout carries the ONE JSON line and nothing else: whatever the legs print on the way (the dataset code echoes its config as the
+    # reference's does, data/dataset.py) goes to stderr
+    json_out, sys.stdout = sys.stdout, sys.stderr
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -1441,7 +1444,8 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args, T, W, a.cpu_seconds, dev)
             except Exception as e:  # the baseline must never hide the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
+    sys.stdout = json_out
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
