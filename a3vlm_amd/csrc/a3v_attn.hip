@@ -222,14 +222,18 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_bf16_kernel(AttnArgs p) {
     if (full_tile(t)) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       AP_ST(t, 6);
+#ifndef AP_NO_BAR
       __syncthreads();
+#endif
     } else {                          // this tile's buffer was last read in iteration t-2, which the barrier of t-1 closed
       load_tile(kv0);
       write_tile(Ks, Vs);
       __syncthreads();
     }
     AP_ST(t, 5);
+#ifndef AP_NO_DMA
     if (t + 1 < n_tiles && full_tile(t + 1)) dma_tile(kv0 + KVB, lds + (1 - BUF) * TILEB, lds + (1 - BUF) * TILEB + KVB * KROW);
+#endif
     AP_ST(t, 1);
     // causal: a tile whose first key lies past this wave's LAST query row contributes nothing to the wave (the block walks the
     // tiles its last wave needs); the wave only keeps the block's barrier / DMA cadence and leaves the SIMD to its partner
@@ -281,6 +285,14 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_bf16_kernel(AttnArgs p) {
     }
     AP_ST(t, 2);
     // ---- mask + online softmax (lane owns query column ql; kv = 32tb + (r&3)+8(r>>2)+4hh) ----
+#ifdef AP_NO_SM
+    bf16x8 pf[2][2];
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pf[tb][r >> 3][r & 7] = f2bf(s[tb][r]);
+    const bool resc = false;
+#else
     const int qlim = CAUSAL ? (qrow + off) : 0x7fffffff;
     // interior tiles (every key of the tile visible to every query row of this wave) skip the 32 compare/selects
     const bool need_mask = (kv0 + KVB > p.Sk) || (CAUSAL && kv0 + KVB - 1 > q0 + off);
@@ -356,6 +368,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_bf16_kernel(AttnArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
     }
+#endif
     AP_ST(t, 3);
     // ---- O^T += V^T . P^T ----
     if constexpr (PSWAP && FRAG_AHEAD) {

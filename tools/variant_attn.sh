@@ -1,6 +1,6 @@
 #!/bin/bash
 # timing experiments on the prefill attention kernel: rebuild a3v_attn.hip with -D switches that remove one ingredient
-# (results are wrong by construction; only the time is read).  usage: tools/variant_attn.sh "" -DAP_NO_EXP -DAP_NO_BAR ...
+# (results are wrong by construction; only the time is read).  usage: tools/variant_attn.sh "" -DAP_NO_EXP -DAP_NO_QK -DAP_NO_PV -DAP_NO_SM -DAP_NO_DMA -DAP_NO_BAR ...
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 for v in "$@"; do
   echo "=== variant: '$v'"
