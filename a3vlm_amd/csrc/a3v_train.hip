@@ -1084,6 +1084,92 @@ extern "C" int a3v_adamw_scaled(float* param, const float* grad, float* exp_avg,
   return A3V_OK;
 }
 
+// ------------------------------------------------------------------ AdamW of a [rows, cols] matrix that also writes the TRANSPOSED bf16 image
+// Full fine-tune input gradients run as dX = dY . (W^T)^T on the NT ring kernel (the NN kernel's transpose reads make it 5-10 % slower
+// per product): W^T [cols][ldt] has to follow W every step.  A separate a3v_transpose pass re-reads and re-writes 4 B per parameter
+// (13.5 GB at 7B, ~6 ms); here the update walks the matrix in 64 x 64 tiles (256-B row segments: every fp32 line still whole), and the
+// bf16 tile leaves twice -- as rows of the forward image and, through an 8.3-KiB LDS patch, as 128-B row segments of the transposed one:
+// +2 B per parameter.  Same expressions as adamw_kernel, element for element.
+namespace {
+template <int TR>                                  // tile rows: 128 where rows % 128 == 0 (256-B segments of the transposed image), else 64
+__global__ __launch_bounds__(256) void adamw_tile_t_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                           float* __restrict__ v, int rows, int cols, float decay, float b1, float b2,
+                                                           float step_size, float inv_bc2_sqrt, float eps, bf16_t* __restrict__ img,
+                                                           bf16_t* __restrict__ imgt, int64_t ldt, const float* __restrict__ gscale) {
+  const float gs = gscale ? *gscale : 1.f;
+  if (!(gs >= 0.f)) return;
+  constexpr int PITCH = TR + 2;                   // bf16 elements per patch row (c-major: patch[c][r]); an odd number of dwords
+  __shared__ bf16_t patch2[2][64 * PITCH];        // alternating patches: ONE barrier per tile (a patch is re-written two tiles later, behind the next tile's barrier)
+  int flip = 0;
+  const int tid = threadIdx.x, tr = tid >> 4, tc = tid & 15;
+  const int tiles_c = cols >> 6, ntiles = (rows / TR) * tiles_c;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int r0 = (t / tiles_c) * TR, c0 = (t % tiles_c) << 6;
+    bf16_t* patch = patch2[flip];
+    flip ^= 1;
+#pragma unroll
+    for (int ps = 0; ps < TR / 16; ++ps) {
+      const int r = ps * 16 + tr;
+      const int64_t i = ((int64_t)(r0 + r) * cols + c0 + tc * 4) >> 2;
+      f32x4 pp = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p) + i);
+      f32x4 gg = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g) + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) gg[e] = __fmul_rn(gg[e], gs);
+      f32x4 mm = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(m) + i);
+      f32x4 vv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(v) + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        pp[e] *= decay;
+        mm[e] += (1.f - b1) * (gg[e] - mm[e]);
+        vv[e] = b2 * vv[e] + (1.f - b2) * gg[e] * gg[e];
+        pp[e] -= step_size * mm[e] / (sqrtf(vv[e]) * inv_bc2_sqrt + eps);
+      }
+      __builtin_nontemporal_store(pp, reinterpret_cast<f32x4*>(p) + i);
+      __builtin_nontemporal_store(mm, reinterpret_cast<f32x4*>(m) + i);
+      __builtin_nontemporal_store(vv, reinterpret_cast<f32x4*>(v) + i);
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = f2bf(pp[e]);
+        patch[(tc * 4 + e) * PITCH + r] = o[e];
+      }
+      if (img) __builtin_nontemporal_store(o, reinterpret_cast<bf16x4*>(img) + i);
+    }
+    __syncthreads();
+    constexpr int LPR = TR / 4;                   // lanes per transposed row (8-B pieces): 16 or 32
+#pragma unroll
+    for (int ps = 0; ps < 64 * LPR / 256; ++ps) {
+      const int c = ps * (256 / LPR) + tid / LPR, rq = (tid % LPR) * 4;
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = patch[c * PITCH + rq + e];
+      __builtin_nontemporal_store(o, reinterpret_cast<bf16x4*>(imgt + (int64_t)(c0 + c) * ldt + r0 + rq));
+    }
+  }
+}
+}  // namespace
+
+extern "C" int a3v_adamw_scaled_t(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int rows, int cols, float lr,
+                                  float beta1, float beta2, float eps, float weight_decay, int64_t step, void* bf16_image,
+                                  void* bf16_image_t, int64_t ldt, const float* grad_scale, void* stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || !bf16_image_t || rows <= 0 || cols <= 0 || step < 1) return A3V_ERR_ARG;
+  if ((rows & 63) || (cols & 63) || ldt < rows || (ldt & 3)) return A3V_ERR_SHAPE;
+  if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return A3V_ERR_SHAPE;
+  if ((bf16_image && ((uintptr_t)bf16_image & 7)) || ((uintptr_t)bf16_image_t & 7)) return A3V_ERR_SHAPE;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr / bc1), inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+  const float decay = (float)(1.0 - (double)lr * (double)weight_decay);
+  const int tr = (rows & 127) || A3V_ENV_INT("A3V_ADAMW_T_ROWS", 128) == 64 ? 64 : 128;
+  int64_t blocks = (int64_t)(rows / tr) * (cols >> 6);
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  if (tr == 128) hipLaunchKernelGGL(adamw_tile_t_kernel<128>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, rows, cols,
+                                    decay, beta1, beta2, step_size, inv_bc2_sqrt, eps, (bf16_t*)bf16_image, (bf16_t*)bf16_image_t, ldt, grad_scale);
+  else hipLaunchKernelGGL(adamw_tile_t_kernel<64>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, rows, cols,
+                          decay, beta1, beta2, step_size, inv_bc2_sqrt, eps, (bf16_t*)bf16_image, (bf16_t*)bf16_image_t, ldt, grad_scale);
+  A3V_LAUNCH_CHECK();
+  return A3V_OK;
+}
+
 // ------------------------------------------------------------------ adapter gradients: the diagonal blocks of a fused group's dB^T
 // dB^T [Rp, N] = t^T . dy is computed for the whole fused group (block-diagonal B: only rows j r .. (j+1) r of the columns of module j
 // matter); module j's gradient [n_j, r] += the transpose of its block.  One launch per group (was one torch add_ per module).

@@ -114,6 +114,7 @@ class FusedAdamW(torch.optim.Optimizer):
         else:
             stream = cur.cuda_stream
         written = set()
+        written_t = set()
         adapters = set()
         last = None
         small = {}                             # id(group) -> [(p, sink)] handled by the multi-tensor launch (not with overlap: per-bucket events)
@@ -125,6 +126,8 @@ class FusedAdamW(torch.optim.Optimizer):
                         continue
                     img = self.image_of(p) if self.image_of is not None else None
                     sink = None
+                    if img is not None and self.engine is not None and hasattr(self.engine, "image_sink_t") and self.engine.image_sink_t(p) is not None:
+                        continue                     # a matrix whose transposed image is in use: the per-tensor a3v_adamw_scaled_t launch below
                     if img is not None:
                         if img.dtype != torch.bfloat16 or img.shape != p.shape or not img.is_contiguous():
                             raise RuntimeError("image_of must return a contiguous bf16 tensor of the parameter's shape")
@@ -158,10 +161,20 @@ class FusedAdamW(torch.optim.Optimizer):
             img = self.image_of(p) if self.image_of is not None else None
             if img is not None and (img.dtype != torch.bfloat16 or img.shape != p.shape or not img.is_contiguous()):
                 raise RuntimeError("image_of must return a contiguous bf16 tensor of the parameter's shape")
-            rc = lib.a3v_adamw_scaled(p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(),
-                                      float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
-                                      int(st["step"].item()), img.data_ptr() if img is not None else None, gs_ptr, stream)
-            _l.check(rc, "a3v_adamw_scaled")
+            imgt = self.engine.image_sink_t(p) if (img is not None and self.engine is not None and hasattr(self.engine, "image_sink_t")) else None
+            if imgt is not None and p.is_contiguous():
+                # full fine-tune with input gradients on the NT kernel: the same pass also writes p's columns of the transposed image
+                rc = lib.a3v_adamw_scaled_t(p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                                            p.shape[0], p.shape[1], float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                            float(group["weight_decay"]), int(st["step"].item()), img.data_ptr(), imgt[0].data_ptr(),
+                                            imgt[1], gs_ptr, stream)
+                _l.check(rc, "a3v_adamw_scaled_t")
+                written_t.add(id(p))
+            else:
+                rc = lib.a3v_adamw_scaled(p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(),
+                                          float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
+                                          int(st["step"].item()), img.data_ptr() if img is not None else None, gs_ptr, stream)
+                _l.check(rc, "a3v_adamw_scaled")
             # the kernel wrote through raw pointers: tell autograd / version-keyed caches (the engine's bf16 weight images)
             torch.autograd.graph.increment_version(p)
             if img is not None:
@@ -200,7 +213,10 @@ class FusedAdamW(torch.optim.Optimizer):
         if overlap:
             self.engine._weights_ready[last if last is not None else "head"] = self._stream.record_event()
         if self.engine is not None:
-            self.engine.images_adopted(written)
+            if written_t:
+                self.engine.images_adopted(written, written_t)
+            else:
+                self.engine.images_adopted(written)
             if adapters and hasattr(self.engine, "adapters_adopted"):
                 self.engine.adapters_adopted(adapters)
         return loss

@@ -48,7 +48,7 @@ class TrainEngine:
     # A/B and test hooks (environment A3V_FUSE_QKV_ROPE=0 / A3V_TN_WGRAD=0 / A3V_NN_DGRAD=0 flips the default for a whole process)
     fuse_qkv_rope = os.environ.get("A3V_FUSE_QKV_ROPE", "1") != "0"   # qkv GEMM with the RoPE / cache-write epilogue
     tn_wgrad = os.environ.get("A3V_TN_WGRAD", "1") != "0"              # weight gradients by a3v_gemm_tn (else transposes + NT)
-    nn_dgrad = os.environ.get("A3V_NN_DGRAD", "1") != "0"              # input gradients by a3v_gemm_nn (else NT on W^T images)
+    nn_dgrad = os.environ.get("A3V_NN_DGRAD", "1") != "0"              # input gradients by a3v_gemm_nn (else NT on W^T images); unset: see __init__
     packed_attn_bwd = os.environ.get("A3V_PACKED_ATTN_BWD", "1") != "0"  # attention backward writes the rotated-back qkv gradient itself
     lora_kext = os.environ.get("A3V_LORA_KEXT", "1") != "0"            # adapters inside the main GEMMs: [x | t] . [W | B]^T (K extended by Rp)
     # LoRA input gradients dx = [dy | dt] . [W ; A]: the base matrices are FROZEN, so a transposed image [W^T | A^T] can be kept for
@@ -96,6 +96,11 @@ class TrainEngine:
         self._saved = None
         self._weights_ready: Dict[str, torch.cuda.Event] = {}   # bucket -> event of FusedAdamW.step(overlap=True), see await_weights
         self.zero1_world = int(zero1_world or 0)
+        if "A3V_NN_DGRAD" not in os.environ:
+            # full fine-tune (round 5): input gradients on the NT ring kernel over transposed images W^T that a3v_adamw_scaled_t keeps
+            # current in the optimizer pass (+2 B of writes per parameter; same-box 336.0 -> 328 ms per 7B step).  ZeRO-1 updates flat
+            # slices (no per-matrix pass to write W^T from): the NN kernel on the forward images stays there.
+            self.nn_dgrad = bool(self.zero1_world)
         self._flat_params: Optional[torch.Tensor] = None    # zero1: the sharded parameters' storage (compute dtype, flat-gradient layout)
         self._z1: List[tuple] = []                          # zero1: (bucket, start, end, shard_start, shard_end, [(seg_start, seg_end, name)])
         self._z1_fresh = True                               # zero1: the sharded gradients restart (store / zero) at the next backward
@@ -117,8 +122,16 @@ class TrainEngine:
         """Where the optimizer may store the bf16 value of the updated parameter p (its rows of the fused forward image)."""
         return self._images().sink(p)
 
-    def images_adopted(self, written_ids) -> None:
-        self._images().adopted(written_ids)
+    def image_sink_t(self, p: torch.Tensor):
+        """(bf16 view of p's columns inside the TRANSPOSED image of its fused matrix, row stride) when that image is in use (full
+        fine-tune input gradients on the NT kernel) -- ``a3v_adamw_scaled_t`` then keeps it current; else None."""
+        if self.nn_dgrad or self.lora:
+            return None
+        return self._images().sink_t(p)
+
+    def images_adopted(self, written_ids, written_t_ids=()) -> None:
+        self._opt_stepped = True
+        self._images().adopted(written_ids, written_t_ids)
 
     def forward_order(self):
         """Gradient buckets in the order the forward first touches their parameters: ``FusedAdamW.step(overlap=True)`` updates
@@ -797,6 +810,11 @@ class TrainEngine:
             # full fine-tune: the same epilogue on the NN kernel (dX = dY . W on the forward image)
             dgu = self._buf("dgu", (rows, 2 * F))
             ops.gemm_nn(dha, im[f"w2.{i}"], dgu, residual=k["gu"], epilogue=ops.EPI_SWIGLU_BWD)
+        elif (not self.lora and self.fuse_swiglu_bwd and not self.nn_dgrad and self.act == torch.bfloat16 and dim % 64 == 0 and F % 8 == 0
+              and dha.stride(0) % 8 == 0 and tuple(im[f"w2.{i}.t"].shape) == (F, dim)):
+            # full fine-tune with input gradients on the NT ring kernel (W^T images): the same epilogue there
+            dgu = self._buf("dgu", (rows, 2 * F))
+            ops.gemm_nt(dha, im[f"w2.{i}.t"], dgu, residual=k["gu"], epilogue=ops.EPI_SWIGLU_BWD)
         else:
             dact = self._buf("dact", (rows, F))
             if kx:
@@ -943,6 +961,19 @@ class TrainEngine:
         self.sync_optimizer()                    # the update reads the gradients this backward overwrites
         im = self._images()
         self.ensure_grads()
+        if not self.nn_dgrad and not self.lora and not getattr(self, "_nt_mem_checked", False):
+            # the transposed images cost 2 B per matrix parameter (12.3 GiB at 7B, 23.9 at 13B): on a replica that would not leave
+            # 8 GiB free after them (13B at DP 8 with persistent wire buckets is at 270 of 288 GiB), stay on the NN kernel
+            self._nt_mem_checked = True
+            need = 2 * sum(q.numel() for g_ in im.groups() if g_ != "vp" for q in im._params(g_)[0])
+            if not getattr(self, "_opt_stepped", False):          # the AdamW moments (8 B per trainable parameter) are allocated by the first step
+                need += 8 * sum(q.numel() for q in m.parameters() if q.requires_grad)
+            free, _ = torch.cuda.mem_get_info(m._device)
+            free += torch.cuda.memory_reserved(m._device) - torch.cuda.memory_allocated(m._device)
+            # (a replica that recomputes its blocks is one sized against the HBM limit -- 13B at micro-batch 4: measured 452.5 / 453.7 ms
+            # with the transposed images against 455.5 / 452.4 without, for 24 GiB: not taken there unless A3V_NN_DGRAD=0 asks for it)
+            if free - need < 8 * 2 ** 30 or (self.recompute and "A3V_NN_DGRAD" not in os.environ):
+                self.nn_dgrad = True
         if self.sumsq_sink is not None:
             self.sumsq_sink.begin_backward()
         B, T, W, S = s["B"], s["T"], s["W"], s["S"]
@@ -1125,7 +1156,10 @@ class _Images:
                 wp = wa
             wt = self.store.get(key)
             if wt is None or wt.shape != (K, Np) or wt.dtype != act:
-                wt = torch.empty(K, Np, dtype=act, device=wa.device)
+                # row pitch off the powers of two: a3v_adamw_scaled_t writes 64 rows of this image per tile, and at an 8-KiB pitch they
+                # all fall on the same HBM channels (w2 / wo at 7B: 281 vs 255 us per update)
+                ld = Np + 64 if (Np * wa.element_size()) % 4096 == 0 else Np
+                wt = torch.empty(K, ld, dtype=act, device=wa.device)[:, :Np]
             ops.transpose(wp, wt, Np, K, Np)
             self.store[key] = wt
             self.tver[key] = ver
@@ -1174,12 +1208,32 @@ class _Images:
             return None
         return img[ent[1]:ent[1] + p.shape[0]] if img.dim() == 2 else img
 
-    def adopted(self, written_ids) -> None:
-        """The optimizer wrote the bf16 values of these parameters into their images: groups written completely are current."""
+    def sink_t(self, p):
+        """(columns of parameter p inside the transposed image of its fused matrix [K, Np], Np) -- only once that image exists (the
+        first backward built it) and p is a 64-aligned block of it."""
+        if self.eng.act != torch.bfloat16 or p.dim() != 2 or (p.shape[0] & 63) or (p.shape[1] & 63):
+            return None
+        self.sink(p)                                   # (builds the parameter -> (key, row) map)
+        ent = self._sinks.get(id(p))
+        if ent is None or ent[0].endswith(".b"):
+            return None
+        wt = self.store.get(ent[0] + ".t")
+        if wt is None or wt.dtype != torch.bfloat16 or wt.dim() != 2 or wt.shape[0] != p.shape[1] or ent[1] + p.shape[0] > wt.shape[1] \
+                or (ent[1] & 3) or self.tver.get(ent[0] + ".t") is None:
+            return None
+        return wt[:, ent[1]:ent[1] + p.shape[0]], int(wt.stride(0))
+
+    def adopted(self, written_ids, written_t_ids=()) -> None:
+        """The optimizer wrote the bf16 values of these parameters into their images: groups written completely are current (and
+        the transposed image of a fused matrix whose every parameter also went through ``a3v_adamw_scaled_t``)."""
         for g in self.groups():
-            ps, _ = self._params(g)
+            ps, where = self._params(g)
             if g in self.ver and all(id(q) in written_ids for q in ps):
+                old = self.ver[g]
                 self.ver[g] = self._key(ps)
+                for key in {k for k, _ in where}:
+                    if self.tver.get(key + ".t") == old and all(id(q) in written_t_ids for q, (k, _) in zip(ps, where) if k == key):
+                        self.tver[key + ".t"] = self.ver[g]
 
     def __getitem__(self, key: str) -> torch.Tensor:
         eng, m = self.eng, self.eng.m
@@ -1232,14 +1286,14 @@ def step_loss(engine: TrainEngine, anchor: torch.Tensor, examples, labels, image
 
 def hbm_budget(dim: int, n_layers: int, n_heads: int, ffn: int, vocab: int, batch: int, seq: int, text: int, n_kv_heads: Optional[int] = None,
                vit_params: int = 304_000_000, proj_in: int = 1024, world: int = 1, wire_bytes: int = 2, recompute: bool = False,
-               stream_bytes: int = 2, zero1: bool = False) -> Dict[str, int]:
+               stream_bytes: int = 2, zero1: bool = False, transposed_images: bool = False) -> Dict[str, int]:
     """Bytes of one pure-DP replica of the FULL fine-tune (every rank of a DP job holds exactly this; SURVEY 7 "13B full fine-tune
     memory", main_finetune.py:241-276): what ``TrainEngine`` + ``FusedAdamW`` + ``dp.GradReducer`` allocate, from their own layouts.
     fp32 masters / flat gradient buffer / two AdamW moments of every trainable parameter, the bf16 GEMM images of the decoder and
     head matrices, the frozen bf16 ViT, the reducer's persistent wire buckets (``wire_bytes`` per gradient element when world > 1
     and the wire dtype is not fp32), the residual-stream checkpoints [L+1, rows, dim] (``stream_bytes`` per element: 2 = the bf16 stream
     of round 3 on, 4 = the fp32 stream of rounds 1-2), the block intermediates (per layer when activations are stored, once when
-    blocks are recomputed), and the CE buffers.  Checked against the measured peaks of the bench
+    blocks are recomputed), and the CE buffers; ``transposed_images``: + the W^T images of the round-5 default.  Checked against the measured peaks of the bench
     (tests/test_dp_cpu.py::test_dp_replica_fits_288_gib)."""
     hkv = n_kv_heads or n_heads
     hd = dim // n_heads
@@ -1268,6 +1322,8 @@ def hbm_budget(dim: int, n_layers: int, n_heads: int, ffn: int, vocab: int, batc
             "masters_fp32": 4 * p_train, "grads_fp32": 4 * p_train, "adamw_moments_fp32": 8 * p_train, "images_bf16": 2 * p_mat,
             "vit_bf16": 2 * vit_params,
             "wire_buckets": wire_bytes * p_train if world > 1 and wire_bytes != 4 else 0}
+    if transposed_images and not zero1:
+        out["images_t_bf16"] = 2 * p_mat          # W^T of every decoder / head matrix (round 5: input gradients on the NT kernel, a3v_adamw_scaled_t)
     out.update({
         "stream_checkpoints": (n_layers + 1) * rows * dim * sb + rows * dim * sb,
         "block_activations": block * (1 if recompute else n_layers),

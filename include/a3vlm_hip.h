@@ -469,6 +469,14 @@ int a3v_lora_gb_scatter(const float* gbt, int64_t ld, int r, int n_mods, float* 
  * LDS: three per CU) so that the stream of X has several stages in flight per CU. */
 int a3v_gemm_tn_strip(const void* T, int64_t ldt, const void* X, int64_t ldx, float* partial, int R, int N, int Kt, int S, void* stream);
 
+/* a3v_adamw_scaled for a [rows, cols] matrix (rows, cols multiples of 64) that ALSO keeps the transposed bf16 image current:
+ * bf16_image_t points at element [0][first row of this parameter] of W^T [cols][ldt] (ldt >= rows, multiple of 4; 8-B aligned), the
+ * operand of the full fine-tune's input-gradient GEMMs on the NT kernel (loss.backward() through F.linear, engine_finetune.py:55-57;
+ * optimizer.step(), :63).  bf16_image (optional) as in a3v_adamw.  Arithmetic identical to a3v_adamw_scaled. */
+int a3v_adamw_scaled_t(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int rows, int cols, float lr, float beta1,
+                       float beta2, float eps, float weight_decay, int64_t step, void* bf16_image, void* bf16_image_t, int64_t ldt,
+                       const float* grad_scale, void* stream);
+
 /* The same update for MANY small tensors of one torch param group in ONE launch (a LoRA step: ~520 adapter / norm tensors; was one
  * launch per tensor plus one a3v_lora_refresh per adapter).  `table` is a DEVICE array of n_tensors descriptors (built once by the
  * host, a3vlm_amd/optim.py); every pointer 16-byte aligned, fp32 contiguous p / g / m / v of n elements viewed as [n / cols, cols].

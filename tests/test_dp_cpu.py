@@ -199,6 +199,11 @@ def test_dp_replica_fits_288_gib():
     d13 = hbm_budget(5120, 40, 40, 13824, 32000, batch=4, seq=1091, text=512, recompute=True, world=8)
     assert d7["wire_buckets"] == 2 * (b7["masters_fp32"] // 4) and d13["wire_buckets"] > 24 * G
     assert d7["total"] < 288 * G * 0.95 and d13["total"] < 288 * G * 0.95          # 5 % left for the allocator / RCCL buffers
+    # round 5: + the transposed images of the NT input-gradient path (the engine falls back to the NN kernel below 8 GiB of headroom)
+    t7 = hbm_budget(4096, 32, 32, 11008, 32000, batch=8, seq=1091, text=512, world=8, transposed_images=True)
+    t13 = hbm_budget(5120, 40, 40, 13824, 32000, batch=4, seq=1091, text=512, recompute=True, world=8, transposed_images=True)
+    assert t7["images_t_bf16"] == t7["images_bf16"] and t7["total"] == d7["total"] + t7["images_bf16"]
+    assert t7["total"] < 288 * G * 0.95 and t13["total"] < 288 * G * 0.95
     # an fp32 wire needs no extra buckets (reduced in place); 13B with stored activations at micro-batch 8 does NOT fit -> recompute
     assert hbm_budget(5120, 40, 40, 13824, 32000, 4, 1091, 512, recompute=True, world=8, wire_bytes=4)["wire_buckets"] == 0
     assert hbm_budget(5120, 40, 40, 13824, 32000, 8, 1091, 512, recompute=False, world=8)["total"] > 288 * G

@@ -2,6 +2,7 @@
 (oracle/ref_cpu.py is built from differentiable torch ops, so its autograd IS the reference gradient:
 engine_finetune.py:44-68 semantics).  fp32 parity path: 1e-3 relative; bf16 compute: stated per check."""
 import math
+import os
 
 import pytest
 import torch
@@ -590,3 +591,100 @@ def test_overlapped_optimizer_step_equals_in_line_step(with_visual):
         assert torch.equal(a, b)
         assert torch.equal(oa.state[a]["exp_avg_sq"], ob.state[b]["exp_avg_sq"]) and float(oa.state[a]["step"]) == float(ob.state[b]["step"]) == 3
     assert torch.equal(ea._images()["qkv.1"], eb._images()["qkv.1"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,cols,row0,ld", [(256, 192, 0, 256), (128, 128, 64, 320), (192, 64, 128, 324), (1024, 512, 512, 2048 + 64)])
+def test_adamw_with_transposed_image_equals_adamw_then_transpose(rows, cols, row0, ld):
+    """a3v_adamw_scaled_t (round 5): same fp32 update and forward image as a3v_adamw_scaled, bit for bit, and the parameter's columns of
+    the transposed image [cols][ld] = the forward image transposed; nothing else of that image is touched; a negative scale is a no-op."""
+    from a3vlm_amd import lib as _l
+    lib = _l.load()
+    g = torch.Generator().manual_seed(rows + cols)
+    p = torch.randn(rows, cols, generator=g).to(DEV)
+    gr = (torch.randn(rows, cols, generator=g) * 0.1).to(DEV)
+    m = (torch.randn(rows, cols, generator=g) * 0.01).to(DEV)
+    v = (torch.rand(rows, cols, generator=g) * 1e-3).to(DEV)
+    p2, m2, v2 = p.clone(), m.clone(), v.clone()
+    img, img2 = torch.zeros(rows, cols, device=DEV, dtype=BF), torch.zeros(rows, cols, device=DEV, dtype=BF)
+    wt = torch.full((cols, ld), 7.0, device=DEV, dtype=BF)
+    view = wt[:, row0:row0 + rows]
+    st = torch.cuda.current_stream().cuda_stream
+    for step, scale in ((1, 0.7), (2, 1.0), (3, -1.0)):
+        gs = torch.tensor([scale], device=DEV)
+        assert lib.a3v_adamw_scaled(p.data_ptr(), gr.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), 1e-2, 0.9, 0.95, 1e-8, 0.1, step,
+                                    img.data_ptr(), gs.data_ptr(), st) == 0
+        assert lib.a3v_adamw_scaled_t(p2.data_ptr(), gr.data_ptr(), m2.data_ptr(), v2.data_ptr(), rows, cols, 1e-2, 0.9, 0.95, 1e-8, 0.1, step,
+                                      img2.data_ptr(), view.data_ptr(), wt.stride(0), gs.data_ptr(), st) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(p, p2) and torch.equal(m, m2) and torch.equal(v, v2) and torch.equal(img, img2)
+        assert torch.equal(view, img.t())
+    rest = wt.clone()
+    rest[:, row0:row0 + rows] = 7.0
+    assert bool((rest == 7.0).all())
+    # shapes the tiled kernel does not take are refused, not mangled
+    assert lib.a3v_adamw_scaled_t(p2.data_ptr(), gr.data_ptr(), m2.data_ptr(), v2.data_ptr(), rows - 1, cols, 1e-2, 0.9, 0.95, 1e-8, 0.1, 1,
+                                  img2.data_ptr(), view.data_ptr(), wt.stride(0), None, st) != 0
+
+
+@pytest.mark.gpu
+def test_full_fine_tune_nt_input_gradients_keep_their_transposed_images_current():
+    """Full fine-tune default (round 5): input gradients on the NT kernel over W^T images that FusedAdamW re-writes in its own pass
+    (a3v_adamw_scaled_t).  Two identical models -- NN input gradients on the forward images / NT on the transposed ones -- fed the
+    SAME gradients: parameters and losses stay bit-equal over three steps, every transposed image equals its forward image after
+    every update, and no a3v_transpose runs after the first backward built them."""
+    from a3vlm_amd.dp import clip_grad_norm
+    from a3vlm_amd.optim import FusedAdamW
+    big = dict(dim=512, n_layers=2, n_heads=4, n_kv_heads=4, vocab_size=1024, multiple_of=256, max_seq_len=512)
+    g = torch.Generator().manual_seed(33)
+    B, T = 2, 96
+    exs = [torch.randint(3, 1024, (B, T), generator=g) for _ in range(3)]
+    side = []
+    for nn in (True, False):
+        m = plugin.Transformer(plugin.ModelArgs(**big), with_visual=False)
+        m.load_state_dict(ref_cpu.make_decoder_weights(ref_cpu.OracleArgs(**big), seed=5, std=0.05))
+        m.to(BF).to(DEV)
+        promote_trainable_params_to_fp32(m)
+        eng = TrainEngine(m, BF)
+        assert eng.nn_dgrad is False or "A3V_NN_DGRAD" in os.environ      # the default of a plain (non-ZeRO-1, non-LoRA) engine
+        eng.nn_dgrad = nn
+        params = [p for p in m.parameters() if p.requires_grad]
+        side.append((eng, params, FusedAdamW(params, lr=1e-2, betas=(0.9, 0.95), weight_decay=0.1, engine=eng)))
+    (ea, pa, oa), (eb, pb, ob) = side
+    calls = {"n": 0}
+    real = ops.transpose
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+
+    ops.transpose = counting
+    try:
+        after_first = None
+        for it, ex in enumerate(exs):
+            ex = ex.to(DEV)
+            ex[:, 0] = 1
+            la, lb = ea.forward_loss(ex, ex, None).clone(), eb.forward_loss(ex, ex, None).clone()
+            assert float(la) == float(lb)
+            ea.backward(1.0)
+            eb.backward(1.0)
+            if it == 0:
+                after_first = calls["n"]
+                assert after_first > 0                     # the first backward built the transposed images
+            rel = float((eb.flat_grads() - ea.flat_grads()).norm() / ea.flat_grads().norm())
+            assert rel < 2e-3, rel                          # NN vs NT input gradients: same products, another accumulation order
+            eb.flat_grads().copy_(ea.flat_grads())
+            _, coef = clip_grad_norm(pa, 0.5, flat=ea.flat_grads(), defer=True)
+            oa.step(grad_scale=coef)
+            ob.step(grad_scale=coef)
+            oa.zero_grad(set_to_none=True)
+            ob.zero_grad(set_to_none=True)
+            im = eb._images()
+            for key in ("qkv.0", "wo.1", "w13.0", "w2.1", "out"):
+                w, wt = im.store[key], im.store[key + ".t"]
+                assert torch.equal(wt[:, :w.shape[0]], w.t()), key
+        assert calls["n"] == after_first, "a transposed image was rebuilt by a3v_transpose after an optimizer step"
+    finally:
+        ops.transpose = real
+    for a, b in zip(pa, pb):
+        assert torch.equal(a, b)
