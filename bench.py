@@ -269,7 +269,7 @@ def time_gemm_shapes(args, B, T, W, dev, train=True):
         (vr, 3 * w, w, Lv, 0), (vr, w, w, Lv, ops.EPI_RESIDUAL), (vr, 4 * w, w, Lv, ops.EPI_GELU), (vr, w, 4 * w, Lv, ops.EPI_RESIDUAL),
         (vr, d, w, 1, 0), (B * g * g, w, 640, 1, 0),
     ]
-    fam = {"nt": [0.0, 0.0], "nn": [0.0, 0.0], "tn": [0.0, 0.0], "nt_dgrad": [0.0, 0.0]}
+    fam = {"nt": [0.0, 0.0], "nn": [0.0, 0.0], "tn": [0.0, 0.0], "nt_dgrad": [0.0, 0.0], "nt_dgrad_ft": [0.0, 0.0]}
     table = []
     # the legs before this one end with frees / allocator work on the host: bring the part back to its loaded clock first
     # (the first shape timed after an idle gap read 15 % low)
@@ -313,6 +313,12 @@ def time_gemm_shapes(args, B, T, W, dev, train=True):
             fam["nt_dgrad"][0] += fl * Lyr
             fam["nt_dgrad"][1] += dt * Lyr
             table.append(dict(kind="nt_dgrad", M=M, N=K, K=N + 64, count=Lyr, us=round(dt * 1e6, 1), tflops=round(fl / dt / 1e12, 1)))
+            # the full fine-tune's form since round 5: dx = dy . (W^T)^T on the NT ring kernel over the transposed image the AdamW pass
+            # keeps current (a3v_adamw_scaled_t); the NN family above is what the ZeRO-1 / recompute engines still run
+            dt = _events(lambda: ops.gemm_nt(dy[:, :N], wt_img[:, :N], dx))
+            fam["nt_dgrad_ft"][0] += fl * Lyr
+            fam["nt_dgrad_ft"][1] += dt * Lyr
+            table.append(dict(kind="nt_dgrad_ft", M=M, N=K, K=N, count=Lyr, us=round(dt * 1e6, 1), tflops=round(fl / dt / 1e12, 1)))
             dt = _events(lambda: ops.gemm_tn(dy[:, :N], x, gw, epilogue=ops.EPI_OUT_F32))
             fam["tn"][0] += fl * Lyr
             fam["tn"][1] += dt * Lyr
@@ -1355,12 +1361,12 @@ def main():
         def _roof():
             fam, table = time_gemm_shapes(args, B, T, W, dev, train=bool({"train", "lora"} & legs))
             # families of the headline step: LoRA = forward (NT) + input gradients, which the LoRA engine runs on the NT ring kernel over
-            # the transposed frozen images (nt_dgrad); the frozen matrices have no weight-gradient GEMMs.  Full fine-tune = NT + NN
-            # (input gradients on the forward image) + TN (weight gradients); inference forward = NT only
-            use = {"lora": ("nt", "nt_dgrad"), "train": ("nt", "nn", "tn"), "forward": ("nt",)}[headline]
+            # the transposed frozen images (nt_dgrad); the frozen matrices have no weight-gradient GEMMs.  Full fine-tune = NT + NT input gradients over
+            # the AdamW-written transposed images (round 5; NN on the forward image before) + TN (weight gradients); inference forward = NT only
+            use = {"lora": ("nt", "nt_dgrad"), "train": ("nt", "nt_dgrad_ft", "tn"), "forward": ("nt",)}[headline]
             tot_f = sum(fam[k][0] for k in use)
             tot_t = sum(fam[k][1] for k in use)
-            ft = ("nt", "nn", "tn")
+            ft = ("nt", "nt_dgrad_ft", "tn")
             all_f = sum(fam[k][0] for k in ft)
             all_t = sum(fam[k][1] for k in ft)
             try:      # what the matrix pipe delivers on this box under its power limit (bare MFMA stream; context, not the price)
