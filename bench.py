@@ -1189,6 +1189,100 @@ def in_step_ring_ms(headline):
             "kernels": "gemm_nt_bf16_ring_kernel<...>" + (" + gemm_tn_bf16_pp_kernel<...>" if headline == "train" else "")}
 
 
+_NOTE_KEYS = ("note", "flop_convention", "pipeline", "assumptions", "source")
+
+
+def _strip_notes(o, path, notes):
+    """Move the long prose fields of every leg out of the JSON line (they go to profiles/bench_notes.md): the driver keeps the last
+    8 KB of stdout, and round 5's line had grown past it (the forward / decode legs fell out of the driver-held record)."""
+    if isinstance(o, dict):
+        for k in list(o):
+            v = o[k]
+            if k in _NOTE_KEYS and isinstance(v, str) and len(v) > 60:
+                notes[path + k] = o.pop(k)
+            elif k == "config" and isinstance(v, str) and len(v) > 60 and path:
+                notes[path + k] = o.pop(k)
+            else:
+                _strip_notes(v, path + k + ".", notes)
+    elif isinstance(o, list):
+        for i, v in enumerate(o):
+            _strip_notes(v, path + f"{i}.", notes)
+
+
+def _g(d, *path):
+    for k in path:
+        if not isinstance(d, dict) or d.get(k) is None:
+            return None
+        d = d[k]
+    return d
+
+
+def finalize_line(out):
+    """(line, notes): the bench line as it is printed.  Scalars of the north-star legs are copied INTO `roofline` (the driver's parsed
+    record keeps that object's scalars), the prose leaves the line, and a compact `summary` of every leg's ms / fraction is the LAST
+    key so that any tail of the line a few KB long contains it."""
+    notes = {}
+    _strip_notes(out, "", notes)
+    roof = out.get("roofline")
+    if isinstance(roof, dict) and "error" not in roof:
+        tr = roof.get("traffic") or {}
+        ins = roof.get("in_step") or {}
+        scal = {
+            "forward_ms": _g(out, "forward", "ms_per_step"), "forward_mfma_frac": _g(out, "forward", "mfma_frac"),
+            "decode_tok_s": _g(out, "decode", "tok_s"), "decode_hbm_frac": _g(out, "decode", "roofline", "frac"),
+            "in_step_ms": ins.get("ms_per_step"), "in_step_file": ins.get("file"),
+            "in_step_frac": (round(roof["achieved"] * roof.get("gemm_ms_per_step", 0) / ins["ms_per_step"] / roof["peak"], 4)
+                             if ins.get("ms_per_step") and roof.get("gemm_ms_per_step") else None),
+            "traffic_ratio": (round(tr["bytes_per_launch"] / tr["algorithmic_bytes_per_launch"], 3)
+                              if tr.get("bytes_per_launch") and tr.get("algorithmic_bytes_per_launch") else None),
+            "l2_hit": tr.get("l2_hit_rate"), "mfma_busy": tr.get("mfma_busy_frac_of_gui_active"),
+        }
+        # scalars first, the big tables (traffic / families / shapes) behind them
+        big = {k: roof.pop(k) for k in list(roof) if isinstance(roof[k], (dict, list))}
+        roof.update(scal)
+        roof.update(big)
+    rnd = lambda v, n=4: (round(v, n) if isinstance(v, float) else v)  # noqa: E731
+    S = {
+        "headline_ms": out.get("ms_per_step"), "headline_samples_s": out.get("value"),
+        "forward": [_g(out, "forward", "ms_per_step"), _g(out, "forward", "mfma_frac")],
+        "decode": [_g(out, "decode", "ms_per_step"), _g(out, "decode", "tok_s"), _g(out, "decode", "roofline", "frac")],
+        "generate": [_g(out, "generate", "tok_s_end_to_end"), _g(out, "generate", "tok_s_after_prefill")],
+        "decode_fp8": [_g(out, "decode_fp8", "ms_per_step"), _g(out, "decode_fp8", "tok_s"), _g(out, "decode_fp8", "hbm_frac")],
+        "forward_w8a8": [_g(out, "decode_fp8", "forward_w8a8", "ms_per_step"), _g(out, "decode_fp8", "forward_w8a8", "tflops")],
+        "geometry_R": [_g(out, "geometry_R", "forward_ms"), _g(out, "geometry_R", "forward_mfma_frac"), _g(out, "geometry_R", "decode_tok_s"),
+                       _g(out, "geometry_R", "decode_hbm_frac")],
+        "config5_bf16": [_g(out, "config5", "bf16", "forward_ms"), _g(out, "config5", "bf16", "decode_tok_s")],
+        "config5_fp8": [_g(out, "config5", "fp8", "forward_ms"), _g(out, "config5", "fp8", "forward_frac_of_fp8_peak"), _g(out, "config5", "fp8", "decode_tok_s")],
+        "train_lora": [_g(out, "train_lora", "ms_per_step"), _g(out, "train_lora", "mfma_frac")],
+        "train_lora_with_loader": [_g(out, "train_lora_with_loader", "ms_per_step"), _g(out, "train_lora_with_loader", "vs_device_resident_synthetic_step")],
+        "train": [_g(out, "train", "ms_per_step"), _g(out, "train", "mfma_frac")],
+        "recipe_train_lora": [_g(out, "recipe", "train_lora", "ms_per_micro_step"), _g(out, "recipe", "train_lora", "mfma_frac"),
+                              _g(out, "recipe", "train_lora", "attention_share")],
+        "recipe_eval_ctx1500_tok_s": _g(out, "recipe", "eval", "ctx_1500", "tok_s_after_prefill"),
+        "m13b": [_g(out, "m13b", "forward_ms"), _g(out, "m13b", "forward_mfma_frac"), _g(out, "m13b", "decode_tok_s"), _g(out, "m13b", "decode_hbm_frac")],
+        "m13b_train_zero1": [_g(out, "m13b", "train_zero1", "ms_per_step"), _g(out, "m13b", "train_zero1", "mfma_frac_3x")],
+        "m13b_train_replica": [_g(out, "m13b", "train_replica", "ms_per_step"), _g(out, "m13b", "train_replica", "mfma_frac_3x")],
+        "roofline": [_g(out, "roofline", "achieved"), _g(out, "roofline", "frac"), _g(out, "roofline", "in_step_frac")],
+        "families": {k: v.get("frac") for k, v in (_g(out, "roofline", "families") or {}).items()},
+        "cpu": [_g(out, "cpu_baseline", "value"), _g(out, "cpu_baseline", "decode_tok_s"), _g(out, "cpu_baseline", "parity_full_depth_rel_err"),
+                _g(out, "cpu_baseline", "parity_full_depth_decided_frac"), _g(out, "cpu_baseline", "parity_full_depth_agreement")],
+        "errors": sorted(k for k, v in out.items() if isinstance(v, dict) and "error" in v),
+        "legend": "[ms, frac] per leg; decode [ms, tok/s, hbm_frac]; notes: profiles/bench_notes.md",
+    }
+    out.pop("summary", None)
+    out["summary"] = {k: ([rnd(x) for x in v] if isinstance(v, list) else v) for k, v in S.items()}
+    return out, notes
+
+
+def write_notes(notes, path):
+    with open(path, "w") as f:
+        f.write("# bench.py: the prose of every leg (what is measured, conventions, caveats)\n\n"
+                "Moved out of the JSON line in round 6 so that the driver-held tail of the line always contains the numbers.\n"
+                "Keys are the paths the fields had in the line.\n\n")
+        for k in sorted(notes):
+            f.write(f"- `{k}`: {notes[k]}\n")
+
+
 def launch_only(a, rank, world):
     """A3V_BENCH_LAUNCH_ONLY=1 (CPU test of the launch contract, no GPU work): every rank joins a gloo group, one all-reduce
     counts them, rank 0 prints the line's launch fields."""
@@ -1221,6 +1315,13 @@ def main():
     # stdout carries the ONE JSON line and nothing else: whatever the legs print on the way (the dataset code echoes its config as the
     # reference's does, data/dataset.py) goes to stderr
     json_out, sys.stdout = sys.stdout, sys.stderr
+    try:
+        return _main_legs(a, rank, world, local, json_out)
+    finally:                                  # an exception outside a guarded() leg must not leave stdout pointing at stderr
+        sys.stdout = json_out
+
+
+def _main_legs(a, rank, world, local, json_out):
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -1450,8 +1551,14 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args, T, W, a.cpu_seconds, dev)
             except Exception as e:  # the baseline must never hide the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
+        out, notes = finalize_line(out)
+        try:
+            npath = os.environ.get("A3V_BENCH_NOTES", os.path.join(ROOT, "gpurun_out", "bench_notes.md"))
+            os.makedirs(os.path.dirname(npath), exist_ok=True)
+            write_notes(notes, npath)
+        except OSError:
+            pass
         print(json.dumps(out), file=json_out, flush=True)
-    sys.stdout = json_out
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -100,3 +100,46 @@ def test_gpus_n_without_a_launcher_starts_n_ranks():
     # one rank: no launcher is started, the line says one
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--model", "tiny"], cwd=ROOT, env=e, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])["n_gpus"] == 1
+
+
+def test_tail_of_the_line_carries_every_leg_and_roofline_holds_the_north_star_scalars():
+    """the driver keeps ~8 KB of stdout tail and the scalars of `roofline` / `cpu_baseline`; the forward / decode
+    legs must be inside both.  finalize_line() is what main() prints."""
+    import copy
+    sample = json.loads(open(os.path.join(ROOT, "profiles", "r05h_bench_7b.json")).read().strip().splitlines()[-1])
+    before = copy.deepcopy(sample)
+    out, notes = bench.finalize_line(sample)
+    line = json.dumps(out)
+    assert list(out)[-1] == "summary"
+    tail = line[-6000:]
+    assert '"summary"' in tail
+    s = json.loads(tail[tail.index('"summary"') + len('"summary": '):-1])
+    for leg in ("forward", "decode", "generate", "train", "train_lora", "decode_fp8", "m13b", "geometry_R"):
+        assert leg in s and all(isinstance(x, (int, float)) for x in s[leg]), leg
+    assert s["forward"] == [before["forward"]["ms_per_step"], before["forward"]["mfma_frac"]]
+    assert s["decode"][1] == before["decode"]["tok_s"] and s["train"][0] == before["train"]["ms_per_step"] and s["errors"] == []
+    r = out["roofline"]
+    assert r["forward_ms"] == before["forward"]["ms_per_step"] and r["forward_mfma_frac"] == before["forward"]["mfma_frac"]
+    assert r["decode_tok_s"] == before["decode"]["tok_s"] and r["decode_hbm_frac"] == before["decode"]["roofline"]["frac"]
+    assert 0.4 < r["in_step_frac"] < 0.7 and r["in_step_file"].endswith(".txt") and 4 < r["traffic_ratio"] < 5.5
+    assert 0.5 < r["l2_hit"] < 1 and 0.5 < r["mfma_busy"] < 1
+    # scalars sit in front of the big tables, and the prose has left the line
+    keys = list(r)
+    assert keys.index("forward_ms") < keys.index("shapes") and keys.index("decode_hbm_frac") < keys.index("traffic")
+    assert "note" not in out["decode"]["roofline"] and "note" not in out["generate"] and any(k.startswith("generate") for k in notes)
+    assert len(line) < 14000
+    # the contract fields are untouched
+    for k in ("metric", "value", "unit", "n_gpus", "ms_per_step", "dtype", "config", "cpu_baseline"):
+        assert out[k] == before[k] or k == "cpu_baseline"
+    assert out["config"]["workload"] == before["config"]["workload"] and out["cpu_baseline"]["sample"] == before["cpu_baseline"]["sample"]
+
+
+def test_stdout_is_restored_when_a_leg_outside_guarded_raises(monkeypatch):
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    monkeypatch.setattr(bench, "_main_legs", lambda *a, **k: (_ for _ in ()).throw(RuntimeError("boom")))
+    keep = sys.stdout
+    try:
+        bench.main()
+    except RuntimeError:
+        pass
+    assert sys.stdout is keep
