@@ -18,6 +18,8 @@
 #include "a3v_common.h"
 #include <type_traits>
 #include <cstdlib>
+#include <atomic>
+#include <mutex>
 
 namespace {
 
@@ -484,6 +486,456 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_bf16_kernel(AttnArgs p) {
       }
   }
 }
+
+#ifdef A3V_EXPERIMENTS   // round 6: built, bit-identical, NOT faster (profiles/r06_dropped.md, profiles/r06a_*): `make EXPERIMENTS=1`, A3V_ATTN_PERSIST=1
+// ------------------------------------------------------------------------------------
+// attn_prefill_persist_kernel (round 6): the 4-wave / 32-rows-per-wave kernel above as PERSISTENT blocks.
+//   profiles/r05_dropped.md: with neither DMA nor arithmetic the launch above still takes 41 of 130 us at B 8 x S 1091 -- 2 304 short
+//   blocks, each paying dispatch, lane constants, a Q fetch from HBM with nothing to hide under, and an O store with a barrier in
+//   front of it.  Here 2 blocks per CU stay resident and WALK the (batch, head, query tile) units:
+//   * eight unit queues (one per XCD = blockIdx & 7, contiguous ranges of the same heavy-first / tile-rank-major order the launch
+//     above uses, so a head group's K / V^T stays in that XCD's L2); a block's first unit is static, the following ones come from ONE
+//     returning atomicAdd per unit, issued at the START of the unit and read at its last tile (the dequeue latency is never waited
+//     for); a block leaves when its queue is empty.  (First build: an exhausted queue sent the block on to the next seven -- every
+//     block then ends with seven BLOCKING atomics on words all 512 blocks hit at the same moment: +42 us on the empty-loop build,
+//     gpurun_out/r06a_skeleton_gate.txt.  The XCDs' shares are as even as the one-block-per-unit launch makes them.)
+//   * unit seam: behind the last P V product the next unit's Q fragments are fetched into the (dead) qf registers, ONE barrier frees
+//     both tile buffers, the next unit's K / V^T tile 0 goes to buffer 0 by LDS-DMA, and only then does this unit's O leave through
+//     the LDS patch (buffer 1) as whole rows: Q fetch, tile-0 DMA and the O stores all run under each other and under the partner
+//     block; the stores are never waited for except by the vmcnt(0) in front of tile 0, whose DMA was issued before them;
+//   * the counters (8 queues + 1 exit count) are left zero by the last block to exit.
+// Same arithmetic, same order of every fp32 sum as the kernel above: outputs are bit-identical (tests/test_gpu_kernels.py).
+// ------------------------------------------------------------------------------------
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_prefill_persist_kernel(AttnArgs p, int* ctr, int n_units) {
+  constexpr int KVB = 64;
+  constexpr int KROW = HD * 2;
+  constexpr int KCH = HD / 8;
+  constexpr int K_LOADS = KVB * KCH / 256;
+  constexpr int V_LOADS = HD * 8 / 256;
+  constexpr int TILEB = KVB * KROW + HD * 128;
+  __shared__ __attribute__((aligned(1024))) char lds[2 * TILEB];
+  __shared__ int next_slot;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int nqt = (p.Sq + 127) / 128;
+  const int off = p.Sk - p.Sq;                 // right alignment (llama_ens5.py:181-185)
+  const int ql = lane & 31, hh = lane >> 5;
+
+  // ---- unit queues
+  const int uq = n_units >> 3, ur = n_units & 7;
+  auto q_start = [&](int x) { return x < ur ? x * (uq + 1) : ur * (uq + 1) + (x - ur) * uq; };
+  auto q_len = [&](int x) { return uq + (x < ur ? 1 : 0); };
+  auto q_blocks = [&](int x) { return ((int)gridDim.x - x + 7) >> 3; };     // blocks whose first (static) unit came from queue x
+  const int cur_q = blockIdx.x & 7;
+  auto decode = [&](int vb, int& b, int& h, int& qt) {
+    int head_slot = vb / nqt;
+    qt = nqt - 1 - (vb - head_slot * nqt);
+    if (CAUSAL && p.head_group > 1) {
+      const int G = p.head_group, per = G * nqt;
+      const int grp = vb / per, r = vb - grp * per;
+      head_slot = grp * G + r % G;
+      qt = nqt - 1 - r / G;
+    }
+    b = head_slot / p.H;
+    h = head_slot - b * p.H;
+  };
+
+  // ---- lane constants of the LDS-DMA image and the fragment reads (head-independent)
+  unsigned koff[K_LOADS], voff[V_LOADS];
+#pragma unroll
+  for (int i = 0; i < K_LOADS; ++i) {
+    const int id = tid + i * 256;
+    const int row = id / KCH, slot = id % KCH;
+    const int sw = (HD == 128) ? (row & 15) : ((row >> 1) & 7);
+    koff[i] = (unsigned)((row * p.k_ss + (slot ^ sw) * 8) * 2);
+  }
+#pragma unroll
+  for (int i = 0; i < V_LOADS; ++i) {
+    const int id = tid + i * 256;
+    const int d = id >> 3, slot = id & 7;
+    voff[i] = (unsigned)((d * p.v_sd + (slot ^ ((d >> 1) & 7)) * 8) * 2);
+  }
+  const int kfb = ql * KROW + ((hh ^ ((HD == 128) ? (ql & 15) : ((ql >> 1) & 7))) << 4);
+  const int vfb = ql * 128 + ((hh ^ ((ql >> 1) & 7)) << 4);
+  auto full_tile = [&](int t) { return t * KVB + KVB <= p.Sk; };
+
+  // the last block to leave puts the counters back to zero for the next launch
+  auto leave = [&]() {
+    if (tid == 0) {
+      const int done = atomicAdd(&ctr[8], 1);
+      if (done == (int)gridDim.x - 1) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) __hip_atomic_store(&ctr[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  };
+  int b, h, qt;
+  {
+    const int loc = blockIdx.x >> 3;
+    if (loc >= q_len(cur_q)) { leave(); return; }            // (host: grid <= n_units, so every block has a first unit)
+    decode(q_start(cur_q) + loc, b, h, qt);
+  }
+  bf16x8 qf[HD / 16];
+  auto fetch_q = [&](int b_, int h_, int qt_) {
+    const bf16_t* Q = (const bf16_t*)p.q + b_ * p.q_sb + h_ * p.q_sh;
+    const int qr = qt_ * 128 + wave * 32 + ql;
+    const int qrc = qr < p.Sq ? qr : p.Sq - 1;
+#pragma unroll
+    for (int ks = 0; ks < HD / 16; ++ks)
+      qf[ks] = *reinterpret_cast<const bf16x8*>(Q + (int64_t)qrc * p.q_ss + ks * 16 + hh * 8);
+  };
+  fetch_q(b, h, qt);
+  const bf16_t* K = (const bf16_t*)p.k + b * p.k_sb + (h / (p.H / p.Hkv)) * p.k_sh;
+  const bf16_t* VT = (const bf16_t*)p.vt + b * p.v_sb + (h / (p.H / p.Hkv)) * p.v_sh;
+  auto dma_tile = [&](const bf16_t* Kb, const bf16_t* Vb, int kv0, char* Ks, char* Vs) {
+    const auto rsK = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, 0x7fffffff, 0x00020000);
+    const auto rsV = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, 0x7fffffff, 0x00020000);
+    const unsigned ks_off = (unsigned)(kv0 * p.k_ss * 2), vs_off = (unsigned)(kv0 * 2);
+#pragma unroll
+    for (int i = 0; i < K_LOADS; ++i) buf_dma16(rsK, Ks + (wave_u * 64 + i * 256) * 16, koff[i], ks_off);
+#pragma unroll
+    for (int i = 0; i < V_LOADS; ++i) buf_dma16(rsV, Vs + (wave_u * 64 + i * 256) * 16, voff[i], vs_off);
+  };
+#ifndef AP_NO_DMA
+  if (full_tile(0)) dma_tile(K, VT, 0, lds, lds + KVB * KROW);
+#endif
+
+#ifdef APP_STAMP
+  unsigned long long* stamps = ((int)blockIdx.x == APP_STAMP && tid == 0) ? reinterpret_cast<unsigned long long*>(p.lse) : nullptr;
+  int unit_no = 0;
+  // every block: [start, end, units, tiles, XCC id] behind the per-unit records
+  unsigned long long* span = tid == 0 ? reinterpret_cast<unsigned long long*>(p.lse) + 32 * 8 + blockIdx.x * 8 : nullptr;
+  unsigned long long tiles_done = 0;
+  if (span) { span[0] = __builtin_amdgcn_s_memrealtime(); span[4] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)); }
+#define APP_ST(k) do { if (stamps && unit_no < 32) stamps[unit_no * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define APP_ST(k) do {} while (0)
+#endif
+  for (;;) {
+    APP_ST(0);
+#ifdef APP_STAMP
+    const unsigned long long unit_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // ---- the NEXT unit's queue position: requested now, looked at behind this unit's last tile
+    int pending = 0;
+    if (tid == 0) pending = atomicAdd(&ctr[cur_q], 1);
+    const int q0 = qt * 128 + wave * 32;
+    const int qrow = q0 + ql;
+    f32x16 o[HD / 32];
+#pragma unroll
+    for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    int kv_end = p.Sk;
+    if (CAUSAL) {
+      const int last_q = min(qt * 128 + 127, p.Sq - 1);
+      kv_end = min(p.Sk, last_q + off + 1);
+    }
+    const int n_tiles = (kv_end + KVB - 1) / KVB;
+
+    u32x4 kreg[K_LOADS], vreg[V_LOADS];
+    auto load_tile = [&](int kv0) {
+#pragma unroll
+      for (int i = 0; i < K_LOADS; ++i) {
+        const int id = tid + i * 256;
+        const int row = id / KCH, ch = id % KCH;
+        int kr = kv0 + row;
+        kr = kr < p.Sk ? kr : p.Sk - 1;
+        kreg[i] = *reinterpret_cast<const u32x4*>(K + (int64_t)kr * p.k_ss + ch * 8);
+      }
+#pragma unroll
+      for (int i = 0; i < V_LOADS; ++i) {
+        const int id = tid + i * 256;
+        const int d = id >> 3, ch = id & 7;
+        const int kv = kv0 + ch * 8;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (kv + 8 <= p.Sk) {
+          v = *reinterpret_cast<const u32x4*>(VT + (int64_t)d * p.v_sd + kv);
+        } else if (kv < p.Sk) {   // ragged tail: zero the columns >= Sk (0 * garbage must stay 0)
+          const unsigned short* src = reinterpret_cast<const unsigned short*>(VT + (int64_t)d * p.v_sd + kv);
+          unsigned short e[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) e[j] = (kv + j < p.Sk) ? src[j] : (unsigned short)0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = (unsigned)e[2 * j] | ((unsigned)e[2 * j + 1] << 16);
+        }
+        vreg[i] = v;
+      }
+    };
+    auto write_tile = [&](char* Ks, char* Vs) {
+#pragma unroll
+      for (int i = 0; i < K_LOADS; ++i) {
+        const int id = tid + i * 256;
+        const int row = id / KCH, ch = id % KCH;
+        const int sw = (HD == 128) ? (row & 15) : ((row >> 1) & 7);
+        *reinterpret_cast<u32x4*>(Ks + row * KROW + ((ch ^ sw) << 4)) = kreg[i];
+      }
+#pragma unroll
+      for (int i = 0; i < V_LOADS; ++i) {
+        const int id = tid + i * 256;
+        const int d = id >> 3, ch = id & 7;
+        *reinterpret_cast<u32x4*>(Vs + d * 128 + ((ch ^ ((d >> 1) & 7)) << 4)) = vreg[i];
+      }
+    };
+
+    auto body = [&](int t, auto bufc) {
+      constexpr int BUF = decltype(bufc)::value;
+      const int kv0 = t * KVB;
+      char* Ks = lds + BUF * TILEB;
+      char* Vs = Ks + KVB * KROW;
+      if (t == n_tiles - 1 && tid == 0) {
+        // resolve the next unit (thread 0; the atomic was issued a whole unit ago) and publish it in front of this tile's barrier
+        const int loc = q_blocks(cur_q) + pending;
+        next_slot = loc < q_len(cur_q) ? q_start(cur_q) + loc : -1;
+      }
+      if (full_tile(t)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (t == 0) APP_ST(1);
+#ifndef AP_NO_BAR
+        __syncthreads();
+#endif
+        if (t == 0) APP_ST(2);
+      } else {                          // this tile's buffer was last read in iteration t-2 (or freed by the unit seam)
+        load_tile(kv0);
+        write_tile(Ks, Vs);
+        __syncthreads();
+      }
+#ifndef AP_NO_DMA
+      if (t + 1 < n_tiles && full_tile(t + 1)) dma_tile(K, VT, kv0 + KVB, lds + (1 - BUF) * TILEB, lds + (1 - BUF) * TILEB + KVB * KROW);
+#endif
+      if (CAUSAL && kv0 > q0 + 31 + off) return;
+      // ---- S^T = K . Q^T : two 32-row kv blocks ----
+      f32x16 s[2];
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[tb][r] = 0.f;
+      constexpr bool FRAG_AHEAD = HD == 128;
+      if constexpr (!FRAG_AHEAD) {
+#pragma unroll
+        for (int ks = 0; ks < HD / 16; ++ks)
+#pragma unroll
+          for (int tb = 0; tb < 2; ++tb) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + tb * 32 * KROW + (kfb ^ (ks << 5)));
+            s[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[tb], 0, 0, 0);
+          }
+      } else {
+        bf16x8 kr[3][2];
+#pragma unroll
+        for (int pre = 0; pre < 2; ++pre)
+#pragma unroll
+          for (int tb = 0; tb < 2; ++tb) kr[pre][tb] = *reinterpret_cast<const bf16x8*>(Ks + tb * 32 * KROW + (kfb ^ (pre << 5)));
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int ks = 0; ks < HD / 16; ++ks) {
+          if (ks + 2 < HD / 16) {
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb) kr[(ks + 2) % 3][tb] = *reinterpret_cast<const bf16x8*>(Ks + tb * 32 * KROW + (kfb ^ ((ks + 2) << 5)));
+            asm volatile("" : "+v"(qf[ks]) :: "memory");
+          }
+#pragma unroll
+          for (int tb = 0; tb < 2; ++tb) {
+#ifdef AP_NO_QK
+            if (ks == 0)
+#endif
+            s[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[ks % 3][tb], qf[ks], s[tb], 0, 0, 0);
+          }
+        }
+      }
+      // ---- mask + online softmax (lane owns query column ql; kv = 32tb + (r&3)+8(r>>2)+4hh) ----
+#ifdef AP_NO_SM
+      bf16x8 pf[2][2];
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pf[tb][r >> 3][r & 7] = f2bf(s[tb][r]);
+#else
+      const int qlim = CAUSAL ? (qrow + off) : 0x7fffffff;
+      const bool need_mask = (kv0 + KVB > p.Sk) || (CAUSAL && kv0 + KVB - 1 > q0 + off);
+      float mx = -INFINITY;
+      if (need_mask) {
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int kv = kv0 + tb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            const bool ok = (kv < p.Sk) && (kv <= qlim);
+            s[tb][r] = ok ? s[tb][r] : -INFINITY;
+          }
+      }
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[tb][r]);
+      if (p.lazy_rescale & 2) mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      else { float x0, x1; xchg32(mx, x0, x1); mx = fmaxf(x0, x1); }
+      const float m_new = fmaxf(m_run, mx);
+      const bool grow = (p.lazy_rescale & 1) ? ((m_new - m_run) * p.scale_log2 > 8.f || m_run == -INFINITY) : true;
+      const bool resc = __builtin_amdgcn_ballot_w64(grow && m_new != m_run) != 0;
+      const float m_tgt = resc ? m_new : m_run;
+      const float m_use = (m_tgt == -INFINITY) ? 0.f : m_tgt;
+      float alpha = 1.f;
+      if (resc) alpha = __builtin_amdgcn_exp2f((m_run - m_use) * p.scale_log2);
+      m_run = m_tgt;
+      float lsum = 0.f;
+      const float mb = m_use * p.scale_log2;
+      bf16x8 pf[2][2];
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(fmaf(s[tb][r], p.scale_log2, -mb));
+          lsum += pv;
+          pf[tb][r >> 3][r & 7] = f2bf(pv);
+        }
+      l_run = resc ? l_run * alpha + lsum : l_run + lsum;
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          u32x4 w;
+          __builtin_memcpy(&w, &pf[tb][c], 16);
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(w[e], w[2 + e], false, false);
+            w[e] = sw[0];
+            w[2 + e] = sw[1];
+          }
+          __builtin_memcpy(&pf[tb][c], &w, 16);
+        }
+      if (resc) {
+#pragma unroll
+        for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+      }
+#endif
+      // ---- O^T += V^T . P^T ----
+      if constexpr (FRAG_AHEAD) {
+        constexpr int ND = HD / 32;
+        bf16x8 vr[2][ND];
+#pragma unroll
+        for (int d = 0; d < ND; ++d) vr[0][d] = *reinterpret_cast<const bf16x8*>(Vs + d * 32 * 128 + (vfb ^ (0 << 4)));
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int gI = 0; gI < 4; ++gI) {
+          const int tb = gI >> 1, c = gI & 1;
+          if (gI + 1 < 4) {
+            const int c16n = 4 * ((gI + 1) >> 1) + 2 * ((gI + 1) & 1);
+#pragma unroll
+            for (int d = 0; d < ND; ++d) vr[(gI + 1) & 1][d] = *reinterpret_cast<const bf16x8*>(Vs + d * 32 * 128 + (vfb ^ (c16n << 4)));
+            asm volatile("" : "+v"(pf[tb][c]) :: "memory");
+          }
+#pragma unroll
+          for (int d = 0; d < ND; ++d) {
+#ifdef AP_NO_PV
+            if (gI == 0)
+#endif
+            o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vr[gI & 1][d], pf[tb][c], o[d], 0, 0, 0);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+          for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int d = 0; d < HD / 32; ++d) {
+              const int c16 = 4 * tb + 2 * c;
+              const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vs + d * 32 * 128 + (vfb ^ (c16 << 4)));
+              o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[tb][c], o[d], 0, 0, 0);
+            }
+      }
+    };
+    {
+      int t = 0;
+      for (; t + 1 < n_tiles; t += 2) {
+        body(t, std::integral_constant<int, 0>{});
+        body(t + 1, std::integral_constant<int, 1>{});
+      }
+      if (t < n_tiles) body(t, std::integral_constant<int, 0>{});
+    }
+
+    // ---- unit seam
+    APP_ST(3);
+    const int vb_next = __builtin_amdgcn_readfirstlane(next_slot);   // published in front of the last tile's barrier
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+#ifndef APP_STAMP
+    if (p.lse && qrow < p.Sq && hh == 0) p.lse[((int64_t)b * p.H + h) * p.Sq + qrow] = m_run * p.scale + __logf(l_tot);
+#endif
+    int nb = 0, nh = 0, nqt_ = 0;
+    if (vb_next >= 0) {
+      decode(vb_next, nb, nh, nqt_);
+      fetch_q(nb, nh, nqt_);                    // qf is dead behind the last tile's K Q^T
+    }
+    const bool staged = p.staged_o && !(p.o_ss & 7) && !(p.o_sh & 7) && !(p.o_sb & 7) && !(reinterpret_cast<uintptr_t>(p.out) & 15);
+    __syncthreads();                            // every wave is past its last tile: both tile buffers are free
+    APP_ST(4);
+    const bf16_t* Kn = K;
+    const bf16_t* VTn = VT;
+    if (vb_next >= 0) {
+      Kn = (const bf16_t*)p.k + nb * p.k_sb + (nh / (p.H / p.Hkv)) * p.k_sh;
+      VTn = (const bf16_t*)p.vt + nb * p.v_sb + (nh / (p.H / p.Hkv)) * p.v_sh;
+#ifndef AP_NO_DMA
+      if (full_tile(0)) dma_tile(Kn, VTn, 0, lds, lds + KVB * KROW);
+#endif
+    }
+    APP_ST(5);
+    if (staged) {
+      // the wave's 32 x HD tile leaves through a private LDS patch in tile buffer 1 as whole rows (see the kernel above); buffer 1 is
+      // next written by the DMA of the next unit's tile 1, issued behind that unit's first barrier, i.e. after every wave's reads below
+      constexpr int ROWB = HD * 2, NPAIR = HD / 8, RPI = 64 / NPAIR;
+      char* patch = lds + TILEB + wave * (32 * ROWB);
+      char* wrow = patch + ql * ROWB;
+      const int wx = (ql & (NPAIR - 1)) << 1;
+#pragma unroll
+      for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          bf16x4 ov;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ov[e] = f2bf(o[d][g4 * 4 + e] * inv);
+          *reinterpret_cast<bf16x4*>(wrow + (((d * 8 + g4 * 2 + hh) ^ wx) << 3)) = ov;
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int pr = lane % NPAIR, rr = lane / NPAIR;
+      bf16_t* Ob = (bf16_t*)p.out + b * p.o_sb + h * p.o_sh + pr * 8;
+#pragma unroll
+      for (int it = 0; it < 32 / RPI; ++it) {
+        const int r = it * RPI + rr;
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(patch + r * ROWB + ((pr ^ (r & (NPAIR - 1))) << 4));
+        if (q0 + r < p.Sq) *reinterpret_cast<bf16x8*>(Ob + (int64_t)(q0 + r) * p.o_ss) = v;
+      }
+    } else if (qrow < p.Sq) {
+      bf16_t* O = (bf16_t*)p.out + b * p.o_sb + (int64_t)qrow * p.o_ss + h * p.o_sh;
+#pragma unroll
+      for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          bf16x4 ov;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ov[e] = f2bf(o[d][g4 * 4 + e] * inv);
+          *reinterpret_cast<bf16x4*>(O + d * 32 + g4 * 8 + hh * 4) = ov;
+        }
+    }
+    APP_ST(6);
+#ifdef APP_STAMP
+    if (stamps && unit_no < 32) stamps[unit_no * 8 + 7] = (unsigned long long)n_tiles;
+    ++unit_no;
+    tiles_done += n_tiles;
+    if (span) { span[1] = __builtin_amdgcn_s_memrealtime(); span[2] = unit_no; span[3] = tiles_done; span[5] = n_tiles; span[6] = unit_t0; }
+#endif
+    if (vb_next < 0) break;
+    b = nb; h = nh; qt = nqt_; K = Kn; VT = VTn;
+  }
+  leave();
+}
+
+#endif  // A3V_EXPERIMENTS (attn_prefill_persist_kernel)
 
 #ifdef A3V_EXPERIMENTS   // measured and not dispatched (profiles/r04g_attn_w64_experiment.txt): built only with `make EXPERIMENTS=1`, A3V_ATTN_W64=1
 // ------------------------------------------------------------------------------------
@@ -1806,6 +2258,41 @@ extern "C" int64_t a3v_attention_scratch_floats(int B, int H, int hd, int Sk) {
   return (int64_t)B * H * ns * (hd + 2);
 }
 
+#ifdef A3V_EXPERIMENTS
+static int attn_cu_count() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v & ~7;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
+// Unit-queue counters of the persistent prefill kernel: 16 ints per launch (8 queues, 1 exit count), handed out round-robin from a
+// per-device pool of 256 slots that is allocated and zeroed ONCE (every launch leaves its slot zero), so launches in flight on
+// different streams never share a slot.  nullptr (e.g. first use under stream capture, where hipMalloc is illegal) = the caller
+// takes the one-block-per-unit launch.
+static int* attn_counter_slot() {
+  constexpr int NSLOT = 256, MAXDEV = 16;
+  static int* pool[MAXDEV] = {};
+  static std::atomic<unsigned> seq{0};
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return nullptr;
+  if (!pool[dev]) {
+    std::lock_guard<std::mutex> g(mu);
+    if (!pool[dev]) {
+      int* ptr = nullptr;
+      if (hipMalloc(&ptr, NSLOT * 16 * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+      if (hipMemset(ptr, 0, NSLOT * 16 * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(ptr); return nullptr; }
+      pool[dev] = ptr;
+    }
+  }
+  return pool[dev] + (seq.fetch_add(1) % NSLOT) * 16;
+}
+#endif
+
 static int attention_impl(const void* q, const void* k, const void* vt, void* out, int B, int Sq, int Sk,
                           int H, int Hkv, int hd, const int64_t* strides, int causal, float* scratch,
                           float* lse, int dtype, void* stream) {
@@ -1915,6 +2402,28 @@ static int attention_impl(const void* q, const void* k, const void* vt, void* ou
     while (G > 1 && ((B * H) / 8) % G) G >>= 1;            // groups must not straddle an XCD's range of heads
     p.head_group = G;
   }
+#ifdef A3V_EXPERIMENTS
+  // persistent walk (round 6 experiment, A3V_ATTN_PERSIST=1): two blocks per CU pull (batch, head, query tile) units from per-XCD
+  // queues; taken whenever there are more units than resident blocks and a counter slot is available
+  const int n_units = (int)grid.x;
+  int* ctr = nullptr;
+  const int bpc = hd == 128 ? 2 : 3;          // resident blocks per CU (registers: 256 / 164 per lane)
+  if (!w64 && A3V_ENV_INT("A3V_ATTN_PERSIST", 0) != 0 && A3V_ENV_INT("A3V_ATTN_PSWAP", 1) != 0 && n_units > bpc * attn_cu_count() &&
+      (causal || hd == 64) &&                 // (hd 128 without the mask is not a shape of this model; its build of the walk spills)
+      (int64_t)Sk * strides[5] * 2 < (1LL << 31) && (int64_t)hd * strides[8] * 2 < (1LL << 31))
+    ctr = attn_counter_slot();
+  if (ctr) {
+    const dim3 pg(bpc * attn_cu_count());
+    if (hd == 128) {
+      hipLaunchKernelGGL((attn_prefill_persist_kernel<128, true>), pg, dim3(256), 0, st, p, ctr, n_units);
+    } else {
+      if (causal) hipLaunchKernelGGL((attn_prefill_persist_kernel<64, true>), pg, dim3(256), 0, st, p, ctr, n_units);
+      else hipLaunchKernelGGL((attn_prefill_persist_kernel<64, false>), pg, dim3(256), 0, st, p, ctr, n_units);
+    }
+    A3V_LAUNCH_CHECK();
+    return A3V_OK;
+  }
+#endif
   if (w64) {
 #ifdef A3V_EXPERIMENTS
     static bool attr_done = false;

@@ -222,8 +222,19 @@ def main(args):
             have = have.to(dev)
             dist.all_reduce(have, op=dist.ReduceOp.MIN)
         have_full, have_legacy = (bool(x) for x in have.tolist())
+        opt_sd = None
         if have_full:
-            optimizer.load_state_dict(torch.load(opt_path, weights_only=False, mmap=True)["optimizer"])
+            # FusedAdamW / torch.optim and ZeRO-1 write the same file name in two formats: a checkpoint of the other mode is
+            # reported and skipped (every rank reads the same file, so the decision is the same everywhere), not handed to the wrong loader
+            opt_sd = torch.load(opt_path, weights_only=False, mmap=True)["optimizer"]
+            is_zero1 = isinstance(opt_sd, dict) and ("zero1_full" in opt_sd or "zero1" in opt_sd)
+            if is_zero1 != bool(args.zero1):
+                if rank == 0:
+                    print(f"resume: {opt_path} holds {'ZeRO-1' if is_zero1 else 'replicated AdamW'} optimizer state but this run is "
+                          f"{'--zero1' if args.zero1 else 'not --zero1'}: the optimizer state is NOT loaded")
+                opt_sd, have_full, have_legacy = None, False, False
+        if have_full:
+            optimizer.load_state_dict(opt_sd)
         elif have_legacy:
             optimizer.load_state_dict(torch.load(legacy, weights_only=False)["optimizer"])
         else:

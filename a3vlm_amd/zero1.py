@@ -336,13 +336,16 @@ class Zero1Optimizer:
             ent = {}
             for k in ("master", "m", "v"):
                 if self.world > 1 and not self.stub_collective:
-                    buf = torch.empty(b["n"] * self.world, dtype=b[k].dtype, device=b[k].device)
-                    self.dist.all_gather_into_tensor(buf, b[k].contiguous(), group=self.group)
-                else:
-                    buf = b[k]
-                if self.rank == 0:
-                    ent[k] = buf.detach().cpu()
-                del buf
+                    # gathered onto rank 0 only (an all-gather put n x world fp32 on EVERY rank -- 3 x 52 GB at 13B -- for a
+                    # file one rank writes); rank 0 holds one bucket's n x world at a time
+                    parts = [torch.empty_like(b[k]) for _ in range(self.world)] if self.rank == 0 else None
+                    dst = self.dist.get_global_rank(self.group, 0) if self.group is not None and hasattr(self.dist, "get_global_rank") else 0
+                    self.dist.gather(b[k].contiguous(), parts, dst=dst, group=self.group)
+                    if self.rank == 0:
+                        ent[k] = torch.cat([q.cpu() for q in parts])
+                    del parts
+                elif self.rank == 0:
+                    ent[k] = b[k].detach().cpu()
             if self.rank == 0:
                 full[b["name"]] = ent
         if self.rank != 0:
@@ -356,7 +359,8 @@ class Zero1Optimizer:
         self.sync_params()
         flat_p = self.eng.flat_params()
         if "zero1_full" in sd:
-            # no collective: every rank reads the same file and keeps its slice; the parameters come from the masters everywhere
+            # every rank reads ITS slice of the same (mmap-ed) file; the parameters are then rebuilt by the all-gather of the slices' compute
+            # images, exactly as a step does (reading every master on every rank was 52 GB of host reads + H2D per rank at 13B)
             z = sd["zero1_full"]
             self.step_count = int(z["step"])
             for b in self.buckets:
@@ -372,8 +376,13 @@ class Zero1Optimizer:
                     if hi > lo:
                         b[k][:hi - lo].copy_(st[k][lo:hi])
                 b["out"].copy_(b["master"])
-                nc = min(n_st, se - ss)
-                flat_p[ss:ss + nc].copy_(st["master"][:nc])
+                if self.world > 1 and not self.stub_collective:
+                    self.dist.all_gather_into_tensor(flat_p[ss:se], b["out"], group=self.group)
+                elif self.world > 1:                        # one-GPU emulation of a shard (bench): no peers to gather from
+                    nc = min(n_st, se - ss)
+                    flat_p[ss:ss + nc].copy_(st["master"][:nc])
+                else:
+                    flat_p[b["mine"][0]:b["mine"][1]].copy_(b["out"])
         else:
             z = sd["zero1"]
             if z["world"] != self.world or z["rank"] != self.rank:
