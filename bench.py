@@ -1283,22 +1283,47 @@ def write_notes(notes, path):
             f.write(f"- `{k}`: {notes[k]}\n")
 
 
+def check_rank_devices(rank_devices, allow_shared=False):
+    """Every rank of a SCALE run must sit on its own GPU (one process per GPU, main_finetune.py:241-263): two ranks on one device
+    ordinal (or one uuid) would time N model replicas sharing a chip and call it N-GPU throughput.  Raises unless ``allow_shared``
+    (the one-GPU emulation the tests use)."""
+    if not rank_devices:
+        return
+    seen = {}
+    for d in rank_devices:
+        key = d.get("uuid") or ("ordinal", d.get("device"))
+        for k in (("ordinal", d.get("device")), key):
+            if k in seen and seen[k] != d.get("rank") and not allow_shared:
+                raise RuntimeError(f"bench.py: ranks {seen[k]} and {d.get('rank')} share GPU {k}: refusing to report an N-GPU number "
+                                   f"(LOCAL_RANK / device map: {[(x.get('rank'), x.get('local_rank'), x.get('device')) for x in rank_devices]})")
+            seen[k] = d.get("rank")
+    locs = [d.get("local_rank") for d in rank_devices]
+    if len(set(locs)) != len(locs) and not allow_shared:
+        raise RuntimeError(f"bench.py: duplicate LOCAL_RANK among the ranks: {locs}")
+
+
 def launch_only(a, rank, world):
     """A3V_BENCH_LAUNCH_ONLY=1 (CPU test of the launch contract, no GPU work): every rank joins a gloo group, one all-reduce
     counts them, rank 0 prints the line's launch fields."""
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    mine = {"rank": rank, "local_rank": local, "device": local, "pid": os.getpid()}      # the ordinal main() would set_device() to
+    devs = [mine]
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
         t = torch.ones(1)
         dist.all_reduce(t)
         seen = int(t.item())
+        devs = [None] * world
+        dist.all_gather_object(devs, mine)
         dist.barrier()
         dist.destroy_process_group()
     else:
         seen = 1
+    check_rank_devices(devs)
     if rank == 0:
-        print(json.dumps({"launch_only": True, "n_gpus": world, "rccl_ranks": seen, "gpus_arg": a.gpus}), flush=True)
+        print(json.dumps({"launch_only": True, "n_gpus": world, "rccl_ranks": seen, "gpus_arg": a.gpus, "rank_devices": devs}), flush=True)
 
 
 def main():
@@ -1346,6 +1371,7 @@ def _main_legs(a, rank, world, local, json_out):
                 "backend": dist.get_backend()}
         rank_devices = [None] * world
         dist.all_gather_object(rank_devices, mine)
+        check_rank_devices(rank_devices, allow_shared=os.environ.get("A3V_BENCH_ONE_DEVICE") == "1")
     timer = Timer(dist, dev)
     legs = set((a.legs.split(",") if a.legs else (ALL_LEGS if world == 1 else CORE_LEGS)))
     if a.model != "7b":

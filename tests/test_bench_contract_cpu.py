@@ -143,3 +143,30 @@ def test_stdout_is_restored_when_a_leg_outside_guarded_raises(monkeypatch):
     except RuntimeError:
         pass
     assert sys.stdout is keep
+
+
+def test_gpus_8_starts_eight_ranks_on_eight_distinct_devices_and_duplicates_are_refused():
+    """the first SCALE run must be self-checking.  `--gpus 8` (launch only: gloo rendezvous, no GPU work) ends in
+    8 children with 8 distinct LOCAL_RANK / device ordinals on the line; two ranks on one device are refused."""
+    import subprocess
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "LOCAL_WORLD_SIZE", "GROUP_RANK", "TORCHELASTIC_RUN_ID"):
+        e.pop(k, None)
+    e["A3V_BENCH_LAUNCH_ONLY"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--model", "tiny"], cwd=ROOT, env=e, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 8 and d["rccl_ranks"] == 8 and d["gpus_arg"] == 8
+    devs = d["rank_devices"]
+    assert sorted(x["rank"] for x in devs) == list(range(8)) and sorted(x["local_rank"] for x in devs) == list(range(8))
+    assert sorted(x["device"] for x in devs) == list(range(8)) and len({x["pid"] for x in devs}) == 8
+    # duplicates: by ordinal, by uuid, by LOCAL_RANK
+    ok = [{"rank": i, "local_rank": i, "device": i, "uuid": f"GPU-{i}"} for i in range(8)]
+    bench.check_rank_devices(ok)
+    import pytest
+    for bad in ([dict(ok[0]), dict(ok[1], device=0)] + ok[2:], [dict(ok[0]), dict(ok[1], uuid="GPU-0")] + ok[2:],
+                [dict(ok[0]), dict(ok[1], local_rank=0)] + ok[2:]):
+        with pytest.raises(RuntimeError):
+            bench.check_rank_devices(bad)
+    bench.check_rank_devices([dict(ok[0]), dict(ok[1], device=0, uuid="GPU-0", local_rank=0)], allow_shared=True)     # the tests' one-GPU emulation

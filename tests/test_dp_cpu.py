@@ -168,6 +168,37 @@ def test_sampler_shards_are_disjoint_and_cover():
     assert len(seen) == len(set(seen)) == 160
 
 
+def test_sampler_shards_at_dp8_with_accumulation_and_resume():
+    """DP 8 x accum 2 -- the eight ranks' index lists are disjoint, cover every sample that fits whole global
+    windows (data/alpaca.py:246-328: groups are cut to multiples of batch x accum x world), are the same length, and a resume at
+    `start_iter` yields exactly the tail of the un-resumed list on every rank."""
+    class DS:
+        def groups(self):
+            return [list(range(0, 1000)), list(range(1000, 1700)), list(range(1700, 1733))]
+    bs, acc, world = 2, 2, 8
+    full = []
+    for r in range(world):
+        s = FinetuneDistSampler(DS(), num_replicas=world, rank=r, shuffle=True, seed=11, batch_size=bs, acc_grad=acc)
+        s.set_epoch(1, 0)
+        full.append(list(iter(s)))
+        assert len(full[-1]) == len(s)
+    assert len({len(x) for x in full}) == 1 and len(full[0]) % (bs * acc) == 0
+    flat = [i for x in full for i in x]
+    assert len(flat) == len(set(flat)), "two ranks drew the same sample"
+    window = bs * acc * world
+    assert len(flat) == (1000 // window) * window + (700 // window) * window + (33 // window) * window
+    # every global window (one optimizer step of all ranks) comes from ONE group: sequence lengths are grouped (dataset.py groups())
+    per = bs * acc
+    gid = lambda i: 0 if i < 1000 else (1 if i < 1700 else 2)  # noqa: E731
+    for w0 in range(0, len(full[0]), per):
+        assert len({gid(i) for x in full for i in x[w0:w0 + per]}) == 1
+    for start_iter in (1, 7, len(full[0]) // bs - 1):
+        for r in range(world):
+            s = FinetuneDistSampler(DS(), num_replicas=world, rank=r, shuffle=True, seed=11, batch_size=bs, acc_grad=acc)
+            s.set_epoch(1, start_iter)
+            assert list(iter(s)) == full[r][start_iter * bs:], (r, start_iter)
+
+
 def test_lr_schedule_and_weight_decay_groups(host):
     opt = types.SimpleNamespace(param_groups=[{"lr": 0.0}, {"lr": 0.0, "lr_scale": 0.5}])
     for e, lr, g0, g1 in host["lr_table"]:
