@@ -155,106 +155,3 @@ extern "C" int a3v_gemm_tn_strip(const void* T, int64_t ldt, const void* X, int6
   A3V_LAUNCH_CHECK();
   return A3V_OK;
 }
-
-// ------------------------------------------------------------------------------------
-// a3v_gemm_nt_narrow (round 6): C[M, 64] = A[M, K] . W[64, K]^T in ONE pass -- the adapter projections t = x . A^T and dt = dy . B of
-// model/peft.py:58-159 (M = tokens, 64 = the padded rank of a fused adapter group, K = 4096 .. 22016).
-// These products are HBM streams of A (71 .. 385 MB) with nothing to compute; the split-K form (a3v_gemm_nt_splitk: 256-row blocks x S
-// K-slices, fp32 planes, a3v_splitk_reduce) paid a second launch and 2 x S x M x 64 x 4 bytes of plane traffic for every one of the
-// 256 products of a LoRA step.  Here a block owns 32 token rows over the WHOLE K: its 8 waves take an eighth of K each (operands straight
-// from global memory into MFMA fragments: a lane's 16 bytes are 8 consecutive k of one row, exactly the 16x16x32 operand), the eight
-// partial 32 x 64 tiles meet in LDS, and the block writes its rows once.  273 blocks at M = 8728, two per CU: one wave of blocks, each
-// with ~24 KiB per wave in flight.  W (0.5 .. 2.8 MB) is re-read by every block from the L2.
-// ------------------------------------------------------------------------------------
-namespace {
-constexpr int NR_ROWS = 32, NR_LD = 68;          // rows per block; LDS row stride in floats (68: a half-wave's 16 rows x 16 B tile all 64 banks)
-template <bool F32OUT>
-__global__ __launch_bounds__(512, 2) void gemm_nt_narrow_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw,
-                                                              void* __restrict__ C, int64_t ldc, int M, int K) {
-  __shared__ __attribute__((aligned(16))) float part[8][NR_ROWS][NR_LD];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 15, c = lane >> 4;
-  const int m0 = blockIdx.x * NR_ROWS;
-  const int kw = K >> 3, kbeg = wave * kw;        // K % 256 == 0: every wave's eighth is a whole number of 32-k steps
-  const bf16_t* ap[2];
-  const bf16_t* wp[4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    int row = m0 + i * 16 + r;
-    row = row < M ? row : M - 1;
-    ap[i] = A + (int64_t)row * lda + kbeg + c * 8;
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) wp[j] = W + (int64_t)(j * 16 + r) * ldw + kbeg + c * 8;
-  f32x4 acc[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  constexpr int U = 4;                            // 32-k steps per trip: 24 x 16 B per lane in flight
-  int k = 0;
-  for (; k + U * 32 <= kw; k += U * 32) {
-    bf16x8 af[U][2], wf[U][4];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) af[u][i] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(ap[i] + k + u * 32));   // A: read once
-#pragma unroll
-      for (int j = 0; j < 4; ++j) wf[u][j] = *reinterpret_cast<const bf16x8*>(wp[j] + k + u * 32);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][j], af[u][i], acc[i][j], 0, 0, 0);
-  }
-  for (; k < kw; k += 32) {
-    bf16x8 af[2], wf[4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) af[i] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(ap[i] + k));
-#pragma unroll
-    for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(wp[j] + k);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
-  }
-  // D = W-rows x A-rows: the lane holds n = 16 j + 4 c + {0..3} of token m = 16 i + r
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(&part[wave][i * 16 + r][j * 16 + c * 4]) = acc[i][j];
-  __syncthreads();
-  const int m = tid >> 4, n4 = (tid & 15) * 4;    // 512 threads = 32 rows x 16 groups of 4 columns
-  f32x4 s = *reinterpret_cast<const f32x4*>(&part[0][m][n4]);
-#pragma unroll
-  for (int w = 1; w < 8; ++w) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(&part[w][m][n4]);
-    s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
-  }
-  if (m0 + m < M) {
-    if (F32OUT) {
-      *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(C) + (int64_t)(m0 + m) * ldc + n4) = s;
-    } else {
-      bf16x4 o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = f2bf(s[e]);
-      *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(C) + (int64_t)(m0 + m) * ldc + n4) = o;
-    }
-  }
-}
-}  // namespace
-
-extern "C" int a3v_gemm_nt_narrow(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int M, int N, int K,
-                                  int out_dtype, void* stream) {
-  if (!A || !W || !C || M <= 0 || K <= 0) return A3V_ERR_ARG;
-  if (N != 64 || (K % 256) || (lda % 8) || (ldw % 8) || (reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(W) & 15)) return A3V_ERR_SHAPE;
-  if (out_dtype != A3V_BF16 && out_dtype != A3V_F32) return A3V_ERR_DTYPE;
-  if (out_dtype == A3V_BF16 ? ((ldc % 4) || (reinterpret_cast<uintptr_t>(C) & 7)) : ((ldc % 4) || (reinterpret_cast<uintptr_t>(C) & 15))) return A3V_ERR_SHAPE;
-  const dim3 grid((M + NR_ROWS - 1) / NR_ROWS);
-  if (out_dtype == A3V_F32) hipLaunchKernelGGL(gemm_nt_narrow_kernel<true>, grid, dim3(512), 0, (hipStream_t)stream, (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, M, K);
-  else hipLaunchKernelGGL(gemm_nt_narrow_kernel<false>, grid, dim3(512), 0, (hipStream_t)stream, (const bf16_t*)A, lda, (const bf16_t*)W, ldw, C, ldc, M, K);
-  A3V_LAUNCH_CHECK();
-  return A3V_OK;
-}

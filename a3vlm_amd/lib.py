@@ -39,7 +39,6 @@ SIGNATURES = {
     "a3v_adamw_scaled": (I, [P, P, P, P, L, F, F, F, F, F, L, P, P, P]),
     "a3v_adamw_scaled_t": (I, [P, P, P, P, I, I, F, F, F, F, F, L, P, P, L, P, P]),
     "a3v_gemm_tn_strip": (I, [P, L, P, L, P, I, I, I, I, P]),
-    "a3v_gemm_nt_narrow": (I, [P, L, P, L, P, L, I, I, I, I, P]),
     "a3v_lora_gb_scatter": (I, [P, L, I, I, P, P, P, P]),
     "a3v_adamw_multi": (I, [P, I, L, F, F, F, F, F, L, P, P]),
     "a3v_scale_cast": (I, [P, I, P, I, L, F, P]),

@@ -124,23 +124,6 @@ def gemm_nt_splitk(a, w, out, scratch, S: int, accumulate: bool = False):
     return out
 
 
-def gemm_nt_narrow_ok(a, w, out) -> bool:
-    """shapes a3v_gemm_nt_narrow takes: 64 weight rows, K a multiple of 256, bf16 operands with 16-byte aligned rows"""
-    return (a.is_cuda and a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and w.shape[0] == 64 and a.shape[1] % 256 == 0
-            and a.stride(0) % 8 == 0 and w.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0
-            and a.stride(1) == 1 and w.stride(1) == 1 and out.stride(1) == 1 and out.stride(0) % 4 == 0
-            and out.dtype in (torch.bfloat16, torch.float32) and out.data_ptr() % (8 if out.dtype == torch.bfloat16 else 16) == 0)
-
-
-def gemm_nt_narrow(a, w, out):
-    """out[M, 64] = a[M, K] @ w[64, K].T in one pass (the adapter projections t = lora_a(x), dt = dy . lora_b; model/peft.py:58-159)."""
-    _dev(a, w, out)
-    M, K = a.shape
-    rc = _l.load().a3v_gemm_nt_narrow(_p(a), a.stride(0), _p(w), w.stride(0), _p(out), out.stride(0), M, w.shape[0], K, dt(out), _stream())
-    _l.check(rc, f"a3v_gemm_nt_narrow(M={M},K={K})")
-    return out
-
-
 def gemm_nn(a, wt, out, *, residual=None, epilogue: int = 0):
     """out[M, N] = epilogue(a[M, K] @ wt[K, N]) -- wt row-indexed by the contracted index (dX = dY @ W on the forward image)."""
     _dev(a, wt, out, residual)

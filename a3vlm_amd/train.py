@@ -55,7 +55,6 @@ class TrainEngine:
     # free and the product runs on the NT ring kernel (1.38-1.42 PF) instead of the NN kernel (1.28-1.30) for the groups named here
     # ("0": none, "all", or a comma list of qkv / wo / w13 / w2).  Same-box LoRA step: 253.0 ms without, 248.9 with wo,w13,w2, 247.9 all
     lora_nt_dgrad = os.environ.get("A3V_LORA_NT_DGRAD", "all")
-    narrow_nt = os.environ.get("A3V_NARROW_NT", "1") != "0"            # adapter projections by a3v_gemm_nt_narrow (0: split-K planes + reduce)
     strip_wgrad = os.environ.get("A3V_STRIP_WGRAD", "1") != "0"        # adapter weight gradients by a3v_gemm_tn_strip (0: the 256 x 256 TN split-K kernel)
     fuse_swiglu_bwd = os.environ.get("A3V_FUSE_SWIGLU_BWD", "1") != "0"   # LoRA: SwiGLU backward in the epilogue of w2's input-gradient GEMM (0: separate pass, A/B)
 
@@ -446,9 +445,6 @@ class TrainEngine:
         reduce pass; a plain launch would be a handful of blocks with a serial K loop (122 us instead of ~25 at 8728 x 64 x 4096)."""
         M, K = a.shape
         N = w.shape[0]
-        if self.narrow_nt and not accumulate and M >= 512 and self.act == torch.bfloat16 and ops.gemm_nt_narrow_ok(a, w, out):
-            ops.gemm_nt_narrow(a, w, out)            # one pass: no split-K planes, no reduce launch (the 256 adapter projections of a step)
-            return
         S = skinny_slices(M, N, K, self._cus(a.device) if a.is_cuda else 0)
         if S == 1 or self.act != torch.bfloat16 or K % 64:
             f32 = out.dtype == torch.float32 and self.act == torch.bfloat16

@@ -469,15 +469,6 @@ int a3v_lora_gb_scatter(const float* gbt, int64_t ld, int r, int n_mods, float* 
  * LDS: three per CU) so that the stream of X has several stages in flight per CU. */
 int a3v_gemm_tn_strip(const void* T, int64_t ldt, const void* X, int64_t ldx, float* partial, int R, int N, int Kt, int S, void* stream);
 
-/* The adapter projections in ONE pass (round 6): C[M, 64] = A[M, K] . W[64, K]^T, bf16 operands, C bf16 or fp32 (out_dtype) with row
- * stride ldc -- t = lora_a(x) and dt = dy . lora_b of model/peft.py:58-159 (`lora_b(lora_a(x))`, autograd's input gradient of
- * lora_b), N = 64 = the padded rank of a fused adapter group (the caller's W holds zero rows beyond its adapters), K % 256 == 0.
- * A block owns 32 rows over the whole K (its eight waves an eighth of K each, partial tiles summed in LDS): no split-K planes and no
- * reduce launch (a3v_gemm_nt_splitk + a3v_splitk_reduce take every other shape).  The fp32 sum runs over eight K-slices per row
- * instead of S: values equal the split-K form's up to the order of the fp32 sum. */
-int a3v_gemm_nt_narrow(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int M, int N, int K,
-                       int out_dtype, void* stream);
-
 /* a3v_adamw_scaled for a [rows, cols] matrix (rows, cols multiples of 64) that ALSO keeps the transposed bf16 image current:
  * bf16_image_t points at element [0][first row of this parameter] of W^T [cols][ldt] (ldt >= rows, multiple of 4; 8-B aligned), the
  * operand of the full fine-tune's input-gradient GEMMs on the NT kernel (loss.backward() through F.linear, engine_finetune.py:55-57;

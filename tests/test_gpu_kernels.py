@@ -512,48 +512,6 @@ def test_gemm_nt_splitk(M, N, K, S):
     assert torch.equal(ob, ob2)
 
 
-@pytest.mark.parametrize("M,K,ld_extra", [(8728, 4096, 64), (1000, 22016, 64), (33, 256, 0), (511, 11008, 64), (2049, 12288, 0)])
-def test_gemm_nt_narrow(M, K, ld_extra):
-    """The adapter projections in one pass (a3v_gemm_nt_narrow: 32 rows x the whole K per block, eight K-slices summed in LDS) == the
-    fp32-accumulate / round-once product of the same bf16 operands (model/peft.py:58-159: lora_a(x), dy . lora_b), bf16 output written
-    INTO the K-extension columns behind its own operand ([x | t] rows), fp32 output, zero weight rows -> exact zeros, rows past M
-    untouched, and the same bf16 values as the split-K form up to one rounding of a different fp32 sum order."""
-    a, w = rt(gen(M, K, seed=41)), rt(gen(64, K, seed=42, scale=0.05))
-    w[48:] = 0.0
-    full = torch.full((M + 2, K + ld_extra), 3.0, dtype=BF, device=DEV)
-    full[:M, :K] = a.to(BF).to(DEV)
-    wd = w.to(BF).to(DEV)
-    want = a @ w.t()
-    tol = dict(rtol=2 ** -7, atol=2e-3 * math.sqrt(K) * 0.05 + 1e-3)
-    ad = full[:M, :K]
-    if ld_extra:
-        out = full[:M, K:]
-        assert ops.gemm_nt_narrow_ok(ad, wd, out)
-        ops.gemm_nt_narrow(ad, wd, out)
-        assert torch.equal(full[:M, :K].cpu().float(), a), "the operand columns were written"
-        assert bool((full[M:] == 3.0).all()), "rows past M were written"
-    else:
-        out = torch.empty(M, 64, dtype=BF, device=DEV)
-        ops.gemm_nt_narrow(ad, wd, out)
-    assert_close(out, want, what="narrow bf16", **tol)
-    assert bool((out[:, 48:] == 0).all())
-    of = torch.empty(M, 64, dtype=torch.float32, device=DEV)
-    ops.gemm_nt_narrow(ad, wd, of)
-    assert_close(of, want, rtol=1e-4, atol=2e-5 * math.sqrt(K), what="narrow f32")
-    S = 4
-    ob = torch.empty(M, 64, dtype=BF, device=DEV)
-    ops.gemm_nt_splitk(ad, wd, ob, torch.empty(S * M * 64, dtype=torch.float32, device=DEV), S)
-    d = (out.float() - ob.float()).abs()
-    assert float(d.max()) <= 2 ** -7 * float(want.abs().max()) and float((d > 0).float().mean()) < 0.02, "narrow vs split-K: more than rounding flips"
-    out2 = torch.empty(M, 64, dtype=BF, device=DEV)
-    ops.gemm_nt_narrow(ad, wd, out2)
-    assert torch.equal(out2, out.contiguous()), "not deterministic"
-    # shapes the one-pass kernel does not take are refused loudly, not mis-computed
-    from a3vlm_amd import lib as _lib
-    with pytest.raises(RuntimeError):
-        ops.gemm_nt_narrow(ad[:, :K - 128] if K > 256 else ad[:, :128], wd[:, :K - 128] if K > 256 else wd[:, :128], out2)
-
-
 @pytest.mark.parametrize("M,N,K,S", [(1000, 64, 22016, 4), (8728, 64, 4096, 3), (8728, 64, 4096, 7), (520, 48, 128, 2), (777, 64, 64, 1), (600, 64, 8768, 7),
                                      (512, 64, 192, 1)])
 def test_skinny_nt_stages_write_the_planes_of_the_two_stage_kernel(M, N, K, S):
