@@ -795,14 +795,21 @@ def recipe_leg(m, args, B, timer, dev, gen_long=1024):
         def one():
             _, ids = mm.generate(prompts, img, max_gen_len=n_new, temperature=0.1, top_p=0.75, additional_stop_symbols=["###"], return_ids=True)
             cnt["n"] = sum(len(t) for t in ids)
+            cnt["steps"] = max(len(t) for t in ids)
         sec = timer(one, 1, 1)
         tok = torch.tensor([mm.tokenizer.encode(p, True, False) for p in prompts], device=dev)
         pre = timer(lambda: mr.forward_inference(tok, 0, img), 1, 1)
         dphase = max(sec - pre, 1e-9)
-        mid = ctx + n_new // 2
-        ev[f"ctx_{ctx}"] = {"prompt_tokens": Tp, "new_tokens": cnt["n"], "tok_s_after_prefill": round(cnt["n"] * world / dphase, 1),
-                            "ms_per_step": round(dphase / max(cnt["n"] // B, 1) * 1e3, 3), "prefill_ms": round(pre * 1e3, 1),
-                            "hbm_frac": round(bytes_decode_step(args, B, mid) / (dphase / max(cnt["n"] // B, 1)) / HBM_PEAK, 4)}
+        # the batch steps until its LONGEST sequence ends: model steps = that length.  A sampled end-of-sequence shortens some rows (random
+        # weights at T = 0.1: run-dependent; r06d drew 1835 of 2048 tokens and the old tokens / B step count made every step look 11 %
+        # slower), so the rate is quoted per batch SLOT (B x steps) and the tokens actually kept are reported beside it
+        steps = max(cnt["steps"], 1)
+        mid = ctx + steps // 2
+        ev[f"ctx_{ctx}"] = {"prompt_tokens": Tp, "new_tokens": cnt["n"], "model_steps": steps,
+                            "tok_s_after_prefill": round(B * steps * world / dphase, 1),
+                            "kept_tok_s_after_prefill": round(cnt["n"] * world / dphase, 1),
+                            "ms_per_step": round(dphase / steps * 1e3, 3), "prefill_ms": round(pre * 1e3, 1),
+                            "hbm_frac": round(bytes_decode_step(args, B, mid) / (dphase / steps) / HBM_PEAK, 4)}
     mm.tokenizer = _SynthTokenizer(1500 - W)
     prompts = [f"eval prompt {i} long" for i in range(B)]
     cnt = {}
@@ -995,6 +1002,24 @@ def m13b_leg(B, T, steps, warmup, timer, dev):
                                              "and the update once per window)"}
     except Exception as e:
         res["train_zero1_recipe"] = {"samples_s": None, "error": repr(e)[:300]}
+    # ... and at the recipe's own memory regime (scripts/a3vlm_train.sh:45-55 + main_finetune.py --checkpointing: batch 2 x accum 8 with
+    # activation checkpointing): per-block recompute, micro-batch 2, eight micro-steps per exchange / update (VERDICT r5 'missing' 4)
+    try:
+        mb3, acc3, T3 = 2, 8, 2048 - W
+        tok3 = torch.randint(3, args.vocab_size, (mb3, T3), device=dev, generator=g)
+        tok3[:, 0] = 1
+        z = zero1_leg(m, mb3, T3, img[:mb3].contiguous(), tok3, 1, 1, timer, shard_of=8, recompute=True, accum=acc3)
+        flz = flops_forward(args, mb3, T3, W)
+        res["train_zero1_recipe_ckpt"] = {"seq_len": 2048, "micro_batch": mb3, "accum": acc3, "recompute": z["recompute"],
+                                          "samples_s": round(mb3 * acc3 * world / z["sec"], 2),
+                                          "ms_per_optimizer_step": round(z["sec"] * 1e3, 1), "ms_per_micro_step": round(z["sec"] / acc3 * 1e3, 1),
+                                          "hbm_gib": round(z["hbm_gib"], 1), "loss": round(z["loss"], 4),
+                                          "mfma_frac_3x": round(3 * acc3 * flz["total"] / z["sec"] / MFMA_PEAK_BF16, 4),
+                                          "collectives": "stubbed (one-GPU emulation of rank 0 of DP-8)" if z["emulated"] else "RCCL",
+                                          "note": "13B ZeRO-1 shard at the reference recipe's own regime: max_words 2048, batch 2 x accum 8, activation "
+                                                  "checkpointing (per-block recompute); 3 x forward FLOP convention although a recomputing step executes 4 x"}
+    except Exception as e:
+        res["train_zero1_recipe_ckpt"] = {"samples_s": None, "error": repr(e)[:300]}
     mb = 4
     try:
         tsec, loss, mem, ntr, rec = train_leg(m, mb, T, img[:mb].contiguous(), tok[:mb].contiguous(), 2, 1, timer, recompute=True)
@@ -1352,6 +1377,8 @@ def finalize_line(out):
         "m13b": [_g(out, "m13b", "forward_ms"), _g(out, "m13b", "forward_mfma_frac"), _g(out, "m13b", "decode_tok_s"), _g(out, "m13b", "decode_hbm_frac")],
         "m13b_train_zero1": [_g(out, "m13b", "train_zero1", "ms_per_step"), _g(out, "m13b", "train_zero1", "mfma_frac_3x")],
         "m13b_train_replica": [_g(out, "m13b", "train_replica", "ms_per_step"), _g(out, "m13b", "train_replica", "mfma_frac_3x")],
+        "m13b_zero1_recipe_ckpt": [_g(out, "m13b", "train_zero1_recipe_ckpt", "ms_per_optimizer_step"), _g(out, "m13b", "train_zero1_recipe_ckpt", "mfma_frac_3x"),
+                                   _g(out, "m13b", "train_zero1_recipe_ckpt", "hbm_gib")],
         "roofline": [_g(out, "roofline", "achieved"), _g(out, "roofline", "frac"), _g(out, "roofline", "in_step_frac")],
         "families": {k: v.get("frac") for k, v in (_g(out, "roofline", "families") or {}).items()},
         "cpu": [_g(out, "cpu_baseline", "value"), _g(out, "cpu_baseline", "decode_tok_s"), _g(out, "cpu_baseline", "parity_full_depth_rel_err"),
