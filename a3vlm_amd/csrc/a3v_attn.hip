@@ -335,27 +335,6 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_bf16_kernel(AttnArgs p) {
     float lsum = 0.f;
     const float mb = m_use * p.scale_log2;
     bf16x8 pf[2][2];
-#ifdef AP_PK      // A/B build (round 6): scale-and-shift and the row sum as packed fp32 ops (two elements per issue slot)
-    {
-      f32x2 ls2 = {0.f, 0.f};
-      const f32x2 sc2 = {p.scale_log2, p.scale_log2}, nmb2 = {-mb, -mb};
-#pragma unroll
-      for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          const f32x2 sv = {s[tb][r], s[tb][r + 1]};
-          f32x2 a;
-          asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(a) : "v"(sv), "s"(sc2), "v"(nmb2));
-          f32x2 pp;
-          pp[0] = __builtin_amdgcn_exp2f(a[0]);
-          pp[1] = __builtin_amdgcn_exp2f(a[1]);
-          asm("v_pk_add_f32 %0, %0, %1" : "+v"(ls2) : "v"(pp));
-          pf[tb][r >> 3][r & 7] = f2bf(pp[0]);
-          pf[tb][(r + 1) >> 3][(r + 1) & 7] = f2bf(pp[1]);
-        }
-      lsum = ls2[0] + ls2[1];
-    }
-#else
 #pragma unroll
     for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
@@ -368,7 +347,6 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_bf16_kernel(AttnArgs p) {
         lsum += pv;
         pf[tb][r >> 3][r & 7] = f2bf(pv);
       }
-#endif
     l_run = resc ? l_run * alpha + lsum : l_run + lsum;
     if constexpr (PSWAP) {
 #pragma unroll
