@@ -78,6 +78,21 @@ def test_committed_bench_lines_follow_the_contract():
             assert w3["wire_ms_one_link_ring"] > w3["wire_ms_all_7_links"] > 0
             assert d["m13b"]["train_zero1_recipe"]["seq_len"] == 2048
         assert c["c1"]["ids_equal"] is True and c["decode_tok_s"] > 0
+        if os.path.basename(files[-1]) >= "r06":
+            # round 6: what the driver's record keeps -- scalars of the north-star legs inside `roofline`, the compact summary as the LAST key,
+            # full-depth parity over every text position of two samples, the 13B recipe at its own memory regime
+            assert list(d)[-1] == "summary" and d["summary"]["errors"] == []
+            assert r["forward_ms"] == d["forward"]["ms_per_step"] and r["decode_tok_s"] == d["decode"]["tok_s"] and 0.3 < r["in_step_frac"] < 0.8
+            assert d["summary"]["forward"][0] == d["forward"]["ms_per_step"] and d["summary"]["train_lora"][0] == d["train_lora"]["ms_per_step"]
+            pf = c["parity_full_depth"]
+            assert pf["samples"] == 2 and pf["positions"] == 1024 and pf["agreement_on_decided"] == 1.0 and pf["decided_frac"] > 0.2
+            assert pf["agreement_on_decided_4sigma"] == 1.0 and pf["argmax_agreement_all_positions"] > 0.9 and "rel_err" in pf["fp8_vs_bf16"]
+            assert c["parity_full_depth_decided_frac"] == pf["decided_frac"] and c["parity_full_depth_agreement"] == 1.0
+            z = d["m13b"]["train_zero1_recipe_ckpt"]
+            assert z["micro_batch"] == 2 and z["accum"] == 8 and z["recompute"] is True and z["hbm_gib"] < 288
+            lo = d["train_lora_with_loader"]
+            assert lo["persistent_workers"] and lo["prefetch_factor"] >= 4 and lo["vs_device_resident_synthetic_step"] > 0.98 and lo["loader_only_samples_s"]
+            assert "note" not in d["generate"] and os.path.isfile(os.path.join(ROOT, "profiles", "bench_notes.md"))
         assert d["generate"]["tok_s_end_to_end"] > 0 and d["decode"]["roofline"]["bound"] == "hbm"
 
 
